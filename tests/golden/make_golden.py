@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference.
+
+Run in the build container only (``/root/reference`` is not on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports ``support.losses`` / ``support.utils`` / ``support.interfaces`` from
+``/root/reference`` (with a stub for the unused ``kornia`` import,
+``support/losses.py:2``) and stores inputs + expected outputs as ``.npz``.  Only
+data is written; no reference source travels.
+
+Fixtures
+  crop_like.npz        G1  support/utils.py:24-42
+  losses_fmse.npz      G2  support/losses.py:9-113   (FeatureMSE, fwd + dL/dP)
+  losses_grs.npz       G3  support/losses.py:116-211 (GlobalRelativeSimilarityLoss)
+  losses_image.npz     G4  support/losses.py:245-320 (RelativeMSE, SMAPE, Tonemapped*)
+  interface_<case>.npz G5  support/interfaces.py:80-333 driven with the build's
+                           oracle modules (``oracle/``) as stand-ins for ``sbmc``.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    k = types.ModuleType("kornia")
+    k.rgb_to_hls = lambda x: x
+    sys.modules["kornia"] = k
+    import matplotlib
+    matplotlib.use("Agg")
+    from support import interfaces as ref_itf
+    from support import losses as ref_losses
+    from support import utils as ref_utils
+    return ref_losses, ref_utils, ref_itf
+
+
+def np_(t):
+    return t.detach().cpu().numpy().copy()   # copy: the tensor may be updated in place later
+
+
+def gen_crop_like(ref_utils):
+    out = {}
+    cases = [((2, 3, 16, 16), (2, 3, 10, 10)), ((1, 2, 3, 15, 12), (1, 7, 8)),
+             ((2, 3, 9, 9), (2, 3, 9, 9)), ((1, 1, 8, 8), (1, 1, 12, 5)),
+             ((2, 4, 3, 128, 128), (2, 3, 92, 92)), ((1, 3, 11, 10), (1, 3, 4, 7))]
+    for i, (ss, ts) in enumerate(cases):
+        src = torch.arange(int(np.prod(ss)), dtype=torch.float32).view(ss)
+        tgt = torch.zeros(ts)
+        out["src_shape_%d" % i] = np.array(ss)
+        out["tgt_shape_%d" % i] = np.array(ts)
+        out["out_%d" % i] = np_(ref_utils.crop_like(src, tgt))
+    out["n"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "crop_like.npz"), **out)
+
+
+def _loss_inputs(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    b, s, c, h, w = shape
+    p = torch.rand(shape, generator=g) * 1.5            # PathNet output is >= 0 (ReLU)
+    ref = torch.randn(b, 3, h, w, generator=g).exp() - 0.5   # includes negatives (clamped)
+    return p, ref
+
+
+def gen_fmse(ref_losses):
+    out = {}
+    cases = [((2, 4, 3, 12, 12), True), ((2, 8, 6, 10, 10), True), ((1, 2, 3, 8, 8), True),
+             ((2, 4, 3, 12, 12), False), ((3, 2, 2, 5, 7), True)]
+    for i, (shape, non_local) in enumerate(cases):
+        p, ref = _loss_inputs(shape, 100 + i)
+        p.requires_grad_(True)
+        b, s, c, h, w = shape
+        torch.manual_seed(1000 + i)
+        idx_patch = torch.randperm(s * h * w)
+        idx_batch = torch.randperm(b * s * h * w) if non_local else None
+        torch.manual_seed(1000 + i)
+        loss = ref_losses.FeatureMSE(non_local=non_local)(p, ref)
+        loss.backward()
+        out["p_%d" % i], out["ref_%d" % i] = np_(p), np_(ref)
+        out["idx_patch_%d" % i] = np_(idx_patch)
+        out["idx_batch_%d" % i] = np_(idx_batch) if non_local else np.zeros(0, np.int64)
+        out["non_local_%d" % i] = np.array(non_local)
+        out["seed_%d" % i] = np.array(1000 + i)
+        out["loss_%d" % i] = np_(loss)
+        out["grad_%d" % i] = np_(p.grad)
+    out["n"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "losses_fmse.npz"), **out)
+
+
+def gen_grs(ref_losses):
+    out = {}
+    cases = [(2, 4, 3, 12, 12), (2, 8, 6, 10, 10), (1, 2, 3, 8, 8)]
+    for i, shape in enumerate(cases):
+        p, ref = _loss_inputs(shape, 200 + i)
+        p.requires_grad_(True)
+        b, s, c, h, w = shape
+        torch.manual_seed(2000 + i)
+        idx_patch = torch.randperm(s * h * w)
+        idx_batch = torch.randperm(b * s * h * w)
+        torch.manual_seed(2000 + i)
+        loss = ref_losses.GlobalRelativeSimilarityLoss()(p, ref)
+        loss.backward()
+        out["p_%d" % i], out["ref_%d" % i] = np_(p), np_(ref)
+        out["idx_patch_%d" % i], out["idx_batch_%d" % i] = np_(idx_patch), np_(idx_batch)
+        out["loss_%d" % i], out["grad_%d" % i] = np_(loss), np_(p.grad)
+    out["n"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "losses_grs.npz"), **out)
+
+
+def gen_image_losses(ref_losses):
+    g = torch.Generator().manual_seed(7)
+    im = torch.randn(2, 3, 16, 16, generator=g).exp() - 0.7
+    ref = torch.randn(2, 3, 16, 16, generator=g).exp() - 0.7
+    ref[0, 0, :2] = 0.0
+    out = {"im": np_(im), "ref": np_(ref)}
+    for name in ("RelativeMSE", "SMAPE", "TonemappedMSE", "TonemappedRelativeMSE"):
+        x = im.clone().requires_grad_(True)
+        loss = getattr(ref_losses, name)()(x, ref)
+        loss.backward()
+        out[name], out[name + "_grad"] = np_(loss), np_(x.grad)
+    x = im.clone().requires_grad_(True)
+    loss = torch.nn.L1Loss()(x, ref)
+    loss.backward()
+    out["L1"], out["L1_grad"] = np_(loss), np_(x.grad)
+    np.savez_compressed(os.path.join(HERE, "losses_image.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------- G5
+INTERFACE_CASES = {
+    # name: (use_llpm, manif_learn, train_branches, option, pnet_out)
+    "vanilla": (False, False, True, "m11r11", 0),
+    "path_only": (True, False, True, "m11r11", 3),
+    "manifold_m11r11": (True, True, True, "m11r11", 3),
+    "manifold_m10r01": (True, True, True, "m10r01", 6),
+    "manifold_m10r11": (True, True, True, "m10r11", 4),
+    "manifold_m11r01": (True, True, True, "m11r01", 4),
+    "post_train": (True, True, False, "m11r11", 3),
+}
+G5_GEOM = dict(B=2, S=2, H=20, KS=5, DEPTH=3, WIDTH=8, INTERMC=4, BASE_IN=11)
+
+
+def small_batch(case_seed, use_llpm):
+    g = torch.Generator().manual_seed(case_seed)
+    B, S, H = G5_GEOM["B"], G5_GEOM["S"], G5_GEOM["H"]
+    n_in = G5_GEOM["BASE_IN"] + (1 if use_llpm else 0)
+    r = lambda *s: torch.rand(*s, generator=g)
+    batch = {
+        "kpcn_diffuse_in": r(B, n_in, H, H) - 0.3,
+        "kpcn_specular_in": r(B, n_in, H, H) - 0.3,
+        "kpcn_diffuse_buffer": r(B, 3, H, H) * 2,
+        "kpcn_specular_buffer": r(B, 3, H, H),
+        "kpcn_albedo": r(B, 3, H, H) + 0.00316,
+        "target_diffuse": r(B, 3, H, H) * 2,
+        "target_specular": r(B, 3, H, H),
+        "target_total": r(B, 3, H, H) * 3,
+    }
+    if use_llpm:
+        batch["paths"] = r(B, S, 36, H, H) - 0.4
+    return batch
+
+
+def build_models(case, seed):
+    from oracle.models import KPCN
+    from oracle.networks import PathNet
+    use_llpm, manif, tb, option, pout = INTERFACE_CASES[case]
+    torch.manual_seed(seed)
+    n_in = G5_GEOM["BASE_IN"]
+    if use_llpm:
+        c_r = pout // 2 if option in ("m10r01", "m11r01") else pout
+        n_in = n_in + 1 + c_r + 1
+    models = {"dncnn": KPCN(n_in, ksize=G5_GEOM["KS"], depth=G5_GEOM["DEPTH"], width=G5_GEOM["WIDTH"])}
+    if use_llpm:
+        models["backbone_diffuse"] = PathNet(36, intermc=G5_GEOM["INTERMC"], outc=pout)
+        models["backbone_specular"] = PathNet(36, intermc=G5_GEOM["INTERMC"], outc=pout)
+    # non-zero biases so that bias handling is exercised
+    with torch.no_grad():
+        for m in models.values():
+            for n, p in m.named_parameters():
+                if n.endswith("bias"):
+                    p.uniform_(-0.1, 0.1)
+    return models
+
+
+def gen_interface(ref_losses, ref_itf):
+    from oracle.step import draw_perms
+    for ci, case in enumerate(INTERFACE_CASES):
+        use_llpm, manif, tb, option, pout = INTERFACE_CASES[case]
+        models = build_models(case, 300 + ci)
+        init_state = {"%s/%s" % (mn, k): np_(v) for mn, m in models.items()
+                      for k, v in m.state_dict().items()}
+        optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+                  for mn, m in models.items()}
+        loss_funcs = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(),
+                      "l_recon": torch.nn.L1Loss(), "l_test": ref_losses.RelativeMSE()}
+        if manif:
+            loss_funcs["l_manif"] = ref_losses.FeatureMSE(non_local=True)
+        args = types.SimpleNamespace(model_name="golden")
+        itf = ref_itf.KPCNInterface(models, optims, loss_funcs, args, use_llpm_buf=use_llpm,
+                                    manif_learn=manif, w_manif=0.1, train_branches=tb,
+                                    disentanglement_option=option)
+        itf.iters = 1            # skip the iters % 1000 == 1 PNG dump (interfaces.py:130-137)
+        batch = small_batch(400 + ci, use_llpm)
+        out = {"batch/" + k: np_(v) for k, v in batch.items()}
+        out.update({"init/" + k: v for k, v in init_state.items()})
+
+        B, S, H = G5_GEOM["B"], G5_GEOM["S"], G5_GEOM["H"]
+        h_out = H - 4 * G5_GEOM["DEPTH"]      # DEPTH valid 5x5 convs
+        seed = 500 + ci
+        torch.manual_seed(seed)
+        perms = [draw_perms(B, S, h_out, h_out), draw_perms(B, S, h_out, h_out)]
+        for i, br in enumerate(("diffuse", "specular")):
+            out["perm/%s_patch" % br] = np_(perms[i][0])
+            out["perm/%s_batch" % br] = np_(perms[i][1])
+        out["seed"] = np.array(seed)
+
+        itf.to_train_mode()
+        torch.manual_seed(seed)
+        itf.preprocess(batch)
+        itf.train_batch(batch)
+        for k, v in itf.m_losses.items():
+            out["m_losses/" + k] = np_(v)
+        for mn, m in models.items():
+            for k, v in m.state_dict().items():
+                out["after/%s/%s" % (mn, k)] = np_(v)
+            for k, p in m.named_parameters():
+                out["grad/%s/%s" % (mn, k)] = np_(p.grad)     # post-clip grads
+        itf.to_eval_mode()
+        with torch.no_grad():
+            rad, pb = itf.validate_batch(batch)
+        out["val/radiance"] = np_(rad)
+        if pb is not None:
+            out["val/p_diffuse"], out["val/p_specular"] = np_(pb["diffuse"]), np_(pb["specular"])
+        out["val/summary"] = np.array(itf.get_epoch_summary(mode="eval", norm=1))
+        np.savez_compressed(os.path.join(HERE, "interface_%s.npz" % case), **out)
+        print("G5", case, {k: float(v) for k, v in itf.m_losses.items()})
+
+
+def main():
+    ref_losses, ref_utils, ref_itf = import_reference()
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            gen_crop_like(ref_utils)
+            gen_fmse(ref_losses)
+            gen_grs(ref_losses)
+            gen_image_losses(ref_losses)
+            gen_interface(ref_losses, ref_itf)
+        finally:
+            os.chdir(cwd)
+    print("goldens written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

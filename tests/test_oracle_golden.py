@@ -1,0 +1,123 @@
+"""The CPU oracle against the golden vectors generated from the real reference
+(tests/golden/make_golden.py).  No GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as ol
+from oracle import step as ostep
+from oracle.utils import crop_like
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import make_golden as mg  # noqa: E402  (geometry + model builders only; the reference is not imported)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_crop_like_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "crop_like.npz"))
+    for i in range(int(d["n"])):
+        ss, ts = tuple(d["src_shape_%d" % i]), tuple(d["tgt_shape_%d" % i])
+        src = torch.arange(int(np.prod(ss)), dtype=torch.float32).view(ss)
+        out = crop_like(src, torch.zeros(ts))
+        assert out.shape == d["out_%d" % i].shape
+        assert np.array_equal(out.numpy(), d["out_%d" % i])
+        assert out.data_ptr() >= src.data_ptr()  # still a view of src
+
+
+def test_feature_mse_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "losses_fmse.npz"))
+    for i in range(int(d["n"])):
+        p = T(d["p_%d" % i]).requires_grad_(True)
+        ref = T(d["ref_%d" % i])
+        ib = T(d["idx_batch_%d" % i]) if bool(d["non_local_%d" % i]) else None
+        loss = ol.feature_mse(p, ref, T(d["idx_patch_%d" % i]), ib)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), d["loss_%d" % i], rtol=1e-6)
+        np.testing.assert_allclose(p.grad.numpy(), d["grad_%d" % i], rtol=1e-5, atol=1e-9)
+
+
+def test_feature_mse_module_draws_like_reference(golden_dir):
+    d = np.load(os.path.join(golden_dir, "losses_fmse.npz"))
+    for i in range(int(d["n"])):
+        p, ref = T(d["p_%d" % i]), T(d["ref_%d" % i])
+        torch.manual_seed(int(d["seed_%d" % i]))
+        m = ol.FeatureMSE(non_local=bool(d["non_local_%d" % i]))
+        loss = m(p, ref)
+        assert np.array_equal(m.last_perms[0].numpy(), d["idx_patch_%d" % i])
+        np.testing.assert_allclose(loss.item(), d["loss_%d" % i], rtol=1e-6)
+
+
+def test_grs_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "losses_grs.npz"))
+    for i in range(int(d["n"])):
+        p = T(d["p_%d" % i]).requires_grad_(True)
+        loss = ol.global_relative_similarity(p, T(d["ref_%d" % i]), T(d["idx_patch_%d" % i]),
+                                             T(d["idx_batch_%d" % i]))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), d["loss_%d" % i], rtol=1e-6)
+        np.testing.assert_allclose(p.grad.numpy(), d["grad_%d" % i], rtol=1e-5, atol=1e-9)
+
+
+def test_image_losses_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "losses_image.npz"))
+    ref = T(d["ref"])
+    table = {"RelativeMSE": ol.RelativeMSE(), "SMAPE": ol.SMAPE(), "TonemappedMSE": ol.TonemappedMSE(),
+             "TonemappedRelativeMSE": ol.TonemappedRelativeMSE(), "L1": torch.nn.L1Loss()}
+    for name, fn in table.items():
+        x = T(d["im"]).requires_grad_(True)
+        loss = fn(x, ref)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), d[name], rtol=1e-6)
+        np.testing.assert_allclose(x.grad.numpy(), d[name + "_grad"], rtol=1e-5, atol=1e-9)
+
+
+def load_case(golden_dir, case):
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    use_llpm, manif, tb, option, pout = mg.INTERFACE_CASES[case]
+    models = mg.build_models(case, 0)
+    for mn, m in models.items():
+        sd = {k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)}
+        m.load_state_dict(sd)
+    batch = {k[len("batch/"):]: T(d[k]) for k in d.files if k.startswith("batch/")}
+    perms = None
+    if manif and tb:
+        perms = [(T(d["perm/%s_patch" % br]), T(d["perm/%s_batch" % br])) for br in ("diffuse", "specular")]
+    cfg = dict(use_llpm_buf=use_llpm, manif_learn=manif, train_branches=tb, disentanglement_option=option,
+               w_manif=0.1)
+    return d, models, batch, perms, cfg
+
+
+@pytest.mark.parametrize("case", list(mg.INTERFACE_CASES))
+def test_interface_step_golden(golden_dir, case):
+    """oracle.step (functional restatement of KPCNInterface) vs the real reference interface."""
+    d, models, batch, perms, cfg = load_case(golden_dir, case)
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    loss_dict, _ = ostep.train_step(models, optims, batch, cfg, perms)
+    for k in d.files:
+        if k.startswith("m_losses/") and k != "m_losses/m_val":
+            np.testing.assert_allclose(loss_dict[k[len("m_losses/m_"):]].item(), d[k], rtol=2e-5, err_msg=k)
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            np.testing.assert_allclose(p.grad.numpy(), d["grad/%s/%s" % (mn, k)], rtol=1e-4, atol=1e-7,
+                                       err_msg="grad %s %s" % (mn, k))
+        for k, v in m.state_dict().items():
+            # Adam's first step is lr*g/(|g|+1e-8): ill-conditioned where |g| ~ eps, so those
+            # entries are only checked to be within one lr of the reference.
+            g = np.abs(d["grad/%s/%s" % (mn, k)])
+            want, got = d["after/%s/%s" % (mn, k)], v.numpy()
+            big = g > 1e-5
+            np.testing.assert_allclose(got[big], want[big], rtol=1e-4, atol=2e-6, err_msg="after %s %s" % (mn, k))
+            np.testing.assert_allclose(got[~big], want[~big], atol=4.1e-3, err_msg="after %s %s" % (mn, k))
+    with torch.no_grad():
+        out, p_regress, losses = ostep.forward_losses(models, batch, cfg, train=False)
+    np.testing.assert_allclose(out["radiance"].numpy(), d["val/radiance"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(losses["val"].item() / 2, d["val/summary"], rtol=1e-5)
+    if p_regress is not None:
+        np.testing.assert_allclose(p_regress["diffuse"].numpy(), d["val/p_diffuse"], rtol=1e-4, atol=1e-6)
