@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 128x128 MC patches/sec of one full KPCN-Manifold train step on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = ``KPCNInterface.preprocess`` + ``train_batch`` (support/interfaces.py:108-192) on config C3 of
+BASELINE.json: KPCN(n_in=39) + 2 x PathNet(36->3) + FeatureMSE (w=0.1, m11r11, train_branches), 8 patches
+of 128x128 with S=8 spp per GPU, inputs resident in HBM, fused clip+Adam, RCCL gradient all-reduce when
+N > 1 (weak scaling: 8 patches per GPU).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line
+  roofline           dominant kernel class (conv implicit-GEMM, MFMA-bound): algorithmic FLOP / launch time
+                     measured with HIP events on the launch stream inside the timed region
+  roofline_kernel_apply   the HBM-bound op the north star puts a >= 40 % target on
+  cpu_baseline       the CPU oracle's train step on this box's host cores (rank 0, N == 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
+B_PER_GPU, SPP, PATCH = 8, 8, 128
+
+
+class EventProfiler:
+    def __init__(self):
+        self.rows = []
+
+    def add(self, name, work, unit, e0, e1):
+        self.rows.append((name, work, unit, e0, e1))
+
+    def summary(self):
+        out = {}
+        for name, work, unit, e0, e1 in self.rows:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+        return out
+
+
+def build_interface(device, group):
+    from wcmc_amd import KPCN
+    from wcmc_amd.optim import FusedClipAdam
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
+    from wcmc_amd.support.networks import PathNet
+    torch.manual_seed(0)                                            # train_kpcn.py:346-348
+    models = {"dncnn": KPCN(39), "backbone_diffuse": PathNet(ic=36, outc=3),
+              "backbone_specular": PathNet(ic=36, outc=3)}
+    for k in models:
+        models[k] = models[k].to(device)
+    optims = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in models.items()}
+    loss_funcs = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(),
+                  "l_recon": torch.nn.L1Loss(), "l_test": RelativeMSE(),
+                  "l_manif": FeatureMSE(non_local=True)}
+    itf = KPCNInterface(models, optims, loss_funcs, types.SimpleNamespace(model_name="bench"),
+                        use_llpm_buf=True, manif_learn=True, w_manif=0.1, train_branches=True,
+                        disentanglement_option="m11r11")
+    itf.fused_optim = FusedClipAdam(models, optims, process_group=group)
+    itf.iters = 1          # not iteration 1: skip the debug PNG dump (interfaces.py:130-137)
+    itf.to_train_mode()
+    return itf
+
+
+def cpu_baseline():
+    """The oracle's step (same architecture, same losses) on the host cores: C3 shape at batch 1."""
+    from oracle import step as ostep
+    from oracle.models import KPCN as OKPCN
+    from oracle.networks import PathNet as OPathNet
+    from wcmc_amd.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    models = {"dncnn": OKPCN(39), "backbone_diffuse": OPathNet(36), "backbone_specular": OPathNet(36)}
+    optims = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in models.items()}
+    cfg = dict(use_llpm_buf=True, manif_learn=True, train_branches=True, disentanglement_option="m11r11",
+               w_manif=0.1)
+
+    def one(b, h):
+        batch = make_batch(b, SPP, h, seed=0, device="cpu")
+        ho = h - 36
+        perms = [ostep.draw_perms(b, SPP, ho, ho), ostep.draw_perms(b, SPP, ho, ho)]
+        t0 = time.perf_counter()
+        ostep.train_step(models, optims, batch, cfg, perms)
+        return time.perf_counter() - t0
+
+    one(1, 64)                       # thread-pool / allocator warm-up on a small patch
+    t = one(1, PATCH)
+    return {"value": 1.0 / t, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 train step of the PyTorch-CPU oracle, KPCN-Manifold C3 shape at batch 1 "
+                      "(128x128, S=8), %.1f s" % t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from wcmc_amd import distributed as wd
+    from wcmc_amd import ops
+    from wcmc_amd.synthetic import make_batch
+    rank, world, local = wd.init("nccl")
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    group = torch.distributed.group.WORLD if world > 1 else None
+    itf = build_interface(device, group)
+    if world > 1:
+        for fl in itf.fused_optim.flats.values():
+            torch.distributed.broadcast(fl.flat, 0)
+    batch = make_batch(B_PER_GPU, SPP, PATCH, seed=wd.shard_seed(0, rank), device=device)
+    torch.manual_seed(1234 + rank)      # FeatureMSE pairings (CPU generator, losses.py:35,50)
+
+    def step():
+        itf.preprocess(batch)
+        itf.train_batch(batch)
+
+    for _ in range(args.warmup):
+        step()
+    prof = EventProfiler()
+    ops.set_profiler(prof)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = wd.max_over_ranks(time.perf_counter() - t0, device)
+    ops.set_profiler(None)
+
+    if rank == 0:
+        summ = prof.summary()
+        global_batch = B_PER_GPU * world
+        value = global_batch * args.steps / elapsed
+
+        def roof(name, bound):
+            d = summ.get(name)
+            if not d or d["ms"] <= 0:
+                return None
+            rate = d["work"] / (d["ms"] * 1e-3)
+            if bound == "mfma":
+                ach, peak, unit = rate / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+            else:
+                ach, peak, unit = rate / 1e9, PEAK_HBM_GBS, "GB/s"
+            return {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "traffic": None, "launches": d["launches"],
+                    "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                    "share_of_step": round(d["ms"] / (elapsed * 1e3), 4)}
+
+        conv_keys = [k for k in ("conv_igemm", "conv_wgrad") if k in summ]
+        dominant = max(conv_keys, key=lambda k: summ[k]["ms"]) if conv_keys else None
+        ka = {"fwd": roof("kernel_apply_fwd", "hbm"), "bwd": roof("kernel_apply_bwd", "hbm")}
+        line = {
+            "metric": "128x128 MC patches/sec (train step), KPCN-Manifold",
+            "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: KPCN-Manifold (KPCN n_in=39 + 2xPathNet 36->3 + "
+                                   "FeatureMSE w=0.1 m11r11, train_branches), 128x128, S=8 spp, "
+                                   "%d patches/GPU, global batch %d" % (B_PER_GPU, global_batch),
+                       "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "precision": "fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate"},
+            "roofline": roof(dominant, "mfma") if dominant else None,
+            "roofline_other_conv": roof([k for k in conv_keys if k != dominant][0], "mfma")
+            if len(conv_keys) > 1 else None,
+            "roofline_kernel_apply": ka,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

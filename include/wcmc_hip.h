@@ -1,0 +1,219 @@
+/*
+ * wcmc_hip.h -- C ABI of libwcmc_hip.so, the MI355X (gfx950) hot path of the
+ * KPCN-Manifold training step (Mephisto405/WCMC).
+ *
+ * The reference is pure Python on PyTorch; the arithmetic of its hot path lives
+ * in torch.nn / cuDNN and in the external `sbmc` package's Halide ops.  There is
+ * no FFI in the reference for this path, so each entry point below names the
+ * reference EXPRESSION it replaces (file:line under the reference tree) and is
+ * what a ctypes binding under support/ would bind.
+ *
+ * Conventions
+ *   - All tensors are fp32 device memory owned by the caller (PyTorch).  The
+ *     library never allocates, frees or retains a pointer past return.
+ *   - "NHWC view" = (ptr, N, H, W, C, sn, sh, sw): element (n,y,x,c) lives at
+ *     ptr[n*sn + y*sh + x*sw + c]; the channel stride is 1.  ptr must be 16-byte
+ *     aligned, sn/sh/sw multiples of 4, and sw >= round_up(C, 4) so that a 16-byte
+ *     access that starts at a channel multiple of 4 stays inside the pixel.
+ *     Slices of wider buffers (concat targets, cropped images) are expressed by
+ *     the strides.
+ *   - Every call only enqueues work on `stream` (a hipStream_t) and returns; no
+ *     host synchronisation, no global mutable state except a thread-local error
+ *     string.
+ *   - Return value: 0 on success, a negative wcmc_status on failure;
+ *     wcmc_last_error() then describes it.  Nothing aborts or throws.
+ */
+#ifndef WCMC_HIP_H
+#define WCMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WCMC_ABI_VERSION 1
+
+enum wcmc_status {
+  WCMC_OK = 0,
+  WCMC_ERR_BAD_ARG = -1,     /* null pointer, negative size, unsupported shape */
+  WCMC_ERR_ALIGNMENT = -2,   /* pointer or stride violates the NHWC-view contract */
+  WCMC_ERR_WORKSPACE = -3,   /* workspace too small */
+  WCMC_ERR_LAUNCH = -4       /* hipGetLastError() after a launch */
+};
+
+enum wcmc_act { WCMC_ACT_LINEAR = 0, WCMC_ACT_RELU = 1, WCMC_ACT_LEAKY_RELU = 2 };
+
+int wcmc_abi_version(void);
+const char* wcmc_last_error(void);
+
+/* ---------------------------------------------------------------- layout helpers
+ * Strided copies between the reference's NCHW tensors (batch dict entries,
+ * support/datasets.py:1080-1126) and NHWC views.  src element (n,c,y,x) at
+ * src[n*ssn + c*ssc + y*ssh + x*ssw]. */
+int wcmc_to_nhwc(const float* src, int64_t ssn, int64_t ssc, int64_t ssh, int64_t ssw,
+                 float* dst, int64_t dsn, int64_t dsh, int64_t dsw,
+                 int N, int C, int H, int W, void* stream);
+int wcmc_from_nhwc(const float* src, int64_t ssn, int64_t ssh, int64_t ssw,
+                   float* dst, int64_t dsn, int64_t dsc, int64_t dsh, int64_t dsw,
+                   int N, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- convolution
+ * Replaces torch.nn.Conv2d forward/backward inside sbmc.modules.ConvChain
+ * (call sites support/networks.py:18-24, train_kpcn.py:213) -- the cuDNN calls
+ * enabled at train_kpcn.py:349.
+ *
+ * Packed weights: wp[n][k], n in [0, Np), k in [0, Kt); k = tap*Kp + ci with
+ * tap = ky*ks + kx, Kp = round_up(Cin,4), Kt = round_up(ks*ks*Kp, 32),
+ * Np = round_up(Cout,16); padding entries are zero.
+ *   mode 0 (forward operand):  wp[co][tap*Kp+ci] = w[co][ci][ky][kx]
+ *   mode 1 (data-gradient operand, rows are INPUT channels):
+ *                              wp[ci][tap'*Kp'+co] = w[co][ci][ks-1-ky'][ks-1-kx'],
+ *                              Kp' = round_up(Cout,4), Np' = round_up(Cin,16)
+ */
+size_t wcmc_conv2d_packed_elems(int rows, int kchan, int ks);
+int wcmc_conv2d_pack_weight(const float* w_oihw, float* wp, int Cout, int Cin, int ks, int mode,
+                            void* stream);
+
+/* y = act(conv(x, wp) + bias) [* gate'].  Implicit GEMM on fp32 MFMA.
+ *   x: NHWC view (N,H,W,Cin); y: NHWC view (N,Ho,Wo,Cout), Ho = H + 2*pad - ks + 1.
+ *   bias: [Cout] or NULL.  act/slope: wcmc_act applied to the result.
+ *   gate (optional NHWC view with y's geometry): if non-NULL the result is
+ *   multiplied by d act_gate / d pre-activation evaluated from the POST-activation
+ *   value stored in gate (1 if gate>0 else gate_slope; gate_act = RELU uses slope 0).
+ *   That is the fused ReLU backward used when this call computes a data gradient.
+ */
+int wcmc_conv2d_igemm(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
+                      int N, int H, int W, int Cin,
+                      const float* wp, const float* bias,
+                      float* y, int64_t ysn, int64_t ysh, int64_t ysw, int Cout,
+                      int ks, int pad, int act, float slope,
+                      const float* gate, int64_t gsn, int64_t gsh, int64_t gsw,
+                      int gate_act, float gate_slope, void* stream);
+
+/* Weight gradient dW[co][ci][ky][kx] = sum_{n,y,x} dy[n,y,x,co] * x[n,y+ky-pad,x+kx-pad,ci]
+ * (+ bias gradient db[co] = sum dy) written in the parameter's own OIHW layout.
+ * Two launches inside: split-K partial slabs into `workspace`, then a fixed-order
+ * reduction (bitwise reproducible).  db may be NULL. */
+size_t wcmc_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks);
+int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
+                      int N, int H, int W, int Cin,
+                      const float* dy, int64_t dsn, int64_t dsh, int64_t dsw, int Cout,
+                      int ks, int pad, float* dw_oihw, float* db,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* dx = dy * act'(y) from the post-activation value y (NHWC views of equal geometry). */
+int wcmc_act_backward(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw,
+                      const float* y, int64_t ysn, int64_t ysh, int64_t ysw,
+                      float* dx, int64_t xsn, int64_t xsh, int64_t xsw,
+                      int N, int H, int W, int C, int act, float slope, void* stream);
+
+/* ---------------------------------------------------------------- kernel apply
+ * Replaces sbmc.modules.KernelApply(softmax=True, splat=False) inside sbmc.KPCN
+ * (call site support/interfaces.py:203-204; upstream a Halide op).
+ *   logits: NHWC view (N,h,w,k*k) -- tap t = (dy+r)*k + (dx+r), r = k/2.
+ *   data/out: (N,C,h,w) with arbitrary element strides (sn,sc,sh,sw), C <= 4.
+ *   out[n,c,y,x] = sum_t softmax_t(logits[n,y,x,:]) * data0[n,c,y+dy,x+dx],
+ *   data0 = data zero-extended outside [0,h)x[0,w).
+ *   lse: [N*h*w] per-pixel log-sum-exp saved for the backward (may be NULL).
+ */
+int wcmc_kernel_apply_fwd(const float* logits, int64_t lsn, int64_t lsh, int64_t lsw,
+                          const float* data, int64_t dsn, int64_t dsc, int64_t dsh, int64_t dsw,
+                          float* out, int64_t osn, int64_t osc, int64_t osh, int64_t osw,
+                          float* lse, int N, int C, int h, int w, int k, void* stream);
+/* d_logits (NHWC view, same geometry as logits) from grad_out; d_data (N,C,h,w
+ * contiguous, accumulated with atomics, must be zeroed by the caller) may be NULL. */
+int wcmc_kernel_apply_bwd(const float* logits, int64_t lsn, int64_t lsh, int64_t lsw,
+                          const float* data, int64_t dsn, int64_t dsc, int64_t dsh, int64_t dsw,
+                          const float* out, int64_t osn, int64_t osc, int64_t osh, int64_t osw,
+                          const float* grad_out, int64_t gsn, int64_t gsc, int64_t gsh, int64_t gsw,
+                          const float* lse,
+                          float* d_logits, int64_t qsn, int64_t qsh, int64_t qsw,
+                          float* d_data, int N, int C, int h, int w, int k, void* stream);
+
+/* ---------------------------------------------------------------- U-Net glue
+ * F.max_pool2d(x,2,2) / F.interpolate(x, scale_factor=2, 'bilinear',
+ * align_corners=False) inside sbmc.modules.Autoencoder (support/networks.py:20-22). */
+int wcmc_maxpool2_fwd(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
+                      float* y, int64_t ysn, int64_t ysh, int64_t ysw,
+                      int N, int H, int W, int C, void* stream);
+/* dx[n,2y+i,2x+j] = dy[n,y,x] where x[...] is the (first) maximum of its window, else 0. */
+int wcmc_maxpool2_bwd(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
+                      const float* dy, int64_t dsn, int64_t dsh, int64_t dsw,
+                      float* dx, int64_t gsn, int64_t gsh, int64_t gsw,
+                      int N, int H, int W, int C, void* stream);
+/* (N,H,W,C) -> (N,2H,2W,C) */
+int wcmc_upsample2_fwd(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
+                       float* y, int64_t ysn, int64_t ysh, int64_t ysw,
+                       int N, int H, int W, int C, void* stream);
+/* dy (N,2H,2W,C) -> dx (N,H,W,C) (gather form of the transposed interpolation) */
+int wcmc_upsample2_bwd(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw,
+                       float* dx, int64_t xsn, int64_t xsh, int64_t xsw,
+                       int N, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------- PathNet glue
+ * support/networks.py:35-36 (`flat.mean(1)`) and :39-40 (`repeat` + `cat`).
+ * x holds B*S images, y holds B images (image b*S+s belongs to patch b).
+ *   reduce:    y[b] = scale * sum_s x[b*S+s]
+ *   broadcast: y[b*S+s] = (accumulate ? y[b*S+s] : 0) + scale * x[b]            */
+int wcmc_spp_reduce(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
+                    float* y, int64_t ysn, int64_t ysh, int64_t ysw,
+                    int B, int S, int H, int W, int C, float scale, void* stream);
+int wcmc_spp_broadcast(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
+                       float* y, int64_t ysn, int64_t ysh, int64_t ysw,
+                       int B, int S, int H, int W, int C, float scale, int accumulate,
+                       void* stream);
+
+/* ---------------------------------------------------------------- P-buffer statistics
+ * support/interfaces.py:165-176: builds the KPCN input
+ *   out = cat([base, mean_s P, (var_s P (unbiased)).mean_c / S], channel)
+ * base: (B,Cb,H,W) strided NCHW-style tensor; P: (B,S,Cp,H,W) strided;
+ * out: NHWC view (B,H,W,Cb+Cp+1).  The backward of the mean term is
+ *   dP[b,s,c,y,x] = g[b,y,x,Cb+c] / S   (the variance term is detached, :165).   */
+int wcmc_pbuffer_cat_fwd(const float* base, int64_t bsn, int64_t bsc, int64_t bsh, int64_t bsw,
+                         const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh,
+                         int64_t psw,
+                         float* out, int64_t osn, int64_t osh, int64_t osw,
+                         int B, int S, int Cb, int Cp, int H, int W, void* stream);
+int wcmc_pbuffer_cat_bwd(const float* g, int64_t gsn, int64_t gsh, int64_t gsw,
+                         float* dp, int64_t psb, int64_t pss, int64_t psc, int64_t psh,
+                         int64_t psw,
+                         int B, int S, int Cb, int Cp, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- FeatureMSE
+ * support/losses.py:33-61,63-65,82-113 (path-disentangling loss, color='rgb').
+ * p: (B,S,C,h,w) strided view (already cropped), C <= 8; ref: (B,3,h,w) strided
+ * (NOT yet tonemapped).  idx_patch: permutation of S*h*w (int64, device);
+ * idx_batch: permutation of B*S*h*w or NULL for non_local=False.
+ * workspace layout is private; loss is a single float.  The forward leaves in the
+ * workspace what the backward needs (tonemapped ref, displacements, inverse
+ * permutations), so the same workspace must be passed to the backward.          */
+size_t wcmc_feature_mse_workspace_bytes(int B, int S, int C, int h, int w);
+int wcmc_feature_mse_fwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh,
+                         int64_t psw,
+                         const float* ref, int64_t rsb, int64_t rsc, int64_t rsh, int64_t rsw,
+                         const int64_t* idx_patch, const int64_t* idx_batch,
+                         float* loss, void* workspace, size_t workspace_bytes,
+                         int B, int S, int C, int h, int w, void* stream);
+/* dp: contiguous (B,S,C,h,w); grad_scale: device pointer to the upstream scalar gradient. */
+int wcmc_feature_mse_bwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh,
+                         int64_t psw,
+                         const int64_t* idx_patch, const int64_t* idx_batch,
+                         const float* grad_scale, float* dp,
+                         void* workspace, size_t workspace_bytes,
+                         int B, int S, int C, int h, int w, void* stream);
+
+/* ---------------------------------------------------------------- clip + Adam
+ * support/interfaces.py:260-261 (clip_grad_value_) + :269-271 (Adam.step,
+ * train_kpcn.py:274-277: default betas/eps, no weight decay, no amsgrad) fused
+ * over one flat parameter buffer.  grad is clamped IN PLACE (the reference leaves
+ * clipped .grad behind), then m,v,param are updated.  step is the 1-based count. */
+int wcmc_clip_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float clip, double lr, double beta1, double beta2, double eps, int step,
+                   float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WCMC_HIP_H */

@@ -1,0 +1,206 @@
+"""Module- and step-level parity on the MI355X: PathNet, KPCN and one full KPCNInterface step of the
+HIP path against (i) the CPU oracle with identical weights / inputs / permutations and (ii) the golden
+fixtures produced by the REAL reference interface (tests/golden/interface_*.npz).
+
+Tolerance: 1e-3 relative (north star) on outputs and loss scalars; gradients 1e-3 of their scale.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import make_golden as mg                      # noqa: E402  (geometry/builders only)
+from oracle import step as ostep              # noqa: E402
+from oracle.models import KPCN as OKPCN       # noqa: E402
+from oracle.networks import PathNet as OPathNet   # noqa: E402
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def assert_close(a, b, tol=1e-3, what=""):
+    assert tuple(a.shape) == tuple(b.shape), (what, a.shape, b.shape)
+    e = rel_err(a, b)
+    assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def randomize_bias(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.rand(p.shape, generator=g) * 0.2 - 0.1)
+
+
+def test_pathnet_matches_oracle():
+    from wcmc_amd.support.networks import PathNet
+    torch.manual_seed(0)
+    ref = OPathNet(36, intermc=16, outc=3)
+    randomize_bias(ref, 1)
+    mod = PathNet(36, intermc=16, outc=3)
+    mod.load_state_dict(ref.state_dict())
+    mod.to(DEV)
+    assert str(mod) == str(ref) == "PathNet i36in16o3"
+    g = torch.Generator().manual_seed(2)
+    paths = torch.rand(2, 3, 36, 16, 24, generator=g) - 0.4
+    out_r = ref({"paths": paths})
+    gout = torch.rand(out_r.shape, generator=g) - 0.5
+    out_r.backward(gout)
+    batch = {"paths": paths.to(DEV)}
+    out = mod(batch)
+    assert out.shape == out_r.shape and (out >= 0).all()
+    out.backward(gout.to(DEV))
+    assert_close(out, out_r, what="PathNet fwd")
+    for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, what="PathNet grad " + k)
+
+
+def test_kpcn_c1_config_matches_oracle():
+    """BASELINE config C1: KPCN-Vanilla, 64x64, batch 2, n_in=34 (the reference's CPU-runnable case)."""
+    from wcmc_amd import KPCN
+    torch.manual_seed(3)
+    ref = OKPCN(34)
+    randomize_bias(ref, 4)
+    mod = KPCN(34)
+    mod.load_state_dict(ref.state_dict())
+    mod.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.rand(*s, generator=g)
+    batch = {"kpcn_diffuse_in": r(2, 34, 64, 64) - 0.3, "kpcn_specular_in": r(2, 34, 64, 64) - 0.3,
+             "kpcn_diffuse_buffer": r(2, 3, 64, 64) * 2, "kpcn_specular_buffer": r(2, 3, 64, 64),
+             "kpcn_albedo": r(2, 3, 64, 64) + 0.00316}
+    out_r = ref(batch)
+    assert out_r["radiance"].shape == (2, 3, 28, 28)
+    (out_r["diffuse"].abs().mean() + out_r["specular"].abs().mean()).backward()
+    out = mod({k: v.to(DEV) for k, v in batch.items()})
+    (out["diffuse"].abs().mean() + out["specular"].abs().mean()).backward()
+    for k in ("radiance", "diffuse", "specular"):
+        assert_close(out[k], out_r[k], what="KPCN " + k)
+    for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, what="KPCN grad " + k)
+
+
+def build_hip_models(case, d):
+    """HIP-path models with the golden's initial weights."""
+    from wcmc_amd import KPCN
+    from wcmc_amd.support.networks import PathNet
+    use_llpm, manif, tb, option, pout = mg.INTERFACE_CASES[case]
+    G = mg.G5_GEOM
+    n_in = G["BASE_IN"]
+    if use_llpm:
+        c_r = pout // 2 if option in ("m10r01", "m11r01") else pout
+        n_in = n_in + 1 + c_r + 1
+    models = {"dncnn": KPCN(n_in, ksize=G["KS"], depth=G["DEPTH"], width=G["WIDTH"])}
+    if use_llpm:
+        models["backbone_diffuse"] = PathNet(36, intermc=G["INTERMC"], outc=pout)
+        models["backbone_specular"] = PathNet(36, intermc=G["INTERMC"], outc=pout)
+    for mn, m in models.items():
+        sd = {k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)}
+        m.load_state_dict(sd)
+        m.to(DEV)
+    return models
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("case", list(mg.INTERFACE_CASES))
+def test_interface_step_against_reference_golden(golden_dir, case, fused):
+    """wcmc_amd.support.interfaces.KPCNInterface on the GPU vs the real reference KPCNInterface."""
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    use_llpm, manif, tb, option, pout = mg.INTERFACE_CASES[case]
+    models = build_hip_models(case, d)
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    loss_funcs = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+                  "l_test": RelativeMSE()}
+    if manif:
+        loss_funcs["l_manif"] = FeatureMSE(non_local=True)
+    itf = KPCNInterface(models, optims, loss_funcs, types.SimpleNamespace(model_name="golden"),
+                        use_llpm_buf=use_llpm, manif_learn=manif, w_manif=0.1, train_branches=tb,
+                        disentanglement_option=option)
+    if fused:
+        from wcmc_amd.optim import FusedClipAdam
+        itf.fused_optim = FusedClipAdam(models, optims)
+    itf.iters = 1
+    batch = {k[len("batch/"):]: T(d[k]).to(DEV) for k in d.files if k.startswith("batch/")}
+    itf.to_train_mode()
+    torch.manual_seed(int(d["seed"]))          # the reference's draws: same generator, same order
+    itf.preprocess(batch)
+    itf.train_batch(batch)
+    if manif and tb:
+        assert np.array_equal(loss_funcs["l_manif"].last_perms[0].numpy(), d["perm/specular_patch"])
+    for k in d.files:
+        if k.startswith("m_losses/") and k != "m_losses/m_val":
+            np.testing.assert_allclose(itf.m_losses[k[len("m_losses/"):]].item(), d[k], rtol=1e-3, err_msg=k)
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            want = T(d["grad/%s/%s" % (mn, k)])
+            assert_close(p.grad, want, tol=2e-3, what="post-clip grad %s %s" % (mn, k))
+        for k, v in m.state_dict().items():
+            g = np.abs(d["grad/%s/%s" % (mn, k)])
+            want, got = d["after/%s/%s" % (mn, k)], v.cpu().numpy()
+            big = g > 1e-4                     # Adam step 1 is lr*sign(g): only well-conditioned entries
+            np.testing.assert_allclose(got[big], want[big], rtol=1e-3, atol=5e-5, err_msg="after %s %s" % (mn, k))
+            np.testing.assert_allclose(got[~big], want[~big], atol=4.1e-3)
+    itf.to_eval_mode()
+    with torch.no_grad():
+        rad, pb = itf.validate_batch(batch)
+    assert_close(rad, T(d["val/radiance"]), tol=5e-3, what="validate radiance")
+    np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=5e-3)
+    if pb is not None:
+        assert_close(pb["diffuse"], T(d["val/p_diffuse"]), tol=5e-3, what="validate p_buffer")
+
+
+def test_full_size_step_against_oracle():
+    """One KPCN-Manifold step at the benchmark geometry (128x128, S=8, pnet_out 3) with B=1 against the
+    CPU oracle: same weights, inputs and permutations."""
+    from wcmc_amd import KPCN
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
+    from wcmc_amd.support.networks import PathNet
+    from wcmc_amd.synthetic import make_batch
+    torch.manual_seed(7)
+    omods = {"dncnn": OKPCN(39), "backbone_diffuse": OPathNet(36), "backbone_specular": OPathNet(36)}
+    hmods = {"dncnn": KPCN(39), "backbone_diffuse": PathNet(36), "backbone_specular": PathNet(36)}
+    for k in omods:
+        randomize_bias(omods[k], 8)
+        hmods[k].load_state_dict(omods[k].state_dict())
+        hmods[k].to(DEV)
+    batch = make_batch(1, 8, 128, seed=9, device="cpu")
+    cfg = dict(use_llpm_buf=True, manif_learn=True, train_branches=True, disentanglement_option="m11r11",
+               w_manif=0.1)
+    torch.manual_seed(10)
+    perms = [ostep.draw_perms(1, 8, 92, 92), ostep.draw_perms(1, 8, 92, 92)]
+    oopt = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in omods.items()}
+    loss_o, out_o = ostep.train_step(omods, oopt, batch, cfg, perms)
+    hopt = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in hmods.items()}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+          "l_test": RelativeMSE(), "l_manif": FeatureMSE(non_local=True)}
+    itf = KPCNInterface(hmods, hopt, lf, types.SimpleNamespace(model_name="t"), use_llpm_buf=True,
+                        manif_learn=True, w_manif=0.1, train_branches=True)
+    itf.iters = 1
+    itf.to_train_mode()
+    dbatch = {k: v.to(DEV) for k, v in batch.items()}
+    torch.manual_seed(10)
+    itf.preprocess(dbatch)
+    itf.train_batch(dbatch)
+    for k, v in loss_o.items():
+        np.testing.assert_allclose(itf.m_losses["m_" + k].item(), v.item(), rtol=1e-3, err_msg=k)
+    for mn in omods:
+        for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
+            assert_close(p.grad, q.grad, tol=2e-3, what="grad %s %s" % (mn, k))

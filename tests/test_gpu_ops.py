@@ -1,0 +1,323 @@
+"""Parity of every HIP op (called through the C ABI) against the CPU oracle.
+
+Tolerance: the north star asks for 1e-3 relative in fp32; these tests hold the ops to 2e-4 of
+the tensor's scale (max |a-b| / max |b|) unless stated, on seeded inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import losses as ol            # noqa: E402
+from oracle import modules as om           # noqa: E402
+from oracle.step import assemble_input     # noqa: E402
+
+DEV = "cuda"
+
+
+def ops():
+    from wcmc_amd import ops as _ops
+    return _ops
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def assert_close(a, b, tol=2e-4, what=""):
+    assert tuple(a.shape) == tuple(b.shape), (what, a.shape, b.shape)
+    e = rel_err(a, b)
+    assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def test_library_loaded_is_in_tree():
+    from wcmc_amd._lib import LIB_PATH, lib
+    assert lib().wcmc_abi_version() == 1
+    assert os.path.isfile(LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libwcmc_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 36, 16, 70), (3, 100, 5, 4)])
+def test_layout_roundtrip(shape):
+    o = ops()
+    x = gen(*shape, seed=1).to(DEV)
+    y = o.to_nhwc_raw(x)
+    assert o.is_nhwc_view(y) and torch.equal(y.cpu(), x.cpu())
+    assert torch.equal(o.from_nhwc_raw(y).cpu(), x.cpu())
+    xs = x[:, :, 1:, 2:]                                    # strided source
+    assert torch.equal(o.to_nhwc_raw(xs).cpu(), xs.cpu())
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, ks, pad, act
+    (2, 39, 20, 20, 100, 5, 0, "relu"),
+    (1, 100, 14, 17, 100, 5, 0, "relu"),
+    (1, 100, 12, 12, 441, 5, 0, "linear"),
+    (2, 34, 11, 13, 100, 5, 0, "relu"),
+    (2, 64, 16, 16, 128, 3, 1, "relu"),
+    (1, 384, 8, 8, 128, 3, 1, "relu"),
+    (2, 192, 8, 12, 64, 3, 1, "leaky_relu"),
+    (3, 36, 9, 10, 64, 1, 0, "relu"),
+    (2, 128, 6, 6, 3, 1, 0, "relu"),
+    (1, 7, 6, 5, 5, 3, 1, "linear"),
+    (1, 256, 8, 8, 256, 3, 1, "relu"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_chain_single_layer_fwd_bwd(case):
+    n, cin, h, w, cout, ks, pad, act = case
+    o = ops()
+    x = gen(n, cin, h, w, seed=2)
+    wt = gen(cout, cin, ks, ks, seed=3, scale=(2.0 / (cin * ks * ks)) ** 0.5 * 1.7)
+    b = gen(cout, seed=4, scale=0.2)
+    # oracle in fp64
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, wt, b))
+    yr = om._activation(F.conv2d(xr, wr, br, padding=pad), act)
+    gy = gen(*yr.shape, seed=5)
+    yr.backward(gy.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, wt, b))
+    y = o.conv_chain(xd, ks, pad, [act], [wd, bd])
+    assert o.is_nhwc_view(y)
+    y.backward(gy.to(DEV))
+    assert_close(y, yr, what="conv fwd")
+    assert_close(xd.grad, xr.grad, what="conv dgrad")
+    assert_close(wd.grad, wr.grad, what="conv wgrad")
+    assert_close(bd.grad, br.grad, what="conv bias grad")
+
+
+def test_conv_chain_deep_matches_oracle_chain():
+    torch.manual_seed(11)
+    ref = om.ConvChain(13, 25, ksize=5, width=20, depth=4, pad=False, output_type="linear").double()
+    from wcmc_amd.modules import ConvChain
+    mod = ConvChain(13, 25, ksize=5, width=20, depth=4, pad=False, output_type="linear")
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mod.to(DEV)
+    x = gen(2, 13, 30, 28, seed=12)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    g = gen(*yr.shape, seed=13)
+    yr.backward(g.double())
+    xd = x.to(DEV).requires_grad_(True)
+    y = mod(xd)
+    y.backward(g.to(DEV))
+    assert_close(y, yr, what="chain fwd")
+    assert_close(xd.grad, xr.grad, what="chain dx")
+    for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, what="chain grad " + k)
+
+
+def test_conv_wgrad_is_bitwise_reproducible():
+    o = ops()
+    x = o.to_nhwc_raw(gen(2, 100, 24, 24, seed=20).to(DEV))
+    dy = o.to_nhwc_raw(gen(2, 100, 20, 20, seed=21).to(DEV))
+    a = o.conv2d_wgrad_raw(x, dy, 5, 0, (100, 100, 5, 5))
+    b = o.conv2d_wgrad_raw(x, dy, 5, 0, (100, 100, 5, 5))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_conv_rejects_bad_views():
+    o = ops()
+    x = torch.zeros(1, 8, 4, 4, device=DEV)           # NCHW contiguous, not an NHWC view
+    wp = torch.zeros(16 * 32, device=DEV)
+    with pytest.raises(RuntimeError, match="NHWC-view contract"):
+        o.conv2d_raw(x, wp, None, 4, 1, 0, "linear")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        o.conv_chain(torch.zeros(1, 4, 4, 4), 1, 0, ["linear"], [torch.zeros(4, 4, 1, 1), torch.zeros(4)])
+
+
+# ---------------------------------------------------------------------------- kernel apply
+@pytest.mark.parametrize("shape", [(2, 3, 19, 23, 21), (1, 3, 8, 8, 21), (2, 3, 12, 9, 5), (1, 2, 30, 33, 7)])
+def test_kernel_apply_fwd_bwd(shape):
+    n, c, h, w, k = shape
+    o = ops()
+    data = gen(n, c, h, w, seed=30) + 0.5
+    logits = gen(n, k * k, h, w, seed=31, scale=3.0)
+    dr, lr = data.double().requires_grad_(True), logits.double().requires_grad_(True)
+    outr = om.kernel_apply(dr, lr)
+    g = gen(*outr.shape, seed=32)
+    outr.backward(g.double())
+    dd, ld = data.to(DEV).requires_grad_(True), logits.to(DEV).requires_grad_(True)
+    out = o.kernel_apply(dd, ld)
+    out.backward(g.to(DEV))
+    assert_close(out, outr, what="kernel_apply fwd")
+    assert_close(ld.grad, lr.grad, what="kernel_apply d_logits")
+    assert_close(dd.grad, dr.grad, what="kernel_apply d_data")
+
+
+def test_kernel_apply_known_answers():
+    o = ops()
+    n, h, w, k = 1, 26, 29, 21
+    data = (gen(n, 3, h, w, seed=33) + 1.0).to(DEV)
+    uniform = torch.zeros(n, k * k, h, w, device=DEV)
+    out = o.kernel_apply(data, uniform)
+    box = F.avg_pool2d(F.pad(data.cpu(), (10, 10, 10, 10)), 21, 1)          # zero-padded box mean
+    assert_close(out, box, tol=1e-5, what="uniform logits = zero-padded box mean")
+    spike = torch.zeros(n, k * k, h, w, device=DEV)
+    spike[:, 10 * 21 + 10] = 80.0                                           # centre tap
+    assert_close(o.kernel_apply(data, spike), data, tol=1e-6, what="centre spike = identity")
+    shifted = torch.zeros(n, k * k, h, w, device=DEV)
+    shifted[:, 10 * 21 + 12] = 80.0                                         # dy=0, dx=+2
+    want = torch.zeros_like(data)
+    want[..., :, :-2] = data[..., :, 2:]
+    assert_close(o.kernel_apply(data, shifted), want, tol=1e-6, what="tap order (dy,dx) row-major")
+    # cropped (strided) radiance view, as KPCN.forward passes it
+    big = (gen(n, 3, h + 8, w + 8, seed=34) + 1.0).to(DEV)
+    view = big[..., 4:-4, 4:-4]
+    lg = gen(n, k * k, h, w, seed=35).to(DEV)
+    assert_close(o.kernel_apply(view, lg), o.kernel_apply(view.contiguous(), lg), tol=1e-7, what="strided data")
+
+
+# ---------------------------------------------------------------------------- U-Net / PathNet glue
+def test_pool_upsample_cat():
+    o = ops()
+    x = gen(2, 20, 12, 16, seed=40)
+    xr = x.double().requires_grad_(True)
+    pr = F.max_pool2d(xr, 2, 2)
+    ur = F.interpolate(pr, scale_factor=2, mode="bilinear", align_corners=False)
+    cr = torch.cat([ur, xr], 1)
+    g = gen(*cr.shape, seed=41)
+    cr.backward(g.double())
+    xd = x.to(DEV).requires_grad_(True)
+    xn = o.as_nhwc(xd)
+    p = o.maxpool2(xn)
+    u = o.upsample2(p)
+    c = o.cat_channels(u, xn)
+    c.backward(g.to(DEV))
+    assert_close(p, pr, tol=1e-7, what="maxpool")
+    assert_close(u, ur, tol=1e-6, what="upsample")
+    assert_close(c, cr, tol=1e-6, what="cat")
+    assert_close(xd.grad, xr.grad, tol=1e-6, what="pool/upsample/cat backward")
+
+
+def test_spp_mean_and_cat_broadcast():
+    o = ops()
+    b, s, c, h, w = 2, 3, 8, 6, 10
+    flat = gen(b * s, c, h, w, seed=42)
+    prop = gen(b, c, h, w, seed=43)
+    fr, pr = flat.double().requires_grad_(True), prop.double().requires_grad_(True)
+    mr = fr.view(b, s, c, h, w).mean(1)
+    catr = torch.cat([fr, pr.unsqueeze(1).repeat(1, s, 1, 1, 1).view(b * s, c, h, w)], 1)
+    g1, g2 = gen(*mr.shape, seed=44), gen(*catr.shape, seed=45)
+    (mr * g1.double()).sum().backward()
+    (catr * g2.double()).sum().backward()
+    fd, pd = flat.to(DEV).requires_grad_(True), prop.to(DEV).requires_grad_(True)
+    m = o.spp_mean(fd, s)
+    cat = o.cat_broadcast(fd, pd, s)
+    ((m * g1.to(DEV)).sum() + (cat * g2.to(DEV)).sum()).backward()
+    assert_close(m, mr, tol=1e-6, what="spp mean")
+    assert_close(cat, catr, tol=1e-7, what="cat broadcast")
+    assert_close(fd.grad, fr.grad, tol=1e-6, what="d flat")
+    assert_close(pd.grad, pr.grad, tol=1e-6, what="d prop")
+
+
+@pytest.mark.parametrize("cp", [3, 2, 6])
+def test_pbuffer_cat(cp):
+    o = ops()
+    b, s, cb, h, w = 2, 4, 35, 10, 70
+    base = gen(b, cb, h, w, seed=46)
+    p = gen(b, s, cp, h, w, seed=47) + 1.0
+    pr = p.double().requires_grad_(True)
+    outr = assemble_input(base.double(), pr)
+    g = gen(*outr.shape, seed=48)
+    outr.backward(g.double())
+    pd = o.to_nhwc_raw(p.view(b * s, cp, h, w).to(DEV)).unflatten(0, (b, s)).requires_grad_(True)
+    out = o.pbuffer_cat(base.to(DEV), pd)
+    out.backward(g.to(DEV))
+    assert_close(out, outr, tol=2e-6, what="pbuffer cat")
+    assert_close(pd.grad, pr.grad, tol=1e-6, what="pbuffer cat backward")
+    # a channel-sliced view (disentanglement) of a wider P-buffer
+    wide = gen(b, s, cp + 3, h, w, seed=49).to(DEV)
+    assert_close(o.pbuffer_cat(base.to(DEV), wide[:, :, :cp]),
+                 assemble_input(base, wide[:, :, :cp].cpu()), tol=2e-6, what="sliced P")
+
+
+# ---------------------------------------------------------------------------- FeatureMSE
+def test_feature_mse_against_reference_goldens(golden_dir):
+    o = ops()
+    d = np.load(os.path.join(golden_dir, "losses_fmse.npz"))
+    for i in range(int(d["n"])):
+        p = torch.from_numpy(d["p_%d" % i]).to(DEV).requires_grad_(True)
+        ref = torch.from_numpy(d["ref_%d" % i]).to(DEV)
+        ip = torch.from_numpy(d["idx_patch_%d" % i]).to(DEV)
+        ib = torch.from_numpy(d["idx_batch_%d" % i]).to(DEV) if bool(d["non_local_%d" % i]) else None
+        loss = o.feature_mse(p, ref, ip, ib)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), d["loss_%d" % i], rtol=1e-5)
+        assert_close(p.grad, torch.from_numpy(d["grad_%d" % i]), tol=1e-5, what="FeatureMSE grad %d" % i)
+
+
+def test_feature_mse_module_strided_and_seeded(golden_dir):
+    from wcmc_amd.support.losses import FeatureMSE
+    d = np.load(os.path.join(golden_dir, "losses_fmse.npz"))
+    i = 0
+    p = torch.from_numpy(d["p_%d" % i])
+    b, s, c, h, w = p.shape
+    o = ops()
+    pn = o.to_nhwc_raw(p.view(b * s, c, h, w).to(DEV)).unflatten(0, (b, s))      # NHWC-backed, as PathNet returns
+    torch.manual_seed(int(d["seed_%d" % i]))
+    loss = FeatureMSE(non_local=True)(pn, torch.from_numpy(d["ref_%d" % i]).to(DEV))
+    np.testing.assert_allclose(loss.item(), d["loss_%d" % i], rtol=1e-5)
+    bad = pn.clone()
+    bad[0, 0, 0, 0, 0] = float("nan")
+    with pytest.raises(RuntimeError, match="Infinite loss at train time."):
+        FeatureMSE(non_local=True)(bad, torch.from_numpy(d["ref_%d" % i]).to(DEV))
+
+
+def test_feature_mse_full_size_properties():
+    """B=8,S=8,92x92 (N = 541,696 rows): identity pairing gives exactly 0; the loss is invariant to
+    relabelling pairs (pi -> pi^-1 gives the same multiset of pairs)."""
+    o = ops()
+    b, s, c, h, w = 8, 8, 3, 92, 92
+    p = (gen(b * s, c, h, w, seed=50) + 1).to(DEV)
+    pn = o.to_nhwc_raw(p).unflatten(0, (b, s))
+    ref = (gen(b, 3, h, w, seed=51) + 1).to(DEV)
+    ident_p = torch.arange(s * h * w, device=DEV)
+    ident_b = torch.arange(b * s * h * w, device=DEV)
+    assert o.feature_mse(pn, ref, ident_p, ident_b).item() == 0.0
+    g = torch.Generator().manual_seed(52)
+    ip, ib = torch.randperm(s * h * w, generator=g).to(DEV), torch.randperm(b * s * h * w, generator=g).to(DEV)
+    inv_p, inv_b = torch.empty_like(ip), torch.empty_like(ib)
+    inv_p[ip] = torch.arange(ip.numel(), device=DEV)
+    inv_b[ib] = torch.arange(ib.numel(), device=DEV)
+    l1, l2 = o.feature_mse(pn, ref, ip, ib).item(), o.feature_mse(pn, ref, inv_p, inv_b).item()
+    np.testing.assert_allclose(l1, l2, rtol=1e-5)
+    want = ol.feature_mse(p.cpu().view(b, s, c, h, w), ref.cpu(), ip.cpu(), ib.cpu()).item()
+    np.testing.assert_allclose(l1, want, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------- optimiser
+def test_clip_adam_matches_torch():
+    o = ops()
+    n = 100003
+    p0, g0 = gen(n, seed=60), gen(n, seed=61, scale=3.0)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        pr.grad = g0.clone() * step
+        torch.nn.utils.clip_grad_value_([pr], 1.0)
+        opt.step()
+        g = (g0 * step * 2).to(DEV)                       # grad_scale=0.5 undoes the factor 2
+        o.clip_adam_(p, g, m, v, step, 1e-3, grad_scale=0.5)
+        assert torch.equal(g.cpu(), pr.grad)              # clipped gradient left behind, like the reference
+    assert_close(p, pr, tol=1e-6, what="clip+adam params")
+    st = opt.state[pr]
+    assert_close(m, st["exp_avg"], tol=1e-6, what="exp_avg")
+    assert_close(v, st["exp_avg_sq"], tol=1e-6, what="exp_avg_sq")

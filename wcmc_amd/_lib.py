@@ -1,0 +1,70 @@
+"""ctypes binding of ``libwcmc_hip.so`` (C ABI: ``include/wcmc_hip.h``).
+
+The library is the product; there is no CPU fallback.  ``lib()`` raises if the
+shared object is missing (run ``python -c 'import __graft_entry__ as g; g.build()'``
+or ``make -C wcmc_amd/csrc``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwcmc_hip.so")
+
+_c = ctypes
+P, I, L, F, D, Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_double, _c.c_size_t
+
+# name -> (restype, [argtypes]); mirrors include/wcmc_hip.h one to one
+SIGNATURES = {
+    "wcmc_abi_version": (I, []),
+    "wcmc_last_error": (_c.c_char_p, []),
+    "wcmc_to_nhwc": (I, [P, L, L, L, L, P, L, L, L, I, I, I, I, P]),
+    "wcmc_from_nhwc": (I, [P, L, L, L, P, L, L, L, L, I, I, I, I, P]),
+    "wcmc_conv2d_packed_elems": (Z, [I, I, I]),
+    "wcmc_conv2d_pack_weight": (I, [P, P, I, I, I, I, P]),
+    "wcmc_conv2d_igemm": (I, [P, L, L, L, I, I, I, I, P, P, P, L, L, L, I, I, I, I, F,
+                              P, L, L, L, I, F, P]),
+    "wcmc_conv2d_wgrad_workspace_bytes": (Z, [I, I, I, I, I, I]),
+    "wcmc_conv2d_wgrad": (I, [P, L, L, L, I, I, I, I, P, L, L, L, I, I, I, P, P, P, Z, P]),
+    "wcmc_act_backward": (I, [P, L, L, L, P, L, L, L, P, L, L, L, I, I, I, I, I, F, P]),
+    "wcmc_kernel_apply_fwd": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, I, I, I, I, I, P]),
+    "wcmc_kernel_apply_bwd": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P,
+                                  P, L, L, L, P, I, I, I, I, I, P]),
+    "wcmc_maxpool2_fwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),
+    "wcmc_maxpool2_bwd": (I, [P, L, L, L, P, L, L, L, P, L, L, L, I, I, I, I, P]),
+    "wcmc_upsample2_fwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),
+    "wcmc_upsample2_bwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),
+    "wcmc_spp_reduce": (I, [P, L, L, L, P, L, L, L, I, I, I, I, I, F, P]),
+    "wcmc_spp_broadcast": (I, [P, L, L, L, P, L, L, L, I, I, I, I, I, F, I, P]),
+    "wcmc_pbuffer_cat_fwd": (I, [P, L, L, L, L, P, L, L, L, L, L, P, L, L, L, I, I, I, I, I, I, P]),
+    "wcmc_pbuffer_cat_bwd": (I, [P, L, L, L, P, L, L, L, L, L, I, I, I, I, I, I, P]),
+    "wcmc_feature_mse_workspace_bytes": (Z, [I, I, I, I, I]),
+    "wcmc_feature_mse_fwd": (I, [P, L, L, L, L, L, P, L, L, L, L, P, P, P, P, Z, I, I, I, I, I, P]),
+    "wcmc_feature_mse_bwd": (I, [P, L, L, L, L, L, P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "wcmc_clip_adam": (I, [P, P, P, P, L, F, D, D, D, D, I, F, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "wcmc_amd: %s is missing -- the HIP hot path has not been built "
+                "(make -C wcmc_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        if h.wcmc_abi_version() != 1:
+            raise RuntimeError("wcmc_amd: ABI version mismatch in %s" % LIB_PATH)
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().wcmc_last_error().decode("utf-8", "replace")
+        raise RuntimeError("wcmc_hip %s failed (%d): %s" % (what, rc, msg))

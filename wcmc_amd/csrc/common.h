@@ -1,0 +1,53 @@
+// Shared helpers for libwcmc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/wcmc_hip.h"
+
+namespace wcmc {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// An NHWC view obeys the contract in wcmc_hip.h.
+inline bool nhwc_view_ok(const void* p, int64_t sn, int64_t sh, int64_t sw, int C) {
+  return p != nullptr && aligned16(p) && (sn % 4 == 0) && (sh % 4 == 0) && (sw % 4 == 0) &&
+         sw >= round_up(C, 4);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  if (act == WCMC_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == WCMC_ACT_LEAKY_RELU) return v > 0.f ? v : v * slope;
+  return v;
+}
+// derivative factor from the POST-activation value
+__device__ __forceinline__ float act_gate(float post, int act, float slope) {
+  if (act == WCMC_ACT_RELU) return post > 0.f ? 1.f : 0.f;
+  if (act == WCMC_ACT_LEAKY_RELU) return post > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace wcmc
+
+#define WCMC_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      wcmc::set_error(__VA_ARGS__);    \
+      return (code);                   \
+    }                                  \
+  } while (0)

@@ -1,0 +1,392 @@
+// HBM-bound glue kernels of the PathNet / U-Net / interface path (gfx950).
+// Everything here moves 16 bytes per lane along the channel axis of an NHWC view.
+//
+//   wcmc_to_nhwc / wcmc_from_nhwc   batch tensors <-> NHWC views (LDS-tiled transpose)
+//   wcmc_maxpool2_*, wcmc_upsample2_*   sbmc.modules.Autoencoder glue (support/networks.py:20-22)
+//   wcmc_spp_reduce / wcmc_spp_broadcast  support/networks.py:35-36,39-40
+//   wcmc_pbuffer_cat_*                 support/interfaces.py:165-176
+#include "common.h"
+
+namespace wcmc {
+
+// ------------------------------------------------------------------ NCHW-style <-> NHWC
+// Tile: 64 consecutive x of one image row times 32 channels through a padded LDS tile.
+__global__ __launch_bounds__(256) void to_nhwc_kernel(const float* __restrict__ src, int64_t ssn, int64_t ssc,
+                                                      int64_t ssh, int64_t ssw, float* __restrict__ dst,
+                                                      int64_t dsn, int64_t dsh, int64_t dsw, int C, int H, int W) {
+  __shared__ float tile[32][65];
+  const int xt = blockIdx.x * 64, y = blockIdx.y % H, n = blockIdx.y / H;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int c0 = blockIdx.z * 32; c0 < C; c0 += gridDim.z * 32) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + grp * 8 + i, x = xt + lane;
+      tile[grp * 8 + i][lane] =
+          (c < C && x < W) ? src[(int64_t)n * ssn + (int64_t)c * ssc + (int64_t)y * ssh + (int64_t)x * ssw] : 0.f;
+    }
+    __syncthreads();
+    // 8 threads write the 32 channels of one pixel as float4; 32 pixels per pass, 2 passes
+    const int c4 = (threadIdx.x & 7) * 4;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int px = (threadIdx.x >> 3) + 32 * ps, x = xt + px;
+      if (x < W && c0 + c4 < C) {
+        float4 v = make_float4(tile[c4][px], tile[c4 + 1][px], tile[c4 + 2][px], tile[c4 + 3][px]);
+        *reinterpret_cast<float4*>(dst + (int64_t)n * dsn + (int64_t)y * dsh + (int64_t)x * dsw + c0 + c4) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void from_nhwc_kernel(const float* __restrict__ src, int64_t ssn, int64_t ssh,
+                                                        int64_t ssw, float* __restrict__ dst, int64_t dsn,
+                                                        int64_t dsc, int64_t dsh, int64_t dsw, int C, int H, int W) {
+  __shared__ float tile[32][65];
+  const int xt = blockIdx.x * 64, y = blockIdx.y % H, n = blockIdx.y / H;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int c0 = blockIdx.z * 32; c0 < C; c0 += gridDim.z * 32) {
+    const int c4 = (threadIdx.x & 7) * 4;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int px = (threadIdx.x >> 3) + 32 * ps, x = xt + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x < W && c0 + c4 < C)
+        v = *reinterpret_cast<const float4*>(src + (int64_t)n * ssn + (int64_t)y * ssh + (int64_t)x * ssw + c0 + c4);
+      tile[c4][px] = v.x; tile[c4 + 1][px] = v.y; tile[c4 + 2][px] = v.z; tile[c4 + 3][px] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + grp * 8 + i, x = xt + lane;
+      if (c < C && x < W)
+        dst[(int64_t)n * dsn + (int64_t)c * dsc + (int64_t)y * dsh + (int64_t)x * dsw] = tile[grp * 8 + i][lane];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ generic float4-per-lane indexer
+struct View { const float* p; int64_t sn, sh, sw; };
+struct MView { float* p; int64_t sn, sh, sw; };
+__device__ __forceinline__ float4 ld4(const View& v, int n, int y, int x, int c) {
+  return *reinterpret_cast<const float4*>(v.p + n * v.sn + y * v.sh + x * v.sw + c);
+}
+__device__ __forceinline__ void st4(const MView& v, int n, int y, int x, int c, float4 a) {
+  *reinterpret_cast<float4*>(v.p + n * v.sn + y * v.sh + x * v.sw + c) = a;
+}
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_fma(float s, float4 a, float4 b) {
+  return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
+}
+__device__ __forceinline__ float4 f4_scale(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+// zero the lanes of a vector that lie at or beyond channel C (keeps pad channels of a buffer at 0)
+__device__ __forceinline__ float4 f4_mask(float4 a, int c, int C) {
+  if (c + 1 >= C) a.y = 0.f;
+  if (c + 2 >= C) a.z = 0.f;
+  if (c + 3 >= C) a.w = 0.f;
+  return a;
+}
+
+#define WCMC_ITER_NHWC(N, H, W, C4)                                                                  \
+  const int64_t total_ = (int64_t)(N) * (H) * (W) * (C4);                                            \
+  for (int64_t idx_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx_ < total_;                 \
+       idx_ += (int64_t)gridDim.x * blockDim.x)
+#define WCMC_DECODE_NHWC(H, W, C4)                           \
+  const int c = (int)(idx_ % (C4)) * 4; int64_t t_ = idx_ / (C4); \
+  const int x = (int)(t_ % (W)); t_ /= (W);                  \
+  const int y = (int)(t_ % (H)); const int n = (int)(t_ / (H));
+
+__global__ void maxpool2_fwd_kernel(View in, MView out, int N, int Ho, int Wo, int C4, int C) {
+  WCMC_ITER_NHWC(N, Ho, Wo, C4) {
+    WCMC_DECODE_NHWC(Ho, Wo, C4)
+    const float4 a = ld4(in, n, 2 * y, 2 * x, c), b = ld4(in, n, 2 * y, 2 * x + 1, c);
+    const float4 d = ld4(in, n, 2 * y + 1, 2 * x, c), e = ld4(in, n, 2 * y + 1, 2 * x + 1, c);
+    float4 m = make_float4(fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y)),
+                           fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z)), fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w)));
+    st4(out, n, y, x, c, f4_mask(m, c, C));
+  }
+}
+
+// first maximum in window order (0,0),(0,1),(1,0),(1,1) takes the gradient, as ATen's max_pool2d does
+__device__ __forceinline__ void route4(float a, float b, float d, float e, float g, float& ga, float& gb, float& gd,
+                                       float& ge) {
+  ga = gb = gd = ge = 0.f;
+  float m = a; int k = 0;
+  if (b > m) { m = b; k = 1; }
+  if (d > m) { m = d; k = 2; }
+  if (e > m) { m = e; k = 3; }
+  if (k == 0) ga = g; else if (k == 1) gb = g; else if (k == 2) gd = g; else ge = g;
+}
+__global__ void maxpool2_bwd_kernel(View in, View dy, MView dx, int N, int Ho, int Wo, int C4, int C) {
+  WCMC_ITER_NHWC(N, Ho, Wo, C4) {
+    WCMC_DECODE_NHWC(Ho, Wo, C4)
+    const float4 a = ld4(in, n, 2 * y, 2 * x, c), b = ld4(in, n, 2 * y, 2 * x + 1, c);
+    const float4 d = ld4(in, n, 2 * y + 1, 2 * x, c), e = ld4(in, n, 2 * y + 1, 2 * x + 1, c);
+    const float4 g = f4_mask(ld4(dy, n, y, x, c), c, C);
+    float4 ga, gb, gd, ge;
+    route4(a.x, b.x, d.x, e.x, g.x, ga.x, gb.x, gd.x, ge.x);
+    route4(a.y, b.y, d.y, e.y, g.y, ga.y, gb.y, gd.y, ge.y);
+    route4(a.z, b.z, d.z, e.z, g.z, ga.z, gb.z, gd.z, ge.z);
+    route4(a.w, b.w, d.w, e.w, g.w, ga.w, gb.w, gd.w, ge.w);
+    st4(dx, n, 2 * y, 2 * x, c, ga); st4(dx, n, 2 * y, 2 * x + 1, c, gb);
+    st4(dx, n, 2 * y + 1, 2 * x, c, gd); st4(dx, n, 2 * y + 1, 2 * x + 1, c, ge);
+  }
+}
+
+// bilinear x2, align_corners=False: out[2i] = .25 in[i-1] + .75 in[i], out[2i+1] = .75 in[i] + .25 in[i+1]
+// with the neighbour index clamped to the image.
+__global__ void upsample2_fwd_kernel(View in, MView out, int N, int H, int W, int C4, int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  WCMC_ITER_NHWC(N, Ho, Wo, C4) {
+    WCMC_DECODE_NHWC(Ho, Wo, C4)
+    const int iy = y >> 1, ix = x >> 1;
+    const int ny = (y & 1) ? min(iy + 1, H - 1) : max(iy - 1, 0);
+    const int nx = (x & 1) ? min(ix + 1, W - 1) : max(ix - 1, 0);
+    const float4 v00 = ld4(in, n, iy, ix, c), v01 = ld4(in, n, iy, nx, c);
+    const float4 v10 = ld4(in, n, ny, ix, c), v11 = ld4(in, n, ny, nx, c);
+    float4 r = f4_scale(0.5625f, v00);
+    r = f4_fma(0.1875f, v01, r); r = f4_fma(0.1875f, v10, r); r = f4_fma(0.0625f, v11, r);
+    st4(out, n, y, x, c, f4_mask(r, c, C));
+  }
+}
+// dx[i] gathers from the <= 3x3 fine pixels it contributed to (per axis: weights of fine rows
+// 2i-1 (.25), 2i (.75), 2i+1 (.75), 2i+2 (.25), plus the clamped contributions at the borders).
+__device__ __forceinline__ int up_taps(int i, int L, int* fine, float* wt) {
+  // fine index f receives from coarse i with weight: f=2i or 2i+1 -> .75 ; f=2i-1 or 2i+2 -> .25;
+  // at the borders the clamped neighbour adds another .25 onto f=0 (i=0) and f=2L-1 (i=L-1).
+  int k = 0;
+  fine[k] = 2 * i; wt[k++] = (i == 0) ? 1.0f : 0.75f;
+  fine[k] = 2 * i + 1; wt[k++] = (i == L - 1) ? 1.0f : 0.75f;
+  if (i > 0) { fine[k] = 2 * i - 1; wt[k++] = 0.25f; }
+  if (i < L - 1) { fine[k] = 2 * i + 2; wt[k++] = 0.25f; }
+  return k;
+}
+__global__ void upsample2_bwd_kernel(View dy, MView dx, int N, int H, int W, int C4, int C) {
+  WCMC_ITER_NHWC(N, H, W, C4) {
+    WCMC_DECODE_NHWC(H, W, C4)
+    int fy[4], fx[4]; float wy[4], wx[4];
+    const int ky = up_taps(y, H, fy, wy), kx = up_taps(x, W, fx, wx);
+    float4 acc = f4_zero();
+    for (int a = 0; a < ky; ++a)
+      for (int b = 0; b < kx; ++b) acc = f4_fma(wy[a] * wx[b], ld4(dy, n, fy[a], fx[b], c), acc);
+    st4(dx, n, y, x, c, f4_mask(acc, c, C));
+  }
+}
+
+__global__ void spp_reduce_kernel(View in, MView out, int B, int S, int H, int W, int C4, int C, float scale) {
+  WCMC_ITER_NHWC(B, H, W, C4) {
+    WCMC_DECODE_NHWC(H, W, C4)
+    float4 acc = f4_zero();
+    for (int s = 0; s < S; ++s) acc = f4_add(acc, ld4(in, n * S + s, y, x, c));
+    st4(out, n, y, x, c, f4_mask(f4_scale(scale, acc), c, C));
+  }
+}
+__global__ void spp_broadcast_kernel(View in, MView out, int B, int S, int H, int W, int C4, int C, float scale,
+                                     int accumulate) {
+  WCMC_ITER_NHWC(B, H, W, C4) {
+    WCMC_DECODE_NHWC(H, W, C4)
+    const float4 v = f4_mask(f4_scale(scale, ld4(in, n, y, x, c)), c, C);
+    for (int s = 0; s < S; ++s) {
+      float4 o = v;
+      if (accumulate) {
+        const View ov = {out.p, out.sn, out.sh, out.sw};
+        o = f4_add(o, f4_mask(ld4(ov, n * S + s, y, x, c), c, C));
+      }
+      st4(out, n * S + s, y, x, c, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ P-buffer statistics + concat
+// One block = 64 consecutive x of one row.  Phase 1 (lane = pixel): base channels and the spp
+// statistics go into a [64][CT+1] LDS tile; phase 2 writes 16-byte NHWC vectors.
+__global__ __launch_bounds__(256) void pbuffer_cat_fwd_kernel(const float* __restrict__ base, int64_t bsn,
+                                                              int64_t bsc, int64_t bsh, int64_t bsw,
+                                                              const float* __restrict__ pb, int64_t psb, int64_t pss,
+                                                              int64_t psc, int64_t psh, int64_t psw,
+                                                              float* __restrict__ out, int64_t osn, int64_t osh,
+                                                              int64_t osw, int S, int Cb, int Cp, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int CT = Cb + Cp + 1, CT4 = (CT + 3) / 4 * 4, LD = CT4 + 1;
+  const int xt = blockIdx.x * 64, y = blockIdx.y % H, b = blockIdx.y / H;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int x = xt + lane;
+  for (int c = grp; c < Cb; c += 4)
+    smem[lane * LD + c] = x < W ? base[(int64_t)b * bsn + (int64_t)c * bsc + (int64_t)y * bsh + (int64_t)x * bsw] : 0.f;
+  if (grp == 0) {
+    float varsum = 0.f;
+    for (int c = 0; c < Cp; ++c) {
+      float s1 = 0.f;
+      const float* q = pb + (int64_t)b * psb + (int64_t)c * psc + (int64_t)y * psh + (int64_t)x * psw;
+      if (x < W) for (int s = 0; s < S; ++s) s1 += q[(int64_t)s * pss];
+      const float mean = s1 / (float)S;
+      float s2 = 0.f;
+      if (x < W) for (int s = 0; s < S; ++s) { const float d = q[(int64_t)s * pss] - mean; s2 += d * d; }
+      smem[lane * LD + Cb + c] = mean;
+      varsum += s2 / (float)(S - 1);            // unbiased, torch.var default (interfaces.py:165)
+    }
+    smem[lane * LD + Cb + Cp] = varsum / (float)Cp / (float)S;
+    for (int c = CT; c < CT4; ++c) smem[lane * LD + c] = 0.f;
+  }
+  __syncthreads();
+  const int nv = CT4 / 4;
+  for (int i = threadIdx.x; i < 64 * nv; i += 256) {
+    const int px = i / nv, c = (i - px * nv) * 4;
+    if (xt + px < W) {
+      const float* t = smem + px * LD + c;
+      *reinterpret_cast<float4*>(out + (int64_t)b * osn + (int64_t)y * osh + (int64_t)(xt + px) * osw + c) =
+          make_float4(t[0], t[1], t[2], t[3]);
+    }
+  }
+}
+
+__global__ void pbuffer_cat_bwd_kernel(const float* __restrict__ g, int64_t gsn, int64_t gsh, int64_t gsw,
+                                       float* __restrict__ dp, int64_t psb, int64_t pss, int64_t psc, int64_t psh,
+                                       int64_t psw, int B, int S, int Cb, int Cp, int H, int W) {
+  const int64_t total = (int64_t)B * H * W;
+  const float inv = 1.f / (float)S;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % W); int64_t t = idx / W;
+    const int y = (int)(t % H); const int b = (int)(t / H);
+    const float* gp = g + (int64_t)b * gsn + (int64_t)y * gsh + (int64_t)x * gsw + Cb;
+    for (int c = 0; c < Cp; ++c) {
+      const float v = gp[c] * inv;
+      float* q = dp + (int64_t)b * psb + (int64_t)c * psc + (int64_t)y * psh + (int64_t)x * psw;
+      for (int s = 0; s < S; ++s) q[(int64_t)s * pss] = v;
+    }
+  }
+}
+
+static unsigned grid_for(int64_t total) {
+  const int64_t g = ceil_div64(total, 256);
+  return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace wcmc
+
+using namespace wcmc;
+
+#define VIEW_OK(p, sn, sh, sw, C) nhwc_view_ok(p, sn, sh, sw, C)
+
+extern "C" int wcmc_to_nhwc(const float* src, int64_t ssn, int64_t ssc, int64_t ssh, int64_t ssw, float* dst,
+                            int64_t dsn, int64_t dsh, int64_t dsw, int N, int C, int H, int W, void* stream) {
+  WCMC_REQUIRE(src && N > 0 && C > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG, "to_nhwc: bad argument");
+  WCMC_REQUIRE(VIEW_OK(dst, dsn, dsh, dsw, C), WCMC_ERR_ALIGNMENT, "to_nhwc: dst violates the NHWC-view contract");
+  WCMC_REQUIRE((int64_t)N * H <= 65535, WCMC_ERR_BAD_ARG, "to_nhwc: N*H > 65535");
+  const dim3 grid((unsigned)((W + 63) / 64), (unsigned)(N * H), (unsigned)((C + 31) / 32 < 4 ? (C + 31) / 32 : 4));
+  hipLaunchKernelGGL(to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ssn, ssc, ssh, ssw, dst, dsn, dsh,
+                     dsw, C, H, W);
+  return check_launch("to_nhwc");
+}
+
+extern "C" int wcmc_from_nhwc(const float* src, int64_t ssn, int64_t ssh, int64_t ssw, float* dst, int64_t dsn,
+                              int64_t dsc, int64_t dsh, int64_t dsw, int N, int C, int H, int W, void* stream) {
+  WCMC_REQUIRE(dst && N > 0 && C > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG, "from_nhwc: bad argument");
+  WCMC_REQUIRE(VIEW_OK(src, ssn, ssh, ssw, C), WCMC_ERR_ALIGNMENT, "from_nhwc: src violates the NHWC-view contract");
+  WCMC_REQUIRE((int64_t)N * H <= 65535, WCMC_ERR_BAD_ARG, "from_nhwc: N*H > 65535");
+  const dim3 grid((unsigned)((W + 63) / 64), (unsigned)(N * H), (unsigned)((C + 31) / 32 < 4 ? (C + 31) / 32 : 4));
+  hipLaunchKernelGGL(from_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ssn, ssh, ssw, dst, dsn, dsc,
+                     dsh, dsw, C, H, W);
+  return check_launch("from_nhwc");
+}
+
+extern "C" int wcmc_maxpool2_fwd(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, float* y, int64_t ysn,
+                                 int64_t ysh, int64_t ysw, int N, int H, int W, int C, void* stream) {
+  WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, WCMC_ERR_BAD_ARG,
+               "maxpool2_fwd: bad shape (H,W must be even)");
+  WCMC_REQUIRE(VIEW_OK(x, xsn, xsh, xsw, C) && VIEW_OK(y, ysn, ysh, ysw, C), WCMC_ERR_ALIGNMENT,
+               "maxpool2_fwd: a view violates the NHWC-view contract");
+  const int C4 = (C + 3) / 4;
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * C4)), dim3(256), 0,
+                     (hipStream_t)stream, View{x, xsn, xsh, xsw}, MView{y, ysn, ysh, ysw}, N, H / 2, W / 2, C4, C);
+  return check_launch("maxpool2_fwd");
+}
+
+extern "C" int wcmc_maxpool2_bwd(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, const float* dy,
+                                 int64_t dsn, int64_t dsh, int64_t dsw, float* dx, int64_t gsn, int64_t gsh,
+                                 int64_t gsw, int N, int H, int W, int C, void* stream) {
+  WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, WCMC_ERR_BAD_ARG,
+               "maxpool2_bwd: bad shape (H,W must be even)");
+  WCMC_REQUIRE(VIEW_OK(x, xsn, xsh, xsw, C) && VIEW_OK(dy, dsn, dsh, dsw, C) && VIEW_OK(dx, gsn, gsh, gsw, C),
+               WCMC_ERR_ALIGNMENT, "maxpool2_bwd: a view violates the NHWC-view contract");
+  const int C4 = (C + 3) / 4;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * C4)), dim3(256), 0,
+                     (hipStream_t)stream, View{x, xsn, xsh, xsw}, View{dy, dsn, dsh, dsw}, MView{dx, gsn, gsh, gsw}, N,
+                     H / 2, W / 2, C4, C);
+  return check_launch("maxpool2_bwd");
+}
+
+extern "C" int wcmc_upsample2_fwd(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, float* y, int64_t ysn,
+                                  int64_t ysh, int64_t ysw, int N, int H, int W, int C, void* stream) {
+  WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, WCMC_ERR_BAD_ARG, "upsample2_fwd: bad shape");
+  WCMC_REQUIRE(VIEW_OK(x, xsn, xsh, xsw, C) && VIEW_OK(y, ysn, ysh, ysw, C), WCMC_ERR_ALIGNMENT,
+               "upsample2_fwd: a view violates the NHWC-view contract");
+  const int C4 = (C + 3) / 4;
+  hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(grid_for((int64_t)N * 4 * H * W * C4)), dim3(256), 0,
+                     (hipStream_t)stream, View{x, xsn, xsh, xsw}, MView{y, ysn, ysh, ysw}, N, H, W, C4, C);
+  return check_launch("upsample2_fwd");
+}
+
+extern "C" int wcmc_upsample2_bwd(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw, float* dx, int64_t xsn,
+                                  int64_t xsh, int64_t xsw, int N, int H, int W, int C, void* stream) {
+  WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, WCMC_ERR_BAD_ARG, "upsample2_bwd: bad shape");
+  WCMC_REQUIRE(VIEW_OK(dy, dsn, dsh, dsw, C) && VIEW_OK(dx, xsn, xsh, xsw, C), WCMC_ERR_ALIGNMENT,
+               "upsample2_bwd: a view violates the NHWC-view contract");
+  const int C4 = (C + 3) / 4;
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C4)), dim3(256), 0, (hipStream_t)stream,
+                     View{dy, dsn, dsh, dsw}, MView{dx, xsn, xsh, xsw}, N, H, W, C4, C);
+  return check_launch("upsample2_bwd");
+}
+
+extern "C" int wcmc_spp_reduce(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, float* y, int64_t ysn,
+                               int64_t ysh, int64_t ysw, int B, int S, int H, int W, int C, float scale,
+                               void* stream) {
+  WCMC_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && C > 0, WCMC_ERR_BAD_ARG, "spp_reduce: bad shape");
+  WCMC_REQUIRE(VIEW_OK(x, xsn, xsh, xsw, C) && VIEW_OK(y, ysn, ysh, ysw, C), WCMC_ERR_ALIGNMENT,
+               "spp_reduce: a view violates the NHWC-view contract");
+  const int C4 = (C + 3) / 4;
+  hipLaunchKernelGGL(spp_reduce_kernel, dim3(grid_for((int64_t)B * H * W * C4)), dim3(256), 0, (hipStream_t)stream,
+                     View{x, xsn, xsh, xsw}, MView{y, ysn, ysh, ysw}, B, S, H, W, C4, C, scale);
+  return check_launch("spp_reduce");
+}
+
+extern "C" int wcmc_spp_broadcast(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, float* y, int64_t ysn,
+                                  int64_t ysh, int64_t ysw, int B, int S, int H, int W, int C, float scale,
+                                  int accumulate, void* stream) {
+  WCMC_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && C > 0, WCMC_ERR_BAD_ARG, "spp_broadcast: bad shape");
+  WCMC_REQUIRE(VIEW_OK(x, xsn, xsh, xsw, C) && VIEW_OK(y, ysn, ysh, ysw, C), WCMC_ERR_ALIGNMENT,
+               "spp_broadcast: a view violates the NHWC-view contract");
+  const int C4 = (C + 3) / 4;
+  hipLaunchKernelGGL(spp_broadcast_kernel, dim3(grid_for((int64_t)B * H * W * C4)), dim3(256), 0, (hipStream_t)stream,
+                     View{x, xsn, xsh, xsw}, MView{y, ysn, ysh, ysw}, B, S, H, W, C4, C, scale, accumulate);
+  return check_launch("spp_broadcast");
+}
+
+extern "C" int wcmc_pbuffer_cat_fwd(const float* base, int64_t bsn, int64_t bsc, int64_t bsh, int64_t bsw,
+                                    const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh, int64_t psw,
+                                    float* out, int64_t osn, int64_t osh, int64_t osw, int B, int S, int Cb, int Cp,
+                                    int H, int W, void* stream) {
+  WCMC_REQUIRE(base && p && B > 0 && S > 1 && Cb > 0 && Cp > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG,
+               "pbuffer_cat_fwd: bad argument (S must be >= 2 for the unbiased variance)");
+  const int CT = Cb + Cp + 1;
+  WCMC_REQUIRE(VIEW_OK(out, osn, osh, osw, CT), WCMC_ERR_ALIGNMENT, "pbuffer_cat_fwd: out violates the NHWC-view contract");
+  WCMC_REQUIRE((int64_t)B * H <= 65535, WCMC_ERR_BAD_ARG, "pbuffer_cat_fwd: B*H > 65535");
+  const size_t lds = (size_t)64 * (round_up(CT, 4) + 1) * sizeof(float);
+  hipLaunchKernelGGL(pbuffer_cat_fwd_kernel, dim3((unsigned)((W + 63) / 64), (unsigned)(B * H)), dim3(256), lds,
+                     (hipStream_t)stream, base, bsn, bsc, bsh, bsw, p, psb, pss, psc, psh, psw, out, osn, osh, osw, S,
+                     Cb, Cp, H, W);
+  return check_launch("pbuffer_cat_fwd");
+}
+
+extern "C" int wcmc_pbuffer_cat_bwd(const float* g, int64_t gsn, int64_t gsh, int64_t gsw, float* dp, int64_t psb,
+                                    int64_t pss, int64_t psc, int64_t psh, int64_t psw, int B, int S, int Cb, int Cp,
+                                    int H, int W, void* stream) {
+  WCMC_REQUIRE(g && dp && B > 0 && S > 0 && Cb > 0 && Cp > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG,
+               "pbuffer_cat_bwd: bad argument");
+  hipLaunchKernelGGL(pbuffer_cat_bwd_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, g,
+                     gsn, gsh, gsw, dp, psb, pss, psc, psh, psw, B, S, Cb, Cp, H, W);
+  return check_launch("pbuffer_cat_bwd");
+}

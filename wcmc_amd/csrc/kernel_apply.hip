@@ -1,0 +1,236 @@
+// Per-pixel softmax(k*k logits) x zero-extended k x k gather of C-channel radiance.
+//
+// Replaces sbmc.modules.KernelApply(softmax=True, splat=False) inside sbmc.KPCN
+// (call site support/interfaces.py:203-204; upstream: Halide kernel_weighting op).
+//
+// HBM-bound: per pixel the forward streams k*k*4 B of logits (1764 B for 21x21) against
+// 12 B of radiance in / 12 B out; the backward reads the logits again and writes as many
+// bytes of d_logits.  Layout: logits are pixel-major (NHWC view, taps contiguous), which
+// is what the conv epilogue writes.  16 lanes own one pixel: each lane loads 16-byte
+// vectors j, j+16, ... of the pixel's tap row (so a wave instruction reads 4 x 256
+// contiguous bytes), keeps its <= 28 logits in registers for the two softmax passes, and
+// gathers radiance from an LDS-resident (tile + 2r)^2 halo of float4 pixels.  The three
+// reductions (max, sum, weighted rgb) are 4-step xor-shuffles inside the 16-lane group.
+#include "common.h"
+
+namespace wcmc {
+
+constexpr int KA_TILE = 8;          // 8x8 output pixels per 256-thread block
+constexpr int KA_MAXV = 7;          // float4 per lane: 16*7*4 = 448 >= 441 taps
+
+struct KAParams {
+  const float* logits; int64_t lsn, lsh, lsw;
+  const float* data; int64_t dsn, dsc, dsh, dsw;
+  const float* out; int64_t osn, osc, osh, osw;           // fwd: written, bwd: read
+  const float* gout; int64_t gsn, gsc, gsh, gsw;          // bwd only
+  float* lse;                                             // fwd: written (may be null), bwd: read
+  float* dlogits; int64_t qsn, qsh, qsw;                  // bwd only
+  float* ddata;                                           // bwd only, may be null
+  int N, C, h, w, k, r, taps, nvec, halo;
+};
+
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Stage the zero-extended radiance halo of this tile as float4 {c0,c1,c2,c3} per pixel.
+__device__ __forceinline__ void ka_load_halo(const KAParams& p, float4* halo, int n, int ty0, int tx0) {
+  const int hs = p.halo;
+  for (int i = threadIdx.x; i < hs * hs; i += blockDim.x) {
+    const int hy = i / hs, hx = i - hy * hs;
+    const int y = ty0 + hy - p.r, x = tx0 + hx - p.r;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w) {
+      const float* d = p.data + (int64_t)n * p.dsn + (int64_t)y * p.dsh + (int64_t)x * p.dsw;
+      for (int c = 0; c < p.C; ++c) v[c] = d[(int64_t)c * p.dsc];
+    }
+    halo[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void kernel_apply_kernel(KAParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float4* halo = reinterpret_cast<float4*>(smem);
+  float* dacc = smem + 4 * p.halo * p.halo;       // BWD with d_data: per-halo-pixel float4 accumulators
+
+  const int tiles_x = (p.w + KA_TILE - 1) / KA_TILE;
+  const int n = blockIdx.y;
+  const int ty0 = (blockIdx.x / tiles_x) * KA_TILE, tx0 = (blockIdx.x % tiles_x) * KA_TILE;
+  ka_load_halo(p, halo, n, ty0, tx0);
+  if (BWD && p.ddata)
+    for (int i = threadIdx.x; i < 4 * p.halo * p.halo; i += blockDim.x) dacc[i] = 0.f;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  // halo offset (in float4 units) of each of this lane's taps; fixed for the whole kernel
+  int toff[KA_MAXV][4];
+#pragma unroll
+  for (int i = 0; i < KA_MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int t = 4 * (j + 16 * i) + e;
+      const int dy = t / p.k, dx = t - dy * p.k;
+      toff[i][e] = t < p.taps ? dy * p.halo + dx : -1;
+    }
+
+  for (int it = 0; it < 4; ++it) {
+    const int pi = wave * 16 + it * 4 + q;            // pixel inside the 8x8 tile
+    const int ty = pi >> 3, tx = pi & 7;
+    const int y = ty0 + ty, x = tx0 + tx;
+    const bool valid = y < p.h && x < p.w;            // uniform across the 16-lane group
+    const int64_t pix = ((int64_t)n * p.h + y) * p.w + x;
+    const float* lrow = p.logits + (int64_t)n * p.lsn + (int64_t)y * p.lsh + (int64_t)x * p.lsw;
+    float4 lv[KA_MAXV];
+#pragma unroll
+    for (int i = 0; i < KA_MAXV; ++i) {
+      const int vi = j + 16 * i;
+      lv[i] = (valid && vi < p.nvec) ? *reinterpret_cast<const float4*>(lrow + 4 * vi)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4* hbase = halo + ty * p.halo + tx;    // tap (dy,dx) reads hbase[dy*halo + dx]
+
+    if (!BWD) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < KA_MAXV; ++i) {
+        const float* l = reinterpret_cast<const float*>(&lv[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (toff[i][e] >= 0) m = fmaxf(m, l[e]);
+      }
+      m = group16_max(m);
+      float s = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int i = 0; i < KA_MAXV; ++i) {
+        const float* l = reinterpret_cast<const float*>(&lv[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (toff[i][e] >= 0) {
+            const float ex = __expf(l[e] - m);
+            const float4 d = hbase[toff[i][e]];
+            s += ex; a0 += ex * d.x; a1 += ex * d.y; a2 += ex * d.z; a3 += ex * d.w;
+          }
+        }
+      }
+      s = group16_sum(s); a0 = group16_sum(a0); a1 = group16_sum(a1); a2 = group16_sum(a2); a3 = group16_sum(a3);
+      if (valid && j == 0) {
+        const float inv = 1.f / s;
+        float* o = const_cast<float*>(p.out) + (int64_t)n * p.osn + (int64_t)y * p.osh + (int64_t)x * p.osw;
+        const float av[4] = {a0 * inv, a1 * inv, a2 * inv, a3 * inv};
+        for (int c = 0; c < p.C; ++c) o[(int64_t)c * p.osc] = av[c];
+        if (p.lse) p.lse[pix] = m + __logf(s);
+      }
+    } else {
+      // w_t = exp(l_t - lse);  d l_t = w_t * (g . data_t - g . out)
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+      float go = 0.f, lse = 0.f;
+      if (valid) {
+        const float* gp = p.gout + (int64_t)n * p.gsn + (int64_t)y * p.gsh + (int64_t)x * p.gsw;
+        const float* op = p.out + (int64_t)n * p.osn + (int64_t)y * p.osh + (int64_t)x * p.osw;
+        for (int c = 0; c < p.C; ++c) {
+          g[c] = gp[(int64_t)c * p.gsc];
+          go += g[c] * op[(int64_t)c * p.osc];
+        }
+        lse = p.lse[pix];
+      }
+      float* qrow = p.dlogits + (int64_t)n * p.qsn + (int64_t)y * p.qsh + (int64_t)x * p.qsw;
+#pragma unroll
+      for (int i = 0; i < KA_MAXV; ++i) {
+        const float* l = reinterpret_cast<const float*>(&lv[i]);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = 0.f;
+          if (toff[i][e] >= 0) {
+            const float wt = __expf(l[e] - lse);
+            const float4 d = hbase[toff[i][e]];
+            o[e] = wt * (g[0] * d.x + g[1] * d.y + g[2] * d.z + g[3] * d.w - go);
+            if (p.ddata && valid) {
+              float* da = dacc + 4 * ((ty * p.halo + tx) + toff[i][e]);
+              atomicAdd(da + 0, wt * g[0]); atomicAdd(da + 1, wt * g[1]);
+              atomicAdd(da + 2, wt * g[2]); atomicAdd(da + 3, wt * g[3]);
+            }
+          }
+        }
+        const int vi = j + 16 * i;
+        if (valid && vi < p.nvec) *reinterpret_cast<float4*>(qrow + 4 * vi) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+
+  if (BWD && p.ddata) {
+    __syncthreads();
+    const int hs = p.halo;
+    for (int i = threadIdx.x; i < hs * hs; i += blockDim.x) {
+      const int hy = i / hs, hx = i - hy * hs;
+      const int y = ty0 + hy - p.r, x = tx0 + hx - p.r;
+      if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w)
+        for (int c = 0; c < p.C; ++c) {
+          const float v = dacc[4 * i + c];
+          if (v != 0.f) atomicAdd(p.ddata + (((int64_t)n * p.C + c) * p.h + y) * p.w + x, v);
+        }
+    }
+  }
+}
+
+static int ka_fill(KAParams& p, int N, int C, int h, int w, int k) {
+  WCMC_REQUIRE(N > 0 && h > 0 && w > 0 && C >= 1 && C <= 4 && k >= 1 && (k & 1) && k * k <= 16 * KA_MAXV * 4,
+               WCMC_ERR_BAD_ARG, "kernel_apply: unsupported shape (N=%d C=%d h=%d w=%d k=%d)", N, C, h, w, k);
+  p.N = N; p.C = C; p.h = h; p.w = w; p.k = k; p.r = k / 2; p.taps = k * k; p.nvec = (k * k + 3) / 4;
+  p.halo = KA_TILE + k - 1;
+  return 0;
+}
+
+}  // namespace wcmc
+
+using namespace wcmc;
+
+extern "C" int wcmc_kernel_apply_fwd(const float* logits, int64_t lsn, int64_t lsh, int64_t lsw, const float* data,
+                                     int64_t dsn, int64_t dsc, int64_t dsh, int64_t dsw, float* out, int64_t osn,
+                                     int64_t osc, int64_t osh, int64_t osw, float* lse, int N, int C, int h, int w,
+                                     int k, void* stream) {
+  KAParams p = {};
+  if (int rc = ka_fill(p, N, C, h, w, k)) return rc;
+  WCMC_REQUIRE(data && out, WCMC_ERR_BAD_ARG, "kernel_apply_fwd: null pointer");
+  WCMC_REQUIRE(nhwc_view_ok(logits, lsn, lsh, lsw, k * k), WCMC_ERR_ALIGNMENT,
+               "kernel_apply_fwd: logits violate the NHWC-view contract");
+  p.logits = logits; p.lsn = lsn; p.lsh = lsh; p.lsw = lsw;
+  p.data = data; p.dsn = dsn; p.dsc = dsc; p.dsh = dsh; p.dsw = dsw;
+  p.out = out; p.osn = osn; p.osc = osc; p.osh = osh; p.osw = osw; p.lse = lse;
+  const dim3 grid((unsigned)(((h + KA_TILE - 1) / KA_TILE) * ((w + KA_TILE - 1) / KA_TILE)), (unsigned)N);
+  const size_t lds = (size_t)p.halo * p.halo * sizeof(float4);
+  hipLaunchKernelGGL(kernel_apply_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  return check_launch("kernel_apply_fwd");
+}
+
+extern "C" int wcmc_kernel_apply_bwd(const float* logits, int64_t lsn, int64_t lsh, int64_t lsw, const float* data,
+                                     int64_t dsn, int64_t dsc, int64_t dsh, int64_t dsw, const float* out,
+                                     int64_t osn, int64_t osc, int64_t osh, int64_t osw, const float* grad_out,
+                                     int64_t gsn, int64_t gsc, int64_t gsh, int64_t gsw, const float* lse,
+                                     float* d_logits, int64_t qsn, int64_t qsh, int64_t qsw, float* d_data, int N,
+                                     int C, int h, int w, int k, void* stream) {
+  KAParams p = {};
+  if (int rc = ka_fill(p, N, C, h, w, k)) return rc;
+  WCMC_REQUIRE(data && out && grad_out && lse, WCMC_ERR_BAD_ARG, "kernel_apply_bwd: null pointer");
+  WCMC_REQUIRE(nhwc_view_ok(logits, lsn, lsh, lsw, k * k) && nhwc_view_ok(d_logits, qsn, qsh, qsw, k * k),
+               WCMC_ERR_ALIGNMENT, "kernel_apply_bwd: logits/d_logits violate the NHWC-view contract");
+  p.logits = logits; p.lsn = lsn; p.lsh = lsh; p.lsw = lsw;
+  p.data = data; p.dsn = dsn; p.dsc = dsc; p.dsh = dsh; p.dsw = dsw;
+  p.out = out; p.osn = osn; p.osc = osc; p.osh = osh; p.osw = osw;
+  p.gout = grad_out; p.gsn = gsn; p.gsc = gsc; p.gsh = gsh; p.gsw = gsw;
+  p.lse = const_cast<float*>(lse);
+  p.dlogits = d_logits; p.qsn = qsn; p.qsh = qsh; p.qsw = qsw; p.ddata = d_data;
+  const dim3 grid((unsigned)(((h + KA_TILE - 1) / KA_TILE) * ((w + KA_TILE - 1) / KA_TILE)), (unsigned)N);
+  const size_t lds = (size_t)p.halo * p.halo * sizeof(float4) * (d_data ? 2 : 1);
+  hipLaunchKernelGGL(kernel_apply_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  return check_launch("kernel_apply_bwd");
+}

@@ -1,0 +1,62 @@
+"""One process per GPU; gradients are summed with RCCL (``torch.distributed`` backend "nccl" on ROCm)
+over xGMI.  The reference's multi-GPU is single-process ``nn.DataParallel``
+(``train_kpcn.py:256-271``): replicas see disjoint slices of the batch and the gradients of the
+replicas are summed before the clip.  Here each rank holds full replicas of KPCN + 2 PathNets,
+steps on its own shard of patches (no data-path collective), and the per-model flat gradient is
+all-reduced once per step (46.8 MB in 3 messages) before the fused clip + Adam.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise from the torchrun environment; returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def broadcast_parameters(models, src=0, group=None):
+    """Make every rank start from rank ``src``'s weights (DataParallel replicates module 0)."""
+    for name in sorted(models):
+        for p in models[name].parameters():
+            dist.broadcast(p.data, src, group=group)
+
+
+def shard_seed(base_seed, rank):
+    """Per-rank data seed: ranks draw disjoint synthetic patches (weak scaling, 8 patches per GPU)."""
+    return base_seed + rank
+
+
+def average_gradients(models, group=None):
+    """Flat per-model all-reduce + mean, written back into ``p.grad`` (the un-fused path)."""
+    world = dist.get_world_size(group)
+    for name in sorted(models):
+        params = [p for p in models[name].parameters() if p.grad is not None]
+        if not params:
+            continue
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat, group=group)
+        flat.div_(world)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad = flat[off:off + n].view(p.shape)
+            off += n
+
+
+def max_over_ranks(value, device):
+    """The bench clock: MAX of a python float over ranks."""
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()

@@ -1,0 +1,30 @@
+"""MI355X-native ``sbmc.KPCN`` (constructed at ``train_kpcn.py:213,229``; result keys consumed
+at ``support/interfaces.py:207-211``).  Same specification as ``oracle/models.py``."""
+import torch
+import torch.nn as nn
+
+from .modules import ConvChain, KernelApply
+from .support.utils import crop_like
+
+
+class KPCN(nn.Module):
+    def __init__(self, n_in, ksize=21, depth=9, width=100):
+        super().__init__()
+        self.ksize = ksize
+        self.diffuse = ConvChain(n_in, ksize * ksize, depth=depth, width=width, ksize=5, pad=False,
+                                 output_type="linear")
+        self.specular = ConvChain(n_in, ksize * ksize, depth=depth, width=width, ksize=5, pad=False,
+                                  output_type="linear")
+        self.kernel_apply = KernelApply(softmax=True, splat=False)
+
+    def forward(self, data):
+        k_diffuse = self.diffuse(data["kpcn_diffuse_in"])
+        k_specular = self.specular(data["kpcn_specular_in"])
+        b_diffuse = crop_like(data["kpcn_diffuse_buffer"], k_diffuse)
+        b_specular = crop_like(data["kpcn_specular_buffer"], k_specular)
+        r_diffuse = self.kernel_apply(b_diffuse, k_diffuse)
+        r_specular = self.kernel_apply(b_specular, k_specular)
+        albedo = crop_like(data["kpcn_albedo"], r_diffuse)
+        # (B,3,92,92) recombination on 200 KB tensors
+        radiance = albedo * r_diffuse + torch.exp(r_specular) - 1
+        return dict(radiance=radiance, diffuse=r_diffuse, specular=r_specular)

@@ -1,0 +1,104 @@
+"""MI355X-native counterparts of the ``sbmc.modules`` pieces used by the hot path
+(``ConvChain``, ``Autoencoder``, ``KernelApply``); constructor signatures follow the
+call sites ``support/networks.py:18-24`` and ``train_kpcn.py:213``.
+
+``sbmc`` is not part of the reference tree, so the definitions are
+this build's stated specification -- identical, parameter name for parameter name, to
+the CPU oracle ``oracle/modules.py`` they are parity-tested against.  Parameters live in
+ordinary ``nn.Conv2d`` containers (``layers.<i>.weight|bias``, OIHW) so ``state_dict()``,
+``optim.Adam`` and ``clip_grad_value_`` in an unmodified caller keep working; the
+arithmetic runs in ``libwcmc_hip.so`` only.
+"""
+import torch.nn as nn
+
+from . import ops
+
+
+class ConvChain(nn.Module):
+    def __init__(self, ninputs, noutputs, ksize=3, width=64, depth=3, pad=True,
+                 activation="relu", output_type="linear"):
+        super().__init__()
+        assert depth >= 1 and activation == "relu"
+        assert output_type in ("linear", "relu", "leaky_relu")
+        self.ninputs, self.noutputs = ninputs, noutputs
+        self.ksize, self.width, self.depth = ksize, width, depth
+        self.padding = ksize // 2 if pad else 0
+        self.output_type = output_type
+        layers, cin = [], ninputs
+        for i in range(depth):
+            cout = width if i < depth - 1 else noutputs
+            layers.append(nn.Conv2d(cin, cout, ksize, padding=self.padding, bias=True))
+            cin = cout
+        self.layers = nn.ModuleList(layers)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        for conv in self.layers:
+            nn.init.xavier_uniform_(conv.weight, gain=gain)
+            nn.init.zeros_(conv.bias)
+
+    def forward(self, x):
+        acts = ["relu"] * (self.depth - 1) + [self.output_type]
+        params = []
+        for conv in self.layers:
+            params += [conv.weight, conv.bias]
+        return ops.conv_chain(x, self.ksize, self.padding, acts, params)
+
+
+class _Level(nn.Module):
+    def __init__(self, n_in, n_out, width, num_convs, ksize, output_type, next_level=None, n_up=None):
+        super().__init__()
+        self.is_last = next_level is None
+        if self.is_last:
+            self.left = ConvChain(n_in, n_out, ksize=ksize, width=width, depth=num_convs, pad=True,
+                                  output_type=output_type)
+        else:
+            self.left = ConvChain(n_in, width, ksize=ksize, width=width, depth=num_convs, pad=True,
+                                  output_type="relu")
+            self.next_level = next_level
+            self.right = ConvChain(n_up + width, n_out, ksize=ksize, width=width, depth=num_convs,
+                                   pad=True, output_type=output_type)
+
+    def forward(self, x):
+        left = self.left(x)
+        if self.is_last:
+            return left
+        deeper = self.next_level(ops.maxpool2(left))
+        return self.right(ops.cat_channels(ops.upsample2(deeper), left))
+
+
+class Autoencoder(nn.Module):
+    def __init__(self, ninputs, noutputs, ksize=3, width=64, num_levels=3, num_convs=2, max_width=512,
+                 increase_factor=1.0, output_type="linear", pooling="max"):
+        super().__init__()
+        assert pooling == "max"
+        self.num_levels = num_levels
+        next_level = None
+        for lvl in range(num_levels - 1, -1, -1):
+            n_in = min(int(width * increase_factor ** (lvl - 1)), max_width)
+            w = min(int(width * increase_factor ** lvl), max_width)
+            n_up = min(int(width * increase_factor ** (lvl + 1)), max_width)
+            n_out, o_type = w, "relu"
+            if lvl == 0:
+                n_in, n_out, o_type = ninputs, noutputs, output_type
+            if lvl == num_levels - 1:
+                n_up = None
+            next_level = _Level(n_in, n_out, w, num_convs, ksize, o_type, next_level=next_level, n_up=n_up)
+        self.net = next_level
+
+    def forward(self, x):
+        div = 1 << (self.num_levels - 1)
+        assert x.shape[-1] % div == 0 and x.shape[-2] % div == 0
+        return self.net(x)
+
+
+class KernelApply(nn.Module):
+    """``sbmc.modules.KernelApply(softmax=True, splat=False)``; returns the tensor only."""
+
+    def __init__(self, softmax=True, splat=False):
+        super().__init__()
+        assert softmax and not splat, "only the softmax gather form is on the KPCN path"
+
+    def forward(self, data, kernels):
+        return ops.kernel_apply(data, kernels)

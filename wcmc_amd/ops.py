@@ -1,0 +1,459 @@
+"""Autograd wrappers over the C ABI of ``libwcmc_hip.so``.
+
+Tensors between ops are *NHWC views*: logically (N,C,H,W) torch tensors whose
+channel stride is 1 and whose pixel stride is padded to a multiple of 4 floats
+(``nhwc_empty``).  Slices / crops / concat targets stay views; every kernel takes
+explicit strides.  PyTorch here is device memory, streams and autograd plumbing
+only -- all arithmetic of the hot path runs in the HIP library.  Nothing in this
+file has a CPU path: a tensor that is not on ``cuda`` raises.
+"""
+import ctypes
+
+import torch
+
+from ._lib import check, lib
+
+ACT = {"linear": 0, "relu": 1, "leaky_relu": 2}
+LEAKY_SLOPE = 0.01
+
+# Optional per-launch timing (bench.py): HIP events recorded on the launch stream around an op.
+_PROFILER = None
+
+
+def set_profiler(prof):
+    """prof: object with .add(name, work, unit, ev_start, ev_end) or None to disable."""
+    global _PROFILER
+    _PROFILER = prof
+
+
+class _Timed:
+    def __init__(self, name, work, unit):
+        self.args = (name, work, unit)
+
+    def __enter__(self):
+        if _PROFILER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROFILER is not None:
+            self.e1.record()
+            _PROFILER.add(*self.args, self.e0, self.e1)
+        return False
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("wcmc_amd ops run on the MI355X only (got a %s tensor); "
+                               "there is no CPU path" % t.device)
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("wcmc_amd ops are fp32 (got %s)" % t.dtype)
+
+
+def nhwc_empty(n, c, h, w, device, zero=False):
+    """(n,c,h,w) tensor backed by an [n][h][w][round_up(c,4)] buffer."""
+    cp = (c + 3) // 4 * 4
+    mk = torch.zeros if zero else torch.empty
+    return mk((n, h, w, cp), device=device, dtype=torch.float32).permute(0, 3, 1, 2)[:, :c]
+
+
+def is_nhwc_view(t):
+    if t.dim() != 4 or t.stride(1) != 1:
+        return False
+    sn, _, sh, sw = t.stride()
+    return (t.data_ptr() % 16 == 0 and sn % 4 == 0 and sh % 4 == 0 and sw % 4 == 0
+            and sw >= (t.shape[1] + 3) // 4 * 4)
+
+
+def _v(t):
+    """(ptr, sn, sh, sw) of an NHWC view."""
+    return _ptr(t), t.stride(0), t.stride(2), t.stride(3)
+
+
+def to_nhwc_raw(x):
+    """Strided (N,C,H,W) -> fresh NHWC view (no autograd)."""
+    n, c, h, w = x.shape
+    out = nhwc_empty(n, c, h, w, x.device)
+    check(lib().wcmc_to_nhwc(_ptr(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3),
+                             *_v(out), n, c, h, w, _stream()), "to_nhwc")
+    return out
+
+
+def from_nhwc_raw(x):
+    """NHWC view -> contiguous NCHW (no autograd)."""
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    check(lib().wcmc_from_nhwc(*_v(x), _ptr(out), out.stride(0), out.stride(1), out.stride(2),
+                               out.stride(3), n, c, h, w, _stream()), "from_nhwc")
+    return out
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return to_nhwc_raw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return from_nhwc_raw(g) if is_nhwc_view(g) else g
+
+
+def as_nhwc(x):
+    _need_cuda(x)
+    return x if is_nhwc_view(x) else _ToNHWC.apply(x)
+
+
+def _as_nhwc_nograd(g):
+    return g if is_nhwc_view(g) else to_nhwc_raw(g)
+
+
+# ------------------------------------------------------------------------ conv chain
+def _pack(weight, mode):
+    cout, cin, ks, _ = weight.shape
+    rows, kch = (cout, cin) if mode == 0 else (cin, cout)
+    n = lib().wcmc_conv2d_packed_elems(rows, kch, ks)
+    wp = torch.empty(n, device=weight.device, dtype=torch.float32)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    check(lib().wcmc_conv2d_pack_weight(_ptr(w), _ptr(wp), cout, cin, ks, mode, _stream()), "pack_weight")
+    return wp
+
+
+def conv2d_raw(x, wp, bias, cout, ks, pad, act, gate=None, gate_act="linear", out=None):
+    """One implicit-GEMM launch: out = act(conv(x) + bias) [* act'(gate)]."""
+    n, cin, h, w = x.shape
+    ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+    if out is None:
+        out = nhwc_empty(n, cout, ho, wo, x.device)
+    g = _v(gate) if gate is not None else (_ptr(None), 0, 0, 0)
+    # algorithmic FLOPs: 2 * pixels * Cout * Cin * ks^2 of the (smaller) valid-conv side
+    pix = min(ho * wo, h * w)
+    with _Timed("conv_igemm", 2.0 * n * pix * cout * cin * ks * ks, "flop"):
+        check(lib().wcmc_conv2d_igemm(*_v(x), n, h, w, cin, _ptr(wp), _ptr(bias), *_v(out), cout, ks, pad,
+                                      ACT[act], LEAKY_SLOPE, *g, ACT[gate_act], LEAKY_SLOPE, _stream()),
+              "conv2d_igemm")
+    return out
+
+
+def conv2d_wgrad_raw(x, dy, ks, pad, weight_shape, want_bias=True):
+    n, cin, h, w = x.shape
+    cout, ho, wo = dy.shape[1], dy.shape[2], dy.shape[3]
+    nbytes = lib().wcmc_conv2d_wgrad_workspace_bytes(n, ho, wo, cout, cin, ks)
+    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty(weight_shape, device=x.device, dtype=torch.float32)
+    db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_bias else None
+    with _Timed("conv_wgrad", 2.0 * n * ho * wo * cout * cin * ks * ks, "flop"):
+        check(lib().wcmc_conv2d_wgrad(*_v(x), n, h, w, cin, *_v(dy), cout, ks, pad, _ptr(dw), _ptr(db),
+                                      _ptr(ws), ws.numel() * 4, _stream()), "conv2d_wgrad")
+    return dw, db
+
+
+def act_backward_raw(dy, y, act):
+    n, c, h, w = y.shape
+    dx = nhwc_empty(n, c, h, w, y.device)
+    check(lib().wcmc_act_backward(*_v(dy), *_v(y), *_v(dx), n, h, w, c, ACT[act], LEAKY_SLOPE, _stream()),
+          "act_backward")
+    return dx
+
+
+class _ConvChain(torch.autograd.Function):
+    """A whole ``sbmc.modules.ConvChain`` as one autograd node.
+
+    spec = (ksize, pad, [act per layer]).  params = w0, b0, w1, b1, ...
+    The backward fuses each hidden ReLU mask into the epilogue of the data-gradient
+    GEMM that produces the masked tensor.
+    """
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        ks, pad, acts = spec
+        _need_cuda(x, *params)
+        nl = len(acts)
+        xs = [x]
+        for l in range(nl):
+            w, b = params[2 * l], params[2 * l + 1]
+            wp = _pack(w, 0)
+            xs.append(conv2d_raw(xs[-1], wp, b.detach(), w.shape[0], ks, pad, acts[l]))
+        ctx.spec = spec
+        ctx.save_for_backward(*xs, *[params[2 * l] for l in range(nl)])
+        return xs[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        ks, pad, acts = ctx.spec
+        nl = len(acts)
+        saved = ctx.saved_tensors
+        xs, ws = saved[:nl + 1], saved[nl + 1:]
+        dy = _as_nhwc_nograd(dy)
+        if acts[-1] != "linear":
+            dy = act_backward_raw(dy, xs[nl], acts[-1])
+        grads = [None] * (2 * nl)
+        dx = None
+        for l in range(nl - 1, -1, -1):
+            w = ws[l]
+            dw, db = conv2d_wgrad_raw(xs[l], dy, ks, pad, w.shape)
+            grads[2 * l], grads[2 * l + 1] = dw, db
+            if l > 0 or ctx.needs_input_grad[0]:
+                wpt = _pack(w, 1)
+                gate = xs[l] if l > 0 else None
+                gate_act = acts[l - 1] if l > 0 else "linear"
+                dy = conv2d_raw(dy, wpt, None, w.shape[1], ks, ks - 1 - pad, "linear",
+                                gate=gate, gate_act=gate_act)
+                dx = dy
+        return (dx if ctx.needs_input_grad[0] else None, None, *grads)
+
+
+def conv_chain(x, ksize, pad, acts, params):
+    return _ConvChain.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
+
+
+# ------------------------------------------------------------------------ kernel apply
+class _KernelApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, logits):
+        _need_cuda(data, logits)
+        n, k2, h, w = logits.shape
+        k = int(round(k2 ** 0.5))
+        c = data.shape[1]
+        assert k * k == k2 and data.shape[0] == n and data.shape[2:] == logits.shape[2:]
+        out = torch.empty((n, c, h, w), device=logits.device, dtype=torch.float32)
+        lse = torch.empty(n * h * w, device=logits.device, dtype=torch.float32)
+        # algorithmic bytes: logits + radiance in + result out (15.13 MB per 92x92 patch-branch)
+        with _Timed("kernel_apply_fwd", 4.0 * n * h * w * (k2 + 2 * c), "byte"):
+            check(lib().wcmc_kernel_apply_fwd(*_v(logits), _ptr(data), *data.stride(), _ptr(out), *out.stride(),
+                                              _ptr(lse), n, c, h, w, k, _stream()), "kernel_apply_fwd")
+        ctx.save_for_backward(data, logits, out, lse)
+        ctx.k = k
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        data, logits, out, lse = ctx.saved_tensors
+        n, k2, h, w = logits.shape
+        c = data.shape[1]
+        dl = nhwc_empty(n, k2, h, w, logits.device)
+        dd = torch.zeros((n, c, h, w), device=logits.device, dtype=torch.float32) \
+            if ctx.needs_input_grad[0] else None
+        # algorithmic bytes: logits in + d_logits out + radiance, result and its gradient in (30.06 MB / patch-branch)
+        with _Timed("kernel_apply_bwd", 4.0 * n * h * w * (2 * k2 + 3 * c), "byte"):
+            check(lib().wcmc_kernel_apply_bwd(*_v(logits), _ptr(data), *data.stride(), _ptr(out), *out.stride(),
+                                              _ptr(g), *g.stride(), _ptr(lse), *_v(dl), _ptr(dd),
+                                              n, c, h, w, ctx.k, _stream()), "kernel_apply_bwd")
+        return dd, dl
+
+
+def kernel_apply(data, logits):
+    """softmax(k*k logits) applied as a zero-extended gather kernel over ``data``."""
+    return _KernelApply.apply(data, as_nhwc(logits))
+
+
+# ------------------------------------------------------------------------ U-Net glue
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        y = nhwc_empty(n, c, h // 2, w // 2, x.device)
+        check(lib().wcmc_maxpool2_fwd(*_v(x), *_v(y), n, h, w, c, _stream()), "maxpool2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        g = _as_nhwc_nograd(g)
+        dx = nhwc_empty(n, c, h, w, x.device)
+        check(lib().wcmc_maxpool2_bwd(*_v(x), *_v(g), *_v(dx), n, h, w, c, _stream()), "maxpool2_bwd")
+        return dx
+
+
+class _Upsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        y = nhwc_empty(n, c, 2 * h, 2 * w, x.device)
+        check(lib().wcmc_upsample2_fwd(*_v(x), *_v(y), n, h, w, c, _stream()), "upsample2_fwd")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h2, w2 = g.shape
+        g = _as_nhwc_nograd(g)
+        dx = nhwc_empty(n, c, h2 // 2, w2 // 2, g.device)
+        check(lib().wcmc_upsample2_bwd(*_v(g), *_v(dx), n, h2 // 2, w2 // 2, c, _stream()), "upsample2_bwd")
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(as_nhwc(x))
+
+
+def upsample2(x):
+    return _Upsample2.apply(as_nhwc(x))
+
+
+class _CatChannels(torch.autograd.Function):
+    """cat([a, b], 1) into one NHWC buffer (channel counts multiples of 4); backward = two views."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        n, ca, h, w = a.shape
+        cb = b.shape[1]
+        assert ca % 4 == 0, "concat offset must keep 16-byte alignment"
+        out = nhwc_empty(n, ca + cb, h, w, a.device)
+        out[:, :ca].copy_(a)      # strided device copies (plumbing, no arithmetic)
+        out[:, ca:].copy_(b)
+        ctx.ca = ca
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _as_nhwc_nograd(g)
+        return g[:, :ctx.ca], g[:, ctx.ca:]
+
+
+def cat_channels(a, b):
+    return _CatChannels.apply(as_nhwc(a), as_nhwc(b))
+
+
+# ------------------------------------------------------------------------ PathNet glue
+class _SppMean(torch.autograd.Function):
+    """(B*S,C,H,W) -> (B,C,H,W): mean over the S samples of a patch (networks.py:35-36)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        bs, c, h, w = x.shape
+        b = bs // s
+        y = nhwc_empty(b, c, h, w, x.device)
+        check(lib().wcmc_spp_reduce(*_v(x), *_v(y), b, s, h, w, c, 1.0 / s, _stream()), "spp_reduce")
+        ctx.s = s
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _as_nhwc_nograd(g)
+        b, c, h, w = g.shape
+        dx = nhwc_empty(b * ctx.s, c, h, w, g.device)
+        check(lib().wcmc_spp_broadcast(*_v(g), *_v(dx), b, ctx.s, h, w, c, 1.0 / ctx.s, 0, _stream()),
+              "spp_broadcast")
+        return dx, None
+
+
+def spp_mean(x, s):
+    return _SppMean.apply(as_nhwc(x), s)
+
+
+class _CatBroadcast(torch.autograd.Function):
+    """cat([flat (B*S,C1), repeat_S(ctx (B,C2))], 1) without materialising the repeat twice
+    (networks.py:39-40)."""
+
+    @staticmethod
+    def forward(ctx, flat, prop, s):
+        bs, c1, h, w = flat.shape
+        b, c2 = prop.shape[0], prop.shape[1]
+        assert c1 % 4 == 0 and bs == b * s
+        out = nhwc_empty(bs, c1 + c2, h, w, flat.device)
+        out[:, :c1].copy_(flat)
+        check(lib().wcmc_spp_broadcast(*_v(prop), *_v(out[:, c1:]), b, s, h, w, c2, 1.0, 0, _stream()),
+              "spp_broadcast")
+        ctx.dims = (b, s, c1, c2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, s, c1, c2 = ctx.dims
+        g = _as_nhwc_nograd(g)
+        _, _, h, w = g.shape
+        dprop = nhwc_empty(b, c2, h, w, g.device)
+        check(lib().wcmc_spp_reduce(*_v(g[:, c1:]), *_v(dprop), b, s, h, w, c2, 1.0, _stream()), "spp_reduce")
+        return g[:, :c1], dprop, None
+
+
+def cat_broadcast(flat, prop, s):
+    return _CatBroadcast.apply(as_nhwc(flat), as_nhwc(prop), s)
+
+
+# ------------------------------------------------------------------------ interface glue
+class _PBufferCat(torch.autograd.Function):
+    """cat([base, P.mean(1), P.var(1).mean(1,keepdim).detach()/S], 1)  (interfaces.py:165-176)."""
+
+    @staticmethod
+    def forward(ctx, base, p):
+        _need_cuda(base, p)
+        b, s, cp, h, w = p.shape
+        cb = base.shape[1]
+        out = nhwc_empty(b, cb + cp + 1, h, w, p.device)
+        check(lib().wcmc_pbuffer_cat_fwd(_ptr(base), *base.stride(), _ptr(p), *p.stride(), *_v(out),
+                                         b, s, cb, cp, h, w, _stream()), "pbuffer_cat_fwd")
+        ctx.dims = (b, s, cb, cp, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, s, cb, cp, h, w = ctx.dims
+        g = _as_nhwc_nograd(g)
+        dp = nhwc_empty(b * s, cp, h, w, g.device).unflatten(0, (b, s))
+        check(lib().wcmc_pbuffer_cat_bwd(*_v(g), _ptr(dp), *dp.stride(), b, s, cb, cp, h, w, _stream()),
+              "pbuffer_cat_bwd")
+        return None, dp
+
+
+def pbuffer_cat(base, p):
+    return _PBufferCat.apply(base, p)
+
+
+class _FeatureMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, ref, idx_patch, idx_batch):
+        _need_cuda(p, ref)
+        b, s, c, h, w = p.shape
+        nbytes = lib().wcmc_feature_mse_workspace_bytes(b, s, c, h, w)
+        ws = torch.empty((nbytes + 3) // 4, device=p.device, dtype=torch.float32)
+        loss = torch.empty((), device=p.device, dtype=torch.float32)
+        check(lib().wcmc_feature_mse_fwd(_ptr(p), *p.stride(), _ptr(ref), *ref.stride(),
+                                         ctypes.c_void_p(idx_patch.data_ptr()),
+                                         ctypes.c_void_p(idx_batch.data_ptr() if idx_batch is not None else 0),
+                                         _ptr(loss), _ptr(ws), ws.numel() * 4, b, s, c, h, w, _stream()),
+              "feature_mse_fwd")
+        ctx.save_for_backward(p, idx_patch, ws)
+        ctx.idx_batch = idx_batch
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, idx_patch, ws = ctx.saved_tensors
+        idx_batch = ctx.idx_batch
+        b, s, c, h, w = p.shape
+        dp = torch.empty((b, s, c, h, w), device=p.device, dtype=torch.float32)
+        g = g.contiguous()
+        check(lib().wcmc_feature_mse_bwd(_ptr(p), *p.stride(), ctypes.c_void_p(idx_patch.data_ptr()),
+                                         ctypes.c_void_p(idx_batch.data_ptr() if idx_batch is not None else 0),
+                                         _ptr(g), _ptr(dp), _ptr(ws), ws.numel() * 4, b, s, c, h, w, _stream()),
+              "feature_mse_bwd")
+        return dp, None, None, None
+
+
+def feature_mse(p, ref, idx_patch, idx_batch):
+    """idx_* are int64 DEVICE tensors (idx_batch may be None for non_local=False)."""
+    return _FeatureMSE.apply(p, ref, idx_patch, idx_batch)
+
+
+# ------------------------------------------------------------------------ optimiser
+def clip_adam_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0,
+               grad_scale=1.0):
+    """In-place fused clip_grad_value_ + Adam over flat fp32 buffers."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq)
+    check(lib().wcmc_clip_adam(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+                               clip, lr, beta1, beta2, eps, int(step), grad_scale, _stream()), "clip_adam")

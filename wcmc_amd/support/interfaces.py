@@ -1,0 +1,319 @@
+"""``support/interfaces.py:18-333`` of the reference: ``BaseInterface`` / ``KPCNInterface``.
+
+Same constructor signature, attributes (``models, optims, loss_funcs, iters, m_losses,
+best_err``), method names and error behaviour, so ``train_kpcn.train_epoch_kpcn`` /
+``validate_kpcn`` / ``train`` drive it unchanged.  Differences, all on purpose:
+
+  * the P-buffer statistics + input assembly (``interfaces.py:165-180``) is one HIP kernel
+    (``ops.pbuffer_cat``) instead of var/mean/cat;
+  * gradients may be averaged across ranks (``grad_sync``) before the clip, which is where
+    ``nn.DataParallel``'s reduce sits in the reference (``train_kpcn.py:266-269``);
+  * clip + Adam may run as the fused HIP kernel (``wcmc_amd.optim.FusedClipAdam``);
+  * the P-buffer PNG dump at ``iters % 1000 == 1`` (``interfaces.py:130-137``) is skipped when
+    ``../LLPM_results`` does not exist instead of raising FileNotFoundError.
+"""
+import os
+from abc import ABCMeta, abstractmethod
+
+import torch
+import torch.nn as nn
+
+from .. import ops as _ops
+from .utils import crop_like
+
+
+class BaseInterface(metaclass=ABCMeta):
+
+    def __init__(self, models, optims, loss_funcs, args, visual=False, use_llpm_buf=False, manif_learn=False,
+                 w_manif=0.1):
+        self.models = models
+        self.optims = optims
+        self.loss_funcs = loss_funcs
+        self.args = args
+        self.visual = visual
+        self.use_llpm_buf = use_llpm_buf
+        self.manif_learn = manif_learn
+        self.w_manif = w_manif
+
+        self.iters = 0
+        self.m_losses = {}
+        self.best_err = 1e10
+        self.fixed_batch = None
+
+    @abstractmethod
+    def to_train_mode(self):
+        pass
+
+    @abstractmethod
+    def preprocess(self, batch=None):
+        pass
+
+    @abstractmethod
+    def train_batch(self, batch):
+        pass
+
+    @abstractmethod
+    def _manifold_forward(self, batch):
+        return {}
+
+    @abstractmethod
+    def _regress_forward(self, batch):
+        return {}
+
+    @abstractmethod
+    def _backward(self, batch, out, p_buffers):
+        return {}
+
+    @abstractmethod
+    def _logging(self, loss_dict):
+        pass
+
+    @abstractmethod
+    def _optimization(self):
+        pass
+
+    @abstractmethod
+    def to_eval_mode(self):
+        pass
+
+    @abstractmethod
+    def validate_batch(self, batch):
+        pass
+
+    @abstractmethod
+    def get_epoch_summary(self, mode, norm):
+        return 0.0
+
+
+_BATCH_KEYS = ('target_total', 'target_diffuse', 'target_specular', 'kpcn_diffuse_in', 'kpcn_specular_in',
+               'kpcn_diffuse_buffer', 'kpcn_specular_buffer', 'kpcn_albedo')
+_OPTIONS = ('m11r11', 'm10r01', 'm11r01', 'm10r11')
+
+
+class KPCNInterface(BaseInterface):
+
+    def __init__(self, models, optims, loss_funcs, args, visual=False, use_llpm_buf=False, manif_learn=False,
+                 w_manif=0.1, train_branches=True, disentanglement_option="m11r11"):
+        if manif_learn:
+            assert 'backbone_diffuse' in models, "argument `models` dictionary should contain `'backbone_diffuse'` key."
+            assert 'backbone_specular' in models, "argument `models` dictionary should contain `'backbone_specular'` key."
+        assert 'dncnn' in models, "argument `models` dictionary should contain `'dncnn'` key."
+        if train_branches:
+            assert 'l_diffuse' in loss_funcs
+            assert 'l_specular' in loss_funcs
+        if manif_learn:
+            assert 'l_manif' in loss_funcs
+        assert 'l_recon' in loss_funcs
+        assert 'l_test' in loss_funcs
+        assert disentanglement_option in _OPTIONS
+
+        super(KPCNInterface, self).__init__(models, optims, loss_funcs, args, visual, use_llpm_buf, manif_learn,
+                                            w_manif)
+        self.train_branches = train_branches
+        self.disentanglement_option = disentanglement_option
+        # build-specific hooks (None = the reference's behaviour)
+        self.grad_sync = None       # callable(models) -> None, averages .grad across ranks
+        self.fused_optim = None     # wcmc_amd.optim.FusedClipAdam
+
+    def __str__(self):
+        return 'KPCNInterface'
+
+    def to_train_mode(self):
+        for model_name in self.models:
+            self.models[model_name].train()
+            assert 'optim_' + model_name in self.optims, \
+                '`optim_%s`: an optimization algorithm is not defined.' % (model_name)
+
+    def preprocess(self, batch=None):
+        for key in _BATCH_KEYS:
+            assert key in batch
+        if self.use_llpm_buf:
+            assert 'paths' in batch
+            batch.pop('_wcmc_paths_nhwc', None)     # one NHWC conversion of `paths` per step, not per run
+        self.iters += 1
+
+    # ------------------------------------------------------------------ forward pieces
+    def _split(self, p_buffers, train):
+        """Feature disentanglement (train interfaces.py:139-163, val :284-291)."""
+        c = p_buffers['diffuse'].shape[2]
+        assert c >= 2
+        opt = self.disentanglement_option
+        lo = {k: v[:, :, :c // 2, ...] for k, v in p_buffers.items()}
+        hi = {k: v[:, :, c // 2:, ...] for k, v in p_buffers.items()}
+        if not train:
+            return None, (lo if opt in ('m10r01', 'm11r01') else p_buffers)
+        if opt == 'm11r11':
+            return p_buffers, p_buffers
+        if opt == 'm10r01':
+            return hi, lo
+        if opt == 'm11r01':
+            return p_buffers, lo
+        return hi, p_buffers                      # m10r11
+
+    @staticmethod
+    def _assemble(batch, p_regress):
+        """interfaces.py:165-180: cat([in, mean_s P, var_s P .mean_c / S (detached)]) in one kernel."""
+        new_batch = {k: batch[k] for k in _BATCH_KEYS}
+        new_batch['kpcn_diffuse_in'] = _ops.pbuffer_cat(batch['kpcn_diffuse_in'], p_regress['diffuse'])
+        new_batch['kpcn_specular_in'] = _ops.pbuffer_cat(batch['kpcn_specular_in'], p_regress['specular'])
+        return new_batch
+
+    def _dump_pbuffers(self, p_buffers):
+        """interfaces.py:130-137 (debug PNGs every 1000 iterations; forces a device sync)."""
+        if not os.path.isdir('../LLPM_results'):
+            return
+        import numpy as np
+        import matplotlib.pyplot as plt
+        for br in ('diffuse', 'specular'):
+            pimg = np.mean(np.transpose(p_buffers[br].detach().cpu().numpy()[0, :, :3, ...], (2, 3, 0, 1)), 2)
+            plt.imsave('../LLPM_results/pbuf_%s_%s.png' % (self.args.model_name, br), np.clip(pimg, 0.0, 1.0))
+
+    def train_batch(self, batch, grad_hook_mode=False):
+        out_manif = None
+
+        if self.use_llpm_buf:
+            self.models['backbone_diffuse'].zero_grad()
+            self.models['backbone_specular'].zero_grad()
+            p_buffers = self._manifold_forward(batch)
+
+            if self.iters % 1000 == 1:
+                self._dump_pbuffers(p_buffers)
+
+            out_manif, p_regress = self._split(p_buffers, train=True)
+            batch = self._assemble(batch, p_regress)
+
+        self.models['dncnn'].zero_grad()
+        out = self._regress_forward(batch)
+
+        loss_dict = self._backward(batch, out, out_manif)
+
+        if grad_hook_mode:  # do not update this model
+            return
+
+        self._logging(loss_dict)
+
+        self._optimization()
+
+    def _manifold_forward(self, batch):
+        return {
+            'diffuse': self.models['backbone_diffuse'](batch),
+            'specular': self.models['backbone_specular'](batch),
+        }
+
+    def _regress_forward(self, batch):
+        return self.models['dncnn'](batch)
+
+    def _backward(self, batch, out, p_buffers):
+        assert 'radiance' in out
+        assert 'diffuse' in out
+        assert 'specular' in out
+
+        total, diffuse, specular = out['radiance'], out['diffuse'], out['specular']
+        loss_dict = {}
+        tgt_total = crop_like(batch['target_total'], total)
+
+        if self.train_branches:  # training diffuse and specular branches
+            tgt_diffuse = crop_like(batch['target_diffuse'], diffuse)
+            L_diffuse = self.loss_funcs['l_diffuse'](diffuse, tgt_diffuse)
+
+            tgt_specular = crop_like(batch['target_specular'], specular)
+            L_specular = self.loss_funcs['l_specular'](specular, tgt_specular)
+
+            if self.manif_learn:
+                p_buffer_diffuse = crop_like(p_buffers['diffuse'], diffuse)
+                L_manif_diffuse = self.loss_funcs['l_manif'](p_buffer_diffuse, tgt_diffuse)
+                L_diffuse = L_diffuse + L_manif_diffuse * self.w_manif
+
+                p_buffer_specular = crop_like(p_buffers['specular'], specular)
+                L_manif_specular = self.loss_funcs['l_manif'](p_buffer_specular, tgt_specular)
+                L_specular = L_specular + L_manif_specular * self.w_manif
+
+                loss_dict['l_manif_diffuse'] = L_manif_diffuse.detach()
+                loss_dict['l_manif_specular'] = L_manif_specular.detach()
+
+            # The reference logs `L_diffuse.detach()` and THEN adds the manifold term in place
+            # (interfaces.py:221,227): the detached alias sees the add, so what it accumulates in
+            # m_l_diffuse is L1 + w_manif * manifold.  Reproduced here on purpose.
+            loss_dict['l_diffuse'] = L_diffuse.detach()
+            loss_dict['l_specular'] = L_specular.detach()
+
+            L_diffuse.backward()
+            L_specular.backward()
+
+            with torch.no_grad():
+                L_total = self.loss_funcs['l_recon'](total, tgt_total)
+                loss_dict['l_total'] = L_total.detach()
+        else:  # post-training the entire system (no manifold term: interfaces.py:243-246)
+            L_total = self.loss_funcs['l_recon'](total, tgt_total)
+            loss_dict['l_total'] = L_total.detach()
+            L_total.backward()
+
+        with torch.no_grad():
+            loss_dict['rmse'] = self.loss_funcs['l_test'](total, tgt_total).detach()
+
+        return loss_dict
+
+    def _logging(self, loss_dict):
+        """ error handling """
+        for key in loss_dict:
+            if not torch.isfinite(loss_dict[key]).all():
+                raise RuntimeError("%s: Non-finite loss at train time." % (key))
+
+        if self.grad_sync is not None:
+            self.grad_sync(self.models)
+
+        if self.fused_optim is None:
+            for model_name in self.models:
+                nn.utils.clip_grad_value_(self.models[model_name].parameters(), clip_value=1.0)
+
+        """ logging """
+        for key in loss_dict:
+            if 'm_' + key not in self.m_losses:
+                self.m_losses['m_' + key] = torch.tensor(0.0, device=loss_dict[key].device)
+            self.m_losses['m_' + key] += loss_dict[key]
+
+    def _optimization(self):
+        if self.fused_optim is not None:
+            self.fused_optim.step(self.models, self.optims)      # clip_grad_value_(1.0) + Adam, fused
+            return
+        for model_name in self.models:
+            self.optims['optim_' + model_name].step()
+
+    def to_eval_mode(self):
+        for model_name in self.models:
+            self.models[model_name].eval()
+        self.m_losses['m_val'] = torch.tensor(0.0)
+
+    def validate_batch(self, batch):
+        p_buffers = None
+
+        if self.use_llpm_buf:
+            batch.pop('_wcmc_paths_nhwc', None)
+            p_buffers = self._manifold_forward(batch)
+            _, p_buffers = self._split(p_buffers, train=False)
+            batch = self._assemble(batch, p_buffers)
+
+        out = self._regress_forward(batch)
+
+        tgt_total = crop_like(batch['target_total'], out['radiance'])
+        L_total = self.loss_funcs['l_test'](out['radiance'], tgt_total)
+        if self.m_losses['m_val'] == 0.0 and self.m_losses['m_val'].device != L_total.device:
+            self.m_losses['m_val'] = torch.tensor(0.0, device=L_total.device)
+        self.m_losses['m_val'] += L_total.detach()
+
+        return out['radiance'], p_buffers
+
+    def get_epoch_summary(self, mode, norm):
+        if mode == 'train':
+            print('[][][]', end=' ')
+            for key in self.m_losses:
+                if key == 'm_val':
+                    continue
+                tr_l_tmp = self.m_losses[key] / (norm * 2)
+                tr_l_tmp *= 1000
+                print('%s: %.3fE-3' % (key, tr_l_tmp), end='\t')
+                self.m_losses[key] = torch.tensor(0.0, device=self.m_losses[key].device)
+            print('')
+            return -1.0
+        else:
+            return self.m_losses['m_val'].item() / (norm * 2)

@@ -1,0 +1,91 @@
+"""``support/losses.py`` of the reference on the MI355X path.
+
+``FeatureMSE`` (the path-disentangling loss, ``losses.py:9-113``) runs as the HIP op
+``wcmc_feature_mse_*``; the pairing permutations are drawn exactly as the reference draws
+them -- ``torch.randperm`` on the global CPU generator, patch then batch
+(``losses.py:35,50,105-109``) -- and handed to the kernel as explicit inputs, so
+``torch.manual_seed`` reproduces the reference's pairs.  ``RelativeMSE`` (``losses.py:245-264``)
+is evaluated on the (B,3,92,92) outputs.
+"""
+import torch
+
+from .. import ops
+
+__all__ = ["GlobalRelativeSimilarityLoss", "FeatureMSE", "RelativeMSE", "SMAPE", "TonemappedMSE",
+           "TonemappedRelativeMSE"]
+
+
+class FeatureMSE(torch.nn.Module):
+    """Feature Mean-Squared Error. Path disentangling loss"""
+
+    def __init__(self, color='rgb', non_local=True):
+        super(FeatureMSE, self).__init__()
+        if color != 'rgb':
+            raise NotImplementedError("FeatureMSE(color=%r): only 'rgb' is on the KPCN-Manifold path "
+                                      "(no caller of the reference uses 'hls')" % (color,))
+        self.color = color
+        self.non_local = non_local
+        self.last_perms = None
+        print('FeatureMSE locality: %s' % ('Non-local' if non_local else 'Local'))
+
+    def draw_permutations(self, b, s, h, w):
+        idx_patch = torch.randperm(s * h * w)
+        idx_batch = torch.randperm(b * s * h * w) if self.non_local else None
+        return idx_patch, idx_batch
+
+    def forward(self, p_buffer, ref, perms=None):
+        """p_buffer (B,S,C,H,W) embedded paths, ref (B,3,H,W) reference radiance -> 0-d loss."""
+        b, s, c, h, w = p_buffer.shape
+        idx_patch, idx_batch = perms if perms is not None else self.draw_permutations(b, s, h, w)
+        self.last_perms = (idx_patch, idx_batch)
+        dev = p_buffer.device
+        ip = idx_patch.to(dev, non_blocking=True)
+        ib = idx_batch.to(dev, non_blocking=True) if idx_batch is not None else None
+        loss = ops.feature_mse(p_buffer, ref, ip, ib)
+        # A non-finite P or reference poisons every displacement it takes part in, so the check
+        # the reference makes on the inputs (losses.py:99-102) is made on the scalar instead.
+        if not torch.isfinite(loss.detach()):
+            raise RuntimeError("Infinite loss at train time.")
+        return loss
+
+
+class GlobalRelativeSimilarityLoss(torch.nn.Module):
+    """``losses.py:116-211``.  Alternative manifold loss (``--manif_loss GRS``); SURVEY.md section 8f
+    'next' row -- not built yet, so it fails loudly instead of running anywhere else."""
+
+    def __init__(self, alpha=2, color='rgb'):
+        super(GlobalRelativeSimilarityLoss, self).__init__()
+        self.color = color
+        self.alpha = alpha
+
+    def forward(self, p_buffer, ref):
+        raise NotImplementedError("GlobalRelativeSimilarityLoss has no HIP kernel yet (SURVEY.md 8f)")
+
+
+class RelativeMSE(torch.nn.Module):
+    """0.5 * mean((im - ref)^2 / (ref^2 + eps))  (``losses.py:245-264``)."""
+
+    def __init__(self, eps=1e-2):
+        super(RelativeMSE, self).__init__()
+        self.eps = eps
+
+    def forward(self, im, ref):
+        mse = torch.pow(im - ref, 2)
+        return 0.5 * torch.mean(mse / (torch.pow(ref, 2) + self.eps))
+
+
+def _unbuilt(name):
+    class _Loss(torch.nn.Module):
+        def __init__(self, eps=1e-2):
+            super().__init__()
+            self.eps = eps
+
+        def forward(self, im, ref):
+            raise NotImplementedError("%s is used only by the SBMC/LBMC scripts (SURVEY.md 8f)" % name)
+    _Loss.__name__ = name
+    return _Loss
+
+
+SMAPE = _unbuilt("SMAPE")
+TonemappedMSE = _unbuilt("TonemappedMSE")
+TonemappedRelativeMSE = _unbuilt("TonemappedRelativeMSE")

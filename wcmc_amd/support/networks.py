@@ -1,0 +1,52 @@
+"""``support/networks.py:7-42`` of the reference: ``PathNet`` on the HIP ops.
+
+Same constructor, attributes, ``__str__`` and I/O contract: ``forward(samples)`` takes the
+batch dict and returns the per-sample P-buffer (B, S, outc, H, W) (>= 0).  The returned
+tensor is a strided view of an NHWC buffer; slicing/cropping it stays free.
+"""
+import torch.nn as nn
+
+from .. import ops
+from ..modules import Autoencoder, ConvChain
+
+
+class PathNet(nn.Module):
+    """Path embedding network"""
+
+    def __init__(self, ic, intermc=64, outc=3):
+        super(PathNet, self).__init__()
+        self.ic = ic
+        self.intermc = intermc
+        self.outc = outc
+        self.final_ic = intermc + intermc
+        self.embedding = ConvChain(ic, intermc, width=intermc, depth=3, ksize=1, pad=False)
+        self.propagation = Autoencoder(intermc, intermc, num_levels=3, increase_factor=2.0, num_convs=3,
+                                       width=intermc, ksize=3, output_type="leaky_relu", pooling="max")
+        self.final = ConvChain(self.final_ic, outc, width=self.final_ic, depth=2, ksize=1, pad=False,
+                               output_type="relu")
+
+    def __str__(self):
+        return "PathNet i{}in{}o{}".format(self.ic, self.intermc, self.outc)
+
+    @staticmethod
+    def _paths_nhwc(samples):
+        """Both backbones read the same ``paths`` (interfaces.py:195-196): convert it once."""
+        paths = samples["paths"]
+        key = (paths.data_ptr(), paths._version, tuple(paths.shape))
+        cached = samples.get("_wcmc_paths_nhwc")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        bs, spp, nf, h, w = paths.shape
+        flat = ops.as_nhwc(paths.reshape(bs * spp, nf, h, w))
+        if not paths.requires_grad:
+            samples["_wcmc_paths_nhwc"] = (key, flat)
+        return flat
+
+    def forward(self, samples):
+        bs, spp, nf, h, w = samples["paths"].shape
+        flat = self.embedding(self._paths_nhwc(samples))            # (B*S, intermc, H, W)
+        reduced = ops.spp_mean(flat, spp)                           # networks.py:36
+        propagated = self.propagation(reduced)
+        flat = ops.cat_broadcast(flat, propagated, spp)             # networks.py:39-40
+        out = self.final(flat)                                      # (B*S, outc, H, W)
+        return out.unflatten(0, (bs, spp))
