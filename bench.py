@@ -81,8 +81,6 @@ def cpu_baseline():
     from oracle.models import KPCN as OKPCN
     from oracle.networks import PathNet as OPathNet
     from wcmc_amd.synthetic import make_batch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
     models = {"dncnn": OKPCN(39), "backbone_diffuse": OPathNet(36), "backbone_specular": OPathNet(36)}
     optims = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in models.items()}
@@ -97,7 +95,19 @@ def cpu_baseline():
         ostep.train_step(models, optims, batch, cfg, perms)
         return time.perf_counter() - t0
 
-    one(1, 64)                       # thread-pool / allocator warm-up on a small patch
+    # Pick the thread count on a small patch: one thread per visible CPU is NOT the fastest on a
+    # many-core host (256 logical CPUs measured 40x slower than 8 threads), so grow while it helps.
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    best_n, best_t = None, None
+    for n in (8, 16, 32, 64, 128, 256):
+        if n > avail and best_n is not None:
+            break
+        torch.set_num_threads(min(n, avail))
+        t = one(1, 64)
+        if best_t is not None and t > 0.9 * best_t:
+            break
+        best_n, best_t = min(n, avail), t
+    torch.set_num_threads(best_n)
     t = one(1, PATCH)
     return {"value": 1.0 / t, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "1 train step of the PyTorch-CPU oracle, KPCN-Manifold C3 shape at batch 1 "

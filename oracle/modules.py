@@ -29,6 +29,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 LEAKY_SLOPE = 0.01
+# Test hook, mirror of wcmc_amd.ops.DEBUG_ACTS: post-activation outputs of every non-linear layer.
+DEBUG_ACTS = None
 
 
 def _activation(x, kind):
@@ -70,7 +72,10 @@ class ConvChain(nn.Module):
     def forward(self, x):
         for i, conv in enumerate(self.layers):
             x = conv(x)
-            x = F.relu(x) if i < self.depth - 1 else _activation(x, self.output_type)
+            kind = "relu" if i < self.depth - 1 else self.output_type
+            x = _activation(x, kind)
+            if DEBUG_ACTS is not None and kind != "linear":
+                DEBUG_ACTS.append(x.detach())
         return x
 
 

@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The oracle runs on host cores; the GPU box shows 256 logical CPUs and PyTorch's default of one
+# thread per CPU is far slower there than a modest pool.
+import torch  # noqa: E402
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -17,3 +22,35 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+class FlipCounter:
+    """Counts ReLU / LeakyReLU sign disagreements between the HIP path and the oracle.
+
+    The gradient of a ReLU network is discontinuous where a pre-activation crosses zero: two correct
+    fp32 implementations that round differently can put a unit with |pre-activation| ~ 1e-6 on opposite
+    sides, and that single unit moves every upstream weight gradient by ~1e-3 relative (measured:
+    scripts/diag_chain.py -- 2e-6 with no flip, 1e-3..6e-3 with one).  Parity tests therefore hold
+    gradients to the tight tolerance when no unit flipped and to `loose` otherwise."""
+
+    def __enter__(self):
+        from oracle import modules as om
+        from wcmc_amd import ops
+        self.om, self.ops = om, ops
+        om.DEBUG_ACTS, ops.DEBUG_ACTS = [], []
+        return self
+
+    def __exit__(self, *exc):
+        self.oracle_acts, self.hip_acts = self.om.DEBUG_ACTS, self.ops.DEBUG_ACTS
+        self.om.DEBUG_ACTS, self.ops.DEBUG_ACTS = None, None
+        return False
+
+    def flips(self):
+        assert len(self.oracle_acts) == len(self.hip_acts), (len(self.oracle_acts), len(self.hip_acts))
+        n = 0
+        for a, b in zip(self.oracle_acts, self.hip_acts):
+            n += int(((a > 0) != (b.detach().cpu() > 0)).sum())
+        return n
+
+    def tol(self, tight, loose=3e-2):
+        return tight if self.flips() == 0 else loose

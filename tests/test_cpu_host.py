@@ -1,0 +1,221 @@
+"""CPU-side checks (no GPU): the C-ABI library builds/loads and exports every declared symbol, the
+host logic of the drop-in interface against the reference goldens (with the device ops swapped for the
+oracle's by monkeypatching -- the product itself has no CPU path), the loud failure without a GPU,
+and the N>1 host path on gloo."""
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_golden as mg  # noqa: E402
+
+from oracle import losses as ol  # noqa: E402
+from oracle.step import assemble_input  # noqa: E402
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from wcmc_amd._lib import SIGNATURES, lib
+    header = open(os.path.join(ROOT, "include", "wcmc_hip.h")).read()
+    declared = set(re.findall(r"\b(wcmc_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(SIGNATURES), declared ^ set(SIGNATURES)
+    h = lib()
+    for name in declared:
+        assert getattr(h, name) is not None
+    assert h.wcmc_abi_version() == 1
+    # pure host-side size queries work without a GPU
+    assert h.wcmc_conv2d_packed_elems(100, 100, 5) == 112 * 2528
+    assert h.wcmc_conv2d_packed_elems(441, 100, 5) == 448 * 2528
+    assert h.wcmc_conv2d_wgrad_workspace_bytes(8, 92, 92, 441, 100, 5) > 0
+    assert h.wcmc_feature_mse_workspace_bytes(8, 8, 3, 92, 92) > 8 * 8 * 92 * 92 * 8
+
+
+def test_header_argument_counts_match_binding():
+    """Each ctypes signature has as many arguments as the prototype in include/wcmc_hip.h."""
+    from wcmc_amd._lib import SIGNATURES
+    header = open(os.path.join(ROOT, "include", "wcmc_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for name, (_, args) in SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, header, flags=re.S)
+        assert m, name
+        body = m.group(1).strip()
+        n = 0 if body in ("", "void") else len(body.split(","))
+        assert n == len(args), (name, n, len(args))
+
+
+def test_ops_fail_loudly_without_gpu():
+    from wcmc_amd import KPCN, ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.conv_chain(torch.zeros(1, 4, 8, 8), 3, 1, ["relu"], [torch.zeros(4, 4, 3, 3), torch.zeros(4)])
+    m = KPCN(11, ksize=5, depth=2, width=8)
+    batch = {k: torch.zeros(1, c, 16, 16) for k, c in (("kpcn_diffuse_in", 11), ("kpcn_specular_in", 11),
+             ("kpcn_diffuse_buffer", 3), ("kpcn_specular_buffer", 3), ("kpcn_albedo", 3))}
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(batch)
+    from wcmc_amd.support.losses import FeatureMSE, GlobalRelativeSimilarityLoss
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FeatureMSE()(torch.zeros(1, 2, 3, 4, 4), torch.zeros(1, 3, 4, 4))
+    with pytest.raises(NotImplementedError):
+        GlobalRelativeSimilarityLoss()(torch.zeros(1, 2, 3, 4, 4), torch.zeros(1, 3, 4, 4))
+
+
+def test_product_never_imports_oracle():
+    import subprocess
+    out = subprocess.run(["grep", "-rn", "-E", r"^\s*(from|import)\s+oracle", os.path.join(ROOT, "wcmc_amd")],
+                         capture_output=True, text=True).stdout
+    assert out == "", out
+
+
+def test_crop_like_product_matches_golden(golden_dir):
+    from wcmc_amd.support.utils import crop_like
+    d = np.load(os.path.join(golden_dir, "crop_like.npz"))
+    for i in range(int(d["n"])):
+        ss, ts = tuple(d["src_shape_%d" % i]), tuple(d["tgt_shape_%d" % i])
+        src = torch.arange(int(np.prod(ss)), dtype=torch.float32).view(ss)
+        assert np.array_equal(crop_like(src, torch.zeros(ts)).numpy(), d["out_%d" % i])
+
+
+class _OracleOps:
+    """Stand-in for wcmc_amd.ops inside the interface (host-logic test only)."""
+
+    @staticmethod
+    def pbuffer_cat(base, p):
+        return assemble_input(base, p)
+
+
+class _OracleFeatureMSE(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.last_perms = None
+
+    def forward(self, p, ref):
+        b, s, c, h, w = p.shape
+        ip, ib = torch.randperm(s * h * w), torch.randperm(b * s * h * w)
+        self.last_perms = (ip, ib)
+        return ol.feature_mse(p, ref, ip, ib)
+
+
+@pytest.mark.parametrize("case", list(mg.INTERFACE_CASES))
+def test_interface_host_logic_against_reference_golden(golden_dir, case, monkeypatch):
+    """wcmc_amd.support.interfaces.KPCNInterface orchestration (splits, loss bookkeeping incl. the
+    in-place logging quirk, clip, Adam, validation, summaries) == the real reference interface."""
+    from wcmc_amd.support import interfaces as itf_mod
+    monkeypatch.setattr(itf_mod, "_ops", _OracleOps)
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    use_llpm, manif, tb, option, pout = mg.INTERFACE_CASES[case]
+    models = mg.build_models(case, 0)
+    for mn, m in models.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+          "l_test": ol.RelativeMSE()}
+    if manif:
+        lf["l_manif"] = _OracleFeatureMSE()
+    itf = itf_mod.KPCNInterface(models, optims, lf, types.SimpleNamespace(model_name="g"), use_llpm_buf=use_llpm,
+                                manif_learn=manif, w_manif=0.1, train_branches=tb, disentanglement_option=option)
+    assert str(itf) == "KPCNInterface" and itf.best_err == 1e10 and itf.iters == 0
+    itf.iters = 1
+    batch = {k[len("batch/"):]: T(d[k]) for k in d.files if k.startswith("batch/")}
+    itf.to_train_mode()
+    torch.manual_seed(int(d["seed"]))
+    itf.preprocess(batch)
+    assert itf.iters == 2
+    itf.train_batch(batch)
+    assert set("m_losses/" + k for k in itf.m_losses) == set(k for k in d.files if k.startswith("m_losses/")) - {"m_losses/m_val"}
+    for k, v in itf.m_losses.items():
+        np.testing.assert_allclose(v.item(), d["m_losses/" + k], rtol=2e-5, err_msg=k)
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            np.testing.assert_allclose(p.grad.numpy(), d["grad/%s/%s" % (mn, k)], rtol=1e-4, atol=1e-7)
+    itf.to_eval_mode()
+    with torch.no_grad():
+        rad, pb = itf.validate_batch(batch)
+    np.testing.assert_allclose(rad.numpy(), d["val/radiance"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(itf.get_epoch_summary("eval", 1), d["val/summary"], rtol=1e-5)
+    assert itf.get_epoch_summary("train", 1) == -1.0
+    assert all(float(v) == 0.0 for k, v in itf.m_losses.items() if k != "m_val")
+
+
+def test_interface_asserts_like_reference():
+    from wcmc_amd.support.interfaces import KPCNInterface
+    lf = {"l_recon": None, "l_test": None}
+    with pytest.raises(AssertionError, match="dncnn"):
+        KPCNInterface({}, {}, lf, None, train_branches=False)
+    with pytest.raises(AssertionError, match="backbone_diffuse"):
+        KPCNInterface({"dncnn": None}, {}, dict(lf, l_manif=None), None, manif_learn=True, train_branches=False)
+    with pytest.raises(AssertionError):
+        KPCNInterface({"dncnn": None}, {}, lf, None, train_branches=False, disentanglement_option="m00r00")
+    itf = KPCNInterface({"dncnn": torch.nn.Linear(1, 1)}, {}, lf, None, train_branches=False)
+    with pytest.raises(AssertionError, match="optim_dncnn"):
+        itf.to_train_mode()
+    with pytest.raises(AssertionError):
+        itf.preprocess({"target_total": 0})
+
+
+def test_synthetic_batch_schema():
+    from wcmc_amd.synthetic import LOG_FLOOR, make_batch
+    b = make_batch(2, 4, 32, seed=3)
+    shapes = {"kpcn_diffuse_in": (2, 35, 32, 32), "kpcn_specular_in": (2, 35, 32, 32),
+              "kpcn_diffuse_buffer": (2, 3, 32, 32), "kpcn_specular_buffer": (2, 3, 32, 32),
+              "kpcn_albedo": (2, 3, 32, 32), "target_diffuse": (2, 3, 32, 32), "target_specular": (2, 3, 32, 32),
+              "target_total": (2, 3, 32, 32), "paths": (2, 4, 36, 32, 32)}
+    assert {k: tuple(v.shape) for k, v in b.items()} == shapes
+    assert all(v.dtype == torch.float32 and torch.isfinite(v).all() for v in b.values())
+    assert torch.equal(b["kpcn_diffuse_in"][:, :3], b["kpcn_diffuse_buffer"])          # datasets.py:1082
+    assert (b["kpcn_diffuse_in"][:, 4:7, :, 0] == 0).all()                             # zero first dx column
+    thr = b["paths"][:, :, 6:24]
+    assert (thr >= LOG_FLOOR - 1e-6).all() and (thr == thr.min()).float().mean() > 0.2  # sparse descriptors
+    assert torch.equal(make_batch(2, 4, 32, seed=3)["paths"], b["paths"])              # seeded
+    assert "paths" not in make_batch(1, 2, 16, use_llpm=False) and make_batch(1, 2, 16, use_llpm=False)["kpcn_diffuse_in"].shape[1] == 34
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from wcmc_amd import distributed as wd
+    r, w, _ = wd.init("gloo")
+    torch.manual_seed(100 + rank)
+    models = {"dncnn": torch.nn.Linear(4, 3), "backbone_diffuse": torch.nn.Linear(2, 2)}
+    wd.broadcast_parameters(models)
+    w0 = torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()]).clone()
+    for i, m in enumerate(models.values()):
+        for p in m.parameters():
+            p.grad = torch.full_like(p, float(rank + 1 + i))
+    wd.average_gradients(models)
+    g = torch.cat([p.grad.reshape(-1) for m in models.values() for p in m.parameters()])
+    t = wd.max_over_ranks(float(rank), torch.device("cpu"))
+    q.put((rank, w0.tolist(), g.tolist(), t, wd.shard_seed(7, rank)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_average_and_broadcast():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, w0, g0, t0, s0), (r1, w1, g1, t1, s1) = res
+    assert w0 == w1                                     # rank 0's weights everywhere
+    assert g0 == g1                                     # same averaged gradient on both ranks
+    assert set(g0) == {1.5, 2.5}                        # mean of (1,2) and of (2,3)
+    assert t0 == t1 == 1.0                              # MAX over ranks
+    assert (s0, s1) == (7, 8)                           # disjoint data shards

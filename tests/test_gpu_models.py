@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 import make_golden as mg                      # noqa: E402  (geometry/builders only)
+from conftest import FlipCounter              # noqa: E402
 from oracle import step as ostep              # noqa: E402
 from oracle.models import KPCN as OKPCN       # noqa: E402
 from oracle.networks import PathNet as OPathNet   # noqa: E402
@@ -57,16 +58,17 @@ def test_pathnet_matches_oracle():
     assert str(mod) == str(ref) == "PathNet i36in16o3"
     g = torch.Generator().manual_seed(2)
     paths = torch.rand(2, 3, 36, 16, 24, generator=g) - 0.4
-    out_r = ref({"paths": paths})
-    gout = torch.rand(out_r.shape, generator=g) - 0.5
-    out_r.backward(gout)
-    batch = {"paths": paths.to(DEV)}
-    out = mod(batch)
+    with FlipCounter() as fc:
+        out_r = ref({"paths": paths})
+        gout = torch.rand(out_r.shape, generator=g) - 0.5
+        out_r.backward(gout)
+        batch = {"paths": paths.to(DEV)}
+        out = mod(batch)
     assert out.shape == out_r.shape and (out >= 0).all()
     out.backward(gout.to(DEV))
     assert_close(out, out_r, what="PathNet fwd")
     for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
-        assert_close(p.grad, q.grad, what="PathNet grad " + k)
+        assert_close(p.grad, q.grad, tol=fc.tol(1e-3), what="PathNet grad " + k)
 
 
 def test_kpcn_c1_config_matches_oracle():
@@ -78,20 +80,22 @@ def test_kpcn_c1_config_matches_oracle():
     mod = KPCN(34)
     mod.load_state_dict(ref.state_dict())
     mod.to(DEV)
+    ref = ref.double()         # fp64 oracle: the fp32 CPU path carries its own ~1e-3 rounding through 9 layers
     g = torch.Generator().manual_seed(5)
     r = lambda *s: torch.rand(*s, generator=g)
     batch = {"kpcn_diffuse_in": r(2, 34, 64, 64) - 0.3, "kpcn_specular_in": r(2, 34, 64, 64) - 0.3,
              "kpcn_diffuse_buffer": r(2, 3, 64, 64) * 2, "kpcn_specular_buffer": r(2, 3, 64, 64),
              "kpcn_albedo": r(2, 3, 64, 64) + 0.00316}
-    out_r = ref(batch)
+    with FlipCounter() as fc:
+        out_r = ref({k: v.double() for k, v in batch.items()})
+        out = mod({k: v.to(DEV) for k, v in batch.items()})
     assert out_r["radiance"].shape == (2, 3, 28, 28)
     (out_r["diffuse"].abs().mean() + out_r["specular"].abs().mean()).backward()
-    out = mod({k: v.to(DEV) for k, v in batch.items()})
     (out["diffuse"].abs().mean() + out["specular"].abs().mean()).backward()
     for k in ("radiance", "diffuse", "specular"):
-        assert_close(out[k], out_r[k], what="KPCN " + k)
+        assert_close(out[k], out_r[k], tol=1e-4, what="KPCN " + k)
     for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
-        assert_close(p.grad, q.grad, what="KPCN grad " + k)
+        assert_close(p.grad, q.grad, tol=fc.tol(1e-4), what="KPCN grad " + k)
 
 
 def build_hip_models(case, d):
@@ -139,9 +143,17 @@ def test_interface_step_against_reference_golden(golden_dir, case, fused):
     itf.iters = 1
     batch = {k[len("batch/"):]: T(d[k]).to(DEV) for k in d.files if k.startswith("batch/")}
     itf.to_train_mode()
-    torch.manual_seed(int(d["seed"]))          # the reference's draws: same generator, same order
-    itf.preprocess(batch)
-    itf.train_batch(batch)
+    # ReLU flips are counted against the oracle forward on the golden's initial weights
+    omods = mg.build_models(case, 0)
+    for mn, m in omods.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+    ocfg = dict(use_llpm_buf=use_llpm, manif_learn=False, train_branches=tb, disentanglement_option=option)
+    with FlipCounter() as fc:
+        with torch.no_grad():
+            ostep.forward_losses(omods, {k: v.cpu() for k, v in batch.items()}, ocfg, None, train=True)
+        torch.manual_seed(int(d["seed"]))          # the reference's draws: same generator, same order
+        itf.preprocess(batch)
+        itf.train_batch(batch)
     if manif and tb:
         assert np.array_equal(loss_funcs["l_manif"].last_perms[0].numpy(), d["perm/specular_patch"])
     for k in d.files:
@@ -150,7 +162,7 @@ def test_interface_step_against_reference_golden(golden_dir, case, fused):
     for mn, m in models.items():
         for k, p in m.named_parameters():
             want = T(d["grad/%s/%s" % (mn, k)])
-            assert_close(p.grad, want, tol=2e-3, what="post-clip grad %s %s" % (mn, k))
+            assert_close(p.grad, want, tol=fc.tol(1e-3), what="post-clip grad %s %s" % (mn, k))
         for k, v in m.state_dict().items():
             g = np.abs(d["grad/%s/%s" % (mn, k)])
             want, got = d["after/%s/%s" % (mn, k)], v.cpu().numpy()
@@ -187,6 +199,7 @@ def test_full_size_step_against_oracle():
     torch.manual_seed(10)
     perms = [ostep.draw_perms(1, 8, 92, 92), ostep.draw_perms(1, 8, 92, 92)]
     oopt = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in omods.items()}
+    fc = FlipCounter().__enter__()
     loss_o, out_o = ostep.train_step(omods, oopt, batch, cfg, perms)
     hopt = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in hmods.items()}
     lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
@@ -199,8 +212,9 @@ def test_full_size_step_against_oracle():
     torch.manual_seed(10)
     itf.preprocess(dbatch)
     itf.train_batch(dbatch)
+    fc.__exit__()
     for k, v in loss_o.items():
         np.testing.assert_allclose(itf.m_losses["m_" + k].item(), v.item(), rtol=1e-3, err_msg=k)
     for mn in omods:
         for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
-            assert_close(p.grad, q.grad, tol=2e-3, what="grad %s %s" % (mn, k))
+            assert_close(p.grad, q.grad, tol=fc.tol(1e-3), what="grad %s %s" % (mn, k))

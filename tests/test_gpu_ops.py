@@ -1,7 +1,8 @@
 """Parity of every HIP op (called through the C ABI) against the CPU oracle.
 
-Tolerance: the north star asks for 1e-3 relative in fp32; these tests hold the ops to 2e-4 of
-the tensor's scale (max |a-b| / max |b|) unless stated, on seeded inputs.
+Tolerance: the north star asks for 1e-3 relative in fp32; these tests hold each op to 2e-5 of the
+tensor's scale (max |a-b| / max |b|) against an fp64 reference unless stated (measured: 1e-7..3e-6,
+scripts/diag_numerics.py), on seeded inputs.
 """
 import os
 
@@ -29,7 +30,7 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def assert_close(a, b, tol=2e-4, what=""):
+def assert_close(a, b, tol=2e-5, what=""):
     assert tuple(a.shape) == tuple(b.shape), (what, a.shape, b.shape)
     e = rel_err(a, b)
     assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
@@ -109,17 +110,19 @@ def test_conv_chain_deep_matches_oracle_chain():
     mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
     mod.to(DEV)
     x = gen(2, 13, 30, 28, seed=12)
+    from conftest import FlipCounter
     xr = x.double().requires_grad_(True)
-    yr = ref(xr)
+    xd = x.to(DEV).requires_grad_(True)
+    with FlipCounter() as fc:
+        yr = ref(xr)
+        y = mod(xd)
     g = gen(*yr.shape, seed=13)
     yr.backward(g.double())
-    xd = x.to(DEV).requires_grad_(True)
-    y = mod(xd)
     y.backward(g.to(DEV))
     assert_close(y, yr, what="chain fwd")
-    assert_close(xd.grad, xr.grad, what="chain dx")
+    assert_close(xd.grad, xr.grad, tol=fc.tol(2e-5), what="chain dx")
     for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
-        assert_close(p.grad, q.grad, what="chain grad " + k)
+        assert_close(p.grad, q.grad, tol=fc.tol(2e-5), what="chain grad " + k)
 
 
 def test_conv_wgrad_is_bitwise_reproducible():

@@ -398,20 +398,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
   }
 }
 
-// dW[co][ci][tap] = sum_s slab[s][tap][co][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int S, int taps,
-                                    int Cout, int Cin, int Np, int Cq) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)taps * Cout * Cin;
-  if (idx >= total) return;
-  const int ci = (int)(idx % Cin);
-  const int64_t t2 = idx / Cin;
-  const int co = (int)(t2 % Cout), tap = (int)(t2 / Cout);
-  const float* q = slabs + ((int64_t)tap * Np + co) * Cq + ci;
+// dW[co][ci][tap] = sum_s slab[s][tap][co][ci].  One block = one cout x 64 cins x all taps:
+// slab reads are coalesced along ci, the OIHW write is contiguous ((ci, tap) row-major) after an
+// LDS transpose.  The s-loop runs in a fixed order -> bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                           int S, int taps, int Cout, int Cin, int Np, int Cq) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [64][taps + 1]
+  const int co = blockIdx.y, ci0 = blockIdx.x * 64;
+  const int LD = taps + 1;
   const int64_t sstride = (int64_t)taps * Np * Cq;
-  float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += q[s * sstride];
-  dw[((int64_t)co * Cin + ci) * taps + tap] = acc;
+  for (int e = threadIdx.x; e < taps * 64; e += 256) {
+    const int tap = e >> 6, cl = e & 63;
+    float acc = 0.f;
+    if (ci0 + cl < Cin) {
+      const float* q = slabs + ((int64_t)tap * Np + co) * Cq + ci0 + cl;
+      for (int s = 0; s < S; ++s) acc += q[s * sstride];
+    }
+    smem[cl * LD + tap] = acc;
+  }
+  __syncthreads();
+  const int ncl = min(64, Cin - ci0);
+  float* out = dw + ((int64_t)co * Cin + ci0) * taps;
+  for (int e = threadIdx.x; e < ncl * taps; e += 256) {
+    const int cl = e / taps, tap = e - cl * taps;
+    out[e] = smem[cl * LD + tap];
+  }
 }
 
 // column sums of an NHWC view: stage 1 partial[g][c], stage 2 out[c]
@@ -436,6 +447,45 @@ __global__ void colsum_partial_kernel(const float* __restrict__ dy, int64_t dsn,
     red[pg][cl] = acc;
     __syncthreads();
     if (pg == 0 && c < C) partial[(int64_t)blockIdx.x * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    __syncthreads();
+  }
+}
+// Fast path for pixel-regular views (dsh == Wo*dsw, dsn == Ho*dsh: every buffer this library
+// allocates, and channel slices of them): pixel p lives at p*dsw.  16-byte loads along channels,
+// 256/C4 pixel lanes per block, LDS tree across the pixel lanes.
+__global__ __launch_bounds__(256) void colsum_partial_flat_kernel(const float* __restrict__ dy, int64_t dsw, int C,
+                                                                   int64_t M, int64_t per_block,
+                                                                   float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float4* red = reinterpret_cast<float4*>(smem);
+  const int C4 = (C + 3) / 4;
+  const int64_t p0 = (int64_t)blockIdx.x * per_block, p1 = min(M, p0 + per_block);
+  for (int cb = 0; cb < C4; cb += 256) {           // C4 > 256 never happens on this path, kept for safety
+    const int cw = min(256, C4 - cb);
+    const int PL = 256 / cw;
+    const int c4 = threadIdx.x % cw, pl = threadIdx.x / cw;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pl < PL) {
+      const int c = (cb + c4) * 4;
+      for (int64_t p = p0 + pl; p < p1; p += PL) {
+        float4 v = *reinterpret_cast<const float4*>(dy + p * dsw + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      red[pl * cw + c4] = acc;
+    }
+    __syncthreads();
+    if (pl == 0) {
+      for (int q = 1; q < PL; ++q) {
+        const float4 v = red[q * cw + c4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      const int c = (cb + c4) * 4;
+      float* o = partial + (int64_t)blockIdx.x * C + c;
+      o[0] = acc.x;
+      if (c + 1 < C) o[1] = acc.y;
+      if (c + 2 < C) o[2] = acc.z;
+      if (c + 3 < C) o[3] = acc.w;
+    }
     __syncthreads();
   }
 }
@@ -491,14 +541,15 @@ static WgradPlan plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks) {
   const int64_t M = (int64_t)N * Ho * Wo;
   const int taps = ks * ks;
   const int64_t tiles = (int64_t)taps * pl.coBlocks * pl.ciBlocks;
-  int64_t S = ceil_div64(1536, tiles);
+  // 2 blocks/CU x 256 CUs = 512 co-resident blocks; land just under a whole number of rounds (3)
+  int64_t S = 1536 / tiles;
   const int64_t maxS = M / 256 > 0 ? M / 256 : 1;     // >= 8 stages of 32 pixels per block
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
   pl.pix_per_split = ceil_div64(ceil_div64(M, S), 32) * 32;
   pl.S = (int)ceil_div64(M, pl.pix_per_split);
   pl.slab_elems = (size_t)pl.S * taps * pl.Np * pl.Cq;
-  pl.G = (int)(M / 1024 > 0 ? (M / 1024 < 512 ? M / 1024 : 512) : 1);
+  pl.G = (int)(M / 256 > 0 ? (M / 256 < 256 ? M / 256 : 256) : 1);
   pl.per_block = ceil_div64(M, pl.G);
   pl.G = (int)ceil_div64(M, pl.per_block);
   pl.bytes = (pl.slab_elems + (size_t)pl.G * Cout) * sizeof(float);
@@ -611,13 +662,18 @@ extern "C" int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64
   int rc = pl.TM == 7 ? launch_wgrad<7>(p, st) : launch_wgrad<4>(p, st);
   if (rc) return rc;
   const int64_t total = (int64_t)ks * ks * Cout * Cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, p.slabs, dw, pl.S,
-                     ks * ks, Cout, Cin, pl.Np, pl.Cq);
+  (void)total;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)Cout), dim3(256),
+                     (size_t)64 * (ks * ks + 1) * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq);
   rc = check_launch("conv2d_wgrad_reduce");
   if (rc || !db) return rc;
   float* partial = (float*)workspace + pl.slab_elems;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)pl.G), dim3(256), 0, st, dy, dsn, dsh, dsw, Ho, Wo, Cout,
-                     p.M, pl.per_block, partial);
+  if (dsh == (int64_t)Wo * dsw && dsn == (int64_t)Ho * dsh && (Cout + 3) / 4 <= 256)
+    hipLaunchKernelGGL(colsum_partial_flat_kernel, dim3((unsigned)pl.G), dim3(256), 256 * sizeof(float4), st, dy, dsw,
+                       Cout, p.M, pl.per_block, partial);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)pl.G), dim3(256), 0, st, dy, dsn, dsh, dsw, Ho, Wo, Cout,
+                       p.M, pl.per_block, partial);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, st, partial, pl.G, Cout,
                      db);
   return check_launch("conv2d_bias_grad");

@@ -168,12 +168,30 @@ def act_backward_raw(dy, y, act):
     return dx
 
 
+# Test hook: when a list, every chain forward appends its post-activation layer outputs (used by the
+# parity tests to count ReLU sign flips against the oracle; a flipped unit changes gradients by ~1e-3).
+DEBUG_ACTS = None
+
+_SIDE_STREAMS = {}
+USE_SIDE_STREAM = True      # weight-gradient GEMMs run beside the data-gradient GEMMs
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class _ConvChain(torch.autograd.Function):
     """A whole ``sbmc.modules.ConvChain`` as one autograd node.
 
     spec = (ksize, pad, [act per layer]).  params = w0, b0, w1, b1, ...
     The backward fuses each hidden ReLU mask into the epilogue of the data-gradient
-    GEMM that produces the masked tensor.
+    GEMM that produces the masked tensor, and puts the weight-gradient GEMM of layer l
+    on a second HIP stream: it only depends on (x_l, dy_l), so it fills the CUs that the
+    tail of the data-gradient launch of the same layer leaves idle (a launch is a whole
+    number of 512-block waves on 256 CUs).
     """
 
     @staticmethod
@@ -188,6 +206,8 @@ class _ConvChain(torch.autograd.Function):
             xs.append(conv2d_raw(xs[-1], wp, b.detach(), w.shape[0], ks, pad, acts[l]))
         ctx.spec = spec
         ctx.save_for_backward(*xs, *[params[2 * l] for l in range(nl)])
+        if DEBUG_ACTS is not None:
+            DEBUG_ACTS.extend(t for t, a in zip(xs[1:], acts) if a != "linear")
         return xs[-1]
 
     @staticmethod
@@ -201,9 +221,20 @@ class _ConvChain(torch.autograd.Function):
             dy = act_backward_raw(dy, xs[nl], acts[-1])
         grads = [None] * (2 * nl)
         dx = None
+        main = torch.cuda.current_stream()
+        side = _side_stream(dy.device) if USE_SIDE_STREAM else None
+        keep = []                       # every dy stays allocated until the side stream has joined
         for l in range(nl - 1, -1, -1):
             w = ws[l]
-            dw, db = conv2d_wgrad_raw(xs[l], dy, ks, pad, w.shape)
+            if side is not None:
+                side.wait_stream(main)                      # dy_l is ready
+                with torch.cuda.stream(side):
+                    dw, db = conv2d_wgrad_raw(xs[l], dy, ks, pad, w.shape)
+                dw.record_stream(main)
+                db.record_stream(main)
+                keep.append(dy)
+            else:
+                dw, db = conv2d_wgrad_raw(xs[l], dy, ks, pad, w.shape)
             grads[2 * l], grads[2 * l + 1] = dw, db
             if l > 0 or ctx.needs_input_grad[0]:
                 wpt = _pack(w, 1)
@@ -212,6 +243,9 @@ class _ConvChain(torch.autograd.Function):
                 dy = conv2d_raw(dy, wpt, None, w.shape[1], ks, ks - 1 - pad, "linear",
                                 gate=gate, gate_act=gate_act)
                 dx = dy
+        if side is not None:
+            main.wait_stream(side)      # join: grads are visible to (and memory reuse ordered after) main
+        del keep
         return (dx if ctx.needs_input_grad[0] else None, None, *grads)
 
 
