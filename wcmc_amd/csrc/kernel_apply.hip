@@ -29,14 +29,25 @@ struct KAParams {
   int N, C, h, w, k, r, taps, nvec, halo;
 };
 
+// Reductions over the 16-lane group that owns a pixel: a DPP row is 16 lanes, and four row
+// rotations (8, 4, 2, 1) leave the full sum / max in every lane -- one VALU op per step, no LDS.
+template <int CTRL>
+__device__ __forceinline__ float dpp_ror(float v) {
+  const int iv = __builtin_bit_cast(int, v);      // old = src: every lane is enabled, no zero-init mov
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, dpp_ror<0x128>(v));
+  v = fmaxf(v, dpp_ror<0x124>(v));
+  v = fmaxf(v, dpp_ror<0x122>(v));
+  v = fmaxf(v, dpp_ror<0x121>(v));
   return v;
 }
 __device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_ror<0x128>(v);
+  v += dpp_ror<0x124>(v);
+  v += dpp_ror<0x122>(v);
+  v += dpp_ror<0x121>(v);
   return v;
 }
 
@@ -55,8 +66,12 @@ __device__ __forceinline__ void ka_load_halo(const KAParams& p, float4* halo, in
   }
 }
 
-template <bool BWD>
-__global__ __launch_bounds__(256) void kernel_apply_kernel(KAParams p) {
+// KS > 0: compile-time kernel size (21 on the KPCN path: tap -> (dy,dx) divisions fold to multiplies);
+// KS == 0: runtime p.k.  128 threads = 2 waves per 8x8 tile, 8 pixel quads per wave.
+constexpr float KA_NEG = -1.0e30f;    // logit of a tap slot beyond k*k: exp() of it is exactly 0
+
+template <bool BWD, int KS, bool C4>
+__global__ __launch_bounds__(128) void kernel_apply_kernel(KAParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float4* halo = reinterpret_cast<float4*>(smem);
   float* dacc = smem + 4 * p.halo * p.halo;       // BWD with d_data: per-halo-pixel float4 accumulators
@@ -64,70 +79,94 @@ __global__ __launch_bounds__(256) void kernel_apply_kernel(KAParams p) {
   const int tiles_x = (p.w + KA_TILE - 1) / KA_TILE;
   const int n = blockIdx.y;
   const int ty0 = (blockIdx.x / tiles_x) * KA_TILE, tx0 = (blockIdx.x % tiles_x) * KA_TILE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int kk = KS > 0 ? KS : p.k;
+  const int taps = KS > 0 ? KS * KS : p.taps;
+  const int nvec = (taps + 3) / 4;
+  constexpr int NIT = 8;                          // 64 pixels / 2 waves / 4 pixels per quad
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  // The logits stream is the whole cost: put the first pixel quad's loads in flight before anything
+  // else, and keep one quad ahead of the arithmetic after that.  Slots beyond k*k get KA_NEG so that
+  // the arithmetic below needs no per-tap predicate.
+  auto load_quad = [&](int it, float4* lv) {
+    const int pi = wave * 32 + it * 4 + q;
+    const int y = ty0 + (pi >> 3), x = tx0 + (pi & 7);
+    const bool valid = y < p.h && x < p.w;
+    const float* lrow = p.logits + (int64_t)n * p.lsn + (int64_t)y * p.lsh + (int64_t)x * p.lsw;
+#pragma unroll
+    for (int i = 0; i < KA_MAXV; ++i) {
+      const int vi = j + 16 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid && vi < nvec) v = *reinterpret_cast<const float4*>(lrow + 4 * vi);
+      v.x *= LOG2E; v.y *= LOG2E; v.z *= LOG2E; v.w *= LOG2E;      // softmax in base 2 from here on
+      if (4 * (15 + 16 * i) + 3 >= taps) {        // only the last vector(s) can run past k*k
+        const int t = 4 * vi;
+        if (t + 0 >= taps) v.x = KA_NEG;
+        if (t + 1 >= taps) v.y = KA_NEG;
+        if (t + 2 >= taps) v.z = KA_NEG;
+        if (t + 3 >= taps) v.w = KA_NEG;
+      }
+      lv[i] = v;
+    }
+  };
+  float4 lvA[KA_MAXV], lvB[KA_MAXV];
+  load_quad(0, lvA);
+
   ka_load_halo(p, halo, n, ty0, tx0);
   if (BWD && p.ddata)
     for (int i = threadIdx.x; i < 4 * p.halo * p.halo; i += blockDim.x) dacc[i] = 0.f;
-  __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = lane >> 4, j = lane & 15;
-  // halo offset (in float4 units) of each of this lane's taps; fixed for the whole kernel
+  // byte offset into the halo of each of this lane's taps (slot beyond k*k -> tap 0: weight is 0)
   int toff[KA_MAXV][4];
 #pragma unroll
   for (int i = 0; i < KA_MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int t = 4 * (j + 16 * i) + e;
-      const int dy = t / p.k, dx = t - dy * p.k;
-      toff[i][e] = t < p.taps ? dy * p.halo + dx : -1;
+      const int dy = t / kk, dx = t - dy * kk;
+      toff[i][e] = t < taps ? (dy * p.halo + dx) * 16 : 0;
     }
+  __syncthreads();
+  const char* halo_b = reinterpret_cast<const char*>(halo);
 
-  for (int it = 0; it < 4; ++it) {
-    const int pi = wave * 16 + it * 4 + q;            // pixel inside the 8x8 tile
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    float4* lv = (it & 1) ? lvB : lvA;
+    if (it + 1 < NIT) load_quad(it + 1, (it & 1) ? lvA : lvB);
+    const int pi = wave * 32 + it * 4 + q;            // pixel inside the 8x8 tile
     const int ty = pi >> 3, tx = pi & 7;
     const int y = ty0 + ty, x = tx0 + tx;
     const bool valid = y < p.h && x < p.w;            // uniform across the 16-lane group
     const int64_t pix = ((int64_t)n * p.h + y) * p.w + x;
-    const float* lrow = p.logits + (int64_t)n * p.lsn + (int64_t)y * p.lsh + (int64_t)x * p.lsw;
-    float4 lv[KA_MAXV];
-#pragma unroll
-    for (int i = 0; i < KA_MAXV; ++i) {
-      const int vi = j + 16 * i;
-      lv[i] = (valid && vi < p.nvec) ? *reinterpret_cast<const float4*>(lrow + 4 * vi)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const float4* hbase = halo + ty * p.halo + tx;    // tap (dy,dx) reads hbase[dy*halo + dx]
+    const char* hbase = halo_b + (ty * p.halo + tx) * 16;   // tap (dy,dx) reads hbase + toff
 
     if (!BWD) {
-      float m = -INFINITY;
+      float m = KA_NEG;
 #pragma unroll
-      for (int i = 0; i < KA_MAXV; ++i) {
-        const float* l = reinterpret_cast<const float*>(&lv[i]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (toff[i][e] >= 0) m = fmaxf(m, l[e]);
-      }
-      m = group16_max(m);
+      for (int i = 0; i < KA_MAXV; ++i) m = fmaxf(fmaxf(m, fmaxf(lv[i].x, lv[i].y)), fmaxf(lv[i].z, lv[i].w));
+      m = group16_max(m);                               // max of the base-2 logits
       float s = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
       for (int i = 0; i < KA_MAXV; ++i) {
         const float* l = reinterpret_cast<const float*>(&lv[i]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (toff[i][e] >= 0) {
-            const float ex = __expf(l[e] - m);
-            const float4 d = hbase[toff[i][e]];
-            s += ex; a0 += ex * d.x; a1 += ex * d.y; a2 += ex * d.z; a3 += ex * d.w;
-          }
+          const float ex = __builtin_amdgcn_exp2f(l[e] - m);
+          const float4 d = *reinterpret_cast<const float4*>(hbase + toff[i][e]);
+          s += ex; a0 = fmaf(ex, d.x, a0); a1 = fmaf(ex, d.y, a1); a2 = fmaf(ex, d.z, a2);
+          if (C4) a3 = fmaf(ex, d.w, a3);
         }
       }
-      s = group16_sum(s); a0 = group16_sum(a0); a1 = group16_sum(a1); a2 = group16_sum(a2); a3 = group16_sum(a3);
+      s = group16_sum(s); a0 = group16_sum(a0); a1 = group16_sum(a1); a2 = group16_sum(a2);
+      if (C4) a3 = group16_sum(a3);
       if (valid && j == 0) {
         const float inv = 1.f / s;
         float* o = const_cast<float*>(p.out) + (int64_t)n * p.osn + (int64_t)y * p.osh + (int64_t)x * p.osw;
         const float av[4] = {a0 * inv, a1 * inv, a2 * inv, a3 * inv};
         for (int c = 0; c < p.C; ++c) o[(int64_t)c * p.osc] = av[c];
-        if (p.lse) p.lse[pix] = m + __logf(s);
+        if (p.lse) p.lse[pix] = (m + __builtin_amdgcn_logf(s)) * 0.6931471805599453f;   // natural-log LSE
       }
     } else {
       // w_t = exp(l_t - lse);  d l_t = w_t * (g . data_t - g . out)
@@ -142,6 +181,7 @@ __global__ __launch_bounds__(256) void kernel_apply_kernel(KAParams p) {
         }
         lse = p.lse[pix];
       }
+      const float lb = lse * LOG2E;
       float* qrow = p.dlogits + (int64_t)n * p.qsn + (int64_t)y * p.qsh + (int64_t)x * p.qsw;
 #pragma unroll
       for (int i = 0; i < KA_MAXV; ++i) {
@@ -149,20 +189,19 @@ __global__ __launch_bounds__(256) void kernel_apply_kernel(KAParams p) {
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o[e] = 0.f;
-          if (toff[i][e] >= 0) {
-            const float wt = __expf(l[e] - lse);
-            const float4 d = hbase[toff[i][e]];
-            o[e] = wt * (g[0] * d.x + g[1] * d.y + g[2] * d.z + g[3] * d.w - go);
-            if (p.ddata && valid) {
-              float* da = dacc + 4 * ((ty * p.halo + tx) + toff[i][e]);
-              atomicAdd(da + 0, wt * g[0]); atomicAdd(da + 1, wt * g[1]);
-              atomicAdd(da + 2, wt * g[2]); atomicAdd(da + 3, wt * g[3]);
-            }
+          const float wt = __builtin_amdgcn_exp2f(l[e] - lb);
+          const float4 d = *reinterpret_cast<const float4*>(hbase + toff[i][e]);
+          const float gd = C4 ? fmaf(g[0], d.x, fmaf(g[1], d.y, fmaf(g[2], d.z, g[3] * d.w)))
+                              : fmaf(g[0], d.x, fmaf(g[1], d.y, g[2] * d.z));
+          o[e] = wt * (gd - go);
+          if (p.ddata && valid && 4 * (j + 16 * i) + e < taps) {
+            float* da = dacc + ((ty * p.halo + tx) * 16 + toff[i][e]) / 4;
+            atomicAdd(da + 0, wt * g[0]); atomicAdd(da + 1, wt * g[1]);
+            atomicAdd(da + 2, wt * g[2]); atomicAdd(da + 3, wt * g[3]);
           }
         }
         const int vi = j + 16 * i;
-        if (valid && vi < p.nvec) *reinterpret_cast<float4*>(qrow + 4 * vi) = make_float4(o[0], o[1], o[2], o[3]);
+        if (valid && vi < nvec) *reinterpret_cast<float4*>(qrow + 4 * vi) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
   }
@@ -208,7 +247,8 @@ extern "C" int wcmc_kernel_apply_fwd(const float* logits, int64_t lsn, int64_t l
   p.out = out; p.osn = osn; p.osc = osc; p.osh = osh; p.osw = osw; p.lse = lse;
   const dim3 grid((unsigned)(((h + KA_TILE - 1) / KA_TILE) * ((w + KA_TILE - 1) / KA_TILE)), (unsigned)N);
   const size_t lds = (size_t)p.halo * p.halo * sizeof(float4);
-  hipLaunchKernelGGL(kernel_apply_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  if (k == 21 && C <= 3) hipLaunchKernelGGL((kernel_apply_kernel<false, 21, false>), grid, dim3(128), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((kernel_apply_kernel<false, 0, true>), grid, dim3(128), lds, (hipStream_t)stream, p);
   return check_launch("kernel_apply_fwd");
 }
 
@@ -231,6 +271,7 @@ extern "C" int wcmc_kernel_apply_bwd(const float* logits, int64_t lsn, int64_t l
   p.dlogits = d_logits; p.qsn = qsn; p.qsh = qsh; p.qsw = qsw; p.ddata = d_data;
   const dim3 grid((unsigned)(((h + KA_TILE - 1) / KA_TILE) * ((w + KA_TILE - 1) / KA_TILE)), (unsigned)N);
   const size_t lds = (size_t)p.halo * p.halo * sizeof(float4) * (d_data ? 2 : 1);
-  hipLaunchKernelGGL(kernel_apply_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  if (k == 21 && C <= 3) hipLaunchKernelGGL((kernel_apply_kernel<true, 21, false>), grid, dim3(128), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((kernel_apply_kernel<true, 0, true>), grid, dim3(128), lds, (hipStream_t)stream, p);
   return check_launch("kernel_apply_bwd");
 }
