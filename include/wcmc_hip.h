@@ -103,6 +103,34 @@ int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
                       int ks, int pad, float* dw_oihw, float* db,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- split-bf16 ("bf16x3") convolution
+ * Same reference expressions as above (torch.nn.Conv2d fwd/bwd in sbmc.modules.ConvChain), computed
+ * with every fp32 operand carried as two bf16 planes hi = bf16(x), lo = bf16(x - hi) and each product
+ * as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation (~2^-17 relative per operand;
+ * 5.3x the fp32-MFMA rate).  Chain-internal "split tensors" are dense u16 [N][H][W][2][Cp],
+ * Cp = round_up(C,8), plane 0 = hi, plane 1 = lo, pad channels zero.  Packed weights:
+ * u16 wp[Np][2][Kt], k = tap*round_up(kchan,8) + c, Kt = round_up(ks*ks*Kp, 32), Np = round_up(rows,16);
+ * `mode` as for wcmc_conv2d_pack_weight. */
+size_t wcmc_split_elems(int N, int H, int W, int C);
+int wcmc_split_bf16(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, void* out_split,
+                    int N, int H, int W, int C, void* stream);
+size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks);
+int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
+                                   void* stream);
+/* Exactly one of y (fp32 NHWC view) and y_split (dense split tensor) receives the result.
+ * gate_split (optional, geometry of the output, requires y_split): fused activation-derivative
+ * mask evaluated from the hi plane of the post-activation tensor. */
+int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin,
+                             const void* wp, const float* bias,
+                             float* y, int64_t ysn, int64_t ysh, int64_t ysw, void* y_split, int Cout,
+                             int ks, int pad, int act, float slope,
+                             const void* gate_split, int gate_act, float gate_slope, void* stream);
+size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks);
+int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W, int Cin,
+                             const void* dy_split, int Cout, int ks, int pad,
+                             float* dw_oihw, float* db, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* dx = dy * act'(y) from the post-activation value y (NHWC views of equal geometry). */
 int wcmc_act_backward(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw,
                       const float* y, int64_t ysn, int64_t ysh, int64_t ysw,

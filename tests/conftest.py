@@ -24,6 +24,20 @@ def golden_dir():
     return GOLDEN
 
 
+@pytest.fixture(params=["fp32", "bf16x3"])
+def precision(request):
+    """Runs a GPU test once per conv arithmetic: exact fp32 MFMA and split-bf16 (3 bf16 MFMAs / product)."""
+    from wcmc_amd import ops
+    old = ops.PRECISION
+    ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision(old)
+
+
+def ptol(precision, fp32_tol, x3_tol):
+    return fp32_tol if precision == "fp32" else x3_tol
+
+
 class FlipCounter:
     """Counts ReLU / LeakyReLU sign disagreements between the HIP path and the oracle.
 

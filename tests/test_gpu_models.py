@@ -47,7 +47,7 @@ def randomize_bias(m, seed):
                 p.copy_(torch.rand(p.shape, generator=g) * 0.2 - 0.1)
 
 
-def test_pathnet_matches_oracle():
+def test_pathnet_matches_oracle(precision):
     from wcmc_amd.support.networks import PathNet
     torch.manual_seed(0)
     ref = OPathNet(36, intermc=16, outc=3)
@@ -71,7 +71,7 @@ def test_pathnet_matches_oracle():
         assert_close(p.grad, q.grad, tol=fc.tol(1e-3), what="PathNet grad " + k)
 
 
-def test_kpcn_c1_config_matches_oracle():
+def test_kpcn_c1_config_matches_oracle(precision):
     """BASELINE config C1: KPCN-Vanilla, 64x64, batch 2, n_in=34 (the reference's CPU-runnable case)."""
     from wcmc_amd import KPCN
     torch.manual_seed(3)
@@ -93,9 +93,9 @@ def test_kpcn_c1_config_matches_oracle():
     (out_r["diffuse"].abs().mean() + out_r["specular"].abs().mean()).backward()
     (out["diffuse"].abs().mean() + out["specular"].abs().mean()).backward()
     for k in ("radiance", "diffuse", "specular"):
-        assert_close(out[k], out_r[k], tol=1e-4, what="KPCN " + k)
+        assert_close(out[k], out_r[k], tol=1e-4 if precision == "fp32" else 1e-3, what="KPCN " + k)
     for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
-        assert_close(p.grad, q.grad, tol=fc.tol(1e-4), what="KPCN grad " + k)
+        assert_close(p.grad, q.grad, tol=fc.tol(1e-4 if precision == "fp32" else 1e-3), what="KPCN grad " + k)
 
 
 def build_hip_models(case, d):
@@ -121,7 +121,7 @@ def build_hip_models(case, d):
 
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("case", list(mg.INTERFACE_CASES))
-def test_interface_step_against_reference_golden(golden_dir, case, fused):
+def test_interface_step_against_reference_golden(golden_dir, case, fused, precision):
     """wcmc_amd.support.interfaces.KPCNInterface on the GPU vs the real reference KPCNInterface."""
     from wcmc_amd.support.interfaces import KPCNInterface
     from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
@@ -178,7 +178,7 @@ def test_interface_step_against_reference_golden(golden_dir, case, fused):
         assert_close(pb["diffuse"], T(d["val/p_diffuse"]), tol=5e-3, what="validate p_buffer")
 
 
-def test_full_size_step_against_oracle():
+def test_full_size_step_against_oracle(precision):
     """One KPCN-Manifold step at the benchmark geometry (128x128, S=8, pnet_out 3) with B=1 against the
     CPU oracle: same weights, inputs and permutations."""
     from wcmc_amd import KPCN

@@ -77,7 +77,9 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_chain_single_layer_fwd_bwd(case):
+def test_conv_chain_single_layer_fwd_bwd(case, precision):
+    from conftest import ptol
+    tol = ptol(precision, 2e-5, 1e-4)        # split-bf16 operands: ~2^-17 per operand
     n, cin, h, w, cout, ks, pad, act = case
     o = ops()
     x = gen(n, cin, h, w, seed=2)
@@ -92,13 +94,15 @@ def test_conv_chain_single_layer_fwd_bwd(case):
     y = o.conv_chain(xd, ks, pad, [act], [wd, bd])
     assert o.is_nhwc_view(y)
     y.backward(gy.to(DEV))
-    assert_close(y, yr, what="conv fwd")
-    assert_close(xd.grad, xr.grad, what="conv dgrad")
-    assert_close(wd.grad, wr.grad, what="conv wgrad")
-    assert_close(bd.grad, br.grad, what="conv bias grad")
+    assert_close(y, yr, tol=tol, what="conv fwd")
+    assert_close(xd.grad, xr.grad, tol=tol, what="conv dgrad")
+    assert_close(wd.grad, wr.grad, tol=tol, what="conv wgrad")
+    assert_close(bd.grad, br.grad, tol=tol, what="conv bias grad")
 
 
-def test_conv_chain_deep_matches_oracle_chain():
+def test_conv_chain_deep_matches_oracle_chain(precision):
+    from conftest import ptol
+    tol = ptol(precision, 2e-5, 2e-4)
     torch.manual_seed(11)
     ref = om.ConvChain(13, 25, ksize=5, width=20, depth=4, pad=False, output_type="linear").double()
     from wcmc_amd.modules import ConvChain
@@ -119,10 +123,10 @@ def test_conv_chain_deep_matches_oracle_chain():
     g = gen(*yr.shape, seed=13)
     yr.backward(g.double())
     y.backward(g.to(DEV))
-    assert_close(y, yr, what="chain fwd")
-    assert_close(xd.grad, xr.grad, tol=fc.tol(2e-5), what="chain dx")
+    assert_close(y, yr, tol=tol, what="chain fwd")
+    assert_close(xd.grad, xr.grad, tol=fc.tol(tol), what="chain dx")
     for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
-        assert_close(p.grad, q.grad, tol=fc.tol(2e-5), what="chain grad " + k)
+        assert_close(p.grad, q.grad, tol=fc.tol(tol), what="chain grad " + k)
 
 
 def test_conv_wgrad_is_bitwise_reproducible():
@@ -132,6 +136,19 @@ def test_conv_wgrad_is_bitwise_reproducible():
     a = o.conv2d_wgrad_raw(x, dy, 5, 0, (100, 100, 5, 5))
     b = o.conv2d_wgrad_raw(x, dy, 5, 0, (100, 100, 5, 5))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    xs, dys = o.split_raw(x), o.split_raw(dy)
+    a = o.conv2d_wgrad_x_raw(xs, (2, 100, 24, 24), dys, 100, 5, 0, (100, 100, 5, 5))
+    b = o.conv2d_wgrad_x_raw(xs, (2, 100, 24, 24), dys, 100, 5, 0, (100, 100, 5, 5))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_split_roundtrip_is_near_fp32():
+    o = ops()
+    x = o.to_nhwc_raw((gen(2, 37, 9, 11, seed=22) * 100).to(DEV))
+    back = o.unsplit_debug(o.split_raw(x), 2, 37, 9, 11)
+    assert_close(back, x, tol=2.0 ** -16, what="hi + lo")
+    raw = o.split_raw(x).view(torch.bfloat16).view(2, 9, 11, 2, 40)
+    assert (raw[..., 37:] == 0).all()                      # pad channels are zero
 
 
 def test_conv_rejects_bad_views():

@@ -8,6 +8,7 @@ only -- all arithmetic of the hot path runs in the HIP library.  Nothing in this
 file has a CPU path: a tensor that is not on ``cuda`` raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -15,6 +16,17 @@ from ._lib import check, lib
 
 ACT = {"linear": 0, "relu": 1, "leaky_relu": 2}
 LEAKY_SLOPE = 0.01
+
+# Arithmetic of the conv GEMMs: "bf16x3" = split-bf16 operands (hi + lo), 3 bf16 MFMAs per product,
+# fp32 accumulate (conv_bf16x3.hip); "fp32" = exact fp32 MFMA (conv.hip).  Both are HIP paths.
+PRECISION = os.environ.get("WCMC_PRECISION", "bf16x3")
+assert PRECISION in ("bf16x3", "fp32"), PRECISION
+
+
+def set_precision(mode):
+    global PRECISION
+    assert mode in ("bf16x3", "fp32"), mode
+    PRECISION = mode
 
 # Optional per-launch timing (bench.py): HIP events recorded on the launch stream around an op.
 _PROFILER = None
@@ -249,8 +261,152 @@ class _ConvChain(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None, None, *grads)
 
 
+# ---- split-bf16 chain ----------------------------------------------------------------------
+def _split_empty(n, c, h, w, device):
+    return torch.empty(lib().wcmc_split_elems(n, h, w, c), device=device, dtype=torch.int16)
+
+
+def split_raw(x):
+    """fp32 NHWC view -> dense split tensor (int16 storage of [N][H][W][2][round_up(C,8)] bf16)."""
+    n, c, h, w = x.shape
+    out = _split_empty(n, c, h, w, x.device)
+    check(lib().wcmc_split_bf16(*_v(x), _ptr(out), n, h, w, c, _stream()), "split_bf16")
+    return out
+
+
+def unsplit_debug(t, n, c, h, w):
+    """split tensor -> fp32 (N,C,H,W) with torch ops; test / debug only."""
+    cp = (c + 7) // 8 * 8
+    v = t.view(torch.bfloat16).view(n, h, w, 2, cp).float()
+    return (v[:, :, :, 0] + v[:, :, :, 1])[..., :c].permute(0, 3, 1, 2)
+
+
+def _pack_x(weight, mode):
+    cout, cin, ks, _ = weight.shape
+    rows, kch = (cout, cin) if mode == 0 else (cin, cout)
+    wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks), device=weight.device, dtype=torch.int16)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    check(lib().wcmc_conv2d_pack_weight_bf16x3(_ptr(w), _ptr(wp), cout, cin, ks, mode, _stream()),
+          "pack_weight_bf16x3")
+    return wp
+
+
+def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, gate_act="linear"):
+    """One split-bf16 implicit-GEMM launch.  xs: split tensor of dims (n,cin,h,w).
+    Returns a split tensor when out_split else an fp32 NHWC view."""
+    n, cin, h, w = dims
+    ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+    dev = xs.device
+    if out_split:
+        ysp, yf, yv = _split_empty(n, cout, ho, wo, dev), None, (_ptr(None), 0, 0, 0)
+    else:
+        yf = nhwc_empty(n, cout, ho, wo, dev)
+        ysp, yv = None, _v(yf)
+    pix = min(ho * wo, h * w)
+    with _Timed("conv_igemm", 2.0 * n * pix * cout * cin * ks * ks, "flop"):
+        check(lib().wcmc_conv2d_igemm_bf16x3(_ptr(xs), n, h, w, cin, _ptr(wp), _ptr(bias), *yv, _ptr(ysp), cout,
+                                             ks, pad, ACT[act], LEAKY_SLOPE, _ptr(gate), ACT[gate_act], LEAKY_SLOPE,
+                                             _stream()), "conv2d_igemm_bf16x3")
+    return ysp if out_split else yf
+
+
+def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape):
+    n, cin, h, w = xdims
+    ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+    nbytes = lib().wcmc_conv2d_wgrad_bf16x3_workspace_bytes(n, ho, wo, cout, cin, ks)
+    ws = torch.empty((nbytes + 3) // 4, device=xs.device, dtype=torch.float32)
+    dw = torch.empty(weight_shape, device=xs.device, dtype=torch.float32)
+    db = torch.empty(cout, device=xs.device, dtype=torch.float32)
+    with _Timed("conv_wgrad", 2.0 * n * ho * wo * cout * cin * ks * ks, "flop"):
+        check(lib().wcmc_conv2d_wgrad_bf16x3(_ptr(xs), n, h, w, cin, _ptr(dys), cout, ks, pad, _ptr(dw), _ptr(db),
+                                             _ptr(ws), ws.numel() * 4, _stream()), "conv2d_wgrad_bf16x3")
+    return dw, db
+
+
+class _ConvChainX(torch.autograd.Function):
+    """``_ConvChain`` on the split-bf16 GEMMs: intermediates live as split tensors (same bytes as
+    fp32), only the chain's input and output are fp32 NHWC views."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        ks, pad, acts = spec
+        _need_cuda(x, *params)
+        nl = len(acts)
+        n, c, h, w = x.shape
+        dims = [(n, c, h, w)]
+        xs = [split_raw(x)]
+        y = None
+        for l in range(nl):
+            wt, b = params[2 * l], params[2 * l + 1]
+            cout = wt.shape[0]
+            wp = _pack_x(wt, 0)
+            out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=(l < nl - 1))
+            hh, ww = dims[l][2] + 2 * pad - ks + 1, dims[l][3] + 2 * pad - ks + 1
+            dims.append((n, cout, hh, ww))
+            if l < nl - 1:
+                xs.append(out)
+            else:
+                y = out
+        ctx.spec, ctx.dims = spec, dims
+        keep_y = [y] if acts[-1] != "linear" else []
+        ctx.save_for_backward(*xs, *keep_y, *[params[2 * l] for l in range(nl)])
+        if DEBUG_ACTS is not None:
+            DEBUG_ACTS.extend(unsplit_debug(xs[l + 1], *dims[l + 1]) for l in range(nl - 1))
+            if acts[-1] != "linear":
+                DEBUG_ACTS.append(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ks, pad, acts = ctx.spec
+        dims = ctx.dims
+        nl = len(acts)
+        saved = ctx.saved_tensors
+        xs = saved[:nl]
+        off = nl
+        dy = _as_nhwc_nograd(dy)
+        if acts[-1] != "linear":
+            dy = act_backward_raw(dy, saved[off], acts[-1])
+            off += 1
+        ws = saved[off:]
+        dys = split_raw(dy)
+        grads = [None] * (2 * nl)
+        dx = None
+        main = torch.cuda.current_stream()
+        side = _side_stream(dy.device) if USE_SIDE_STREAM else None
+        keep = []
+        for l in range(nl - 1, -1, -1):
+            wt = ws[l]
+            cout = wt.shape[0]
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape)
+                dw.record_stream(main)
+                db.record_stream(main)
+                keep.append(dys)
+            else:
+                dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape)
+            grads[2 * l], grads[2 * l + 1] = dw, db
+            if l > 0:
+                wpt = _pack_x(wt, 1)
+                dys = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
+                                   out_split=True, gate=xs[l], gate_act=acts[l - 1])
+            elif ctx.needs_input_grad[0]:
+                wpt = _pack_x(wt, 1)
+                dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
+                                  out_split=False)
+        if side is not None:
+            main.wait_stream(side)
+        del keep
+        return (dx, None, *grads)
+
+
 def conv_chain(x, ksize, pad, acts, params):
-    return _ConvChain.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
+    fn = _ConvChainX if PRECISION == "bf16x3" else _ConvChain
+    return fn.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
 
 
 # ------------------------------------------------------------------------ kernel apply
