@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
 B_PER_GPU, SPP, PATCH = 8, 8, 128
 
@@ -51,7 +52,7 @@ class EventProfiler:
         return out
 
 
-def build_interface(device, group):
+def build_interface(device, group, rng="device"):
     from wcmc_amd import KPCN
     from wcmc_amd.optim import FusedClipAdam
     from wcmc_amd.support.interfaces import KPCNInterface
@@ -65,7 +66,7 @@ def build_interface(device, group):
     optims = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in models.items()}
     loss_funcs = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(),
                   "l_recon": torch.nn.L1Loss(), "l_test": RelativeMSE(),
-                  "l_manif": FeatureMSE(non_local=True)}
+                  "l_manif": FeatureMSE(non_local=True, rng=rng)}
     itf = KPCNInterface(models, optims, loss_funcs, types.SimpleNamespace(model_name="bench"),
                         use_llpm_buf=True, manif_learn=True, w_manif=0.1, train_branches=True,
                         disentanglement_option="m11r11")
@@ -120,6 +121,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of one hipGraph")
+    ap.add_argument("--cpu-rng", action="store_true",
+                    help="draw the FeatureMSE pairings on the global CPU generator like the reference (+46 ms/step)")
     args = ap.parse_args()
 
     from wcmc_amd import distributed as wd
@@ -132,21 +136,29 @@ def main():
     device = torch.device("cuda", local)
 
     group = torch.distributed.group.WORLD if world > 1 else None
-    itf = build_interface(device, group)
+    itf = build_interface(device, group, rng="cpu" if args.cpu_rng else "device")
     if world > 1:
         for fl in itf.fused_optim.flats.values():
             torch.distributed.broadcast(fl.flat, 0)
     batch = make_batch(B_PER_GPU, SPP, PATCH, seed=wd.shard_seed(0, rank), device=device)
     torch.manual_seed(1234 + rank)      # FeatureMSE pairings (CPU generator, losses.py:35,50)
 
-    def step():
+    def eager_step():
         itf.preprocess(batch)
         itf.train_batch(batch)
+
+    if args.eager:
+        step = eager_step
+    else:
+        from wcmc_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(itf, batch)
+        step = lambda: graphed(batch)
 
     for _ in range(args.warmup):
         step()
     prof = EventProfiler()
-    ops.set_profiler(prof)
+    if args.eager:
+        ops.set_profiler(prof)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -158,6 +170,24 @@ def main():
         torch.distributed.barrier()
     elapsed = wd.max_over_ranks(time.perf_counter() - t0, device)
     ops.set_profiler(None)
+    prof_elapsed = elapsed
+    if not args.eager:
+        # The timed region above replays one hipGraph per step (no per-kernel events inside a graph).
+        # Per-kernel durations for the roofline come from the same step launched eagerly right after,
+        # HIP events on the launch stream around every conv / kernel-apply launch (same kernels, same shapes).
+        itf.fused_optim.leave_grads = True
+        if itf.loss_funcs["l_manif"].static_perms is not None:
+            itf.loss_funcs["l_manif"].static_perms = None
+        nprof = max(2, min(5, args.steps))
+        eager_step()
+        ops.set_profiler(prof)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nprof):
+            eager_step()
+        torch.cuda.synchronize()
+        prof_elapsed = time.perf_counter() - t1
+        ops.set_profiler(None)
 
     if rank == 0:
         summ = prof.summary()
@@ -170,13 +200,14 @@ def main():
                 return None
             rate = d["work"] / (d["ms"] * 1e-3)
             if bound == "mfma":
-                ach, peak, unit = rate / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+                peak = PEAK_BF16_MFMA_TFLOPS if ops.PRECISION == "bf16x3" else PEAK_FP32_MFMA_TFLOPS
+                ach, unit = rate / 1e12, "TFLOP/s"
             else:
                 ach, peak, unit = rate / 1e9, PEAK_HBM_GBS, "GB/s"
             return {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": None, "launches": d["launches"],
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                    "share_of_step": round(d["ms"] / (elapsed * 1e3), 4)}
+                    "share_of_profiled_region": round(d["ms"] / (prof_elapsed * 1e3), 4)}
 
         conv_keys = [k for k in ("conv_igemm", "conv_wgrad") if k in summ]
         dominant = max(conv_keys, key=lambda k: summ[k]["ms"]) if conv_keys else None
@@ -185,13 +216,19 @@ def main():
             "metric": "128x128 MC patches/sec (train step), KPCN-Manifold",
             "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3" if ops.PRECISION == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: KPCN-Manifold (KPCN n_in=39 + 2xPathNet 36->3 + "
                                    "FeatureMSE w=0.1 m11r11, train_branches), 128x128, S=8 spp, "
                                    "%d patches/GPU, global batch %d" % (B_PER_GPU, global_batch),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
-                       "precision": "fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate"},
+                       "launch": "eager" if args.eager else "one hipGraph replay per step + eager all-reduce/clip+Adam",
+                       "feature_mse_rng": "cpu (reference stream)" if args.cpu_rng else "device",
+                       "precision": ("conv GEMMs: split-bf16 operands (hi+lo), 3 x v_mfma_f32_16x16x32_bf16 per "
+                                     "product, fp32 accumulate (roofline counts algorithmic FLOPs once against "
+                                     "the dense bf16 MFMA peak, so frac <= 1/3); everything else fp32")
+                       if ops.PRECISION == "bf16x3" else "fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate"},
             "roofline": roof(dominant, "mfma") if dominant else None,
             "roofline_other_conv": roof([k for k in conv_keys if k != dominant][0], "mfma")
             if len(conv_keys) > 1 else None,

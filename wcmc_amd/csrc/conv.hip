@@ -629,8 +629,8 @@ extern "C" int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64
   if (rc) return rc;
   const int64_t total = (int64_t)ks * ks * Cout * Cin;
   (void)total;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)Cout), dim3(256),
-                     (size_t)64 * (ks * ks + 1) * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + WR_CI - 1) / WR_CI), (unsigned)Cout), dim3(256),
+                     (size_t)WR_CI * (ks * ks + 1) * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq);
   rc = check_launch("conv2d_wgrad_reduce");
   if (rc || !db) return rc;
   float* partial = (float*)workspace + pl.slab_elems;
@@ -640,7 +640,7 @@ extern "C" int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64
   else
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)pl.G), dim3(256), 0, st, dy, dsn, dsh, dsw, Ho, Wo, Cout,
                        p.M, pl.per_block, partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, st, partial, pl.G, Cout,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st, partial, pl.G, Cout,
                      db);
   return check_launch("conv2d_bias_grad");
 }

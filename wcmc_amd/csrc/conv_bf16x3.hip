@@ -409,27 +409,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
   }
 }
 
-// bias gradient from a split tensor: out partial[g][c] = sum over the block's pixels of hi + lo
+// bias gradient from a split tensor: partial[g][c] = sum over the block's pixels of hi + lo.
+// One thread = 8 channels (two 16-byte loads per pixel), 256/V pixel lanes, LDS tree across them.
 __global__ __launch_bounds__(256) void colsum_split_kernel(const u16* __restrict__ dy, int Cp, int C, int64_t M,
                                                             int64_t per_block, float* __restrict__ partial) {
-  __shared__ float red[256];
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [PL][V][8]
+  const int V = Cp / 8;                      // <= 256 (C <= 2048)
+  const int PL = 256 / V;
+  const int v = threadIdx.x % V, pl = threadIdx.x / V;
   const int64_t p0 = (int64_t)blockIdx.x * per_block, p1 = min(M, p0 + per_block);
-  for (int cb = 0; cb < C; cb += 64) {
-    const int cw = min(64, C - cb), PL = 256 / cw;
-    const int c = threadIdx.x % cw, pl = threadIdx.x / cw;
-    float acc = 0.f;
-    if (pl < PL)
-      for (int64_t q = p0 + pl; q < p1; q += PL) {
-        const u16* r = dy + q * 2 * Cp + cb + c;
-        acc += bf2f(r[0]) + bf2f(r[Cp]);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (pl < PL) {
+    for (int64_t q = p0 + pl; q < p1; q += PL) {
+      const u16* r = dy + q * 2 * Cp + v * 8;
+      const uint4 h = *reinterpret_cast<const uint4*>(r), l = *reinterpret_cast<const uint4*>(r + Cp);
+      const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] += __builtin_bit_cast(float, hw[e] << 16) + __builtin_bit_cast(float, lw[e] << 16);
+        acc[2 * e + 1] += __builtin_bit_cast(float, hw[e] & 0xffff0000u) + __builtin_bit_cast(float, lw[e] & 0xffff0000u);
       }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (pl == 0) {
-      for (int q = 1; q < PL; ++q) acc += red[q * cw + c];
-      partial[(int64_t)blockIdx.x * C + cb + c] = acc;
     }
-    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) smem[(pl * V + v) * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  if (pl == 0) {
+    for (int q = 1; q < PL; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += smem[(q * V + v) * 8 + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (v * 8 + e < C) partial[(int64_t)blockIdx.x * C + v * 8 + e] = acc[e];
   }
 }
 
@@ -594,14 +605,15 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
   p.pix_per_split = pl.pix_per_split; p.Np = pl.Np; p.Cq = pl.Cq; p.coBlocks = pl.coBlocks; p.ciBlocks = pl.ciBlocks;
   int rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)Cout), dim3(256),
-                     (size_t)64 * (ks * ks + 1) * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + WR_CI - 1) / WR_CI), (unsigned)Cout), dim3(256),
+                     (size_t)WR_CI * (ks * ks + 1) * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq);
   rc = check_launch("conv2d_wgrad_bf16x3_reduce");
   if (rc || !db) return rc;
   float* partial = (float*)workspace + pl.slab_elems;
-  hipLaunchKernelGGL(colsum_split_kernel, dim3((unsigned)pl.G), dim3(256), 0, st, p.dy, p.Cpo, Cout, p.M, pl.per_block,
-                     partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, st, partial, pl.G, Cout,
+  WCMC_REQUIRE(p.Cpo / 8 <= 256, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: Cout > 2048 unsupported");
+  hipLaunchKernelGGL(colsum_split_kernel, dim3((unsigned)pl.G), dim3(256), (size_t)256 * 8 * sizeof(float), st, p.dy,
+                     p.Cpo, Cout, p.M, pl.per_block, partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st, partial, pl.G, Cout,
                      db);
   return check_launch("conv2d_bias_grad_bf16x3");
 }

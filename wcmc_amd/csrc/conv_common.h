@@ -5,26 +5,33 @@
 
 namespace wcmc {
 
-// dW[co][ci][tap] = sum_s slab[s][tap][co][ci].  One block = one cout x 64 cins x all taps:
-// slab reads are coalesced along ci, the OIHW write is contiguous ((ci, tap) row-major) after an
-// LDS transpose.  The s-loop runs in a fixed order -> bitwise reproducible.
+// dW[co][ci][tap] = sum_s slab[s][tap][co][ci].  One block = one cout x 32 cins x all taps:
+// slab reads are coalesced along ci (128 B per half wave), the OIHW write is contiguous ((ci, tap)
+// row-major) after an LDS transpose.  The s-loop runs in a fixed order -> bitwise reproducible.
+constexpr int WR_CI = 32;
 static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                           int S, int taps, int Cout, int Cin, int Np, int Cq) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [64][taps + 1]
-  const int co = blockIdx.y, ci0 = blockIdx.x * 64;
+                                                                  int S, int taps, int Cout, int Cin, int Np, int Cq) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [WR_CI][taps + 1]
+  const int co = blockIdx.y, ci0 = blockIdx.x * WR_CI;
   const int LD = taps + 1;
   const int64_t sstride = (int64_t)taps * Np * Cq;
-  for (int e = threadIdx.x; e < taps * 64; e += 256) {
-    const int tap = e >> 6, cl = e & 63;
+  for (int e = threadIdx.x; e < taps * WR_CI; e += 256) {
+    const int tap = e / WR_CI, cl = e - tap * WR_CI;
     float acc = 0.f;
     if (ci0 + cl < Cin) {
       const float* q = slabs + ((int64_t)tap * Np + co) * Cq + ci0 + cl;
-      for (int s = 0; s < S; ++s) acc += q[s * sstride];
+      int s = 0;
+      for (; s + 4 <= S; s += 4) {             // 4 independent loads in flight, summed in slab order
+        const float v0 = q[(s + 0) * sstride], v1 = q[(s + 1) * sstride];
+        const float v2 = q[(s + 2) * sstride], v3 = q[(s + 3) * sstride];
+        acc = (((acc + v0) + v1) + v2) + v3;
+      }
+      for (; s < S; ++s) acc += q[s * sstride];
     }
     smem[cl * LD + tap] = acc;
   }
   __syncthreads();
-  const int ncl = min(64, Cin - ci0);
+  const int ncl = min(WR_CI, Cin - ci0);
   float* out = dw + ((int64_t)co * Cin + ci0) * taps;
   for (int e = threadIdx.x; e < ncl * taps; e += 256) {
     const int cl = e / taps, tap = e - cl * taps;
@@ -32,13 +39,18 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
   }
 }
 
-static __global__ void colsum_final_kernel(const float* __restrict__ partial, int G, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] = sum_g partial[g][c]; 4 g-groups x 64 channels per block, fixed order.
+static __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int G, int C,
+                                                                  float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, gg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float acc = 0.f;
-  for (int g = 0; g < G; ++g) acc += partial[(int64_t)g * C + c];
-  out[c] = acc;
+  if (c < C)
+    for (int g = gg; g < G; g += 4) acc += partial[(int64_t)g * C + c];
+  red[gg][cl] = acc;
+  __syncthreads();
+  if (gg == 0 && c < C) out[c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
 }
-
 
 }  // namespace wcmc

@@ -1,0 +1,74 @@
+"""One hipGraph per training step.
+
+``KPCNInterface._forward_backward`` (two PathNet forwards, input assembly, KPCN forward, losses, both
+backward passes) is ~2,400 kernel launches whose shapes never change during training
+(``train_kpcn.py:45`` feeds fixed-size batches).  Eagerly the host needs ~40 ms to enqueue them from
+Python -- as long as the MI355X needs to run them -- so the step is captured once with
+``torch.cuda.graph`` (HIP stream capture) and replayed with one launch.  What stays eager is what
+talks to the host or other ranks: drawing the FeatureMSE pairings, the non-finite-loss check
+(``interfaces.py:254-257``), loss bookkeeping, the RCCL gradient all-reduce and the fused clip + Adam.
+"""
+import torch
+
+from . import ops
+
+
+class GraphedTrainStep:
+    """``step = GraphedTrainStep(itf, example_batch); step(batch)`` == ``itf.preprocess(batch); itf.train_batch(batch)``."""
+
+    def __init__(self, itf, batch, warmup=2):
+        self.itf = itf
+        self.static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        self.fm = itf.loss_funcs.get('l_manif') if itf.manif_learn and itf.train_branches else None
+        dev = next(iter(self.static.values())).device
+        cur = torch.cuda.current_stream()
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):                        # warm-up off the default stream (torch.cuda.graph rule)
+            for _ in range(warmup):
+                self.static.pop('_wcmc_paths_nhwc', None)
+                itf._forward_backward(self.static)
+        cur.wait_stream(s)
+        torch.cuda.synchronize()
+        if self.fm is not None:
+            # the step calls FeatureMSE twice (diffuse, specular): two static pairs of device permutations
+            ip, ib = self.fm.last_perms
+            self.perm_sizes = (ip.numel(), ib.numel() if ib is not None else 0)
+            self.perms = [(torch.empty(self.perm_sizes[0], dtype=torch.int64, device=dev),
+                           torch.empty(self.perm_sizes[1], dtype=torch.int64, device=dev) if ib is not None else None)
+                          for _ in range(2)]
+            self._draw()
+            self.fm.static_perms, self.fm._static_i, self.fm.check_finite = self.perms, 0, False
+        side = ops.USE_SIDE_STREAM
+        ops.USE_SIDE_STREAM = False                       # a captured graph is replayed as one stream
+        self.static.pop('_wcmc_paths_nhwc', None)
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.losses = itf._forward_backward(self.static)
+        finally:
+            ops.USE_SIDE_STREAM = side
+        if getattr(itf, 'fused_optim', None) is not None:
+            itf.fused_optim.leave_grads = False           # .grad must keep pointing at the captured buffers
+
+    def _draw(self):
+        """Fresh pairings, in the reference's call order (diffuse: patch, batch; specular: patch, batch)."""
+        dev = self.perms[0][0].device if self.fm.rng == 'device' else None
+        for ip, ib in self.perms:
+            ip.copy_(torch.randperm(self.perm_sizes[0], device=dev), non_blocking=True)
+            if ib is not None:
+                ib.copy_(torch.randperm(self.perm_sizes[1], device=dev), non_blocking=True)
+
+    def __call__(self, batch):
+        itf = self.itf
+        itf.preprocess(batch)                             # key asserts + iters += 1
+        for k, v in self.static.items():
+            src = batch[k]
+            if src.data_ptr() != v.data_ptr():
+                v.copy_(src, non_blocking=True)
+        if self.fm is not None:
+            self._draw()
+            self.fm._static_i = 0
+        self.graph.replay()
+        itf._logging(self.losses)
+        itf._optimization()

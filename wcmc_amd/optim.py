@@ -67,6 +67,7 @@ class _Flat:
 class FusedClipAdam:
     def __init__(self, models, optims, process_group=None, clip=1.0):
         self.clip = clip
+        self.leave_grads = True      # re-point p.grad at the clipped flat gradient like clip_grad_value_ leaves it
         self.group = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.flats = {name: _Flat(models[name], optims["optim_" + name]) for name in models}
@@ -85,7 +86,8 @@ class FusedClipAdam:
             ops.clip_adam_(fl.flat, flat_g, fl.m, fl.v, fl.steps, float(g0["lr"]), float(g0["betas"][0]),
                            float(g0["betas"][1]), float(g0["eps"]), clip=self.clip, grad_scale=1.0 / self.world)
             # leave the (averaged, clipped) gradients behind as the reference does
-            for p, gv in zip(fl.params, fl._views(flat_g)):
-                p.grad = gv
+            if self.leave_grads:
+                for p, gv in zip(fl.params, fl._views(flat_g)):
+                    p.grad = gv
             for p in fl.params:
                 optim.state[p]["step"] = torch.tensor(float(fl.steps))

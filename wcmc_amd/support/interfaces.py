@@ -168,7 +168,9 @@ class KPCNInterface(BaseInterface):
             pimg = np.mean(np.transpose(p_buffers[br].detach().cpu().numpy()[0, :, :3, ...], (2, 3, 0, 1)), 2)
             plt.imsave('../LLPM_results/pbuf_%s_%s.png' % (self.args.model_name, br), np.clip(pimg, 0.0, 1.0))
 
-    def train_batch(self, batch, grad_hook_mode=False):
+    def _forward_backward(self, batch):
+        """Everything of ``train_batch`` up to (not including) ``_logging``: no host sync inside, so
+        ``wcmc_amd.graph.GraphedTrainStep`` can capture it into one hipGraph."""
         out_manif = None
 
         if self.use_llpm_buf:
@@ -176,7 +178,7 @@ class KPCNInterface(BaseInterface):
             self.models['backbone_specular'].zero_grad()
             p_buffers = self._manifold_forward(batch)
 
-            if self.iters % 1000 == 1:
+            if self.iters % 1000 == 1 and not torch.cuda.is_current_stream_capturing():
                 self._dump_pbuffers(p_buffers)
 
             out_manif, p_regress = self._split(p_buffers, train=True)
@@ -185,7 +187,10 @@ class KPCNInterface(BaseInterface):
         self.models['dncnn'].zero_grad()
         out = self._regress_forward(batch)
 
-        loss_dict = self._backward(batch, out, out_manif)
+        return self._backward(batch, out, out_manif)
+
+    def train_batch(self, batch, grad_hook_mode=False):
+        loss_dict = self._forward_backward(batch)
 
         if grad_hook_mode:  # do not update this model
             return
@@ -255,8 +260,10 @@ class KPCNInterface(BaseInterface):
 
     def _logging(self, loss_dict):
         """ error handling """
-        for key in loss_dict:
-            if not torch.isfinite(loss_dict[key]).all():
+        keys = list(loss_dict)
+        finite = torch.isfinite(torch.stack([loss_dict[k].reshape(()) for k in keys])).tolist()   # one sync
+        for key, ok in zip(keys, finite):
+            if not ok:
                 raise RuntimeError("%s: Non-finite loss at train time." % (key))
 
         if self.grad_sync is not None:
