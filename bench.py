@@ -176,8 +176,8 @@ def main():
         # Per-kernel durations for the roofline come from the same step launched eagerly right after,
         # HIP events on the launch stream around every conv / kernel-apply launch (same kernels, same shapes).
         itf.fused_optim.leave_grads = True
-        if itf.loss_funcs["l_manif"].static_perms is not None:
-            itf.loss_funcs["l_manif"].static_perms = None
+        itf.loss_funcs["l_manif"].static_perms = None
+        itf.loss_funcs["l_manif"].check_finite = True
         nprof = max(2, min(5, args.steps))
         eager_step()
         ops.set_profiler(prof)

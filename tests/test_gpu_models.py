@@ -218,3 +218,55 @@ def test_full_size_step_against_oracle(precision):
     for mn in omods:
         for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
             assert_close(p.grad, q.grad, tol=fc.tol(1e-3), what="grad %s %s" % (mn, k))
+
+
+def test_graphed_step_equals_eager_step():
+    """GraphedTrainStep (one hipGraph replay + eager optimiser) == preprocess + train_batch, bit for bit
+    in fp32 MFMA mode (deterministic kernels, same CPU-generator pairings)."""
+    from wcmc_amd import KPCN, ops
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.optim import FusedClipAdam
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
+    from wcmc_amd.support.networks import PathNet
+    from wcmc_amd.synthetic import make_batch
+    old = ops.PRECISION
+    ops.set_precision("fp32")
+    try:
+        results = []
+        for graphed in (False, True):
+            torch.manual_seed(21)
+            kw = dict(ksize=21, depth=3, width=24)
+            models = {"dncnn": KPCN(39, **kw), "backbone_diffuse": PathNet(36, intermc=16),
+                      "backbone_specular": PathNet(36, intermc=16)}
+            for m in models.values():
+                m.to(DEV)
+            optims = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-3) for k, m in models.items()}
+            lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+                  "l_test": RelativeMSE(), "l_manif": FeatureMSE(non_local=True, rng="cpu")}
+            itf = KPCNInterface(models, optims, lf, types.SimpleNamespace(model_name="g"), use_llpm_buf=True,
+                                manif_learn=True, w_manif=0.1, train_branches=True)
+            itf.fused_optim = FusedClipAdam(models, optims)
+            itf.iters = 1
+            itf.to_train_mode()
+            batches = [make_batch(2, 4, 48, seed=30 + i, device=DEV) for i in range(3)]
+            if graphed:
+                step = GraphedTrainStep(itf, batches[0])
+            else:
+                def step(b):
+                    itf.preprocess(b)
+                    itf.train_batch(b)
+            torch.manual_seed(22)
+            for b in batches:
+                step(b)
+            results.append(({k: v.item() for k, v in itf.m_losses.items()},
+                            torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()]).cpu(),
+                            itf.iters))
+        (l0, p0, i0), (l1, p1, i1) = results
+        assert i0 == i1 == 4
+        assert l0.keys() == l1.keys()
+        for k in l0:
+            np.testing.assert_allclose(l1[k], l0[k], rtol=1e-6, err_msg=k)
+        assert torch.equal(p0, p1)
+    finally:
+        ops.set_precision(old)
