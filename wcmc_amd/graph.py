@@ -19,6 +19,7 @@ class GraphedTrainStep:
     def __init__(self, itf, batch, warmup=2):
         self.itf = itf
         self.static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        self.keys = list(self.static)                     # (PathNet stashes a converted copy of `paths` in the dict)
         self.fm = itf.loss_funcs.get('l_manif') if itf.manif_learn and itf.train_branches else None
         dev = next(iter(self.static.values())).device
         cur = torch.cuda.current_stream()
@@ -62,8 +63,8 @@ class GraphedTrainStep:
     def __call__(self, batch):
         itf = self.itf
         itf.preprocess(batch)                             # key asserts + iters += 1
-        for k, v in self.static.items():
-            src = batch[k]
+        for k in self.keys:
+            v, src = self.static[k], batch[k]
             if src.data_ptr() != v.data_ptr():
                 v.copy_(src, non_blocking=True)
         if self.fm is not None:
