@@ -102,7 +102,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16x3_kernel(XIgemmParams 
   constexpr int A_ELEMS = 2 * XBM * XLD, B_ELEMS = 2 * BN * XLD, BUF = A_ELEMS + B_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * XBM;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private 4 MB L2 each), so
+  // give each XCD one contiguous run of pixel tiles -- vertically adjacent tiles then share their 5x5
+  // halo rows through the same L2 instead of each XCD streaming the whole image (speed only).
+  int tile;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int64_t m0 = (int64_t)tile * XBM;
   const int n0 = blockIdx.y * BN;
 
   // loader mapping: 8 consecutive threads = one row's 2 planes x 4 vectors of 8 bf16
