@@ -1,0 +1,33 @@
+"""Micro-bench of the dominant kernels at the benchmark shapes (for rocprofv3 --pmc passes).
+   python3 scripts/bench_kernels.py [iters]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wcmc_amd import ops as o
+it = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dev = "cuda"
+torch.manual_seed(0)
+n, c, h = 8, 100, 116
+x = o.to_nhwc_raw(torch.randn(n, c, h, h, device=dev))
+w = torch.randn(100, 100, 5, 5, device=dev) * 0.02
+b = torch.zeros(100, device=dev)
+dy = o.to_nhwc_raw(torch.randn(n, 100, h - 4, h - 4, device=dev))
+xs, dys = o.split_raw(x), o.split_raw(dy)
+wp, wpt = o._pack_x(w, 0), o._pack_x(w, 1)
+wpf, wptf = o._pack(w, 0), o._pack(w, 1)
+logits = o.to_nhwc_raw(torch.randn(8, 441, 92, 92, device=dev))
+data = torch.rand(8, 3, 92, 92, device=dev)
+g = torch.randn(8, 3, 92, 92, device=dev)
+def run():
+    y = o.conv2d_x_raw(xs, (n, c, h, h), wp, b, 100, 5, 0, "relu", out_split=True)          # bf16x3 fwd
+    o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu")
+    o.conv2d_wgrad_x_raw(xs, (n, c, h, h), dys, 100, 5, 0, (100, 100, 5, 5))
+    o.conv2d_raw(x, wpf, b, 100, 5, 0, "relu")                                               # fp32 fwd
+    o.conv2d_wgrad_raw(x, dy, 5, 0, (100, 100, 5, 5))
+    ld = logits.clone().requires_grad_(True)
+    out = o.kernel_apply(data, ld)
+    out.backward(g)
+for _ in range(it):
+    run()
+torch.cuda.synchronize()
+print("done")
