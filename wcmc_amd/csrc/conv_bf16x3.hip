@@ -77,9 +77,19 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __res
 }
 
 // ------------------------------------------------------------------ implicit GEMM (fwd + dgrad)
+// PMC profile of the first version (profiles/): 97 % L2 hits, but 3.3 VALU + 1.5 SALU per MFMA, half of
+// the LDS cycles bank conflicts, 37 % of wave time parked on vmcnt/barrier.  Hence:
+//   * operand loads are buffer loads: out-of-image taps / rows past the tensor use an out-of-range
+//     offset and the hardware returns zeros (no branches, no zero-fill moves, 32-bit offsets);
+//   * LDS rows are 64 B (one 32-k stage of one plane) with the 16-byte slot XOR-swizzled by
+//     (row >> 1) & 3 and the lo plane shifted by 64 B: ds_read_b128 and ds_write_b128 conflict-free;
+//   * the register prefetch runs TWO stages ahead of the MFMAs.
 constexpr int XBM = 128;   // pixels per block
 constexpr int XKC = 32;    // k per LDS stage = one MFMA k-step
-constexpr int XLD = 40;    // LDS row stride in bf16 (80 B: 16-byte aligned, spreads the b128 reads)
+constexpr int XROW = 32;   // bf16 per LDS row
+constexpr unsigned XOOB = 0x80000000u;   // byte offset beyond any buffer (num_records < 2 GiB)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct XIgemmParams {
   const u16* x; int N, H, W, Cin, Cpi;
@@ -91,20 +101,22 @@ struct XIgemmParams {
   int ks, pad, act; float slope;
   int Kp, Kt, Np;
   int64_t M;
+  unsigned x_bytes, wp_bytes;
 };
 
-template <int NT>
+template <int NT, bool PADDED>
 __global__ __launch_bounds__(256, 2) void conv_igemm_bf16x3_kernel(XIgemmParams p) {
   constexpr int BN = NT * 16;
   constexpr int NJ = (BN + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
-  // per buffer: A[2 planes][XBM][XLD], B[2 planes][BN][XLD]
-  constexpr int A_ELEMS = 2 * XBM * XLD, B_ELEMS = 2 * BN * XLD, BUF = A_ELEMS + B_ELEMS;
+  // per buffer (u16 units): A hi [XBM][32], A lo at +XBM*32+32 (64 B shift), then B hi / B lo likewise
+  constexpr int A_LO = XBM * XROW + 32, A_ELEMS = 2 * XBM * XROW + 64;
+  constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
+  constexpr int BUF = A_ELEMS + B_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private 4 MB L2 each), so
-  // give each XCD one contiguous run of pixel tiles -- vertically adjacent tiles then share their 5x5
-  // halo rows through the same L2 instead of each XCD streaming the whole image (speed only).
+  // give each XCD one contiguous run of pixel tiles (speed only, any placement is correct).
   int tile;
   {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -113,11 +125,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16x3_kernel(XIgemmParams 
   const int64_t m0 = (int64_t)tile * XBM;
   const int n0 = blockIdx.y * BN;
 
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+
   // loader mapping: 8 consecutive threads = one row's 2 planes x 4 vectors of 8 bf16
   const int vq = tid & 3, pl = (tid >> 2) & 1, prow = tid >> 3;
-  int64_t abase[4]; int aiy[4], aix[4];
+  unsigned abase[4]; int aiy[4], aix[4];
   const int64_t HoWo = (int64_t)p.Ho * p.Wo;
-  const int64_t pixs = 2 * p.Cpi;                       // u16 per input pixel
+  const int pixb = 4 * p.Cpi;                           // bytes per input pixel (2 planes of bf16)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int64_t m = m0 + prow + 32 * j;
@@ -126,49 +141,48 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16x3_kernel(XIgemmParams 
       const int r = (int)(m - (int64_t)n * HoWo);
       const int oy = r / p.Wo, ox = r - oy * p.Wo;
       aiy[j] = oy - p.pad; aix[j] = ox - p.pad;
-      abase[j] = (((int64_t)n * p.H + aiy[j]) * p.W + aix[j]) * pixs + (int64_t)pl * p.Cpi;
+      abase[j] = (unsigned)((((int64_t)n * p.H + aiy[j]) * p.W + aix[j]) * pixb + pl * 2 * p.Cpi);
     } else {
-      aiy[j] = -(1 << 28); aix[j] = -(1 << 28); abase[j] = 0;
+      aiy[j] = -(1 << 28); aix[j] = -(1 << 28); abase[j] = XOOB;      // stays out of range for every tap
     }
   }
-  int ci = vq * 8, tap = 0, tdy = 0, tdx = 0;
-  while (ci >= p.Kp) { ci -= p.Kp; ++tap; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
-  const int ntaps = p.ks * p.ks;
+  unsigned wbase[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int nrow = prow + 32 * j;
+    wbase[j] = (nrow < BN && n0 + nrow < p.Np) ? (unsigned)((((n0 + nrow) * 2 + pl) * p.Kt + vq * 8) * 2) : XOOB;
+  }
+  int ci = vq * 8, tdy = 0, tdx = 0;
+  while (ci >= p.Kp) { ci -= p.Kp; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
   const int nchunks = p.Kt / XKC;
 
-  uint4 ra[4], rb[NJ];
-  auto load_chunk = [&](int c) {
-    const bool tap_ok = tap < ntaps;
-    const int64_t toff = ((int64_t)tdy * p.W + tdx) * pixs + ci;
+  auto load_chunk = [&](int c, u32x4* ra, u32x4* rb) {
+    // taps past ks*ks fall outside the tensor (or hit zero weights): no tap predicate needed
+    const unsigned toff = (unsigned)((tdy * p.W + tdx) * pixb + ci * 2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int iy = aiy[j] + tdy, ix = aix[j] + tdx;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        v = *reinterpret_cast<const uint4*>(p.x + abase[j] + toff);
-      ra[j] = v;
+      unsigned off = abase[j] + toff;
+      if (PADDED) {
+        const int iy = aiy[j] + tdy, ix = aix[j] + tdx;
+        off = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? off : XOOB;
+      }
+      ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int nrow = prow + 32 * j;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (nrow < BN && n0 + nrow < p.Np)
-        v = *reinterpret_cast<const uint4*>(p.wp + ((int64_t)(n0 + nrow) * 2 + pl) * p.Kt + (int64_t)c * XKC + vq * 8);
-      rb[j] = v;
-    }
+    for (int j = 0; j < NJ; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, wbase[j] + (unsigned)(c * XKC * 2), 0, 0);
     ci += XKC;
-    while (ci >= p.Kp) { ci -= p.Kp; ++tap; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
+    while (ci >= p.Kp) { ci -= p.Kp; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
   };
-  auto store_chunk = [&](int buf) {
-    u16* a = smem16 + buf * BUF + pl * (XBM * XLD);
-    u16* b = smem16 + buf * BUF + A_ELEMS + pl * (BN * XLD);
+  const int wslot = (vq ^ ((prow >> 1) & 3)) * 8;       // swizzled 16-byte slot of this thread's vector
+  auto store_chunk = [&](int buf, const u32x4* ra, const u32x4* rb) {
+    u16* a = smem16 + buf * BUF + pl * A_LO + wslot;
+    u16* b = smem16 + buf * BUF + A_ELEMS + pl * B_LO + wslot;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<uint4*>(a + (prow + 32 * j) * XLD + vq * 8) = ra[j];
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(a + (prow + 32 * j) * XROW) = ra[j];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int nrow = prow + 32 * j;
-      if (nrow < BN) *reinterpret_cast<uint4*>(b + nrow * XLD + vq * 8) = rb[j];
+      if (nrow < BN) *reinterpret_cast<u32x4*>(b + nrow * XROW) = rb[j];
     }
   };
 
@@ -176,26 +190,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16x3_kernel(XIgemmParams 
 #pragma unroll
   for (int j = 0; j < NT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
-  const int frow = lane & 15, fk = (lane >> 4) * 8;     // MFMA 16x16x32: lane holds k = 8*(lane>>4) .. +7
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunks) load_chunk(c + 1);
-    const u16* a = smem16 + buf * BUF + (wave * 32 + frow) * XLD + fk;
-    const u16* b = smem16 + buf * BUF + A_ELEMS + frow * XLD + fk;
+  const int frow = lane & 15;
+  const int fslot = ((lane >> 4) ^ ((frow >> 1) & 3)) * 8;   // MFMA 16x16x32: lane holds k = 8*(lane>>4) .. +7
+  auto compute = [&](int buf) {
+    const u16* a = smem16 + buf * BUF + (wave * 32 + frow) * XROW + fslot;
+    const u16* b = smem16 + buf * BUF + A_ELEMS + frow * XROW + fslot;
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      ah[i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * XLD);
-      al[i] = *reinterpret_cast<const bf16x8*>(a + XBM * XLD + i * 16 * XLD);
+      ah[i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * XROW);
+      al[i] = *reinterpret_cast<const bf16x8*>(a + A_LO + i * 16 * XROW);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(b + j * 16 * XLD);
-      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(b + BN * XLD + j * 16 * XLD);
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(b + j * 16 * XROW);
+      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(b + B_LO + j * 16 * XROW);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[i], acc[j][i], 0, 0, 0);   // small terms first
@@ -203,7 +212,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16x3_kernel(XIgemmParams 
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[i], acc[j][i], 0, 0, 0);
       }
     }
-    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+  };
+
+  // prologue: stage 0 in LDS, stage 1 in flight in the second register set
+  u32x4 ra0[4], rb0[NJ], ra1[4], rb1[NJ];
+  load_chunk(0, ra0, rb0);
+  if (nchunks > 1) load_chunk(1, ra1, rb1);
+  store_chunk(0, ra0, rb0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    // even stage c (LDS buffer 0); registers set 0 is free, set 1 holds stage c+1
+    if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
+    compute(0);
+    if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    // odd stage c+1 (LDS buffer 1); set 1 is free, set 0 holds stage c+2
+    if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
+    compute(1);
+    if (c + 2 < nchunks) store_chunk(0, ra0, rb0);
     __syncthreads();
   }
 
@@ -256,19 +283,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16x3_kernel(XIgemmParams 
 // transposing LDS load (ds_read_b64_tr_b16): the tiles sit in LDS as [pixel][channel] exactly as
 // they come from HBM, and a lane receives 4 consecutive PIXELS (= MFMA k) of its channel column.
 // Block = 64-pixel stage x (TM*16 couts) x 64 cins; waves: 2 (pixel halves = MFMA k-steps) x 2 (cin halves).
+// PMC profile of the first version: 36 % L2 hit rate and 2.7 GB fetched per launch -- the 50 blocks
+// that share a pixel range (25 taps x 2 cin blocks) ran on different XCDs at different times.  The
+// 1-D grid is therefore remapped so that one XCD runs the (tap, tile) blocks of a pixel split back to
+// back (speed only), rows of the LDS tiles are an odd multiple of 32 B and the k -> pixel assignment
+// of the transposing reads is {4g..4g+3, 16+4g..16+4g+3} (conflict-free, identical for both operands).
 struct XWgradParams {
   const u16* x; int N, H, W, Cin, Cpi;
   const u16* dy; int Ho, Wo, Cout, Cpo;
   int ks, pad;
   float* slabs; int S; int64_t M, pix_per_split;
   int Np, Cq, coBlocks, ciBlocks;
+  unsigned x_bytes, dy_bytes;
 };
+
+constexpr int xw_stride(int ch) { return ((ch / 16) & 1) ? ch : ch + 16; }   // bf16 elements; bytes = odd * 32
 
 template <int TM>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams p) {
   constexpr int PK = 64;
   constexpr int YC = TM * 16, XC = 64;
-  constexpr int SA = YC + 8, SB = XC + 8;          // bf16 row strides (16-byte aligned, odd multiple of 16 B)
+  constexpr int SA = xw_stride(YC), SB = xw_stride(XC);
   constexpr int YV = YC / 8, XV = XC / 8;          // 16-byte vectors per plane per pixel
   constexpr int NV = (2 * YV + 2 * XV) / 4;        // vectors per thread (4 threads share a pixel)
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
@@ -276,8 +311,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
   u16* Xs = smem16 + 2 * PK * SA;          // [2][PK][SB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int s = blockIdx.x, tap = blockIdx.y;
-  const int cob = blockIdx.z / p.ciBlocks, cib = blockIdx.z - cob * p.ciBlocks;
+  // block -> (split, tap, tile): XCD x (= blockIdx & 7) owns splits s = x, x+8, ...; its consecutive
+  // blocks sweep the taps and tiles of one split.
+  const int taps = p.ks * p.ks;
+  const int per_split = taps * p.coBlocks * p.ciBlocks;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int s = (local / per_split) * 8 + xcd;
+  if (s >= p.S) return;
+  const int within = local - (local / per_split) * per_split;
+  const int tap = within % taps, tileid = within / taps;
+  const int cob = tileid / p.ciBlocks, cib = tileid - cob * p.ciBlocks;
   const int co0 = cob * YC, ci0 = cib * XC;
   const int tdy = tap / p.ks - p.pad, tdx = tap % p.ks - p.pad;
   const int tm_valid = min(TM, (p.Np - co0) / 16);
@@ -288,8 +331,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
   const int64_t pend = min(p.M, pstart + p.pix_per_split);
   const int nstages = (int)((pend - pstart + PK - 1) / PK);
 
-  // loader: thread -> pixel tid/4 of the stage, vectors (tid&3) + 4*j
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+
+  // loader: thread -> pixel tid/4 of the stage, vectors (tid&3) + 4*j; per-vector constant parts
   const int lpx = tid >> 2, lv0 = tid & 3;
+  unsigned voff[NV]; int lds_off[NV]; bool isy[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = lv0 + 4 * j;
+    if (v < 2 * YV) {
+      const int plane = v >= YV, vec = v - plane * YV;
+      const int co = co0 + vec * 8;
+      isy[j] = true;
+      voff[j] = co < p.Cpo ? (unsigned)((plane * p.Cpo + co) * 2) : XOOB;
+      lds_off[j] = (plane * PK + lpx) * SA + vec * 8;
+    } else {
+      const int u = v - 2 * YV;
+      const int plane = u >= XV, vec = u - plane * XV;
+      const int ci = ci0 + vec * 8;
+      isy[j] = false;
+      voff[j] = ci < p.Cpi ? (unsigned)((plane * p.Cpi + ci) * 2) : XOOB;
+      lds_off[j] = 2 * PK * SA + (plane * PK + lpx) * SB + vec * 8;
+    }
+  }
   int cn, coy, cox; int64_t cp = pstart + lpx;
   {
     const int64_t hw = (int64_t)p.Ho * p.Wo;
@@ -297,62 +362,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
     const int r = (int)(cp - (int64_t)cn * hw);
     coy = r / p.Wo; cox = r - coy * p.Wo;
   }
-  uint4 rv[NV];
+  u32x4 rv[NV];
   auto load_stage = [&]() {
     const bool pv = cp < pend;
     const int iy = coy + tdy, ix = cox + tdx;
     const bool xv = pv && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    const u16* yb = p.dy + (((int64_t)cn * p.Ho + coy) * p.Wo + cox) * 2 * p.Cpo;
-    const u16* xb = p.x + (((int64_t)cn * p.H + iy) * p.W + ix) * 2 * p.Cpi;
+    const unsigned yb = pv ? (unsigned)((((int64_t)cn * p.Ho + coy) * p.Wo + cox) * 4 * p.Cpo) : XOOB;
+    const unsigned xb = xv ? (unsigned)((((int64_t)cn * p.H + iy) * p.W + ix) * 4 * p.Cpi) : XOOB;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int v = lv0 + 4 * j;
-      uint4 val = make_uint4(0u, 0u, 0u, 0u);
-      if (v < 2 * YV) {
-        const int plane = v >= YV, vec = v - plane * YV;
-        const int co = co0 + vec * 8;
-        if (pv && co < p.Cpo) val = *reinterpret_cast<const uint4*>(yb + plane * p.Cpo + co);
-      } else {
-        const int u = v - 2 * YV;
-        const int plane = u >= XV, vec = u - plane * XV;
-        const int ci = ci0 + vec * 8;
-        if (xv && ci < p.Cpi) val = *reinterpret_cast<const uint4*>(xb + plane * p.Cpi + ci);
-      }
-      rv[j] = val;
-    }
+    for (int j = 0; j < NV; ++j)
+      rv[j] = isy[j] ? __builtin_amdgcn_raw_buffer_load_b128(yr, (yb | voff[j]) >= XOOB ? XOOB : yb + voff[j], 0, 0)
+                     : __builtin_amdgcn_raw_buffer_load_b128(xr, (xb | voff[j]) >= XOOB ? XOOB : xb + voff[j], 0, 0);
     cp += PK; cox += PK;
     while (cox >= p.Wo) { cox -= p.Wo; if (++coy == p.Ho) { coy = 0; ++cn; } }
   };
   auto store_stage = [&]() {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int v = lv0 + 4 * j;
-      if (v < 2 * YV) {
-        const int plane = v >= YV, vec = v - plane * YV;
-        *reinterpret_cast<uint4*>(Ys + (plane * PK + lpx) * SA + vec * 8) = rv[j];
-      } else {
-        const int u = v - 2 * YV;
-        const int plane = u >= XV, vec = u - plane * XV;
-        *reinterpret_cast<uint4*>(Xs + (plane * PK + lpx) * SB + vec * 8) = rv[j];
-      }
-    }
+    for (int j = 0; j < NV; ++j) *reinterpret_cast<u32x4*>(smem16 + lds_off[j]) = rv[j];
   };
 
   f32x4 acc[TM][2];
 #pragma unroll
   for (int i = 0; i < TM; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  // transposing read: lane (group g = lane>>4, i = lane&15, q = i>>2, pp = i&3) addresses row
-  // (pixel) 8g + q (+4 for the second half) and columns 4pp..4pp+3 of the 16-channel tile; it
-  // receives column i of those 4 rows.
+  // transposing read: lane (group g = lane>>4, i = lane&15, q = i>>2, pp = i&3) addresses pixel row
+  // 4g + q (first read) / 16 + 4g + q (second read) and channels 4pp..4pp+3 of a 16-channel tile;
+  // it receives channel i of those 4 pixels.  Both MFMA operands use the same pixel order.
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  const int prow0 = wk * 32 + 8 * g + tq;
+  const int prow0 = wk * 32 + 4 * g + tq;
   auto tr_read = [&](const u16* base, int stride, int col0, bf16x8& out) {
     const u16* a0 = base + prow0 * stride + col0 + 4 * tp;
     const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (s16x4 __attribute__((address_space(3)))*)(a0));
     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (s16x4 __attribute__((address_space(3)))*)(a0 + 4 * stride));
+        (s16x4 __attribute__((address_space(3)))*)(a0 + 16 * stride));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 cat = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     out = __builtin_bit_cast(bf16x8, cat);
@@ -407,7 +450,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
     }
     __syncthreads();
   }
-  const int taps = p.ks * p.ks;
   float* slab = p.slabs + ((int64_t)s * taps + tap) * p.Np * p.Cq;
   for (int idx = tid; idx < YC * (XC / 4); idx += 256) {
     const int r = idx / (XC / 4), c = (idx - r * (XC / 4)) * 4;
@@ -527,18 +569,22 @@ extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout
   return check_launch("conv2d_pack_weight_bf16x3");
 }
 
-template <int NT>
-static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)2 * 2 * (XBM + NT * 16) * XLD * sizeof(u16);
+template <int NT, bool PADDED>
+static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)2 * (2 * XBM * XROW + 64 + 2 * NT * 16 * XROW + 64) * sizeof(u16);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<NT, PADDED>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const dim3 grid((unsigned)ceil_div64(p.M, XBM), (unsigned)((p.Np / 16 + NT - 1) / NT));
-  hipLaunchKernelGGL(conv_igemm_bf16x3_kernel<NT>, grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<NT, PADDED>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3");
+}
+template <int NT>
+static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
+  return p.pad > 0 ? launch_xigemm2<NT, true>(p, stream) : launch_xigemm2<NT, false>(p, stream);
 }
 
 extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin, const void* wp,
@@ -568,6 +614,10 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   p.ks = ks; p.pad = pad; p.act = act; p.slope = slope;
   p.Kp = p.Cpi; p.Kt = round_up(ks * ks * p.Kp, 32); p.Np = round_up(Cout, 16);
   p.M = (int64_t)N * Ho * Wo;
+  const size_t xb = wcmc_split_elems(N, H, W, Cin) * sizeof(u16), wb = (size_t)p.Np * 2 * p.Kt * sizeof(u16);
+  WCMC_REQUIRE(xb < 0x7ff00000u && wb < 0x7ff00000u, WCMC_ERR_BAD_ARG,
+               "conv2d_igemm_bf16x3: operand larger than 2 GiB (split the batch)");
+  p.x_bytes = (unsigned)xb; p.wp_bytes = (unsigned)wb;
   hipStream_t st = (hipStream_t)stream;
   switch (x_pick_nt(p.Np / 16)) {
     case 7: return launch_xigemm<7>(p, st);
@@ -584,10 +634,11 @@ extern "C" size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo
 
 template <int TM>
 static int launch_xwgrad(const XWgradParams& p, hipStream_t stream) {
-  constexpr size_t lds_stage = (size_t)2 * 64 * ((TM * 16 + 8) + (64 + 8)) * sizeof(u16);
+  constexpr size_t lds_stage = (size_t)2 * 64 * (xw_stride(TM * 16) + xw_stride(64)) * sizeof(u16);
   constexpr size_t lds_red = (size_t)TM * 16 * (64 + 4) * sizeof(float);
   constexpr size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
-  const dim3 grid((unsigned)p.S, (unsigned)(p.ks * p.ks), (unsigned)(p.coBlocks * p.ciBlocks));
+  const int per_split = p.ks * p.ks * p.coBlocks * p.ciBlocks;
+  const dim3 grid((unsigned)(((p.S + 7) / 8) * 8 * per_split));
   hipLaunchKernelGGL(conv_wgrad_bf16x3_kernel<TM>, grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_wgrad_bf16x3");
 }
@@ -611,6 +662,10 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
   p.dy = (const u16*)dy_split; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.Cpo = round_up(Cout, 8);
   p.ks = ks; p.pad = pad; p.slabs = (float*)workspace; p.S = pl.S; p.M = (int64_t)N * Ho * Wo;
   p.pix_per_split = pl.pix_per_split; p.Np = pl.Np; p.Cq = pl.Cq; p.coBlocks = pl.coBlocks; p.ciBlocks = pl.ciBlocks;
+  const size_t xb = wcmc_split_elems(N, H, W, Cin) * sizeof(u16), yb = wcmc_split_elems(N, Ho, Wo, Cout) * sizeof(u16);
+  WCMC_REQUIRE(xb < 0x7ff00000u && yb < 0x7ff00000u, WCMC_ERR_BAD_ARG,
+               "conv2d_wgrad_bf16x3: operand larger than 2 GiB (split the batch)");
+  p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
   int rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
   if (rc) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + WR_CI - 1) / WR_CI), (unsigned)Cout), dim3(256),
