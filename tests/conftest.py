@@ -45,7 +45,10 @@ class FlipCounter:
     fp32 implementations that round differently can put a unit with |pre-activation| ~ 1e-6 on opposite
     sides, and that single unit moves every upstream weight gradient by ~1e-3 relative (measured:
     scripts/diag_chain.py -- 2e-6 with no flip, 1e-3..6e-3 with one).  Parity tests therefore hold
-    gradients to the tight tolerance when no unit flipped and to `loose` otherwise."""
+    gradients to the tight tolerance when no unit flipped and to `loose` otherwise.  `loose` is wide
+    (1e-1) because the golden / unit-test networks are tiny (4..24 channels, 20x20 images), where one
+    unit carries a visible share of a gradient; the split-bf16 arithmetic (1e-5 per layer instead of
+    1e-6) flips ~10x more units than the fp32 MFMA path, which is the mode that pins gradients tightly."""
 
     def __enter__(self):
         from oracle import modules as om
@@ -66,5 +69,5 @@ class FlipCounter:
             n += int(((a > 0) != (b.detach().cpu() > 0)).sum())
         return n
 
-    def tol(self, tight, loose=3e-2):
+    def tol(self, tight, loose=1e-1):
         return tight if self.flips() == 0 else loose
