@@ -16,7 +16,7 @@ from . import ops
 class GraphedTrainStep:
     """``step = GraphedTrainStep(itf, example_batch); step(batch)`` == ``itf.preprocess(batch); itf.train_batch(batch)``."""
 
-    def __init__(self, itf, batch, warmup=2):
+    def __init__(self, itf, batch, warmup=2, side_stream=True):
         self.itf = itf
         self.static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
         self.keys = list(self.static)                     # (PathNet stashes a converted copy of `paths` in the dict)
@@ -41,7 +41,7 @@ class GraphedTrainStep:
             self._draw()
             self.fm.static_perms, self.fm._static_i, self.fm.check_finite = self.perms, 0, False
         side = ops.USE_SIDE_STREAM
-        ops.USE_SIDE_STREAM = False                       # a captured graph is replayed as one stream
+        ops.USE_SIDE_STREAM = side and side_stream        # forked capture: wgrad branches run beside dgrad in the graph
         self.static.pop('_wcmc_paths_nhwc', None)
         self.graph = torch.cuda.CUDAGraph()
         try:
