@@ -13,6 +13,8 @@
 // plane 0 = hi, plane 1 = lo; pad channels are ZERO (producers guarantee it), so loaders need no
 // channel masks.  Packed weights: u16 wp[Np][2][Kt], k = tap*Kp + c, Kp = round_up(kchan, 8),
 // Kt = round_up(taps*Kp, 32), Np = round_up(rows, 16).
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_common.h"
 
@@ -104,8 +106,10 @@ struct XIgemmParams {
   unsigned x_bytes, wp_bytes;
 };
 
-template <int NT, bool PADDED>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bf16x3_kernel(XIgemmParams p) {
+// DBUF: two LDS stage buffers and one barrier per stage (2 workgroups per CU), or one buffer and two
+// barriers per stage (3 workgroups per CU = 3 waves per SIMD to cover the barriers and LDS latency).
+template <int NT, bool PADDED, bool DBUF>
+__global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XIgemmParams p) {
   constexpr int BN = NT * 16;
   constexpr int NJ = (BN + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
@@ -220,18 +224,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16x3_kernel(XIgemmParams 
   if (nchunks > 1) load_chunk(1, ra1, rb1);
   store_chunk(0, ra0, rb0);
   __syncthreads();
-  for (int c = 0; c < nchunks; c += 2) {
-    // even stage c (LDS buffer 0); registers set 0 is free, set 1 holds stage c+1
-    if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
-    compute(0);
-    if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
-    __syncthreads();
-    if (c + 1 >= nchunks) break;
-    // odd stage c+1 (LDS buffer 1); set 1 is free, set 0 holds stage c+2
-    if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
-    compute(1);
-    if (c + 2 < nchunks) store_chunk(0, ra0, rb0);
-    __syncthreads();
+  if (DBUF) {
+    for (int c = 0; c < nchunks; c += 2) {
+      // even stage c (LDS buffer 0); registers set 0 is free, set 1 holds stage c+1
+      if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
+      compute(0);
+      if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
+      __syncthreads();
+      if (c + 1 >= nchunks) break;
+      // odd stage c+1 (LDS buffer 1); set 1 is free, set 0 holds stage c+2
+      if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
+      compute(1);
+      if (c + 2 < nchunks) store_chunk(0, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    for (int c = 0; c < nchunks; c += 2) {
+      if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
+      compute(0);
+      __syncthreads();                                   // every wave has read stage c
+      if (c + 1 >= nchunks) break;
+      store_chunk(0, ra1, rb1);
+      __syncthreads();
+      if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
+      compute(0);
+      __syncthreads();
+      if (c + 2 < nchunks) { store_chunk(0, ra0, rb0); __syncthreads(); }
+    }
   }
 
   // ---- epilogue: lane holds couts n0 + j*16 + 4*(lane>>4) + {0..3} of pixel (lane&15)
@@ -516,14 +535,14 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
   const int64_t M = (int64_t)N * Ho * Wo;
   const int taps = ks * ks;
   const int64_t tiles = (int64_t)taps * pl.coBlocks * pl.ciBlocks;
-  int64_t S = 1536 / tiles;
+  int64_t S = 1024 / tiles;                           // ~2 waves of 512 co-resident blocks; fewer, larger slabs
   const int64_t maxS = M / 512 > 0 ? M / 512 : 1;     // >= 8 stages of 64 pixels per block
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
   pl.pix_per_split = ceil_div64(ceil_div64(M, S), 64) * 64;
   pl.S = (int)ceil_div64(M, pl.pix_per_split);
   pl.slab_elems = (size_t)pl.S * taps * pl.Np * pl.Cq;
-  pl.G = (int)(M / 256 > 0 ? (M / 256 < 256 ? M / 256 : 256) : 1);
+  pl.G = (int)(M / 64 > 0 ? (M / 64 < 1024 ? M / 64 : 1024) : 1);
   pl.per_block = ceil_div64(M, pl.G);
   pl.G = (int)ceil_div64(M, pl.per_block);
   pl.bytes = (pl.slab_elems + (size_t)pl.G * Cout) * sizeof(float);
@@ -569,18 +588,27 @@ extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout
   return check_launch("conv2d_pack_weight_bf16x3");
 }
 
-template <int NT, bool PADDED>
-static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)2 * (2 * XBM * XROW + 64 + 2 * NT * 16 * XROW + 64) * sizeof(u16);
+static int g_xigemm_dbuf = -1;      // WCMC_IGEMM_DBUF=0/1 (A/B switch); default: double buffer
+template <int NT, bool PADDED, bool DBUF>
+static int launch_xigemm3(const XIgemmParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)(DBUF ? 2 : 1) * (2 * XBM * XROW + 64 + 2 * NT * 16 * XROW + 64) * sizeof(u16);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<NT, PADDED>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const dim3 grid((unsigned)ceil_div64(p.M, XBM), (unsigned)((p.Np / 16 + NT - 1) / NT));
-  hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<NT, PADDED>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3");
+}
+template <int NT, bool PADDED>
+static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
+  if (g_xigemm_dbuf < 0) {
+    const char* e = getenv("WCMC_IGEMM_DBUF");
+    g_xigemm_dbuf = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_xigemm_dbuf ? launch_xigemm3<NT, PADDED, true>(p, stream) : launch_xigemm3<NT, PADDED, false>(p, stream);
 }
 template <int NT>
 static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
