@@ -253,45 +253,91 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
     }
   }
 
-  // ---- epilogue: lane holds couts n0 + j*16 + 4*(lane>>4) + {0..3} of pixel (lane&15)
+  // ---- epilogue: lane holds couts n0 + j*16 + 4*(lane>>4) + {0..3} of pixel (lane&15).
+  // Bias / activation / gate in registers, then the tile goes through LDS (free after the last
+  // barrier) so that HBM sees whole 16-byte-per-lane contiguous rows instead of 8-byte fragments.
   const int fq = (lane >> 4) * 4;
+  if (p.ys) {
+    constexpr int OLD = 2 * BN + 8;                      // bf16 per LDS pixel row: [hi BN][lo BN] + pad
+    u16* so = smem16;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int64_t m = m0 + wave * 32 + i * 16 + frow;
-    if (m >= p.M) continue;
-    const int n = (int)(m / HoWo);
-    const int r = (int)(m - (int64_t)n * HoWo);
-    const int oy = r / p.Wo, ox = r - oy * p.Wo;
-    float* yp = p.yf ? p.yf + (int64_t)n * p.ysn + (int64_t)oy * p.ysh + (int64_t)ox * p.ysw : nullptr;
-    u16* sp = p.ys ? p.ys + (int64_t)m * 2 * p.Cpo : nullptr;
-    const u16* gp = p.gate ? p.gate + (int64_t)m * 2 * p.Cpo : nullptr;   // gate shares y's geometry (hi plane)
+    for (int i = 0; i < 2; ++i) {
+      const int pr = wave * 32 + i * 16 + frow;
+      const int64_t m = m0 + pr;
+      const u16* gp = (p.gate && m < p.M) ? p.gate + (int64_t)m * 2 * p.Cpo : nullptr;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int co = n0 + j * 16 + fq;
-      if (co >= p.Cpo) continue;                       // Cpo = round_up(Cout, 8) (fp32 output: round_up(Cout, 4))
-      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + fq;
+        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (co + e < p.Cout) {
-          if (p.bias) v[e] += p.bias[co + e];
-          v[e] = act_apply(v[e], p.act, p.slope);
-        } else {
-          v[e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+          if (co + e < p.Cout) {
+            if (p.bias) v[e] += p.bias[co + e];
+            v[e] = act_apply(v[e], p.act, p.slope);
+          } else {
+            v[e] = 0.f;
+          }
         }
-      }
-      if (gp) {
-        const uint2 g2 = *reinterpret_cast<const uint2*>(gp + co);
-        const u16 g[4] = {(u16)(g2.x & 0xffff), (u16)(g2.x >> 16), (u16)(g2.y & 0xffff), (u16)(g2.y >> 16)};
+        if (gp && co < p.Cpo) {
+          const uint2 g2 = *reinterpret_cast<const uint2*>(gp + co);
+          const u16 g[4] = {(u16)(g2.x & 0xffff), (u16)(g2.x >> 16), (u16)(g2.y & 0xffff), (u16)(g2.y >> 16)};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_gate(bf2f(g[e]), p.gate_act, p.gate_slope);
-      }
-      if (yp) *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
-      if (sp) {
+          for (int e = 0; e < 4; ++e) v[e] *= act_gate(bf2f(g[e]), p.gate_act, p.gate_slope);
+        }
         u16 hi[4], lo[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split1(v[e], hi[e], lo[e]);
-        *reinterpret_cast<uint2*>(sp + co) = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
-        *reinterpret_cast<uint2*>(sp + p.Cpo + co) = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+        *reinterpret_cast<uint2*>(so + pr * OLD + j * 16 + fq) =
+            make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+        *reinterpret_cast<uint2*>(so + pr * OLD + BN + j * 16 + fq) =
+            make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+      }
+    }
+    __syncthreads();
+    constexpr int VPP = BN / 8;                          // 16-byte vectors per plane per pixel
+    for (int v = tid; v < XBM * 2 * VPP; v += 256) {
+      const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
+      const int plane = q >= VPP, vec = q - plane * VPP;
+      const int64_t m = m0 + pr;
+      const int co = n0 + vec * 8;
+      if (m < p.M && co < p.Cpo)
+        *reinterpret_cast<u32x4*>(p.ys + (int64_t)m * 2 * p.Cpo + plane * p.Cpo + co) =
+            *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+    }
+  } else {
+    constexpr int OLD = BN + 4;                          // floats per LDS pixel row
+    float* so = reinterpret_cast<float*>(smem16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pr = wave * 32 + i * 16 + frow;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + fq;
+        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (co + e < p.Cout) {
+            if (p.bias) v[e] += p.bias[co + e];
+            v[e] = act_apply(v[e], p.act, p.slope);
+          } else {
+            v[e] = 0.f;
+          }
+        }
+        *reinterpret_cast<float4*>(so + pr * OLD + j * 16 + fq) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();
+    constexpr int VPP = BN / 4;                          // float4 per pixel
+    for (int v = tid; v < XBM * VPP; v += 256) {
+      const int pr = v / VPP, vec = v - pr * VPP;
+      const int64_t m = m0 + pr;
+      const int co = n0 + vec * 4;
+      if (m < p.M && co < p.Cpo) {                       // Cpo = round_up(Cout, 4) here
+        const int n = (int)(m / HoWo);
+        const int r = (int)(m - (int64_t)n * HoWo);
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        *reinterpret_cast<float4*>(p.yf + (int64_t)n * p.ysn + (int64_t)oy * p.ysh + (int64_t)ox * p.ysw + co) =
+            *reinterpret_cast<const float4*>(so + pr * OLD + vec * 4);
       }
     }
   }
@@ -591,7 +637,9 @@ extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout
 static int g_xigemm_dbuf = -1;      // WCMC_IGEMM_DBUF=0/1 (A/B switch); default: double buffer
 template <int NT, bool PADDED, bool DBUF>
 static int launch_xigemm3(const XIgemmParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)(DBUF ? 2 : 1) * (2 * XBM * XROW + 64 + 2 * NT * 16 * XROW + 64) * sizeof(u16);
+  const size_t lds_stage = (size_t)(DBUF ? 2 : 1) * (2 * XBM * XROW + 64 + 2 * NT * 16 * XROW + 64) * sizeof(u16);
+  const size_t lds_out = (size_t)XBM * (2 * NT * 16 + 8) * sizeof(u16);      // epilogue staging tile
+  const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>),
