@@ -560,9 +560,9 @@ __global__ __launch_bounds__(256) void colsum_split_kernel(const u16* __restrict
 }
 
 static int x_pick_nt(int tiles) {
-  const int cand[5] = {8, 7, 4, 2, 1};
+  const int cand[4] = {7, 4, 2, 1};
   int best = 1, best_cost = 1 << 30;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int nt = cand[i];
     const int cost = ((tiles + nt - 1) / nt) * (nt + 2);
     if (cost < best_cost) { best_cost = cost; best = nt; }
@@ -696,7 +696,6 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   p.x_bytes = (unsigned)xb; p.wp_bytes = (unsigned)wb;
   hipStream_t st = (hipStream_t)stream;
   switch (x_pick_nt(p.Np / 16)) {
-    case 8: return launch_xigemm<8>(p, st);
     case 7: return launch_xigemm<7>(p, st);
     case 4: return launch_xigemm<4>(p, st);
     case 2: return launch_xigemm<2>(p, st);
