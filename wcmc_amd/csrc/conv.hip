@@ -640,7 +640,7 @@ extern "C" int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64
   else
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)pl.G), dim3(256), 0, st, dy, dsn, dsh, dsw, Ho, Wo, Cout,
                        p.M, pl.per_block, partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st, partial, pl.G, Cout,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(1024), 0, st, partial, pl.G, Cout,
                      db);
   return check_launch("conv2d_bias_grad");
 }

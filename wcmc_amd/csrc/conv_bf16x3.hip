@@ -752,7 +752,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
   WCMC_REQUIRE(p.Cpo / 8 <= 256, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: Cout > 2048 unsupported");
   hipLaunchKernelGGL(colsum_split_kernel, dim3((unsigned)pl.G), dim3(256), (size_t)256 * 8 * sizeof(float), st, p.dy,
                      p.Cpo, Cout, p.M, pl.per_block, partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st, partial, pl.G, Cout,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(1024), 0, st, partial, pl.G, Cout,
                      db);
   return check_launch("conv2d_bias_grad_bf16x3");
 }

@@ -39,18 +39,23 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
   }
 }
 
-// out[c] = sum_g partial[g][c]; 4 g-groups x 64 channels per block, fixed order.
-static __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int G, int C,
-                                                                  float* __restrict__ out) {
-  __shared__ float red[4][64];
+// out[c] = sum_g partial[g][c]; 16 g-groups x 64 channels per 1024-thread block, fixed order.
+static __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int G, int C,
+                                                                   float* __restrict__ out) {
+  __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, gg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float acc = 0.f;
   if (c < C)
-    for (int g = gg; g < G; g += 4) acc += partial[(int64_t)g * C + c];
+    for (int g = gg; g < G; g += 16) acc += partial[(int64_t)g * C + c];
   red[gg][cl] = acc;
   __syncthreads();
-  if (gg == 0 && c < C) out[c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+  if (gg == 0 && c < C) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][cl];
+    out[c] = t;
+  }
 }
 
 }  // namespace wcmc
