@@ -76,6 +76,65 @@ def build_interface(device, group, rng="device"):
     return itf
 
 
+def kernel_apply_probe(device, iters=20):
+    """Back-to-back launches of the kernel-apply op at the step's shapes ((8,441,92,92) logits per branch),
+    HIP events around the whole train so launch gaps of the eager host do not count."""
+    from wcmc_amd import ops
+    n, k2, h = B_PER_GPU, 441, PATCH - 36
+    logits = ops.nhwc_empty(n, k2, h, h, device).normal_()
+    data = torch.rand(n, 3, h, h, device=device)
+    g = torch.randn(n, 3, h, h, device=device)
+    out = {}
+    lg = logits.detach().requires_grad_(True)
+    res = ops.kernel_apply(data, lg)
+    res.backward(g)                                            # warm-up of both kernels
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        e[0].record()
+        for _ in range(iters):
+            ops.kernel_apply(data, logits)
+        e[1].record()
+    torch.cuda.synchronize()
+    fwd_ms = e[0].elapsed_time(e[1]) / iters
+    # backward launches only: reuse one graph node, call its backward repeatedly
+    res = ops.kernel_apply(data, lg)
+    torch.cuda.synchronize()
+    e[1].record()
+    for _ in range(iters):
+        res.backward(g, retain_graph=True)
+    e[2].record()
+    torch.cuda.synchronize()
+    bwd_ms = e[1].elapsed_time(e[2]) / iters
+    px = n * h * h
+    for name, ms, nbytes in (("fwd", fwd_ms, 4.0 * px * (k2 + 6)), ("bwd", bwd_ms, 4.0 * px * (2 * k2 + 9))):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {"kernel": "kernel_apply_" + name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                     "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                     "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
+                     "sample": "%d back-to-back launches, logits (%d,441,%d,%d)" % (iters, n, h, h)}
+    return out
+
+
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_summary.json):
+    (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md section HBM."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if not os.path.isfile(path):
+        return {}
+    with open(path) as f:
+        d = json.load(f)
+    pick = {}
+    for k, v in d.items():
+        for tag, key in (("conv_igemm_bf16x3_kernel<7, false", "conv_igemm"), ("conv_wgrad_bf16x3_kernel<7>", "conv_wgrad"),
+                         ("kernel_apply_kernel<false", "kernel_apply_fwd"), ("kernel_apply_kernel<true", "kernel_apply_bwd")):
+            if tag in k and v.get("hbm_bytes_per_launch_corrected"):
+                pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"],
+                             "shape": "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else
+                                      "logits (8,441,92,92)", "source": "profiles/r01_pmc_summary.json"}
+    return pick
+
+
 def cpu_baseline():
     """The oracle's step (same architecture, same losses) on the host cores: C3 shape at batch 1."""
     from oracle import step as ostep
@@ -211,7 +270,10 @@ def main():
 
         conv_keys = [k for k in ("conv_igemm", "conv_wgrad") if k in summ]
         dominant = max(conv_keys, key=lambda k: summ[k]["ms"]) if conv_keys else None
-        ka = {"fwd": roof("kernel_apply_fwd", "hbm"), "bwd": roof("kernel_apply_bwd", "hbm")}
+        ka = kernel_apply_probe(device)
+        traffic = pmc_traffic()
+        for nm in ("fwd", "bwd"):
+            ka[nm]["traffic"] = traffic.get("kernel_apply_" + nm)
         line = {
             "metric": "128x128 MC patches/sec (train step), KPCN-Manifold",
             "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
@@ -229,8 +291,9 @@ def main():
                                      "product, fp32 accumulate (roofline counts algorithmic FLOPs once against "
                                      "the dense bf16 MFMA peak, so frac <= 1/3); everything else fp32")
                        if ops.PRECISION == "bf16x3" else "fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate"},
-            "roofline": roof(dominant, "mfma") if dominant else None,
-            "roofline_other_conv": roof([k for k in conv_keys if k != dominant][0], "mfma")
+            "roofline": dict(roof(dominant, "mfma"), traffic=traffic.get(dominant)) if dominant else None,
+            "roofline_other_conv": dict(roof([k for k in conv_keys if k != dominant][0], "mfma"),
+                                        traffic=traffic.get([k for k in conv_keys if k != dominant][0]))
             if len(conv_keys) > 1 else None,
             "roofline_kernel_apply": ka,
         }
