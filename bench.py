@@ -87,7 +87,7 @@ def kernel_apply_probe(device, iters=20):
     out = {}
     lg = logits.detach().requires_grad_(True)
     res = ops.kernel_apply(data, lg)
-    res.backward(g)                                            # warm-up of both kernels
+    torch.autograd.grad(res, lg, g)                            # warm-up of both kernels
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     torch.cuda.synchronize()
     with torch.no_grad():
@@ -102,7 +102,7 @@ def kernel_apply_probe(device, iters=20):
     torch.cuda.synchronize()
     e[1].record()
     for _ in range(iters):
-        res.backward(g, retain_graph=True)
+        torch.autograd.grad(res, lg, g, retain_graph=True)     # one kernel_apply_bwd launch each
     e[2].record()
     torch.cuda.synchronize()
     bwd_ms = e[1].elapsed_time(e[2]) / iters
