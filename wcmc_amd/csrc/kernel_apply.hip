@@ -52,21 +52,20 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 // Stage the zero-extended radiance halo of this tile as one float4 per pixel:
-//   C <= 3:  {1, c0, c1, c2}  -- the constant 1 makes sum_t w_t fall out of the same packed FMAs that
+//   C <= 3:  {c0, c1, c2, 1}  -- the constant 1 makes sum_t w_t fall out of the same packed FMAs that
 //            accumulate the weighted radiance (it is 1 outside the image too: the softmax runs over
 //            all k*k taps, only the radiance is zero-extended);
 //   C == 4:  {c0, c1, c2, c3}.
 template <bool C4>
 __device__ __forceinline__ void ka_load_halo(const KAParams& p, float4* halo, int n, int ty0, int tx0) {
   const int hs = p.halo;
-  constexpr int O = C4 ? 0 : 1;
   for (int i = threadIdx.x; i < hs * hs; i += blockDim.x) {
     const int hy = i / hs, hx = i - hy * hs;
     const int y = ty0 + hy - p.r, x = tx0 + hx - p.r;
-    float v[4] = {C4 ? 0.f : 1.f, 0.f, 0.f, 0.f};
+    float v[4] = {0.f, 0.f, 0.f, C4 ? 0.f : 1.f};
     if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w) {
       const float* d = p.data + (int64_t)n * p.dsn + (int64_t)y * p.dsh + (int64_t)x * p.dsw;
-      for (int c = 0; c < p.C; ++c) v[c + O] = d[(int64_t)c * p.dsc];
+      for (int c = 0; c < p.C; ++c) v[c] = d[(int64_t)c * p.dsc];
     }
     halo[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -163,8 +162,8 @@ __global__ __launch_bounds__(128) void kernel_apply_kernel(KAParams p) {
           const float4 d = *reinterpret_cast<const float4*>(hbase + toff[i][e]);
           if (C4) {
             s += ex; a0 = fmaf(ex, d.x, a0); a1 = fmaf(ex, d.y, a1); a2 = fmaf(ex, d.z, a2); a3 = fmaf(ex, d.w, a3);
-          } else {                                  // d = {1, r, g, b}: two packed FMAs per tap
-            s = fmaf(ex, d.x, s); a0 = fmaf(ex, d.y, a0); a1 = fmaf(ex, d.z, a1); a2 = fmaf(ex, d.w, a2);
+          } else {                                  // d = {r, g, b, 1}: two packed FMAs per tap
+            a0 = fmaf(ex, d.x, a0); a1 = fmaf(ex, d.y, a1); a2 = fmaf(ex, d.z, a2); s = fmaf(ex, d.w, s);
           }
         }
       }
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(128) void kernel_apply_kernel(KAParams p) {
           const float wt = __builtin_amdgcn_exp2f(l[e] - lb);
           const float4 d = *reinterpret_cast<const float4*>(hbase + toff[i][e]);
           const float gd = C4 ? fmaf(g[0], d.x, fmaf(g[1], d.y, fmaf(g[2], d.z, g[3] * d.w)))
-                              : fmaf(g[0], d.y, fmaf(g[1], d.z, g[2] * d.w));
+                              : fmaf(g[0], d.x, fmaf(g[1], d.y, g[2] * d.z));
           o[e] = wt * (gd - go);
           if (p.ddata && valid && 4 * (j + 16 * i) + e < taps) {
             float* da = dacc + ((ty * p.halo + tx) * 16 + toff[i][e]) / 4;     // channel-major like the gradient
