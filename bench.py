@@ -77,37 +77,42 @@ def build_interface(device, group, rng="device"):
 
 
 def kernel_apply_probe(device, iters=20):
-    """Back-to-back launches of the kernel-apply op at the step's shapes ((8,441,92,92) logits per branch),
-    HIP events around the whole train so launch gaps of the eager host do not count."""
+    """Back-to-back launches of the kernel-apply op through the C ABI at the step's shapes
+    ((8,441,92,92) logits per branch) into preallocated buffers, HIP events around the whole train so
+    that neither host launch gaps nor the allocator are inside the measurement."""
     from wcmc_amd import ops
+    from wcmc_amd._lib import check, lib
     n, k2, h = B_PER_GPU, 441, PATCH - 36
     logits = ops.nhwc_empty(n, k2, h, h, device).normal_()
+    dlog = ops.nhwc_empty(n, k2, h, h, device)
     data = torch.rand(n, 3, h, h, device=device)
     g = torch.randn(n, 3, h, h, device=device)
+    res = torch.empty(n, 3, h, h, device=device)
+    lse = torch.empty(n * h * h, device=device)
+    P, V, S = ops._ptr, ops._v, ops._stream
+
+    def fwd():
+        check(lib().wcmc_kernel_apply_fwd(*V(logits), P(data), *data.stride(), P(res), *res.stride(), P(lse),
+                                          n, 3, h, h, 21, S()), "kernel_apply_fwd")
+
+    def bwd():
+        check(lib().wcmc_kernel_apply_bwd(*V(logits), P(data), *data.stride(), P(res), *res.stride(), P(g),
+                                          *g.stride(), P(lse), *V(dlog), P(None), n, 3, h, h, 21, S()),
+              "kernel_apply_bwd")
+
     out = {}
-    lg = logits.detach().requires_grad_(True)
-    res = ops.kernel_apply(data, lg)
-    torch.autograd.grad(res, lg, g)                            # warm-up of both kernels
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    torch.cuda.synchronize()
-    with torch.no_grad():
-        e[0].record()
-        for _ in range(iters):
-            ops.kernel_apply(data, logits)
-        e[1].record()
-    torch.cuda.synchronize()
-    fwd_ms = e[0].elapsed_time(e[1]) / iters
-    # backward launches only: reuse one graph node, call its backward repeatedly
-    res = ops.kernel_apply(data, lg)
-    torch.cuda.synchronize()
-    e[1].record()
-    for _ in range(iters):
-        torch.autograd.grad(res, lg, g, retain_graph=True)     # one kernel_apply_bwd launch each
-    e[2].record()
-    torch.cuda.synchronize()
-    bwd_ms = e[1].elapsed_time(e[2]) / iters
     px = n * h * h
-    for name, ms, nbytes in (("fwd", fwd_ms, 4.0 * px * (k2 + 6)), ("bwd", bwd_ms, 4.0 * px * (2 * k2 + 9))):
+    for name, fn, nbytes in (("fwd", fwd, 4.0 * px * (k2 + 6)), ("bwd", bwd, 4.0 * px * (2 * k2 + 9))):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
         gbs = nbytes / (ms * 1e-3) / 1e9
         out[name] = {"kernel": "kernel_apply_" + name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                      "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
