@@ -232,6 +232,20 @@ int wcmc_feature_mse_bwd(const float* p, int64_t psb, int64_t pss, int64_t psc, 
                          void* workspace, size_t workspace_bytes,
                          int B, int S, int C, int h, int w, void* stream);
 
+/* GlobalRelativeSimilarityLoss (support/losses.py:116-211, `--manif_loss GRS`): same pairings and
+ * displacements, loss = (logsumexp(alpha*[d_p, d_b, -d_p, -d_b, 0]) - log(1 + 4N)) / sqrt(alpha).
+ * Same workspace (wcmc_feature_mse_workspace_bytes) and calling convention as FeatureMSE. */
+int wcmc_grs_fwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh, int64_t psw,
+                 const float* ref, int64_t rsb, int64_t rsc, int64_t rsh, int64_t rsw,
+                 const int64_t* idx_patch, const int64_t* idx_batch, float alpha,
+                 float* loss, void* workspace, size_t workspace_bytes,
+                 int B, int S, int C, int h, int w, void* stream);
+int wcmc_grs_bwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh, int64_t psw,
+                 const int64_t* idx_patch, const int64_t* idx_batch,
+                 const float* grad_scale, float* dp,
+                 void* workspace, size_t workspace_bytes,
+                 int B, int S, int C, int h, int w, void* stream);
+
 /* ---------------------------------------------------------------- clip + Adam
  * support/interfaces.py:260-261 (clip_grad_value_) + :269-271 (Adam.step,
  * train_kpcn.py:274-277: default betas/eps, no weight decay, no amsgrad) fused

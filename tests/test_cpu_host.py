@@ -66,7 +66,7 @@ def test_ops_fail_loudly_without_gpu():
     from wcmc_amd.support.losses import FeatureMSE, GlobalRelativeSimilarityLoss
     with pytest.raises(RuntimeError, match="no CPU path"):
         FeatureMSE()(torch.zeros(1, 2, 3, 4, 4), torch.zeros(1, 3, 4, 4))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU path"):
         GlobalRelativeSimilarityLoss()(torch.zeros(1, 2, 3, 4, 4), torch.zeros(1, 3, 4, 4))
 
 

@@ -282,6 +282,25 @@ def test_feature_mse_against_reference_goldens(golden_dir):
         assert_close(p.grad, torch.from_numpy(d["grad_%d" % i]), tol=1e-5, what="FeatureMSE grad %d" % i)
 
 
+def test_grs_against_reference_goldens(golden_dir):
+    from wcmc_amd.support.losses import GlobalRelativeSimilarityLoss
+    o = ops()
+    d = np.load(os.path.join(golden_dir, "losses_grs.npz"))
+    for i in range(int(d["n"])):
+        p = torch.from_numpy(d["p_%d" % i]).to(DEV).requires_grad_(True)
+        ref = torch.from_numpy(d["ref_%d" % i]).to(DEV)
+        ip, ib = torch.from_numpy(d["idx_patch_%d" % i]).to(DEV), torch.from_numpy(d["idx_batch_%d" % i]).to(DEV)
+        loss = o.grs_loss(p, ref, ip, ib, 2.0)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), d["loss_%d" % i], rtol=1e-5)
+        assert_close(p.grad, torch.from_numpy(d["grad_%d" % i]), tol=1e-5, what="GRS grad %d" % i)
+    # module form draws like the reference (patch then batch on the CPU generator)
+    torch.manual_seed(2000)
+    m = GlobalRelativeSimilarityLoss()
+    loss = m(torch.from_numpy(d["p_0"]).to(DEV), torch.from_numpy(d["ref_0"]).to(DEV))
+    np.testing.assert_allclose(loss.item(), d["loss_0"], rtol=1e-5)
+
+
 def test_feature_mse_module_strided_and_seeded(golden_dir):
     from wcmc_amd.support.losses import FeatureMSE
     d = np.load(os.path.join(golden_dir, "losses_fmse.npz"))

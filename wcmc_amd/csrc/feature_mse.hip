@@ -24,11 +24,12 @@ struct FMParams {
   float* rt;            // [B][h][w][4] tonemapped reference
   float* d_patch; float* d_batch;       // [N]
   int64_t* inv_patch; int64_t* inv_batch;
-  float* partial;       // [FM_BLOCKS][2]
+  float* partial;       // [FM_BLOCKS][4]: sum d_patch^2, sum d_batch^2, max |d|, -
+  float* grs;           // GRS scratch: [0] = log-sum-exp, [1] = alpha, [4+blk] = per-block exp sums
   int B, S, C, h, w; int64_t SHW, N;
 };
 
-struct FMLayout { size_t rt, d_patch, d_batch, inv_patch, inv_batch, partial, bytes; };
+struct FMLayout { size_t rt, d_patch, d_batch, inv_patch, inv_batch, partial, grs, bytes; };
 static FMLayout fm_layout(int B, int S, int h, int w) {
   FMLayout L; size_t o = 0;
   const size_t N = (size_t)B * S * h * w, SHW = (size_t)S * h * w;
@@ -38,7 +39,8 @@ static FMLayout fm_layout(int B, int S, int h, int w) {
   L.d_batch = take(N * sizeof(float));
   L.inv_patch = take(SHW * sizeof(int64_t));
   L.inv_batch = take(N * sizeof(int64_t));
-  L.partial = take((size_t)FM_BLOCKS * 2 * sizeof(float));
+  L.partial = take((size_t)FM_BLOCKS * 4 * sizeof(float));
+  L.grs = take((size_t)(FM_BLOCKS + 4) * sizeof(float));     // [0]=lse, [1]=alpha, [4..] per-block exp sums
   L.bytes = o;
   return L;
 }
@@ -89,8 +91,8 @@ __device__ __forceinline__ float fm_disp(const float* pi, float4 ri, const float
 }
 
 __global__ __launch_bounds__(256) void fm_fwd_kernel(FMParams q) {
-  __shared__ float red[2][4];
-  float s1 = 0.f, s2 = 0.f;
+  __shared__ float red[3][4];
+  float s1 = 0.f, s2 = 0.f, mx = 0.f;
   const float4* rt = reinterpret_cast<const float4*>(q.rt);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q.N; i += (int64_t)gridDim.x * blockDim.x) {
     const RowRef ri = fm_row(q, i);
@@ -101,21 +103,24 @@ __global__ __launch_bounds__(256) void fm_fwd_kernel(FMParams q) {
     const RowRef rj = fm_row(q, j1);
     fm_load_p(q, rj.poff, pj);
     const float d1 = fm_disp(pi, r_i, pj, rt[rj.roff]);
-    q.d_patch[i] = d1; s1 += d1 * d1;
+    q.d_patch[i] = d1; s1 += d1 * d1; mx = fmaxf(mx, fabsf(d1));
     if (q.idx_batch) {
       const RowRef rk = fm_row(q, q.idx_batch[i]);
       fm_load_p(q, rk.poff, pj);
       const float d2 = fm_disp(pi, r_i, pj, rt[rk.roff]);
-      q.d_batch[i] = d2; s2 += d2 * d2;
+      q.d_batch[i] = d2; s2 += d2 * d2; mx = fmaxf(mx, fabsf(d2));
     }
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; red[2][wave] = mx; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    q.partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    q.partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    q.partial[4 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    q.partial[4 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    q.partial[4 * blockIdx.x + 2] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
   }
 }
 
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void fm_final_kernel(const float* partial, int
                                                        float* loss) {
   __shared__ double red[2][4];
   double s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += 256) { s1 += partial[2 * i]; s2 += partial[2 * i + 1]; }
+  for (int i = threadIdx.x; i < nblk; i += 256) { s1 += partial[4 * i]; s2 += partial[4 * i + 1]; }
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
@@ -136,8 +141,54 @@ __global__ __launch_bounds__(256) void fm_final_kernel(const float* partial, int
 }
 
 // dL/dP_i = (gs/N) * sum over pairings [ d_i (P_i - P_pi(i)) + d_i' (P_i - P_i') ],  pi(i') = i
+// GRS (losses.py:116-211): with e = alpha*[d_p, d_b, -d_p, -d_b, 0],
+//   loss = (logsumexp(e) - log(1 + 4N)) / sqrt(alpha);  dloss/dd_i = sqrt(alpha) * (exp(a d_i - lse) - exp(-a d_i - lse)).
+__global__ __launch_bounds__(256) void grs_sum_kernel(FMParams q, int nblk_fwd, float alpha) {
+  __shared__ float red[4];
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < nblk_fwd; i += 256) mx = fmaxf(mx, q.partial[4 * i + 2]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  const float M = alpha * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));     // max of every exponent (>= 0)
+  __syncthreads();
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q.N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = alpha * q.d_patch[i], b = alpha * q.d_batch[i];
+    acc += __expf(a - M) + __expf(-a - M) + __expf(b - M) + __expf(-b - M);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    q.grs[4 + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (blockIdx.x == 0) { q.grs[2] = M; q.grs[1] = alpha; }
+  }
+}
+__global__ __launch_bounds__(256) void grs_final_kernel(FMParams q, int nblk, float alpha, float* loss) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) acc += q.grs[4 + i];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double M = q.grs[2];
+    const double S = red[0] + red[1] + red[2] + red[3] + exp(-M);        // the appended zero exponent
+    const double lse = M + log(S);
+    q.grs[0] = (float)lse;
+    *loss = (float)((lse - log(1.0 + 4.0 * (double)q.N)) / sqrt((double)alpha));
+  }
+}
+
+template <bool GRS>
 __global__ __launch_bounds__(256) void fm_bwd_kernel(FMParams q, const float* grad_scale, float* dp) {
-  const float gs = grad_scale[0] / (float)q.N * (q.idx_batch ? 1.f : 2.f);
+  const float lse = GRS ? q.grs[0] : 0.f, alpha = GRS ? q.grs[1] : 0.f, sa = GRS ? sqrtf(alpha) : 0.f;
+  auto coef = [&](float d) { return GRS ? sa * (__expf(alpha * d - lse) - __expf(-alpha * d - lse)) : d; };
+  const float gs = GRS ? grad_scale[0] : grad_scale[0] / (float)q.N * (q.idx_batch ? 1.f : 2.f);
   const int64_t hw = (int64_t)q.h * q.w;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q.N; i += (int64_t)gridDim.x * blockDim.x) {
     const RowRef ri = fm_row(q, i);
@@ -147,23 +198,23 @@ __global__ __launch_bounds__(256) void fm_bwd_kernel(FMParams q, const float* gr
     for (int c = 0; c < FM_MAXC; ++c) g[c] = 0.f;
     const int64_t boff = (int64_t)ri.b * q.SHW, r = i - boff;
     {
-      const float d = q.d_patch[i];
+      const float d = coef(q.d_patch[i]);
       fm_load_p(q, fm_row(q, boff + q.idx_patch[r]).poff, pj);
 #pragma unroll
       for (int c = 0; c < FM_MAXC; ++c) g[c] += d * (pi[c] - pj[c]);
       const int64_t ip = boff + q.inv_patch[r];
-      const float d2 = q.d_patch[ip];
+      const float d2 = coef(q.d_patch[ip]);
       fm_load_p(q, fm_row(q, ip).poff, pj);
 #pragma unroll
       for (int c = 0; c < FM_MAXC; ++c) g[c] += d2 * (pi[c] - pj[c]);
     }
     if (q.idx_batch) {
-      const float d = q.d_batch[i];
+      const float d = coef(q.d_batch[i]);
       fm_load_p(q, fm_row(q, q.idx_batch[i]).poff, pj);
 #pragma unroll
       for (int c = 0; c < FM_MAXC; ++c) g[c] += d * (pi[c] - pj[c]);
       const int64_t ip = q.inv_batch[i];
-      const float d2 = q.d_batch[ip];
+      const float d2 = coef(q.d_batch[ip]);
       fm_load_p(q, fm_row(q, ip).poff, pj);
 #pragma unroll
       for (int c = 0; c < FM_MAXC; ++c) g[c] += d2 * (pi[c] - pj[c]);
@@ -190,7 +241,7 @@ static int fm_fill(FMParams& q, const float* p, int64_t psb, int64_t pss, int64_
   q.idx_patch = idx_patch; q.idx_batch = idx_batch;
   q.rt = (float*)(base + L.rt); q.d_patch = (float*)(base + L.d_patch); q.d_batch = (float*)(base + L.d_batch);
   q.inv_patch = (int64_t*)(base + L.inv_patch); q.inv_batch = (int64_t*)(base + L.inv_batch);
-  q.partial = (float*)(base + L.partial);
+  q.partial = (float*)(base + L.partial); q.grs = (float*)(base + L.grs);
   q.B = B; q.S = S; q.C = C; q.h = h; q.w = w; q.SHW = (int64_t)S * h * w; q.N = (int64_t)B * q.SHW;
   return 0;
 }
@@ -235,6 +286,42 @@ extern "C" int wcmc_feature_mse_bwd(const float* p, int64_t psb, int64_t pss, in
     return rc;
   WCMC_REQUIRE(grad_scale && dp, WCMC_ERR_BAD_ARG, "feature_mse_bwd: null pointer");
   const unsigned gb = (unsigned)(ceil_div64(q.N, 256) < 4096 ? ceil_div64(q.N, 256) : 4096);
-  hipLaunchKernelGGL(fm_bwd_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, q, grad_scale, dp);
+  hipLaunchKernelGGL(fm_bwd_kernel<false>, dim3(gb), dim3(256), 0, (hipStream_t)stream, q, grad_scale, dp);
   return check_launch("feature_mse_bwd");
+}
+
+extern "C" int wcmc_grs_fwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh, int64_t psw,
+                            const float* ref, int64_t rsb, int64_t rsc, int64_t rsh, int64_t rsw,
+                            const int64_t* idx_patch, const int64_t* idx_batch, float alpha, float* loss,
+                            void* workspace, size_t workspace_bytes, int B, int S, int C, int h, int w,
+                            void* stream) {
+  FMParams q = {};
+  WCMC_REQUIRE(idx_batch && alpha > 0.f, WCMC_ERR_BAD_ARG, "grs_fwd: needs both pairings and alpha > 0");
+  if (int rc = fm_fill(q, p, psb, pss, psc, psh, psw, idx_patch, idx_batch, workspace, workspace_bytes, B, S, C, h, w))
+    return rc;
+  WCMC_REQUIRE(ref && loss, WCMC_ERR_BAD_ARG, "grs_fwd: null pointer");
+  q.ref = ref; q.rsb = rsb; q.rsc = rsc; q.rsh = rsh; q.rsw = rsw;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t npix = (int64_t)B * h * w;
+  hipLaunchKernelGGL(fm_tonemap_kernel, dim3((unsigned)(ceil_div64(npix, 256) < 2048 ? ceil_div64(npix, 256) : 2048)),
+                     dim3(256), 0, st, q);
+  const unsigned gb = (unsigned)(ceil_div64(q.N, 256) < FM_BLOCKS ? ceil_div64(q.N, 256) : FM_BLOCKS);
+  hipLaunchKernelGGL(fm_inverse_kernel, dim3(gb), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(fm_fwd_kernel, dim3(gb), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(grs_sum_kernel, dim3(gb), dim3(256), 0, st, q, (int)gb, alpha);
+  hipLaunchKernelGGL(grs_final_kernel, dim3(1), dim3(256), 0, st, q, (int)gb, alpha, loss);
+  return check_launch("grs_fwd");
+}
+
+extern "C" int wcmc_grs_bwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh, int64_t psw,
+                            const int64_t* idx_patch, const int64_t* idx_batch, const float* grad_scale, float* dp,
+                            void* workspace, size_t workspace_bytes, int B, int S, int C, int h, int w, void* stream) {
+  FMParams q = {};
+  WCMC_REQUIRE(idx_batch, WCMC_ERR_BAD_ARG, "grs_bwd: needs both pairings");
+  if (int rc = fm_fill(q, p, psb, pss, psc, psh, psw, idx_patch, idx_batch, workspace, workspace_bytes, B, S, C, h, w))
+    return rc;
+  WCMC_REQUIRE(grad_scale && dp, WCMC_ERR_BAD_ARG, "grs_bwd: null pointer");
+  const unsigned gb = (unsigned)(ceil_div64(q.N, 256) < 4096 ? ceil_div64(q.N, 256) : 4096);
+  hipLaunchKernelGGL(fm_bwd_kernel<true>, dim3(gb), dim3(256), 0, (hipStream_t)stream, q, grad_scale, dp);
+  return check_launch("grs_bwd");
 }

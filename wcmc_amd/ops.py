@@ -635,6 +635,38 @@ class _FeatureMSE(torch.autograd.Function):
         return dp, None, None, None
 
 
+class _GRS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, ref, idx_patch, idx_batch, alpha):
+        _need_cuda(p, ref)
+        b, s, c, h, w = p.shape
+        nbytes = lib().wcmc_feature_mse_workspace_bytes(b, s, c, h, w)
+        ws = torch.empty((nbytes + 3) // 4, device=p.device, dtype=torch.float32)
+        loss = torch.empty((), device=p.device, dtype=torch.float32)
+        check(lib().wcmc_grs_fwd(_ptr(p), *p.stride(), _ptr(ref), *ref.stride(),
+                                 ctypes.c_void_p(idx_patch.data_ptr()), ctypes.c_void_p(idx_batch.data_ptr()),
+                                 float(alpha), _ptr(loss), _ptr(ws), ws.numel() * 4, b, s, c, h, w, _stream()),
+              "grs_fwd")
+        ctx.save_for_backward(p, idx_patch, idx_batch, ws)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, idx_patch, idx_batch, ws = ctx.saved_tensors
+        b, s, c, h, w = p.shape
+        dp = torch.empty((b, s, c, h, w), device=p.device, dtype=torch.float32)
+        g = g.contiguous()
+        check(lib().wcmc_grs_bwd(_ptr(p), *p.stride(), ctypes.c_void_p(idx_patch.data_ptr()),
+                                 ctypes.c_void_p(idx_batch.data_ptr()), _ptr(g), _ptr(dp), _ptr(ws),
+                                 ws.numel() * 4, b, s, c, h, w, _stream()), "grs_bwd")
+        return dp, None, None, None, None
+
+
+def grs_loss(p, ref, idx_patch, idx_batch, alpha=2.0):
+    """GlobalRelativeSimilarityLoss on int64 DEVICE permutations."""
+    return _GRS.apply(p, ref, idx_patch, idx_batch, alpha)
+
+
 def feature_mse(p, ref, idx_patch, idx_batch):
     """idx_* are int64 DEVICE tensors (idx_batch may be None for non_local=False)."""
     return _FeatureMSE.apply(p, ref, idx_patch, idx_batch)

@@ -69,16 +69,30 @@ class FeatureMSE(torch.nn.Module):
 
 
 class GlobalRelativeSimilarityLoss(torch.nn.Module):
-    """``losses.py:116-211``.  Alternative manifold loss (``--manif_loss GRS``); SURVEY.md section 8f
-    'next' row -- not built yet, so it fails loudly instead of running anywhere else."""
+    """Global Relative Similarity Loss (``losses.py:116-211``, ``--manif_loss GRS``): same pairings and
+    displacements as FeatureMSE, ``(logsumexp(alpha*[d_p, d_b, -d_p, -d_b, 0]) - log(1+4N)) / sqrt(alpha)``.
+    Permutations are drawn like the reference: patch then batch on the global CPU generator."""
 
-    def __init__(self, alpha=2, color='rgb'):
+    def __init__(self, alpha=2, color='rgb', rng='cpu'):
         super(GlobalRelativeSimilarityLoss, self).__init__()
+        assert rng in ('cpu', 'device')
         self.color = color
         self.alpha = alpha
+        self.rng = rng
+        self.last_perms = None
 
-    def forward(self, p_buffer, ref):
-        raise NotImplementedError("GlobalRelativeSimilarityLoss has no HIP kernel yet (SURVEY.md 8f)")
+    def forward(self, p_buffer, ref, perms=None):
+        b, s, c, h, w = p_buffer.shape
+        dev = p_buffer.device
+        if perms is None:
+            d = dev if self.rng == 'device' else None
+            perms = (torch.randperm(s * h * w, device=d), torch.randperm(b * s * h * w, device=d))
+        self.last_perms = perms
+        loss = ops.grs_loss(p_buffer, ref, perms[0].to(dev, non_blocking=True), perms[1].to(dev, non_blocking=True),
+                            float(self.alpha))
+        if not torch.isfinite(loss.detach()):       # losses.py:192-195, checked on the scalar
+            raise RuntimeError("Infinite loss at train time.")
+        return loss
 
 
 class RelativeMSE(torch.nn.Module):
