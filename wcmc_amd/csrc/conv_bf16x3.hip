@@ -161,8 +161,10 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
   const int nchunks = p.Kt / XKC;
 
   auto load_chunk = [&](int c, u32x4* ra, u32x4* rb) {
-    // taps past ks*ks fall outside the tensor (or hit zero weights): no tap predicate needed
-    const unsigned toff = (unsigned)((tdy * p.W + tdx) * pixb + ci * 2);
+    // taps past ks*ks fall outside the tensor (or hit zero weights): no tap predicate needed.
+    // Stages past the end (the K loop is run in pairs) load nothing: out-of-range offsets.
+    const unsigned kill = c < nchunks ? 0u : XOOB;
+    const unsigned toff = (unsigned)((tdy * p.W + tdx) * pixb + ci * 2) | kill;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned off = abase[j] + toff;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
       ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, wbase[j] + (unsigned)(c * XKC * 2), 0, 0);
+    for (int j = 0; j < NJ; ++j)
+      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (wbase[j] + (unsigned)(c * XKC * 2)) | kill, 0, 0);
     ci += XKC;
     while (ci >= p.Kp) { ci -= p.Kp; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
   };
@@ -199,7 +202,9 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
   auto compute = [&](int buf) {
     const u16* a = smem16 + buf * BUF + (wave * 32 + frow) * XROW + fslot;
     const u16* b = smem16 + buf * BUF + A_ELEMS + frow * XROW + fslot;
-    bf16x8 ah[2], al[2];
+    // every fragment read of the stage is issued before the first MFMA (hipcc otherwise emits
+    // read -> lgkmcnt(0) -> 6 MFMAs per cout tile and exposes the LDS latency seven times per stage)
+    bf16x8 ah[2], al[2], wh[NT], wl[NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       ah[i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * XROW);
@@ -207,13 +212,17 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(b + j * 16 * XROW);
-      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(b + B_LO + j * 16 * XROW);
+      wh[j] = *reinterpret_cast<const bf16x8*>(b + j * 16 * XROW);
+      wl[j] = *reinterpret_cast<const bf16x8*>(b + B_LO + j * 16 * XROW);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[i], acc[j][i], 0, 0, 0);   // small terms first
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[i], acc[j][i], 0, 0, 0);
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[i], acc[j][i], 0, 0, 0);
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
       }
     }
   };
@@ -221,21 +230,20 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
   // prologue: stage 0 in LDS, stage 1 in flight in the second register set
   u32x4 ra0[4], rb0[NJ], ra1[4], rb1[NJ];
   load_chunk(0, ra0, rb0);
-  if (nchunks > 1) load_chunk(1, ra1, rb1);
+  load_chunk(1, ra1, rb1);
   store_chunk(0, ra0, rb0);
   __syncthreads();
   if (DBUF) {
+    // Straight-line body, two stages per trip (a stage past the end multiplies zeros): no branch
+    // between a load and its use, so hipcc's vmcnt bookkeeping keeps both register sets in flight.
     for (int c = 0; c < nchunks; c += 2) {
-      // even stage c (LDS buffer 0); registers set 0 is free, set 1 holds stage c+1
-      if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
-      compute(0);
-      if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
+      load_chunk(c + 2, ra0, rb0);          // set 0 is free; set 1 holds stage c+1
+      compute(0);                           // stage c from LDS buffer 0
+      store_chunk(1, ra1, rb1);
       __syncthreads();
-      if (c + 1 >= nchunks) break;
-      // odd stage c+1 (LDS buffer 1); set 1 is free, set 0 holds stage c+2
-      if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
-      compute(1);
-      if (c + 2 < nchunks) store_chunk(0, ra0, rb0);
+      load_chunk(c + 3, ra1, rb1);          // set 1 is free; set 0 holds stage c+2
+      compute(1);                           // stage c+1 from LDS buffer 1
+      store_chunk(0, ra0, rb0);
       __syncthreads();
     }
   } else {
@@ -694,6 +702,12 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   WCMC_REQUIRE(xb < 0x7ff00000u && wb < 0x7ff00000u, WCMC_ERR_BAD_ARG,
                "conv2d_igemm_bf16x3: operand larger than 2 GiB (split the batch)");
   p.x_bytes = (unsigned)xb; p.wp_bytes = (unsigned)wb;
+  {  // timing-only experiments (guide section 7: zero-record descriptors drop one operand's traffic)
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("WCMC_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
+    if (dbg & 1) p.x_bytes = 0;
+    if (dbg & 2) p.wp_bytes = 0;
+  }
   hipStream_t st = (hipStream_t)stream;
   switch (x_pick_nt(p.Np / 16)) {
     case 7: return launch_xigemm<7>(p, st);
