@@ -108,7 +108,9 @@ struct XIgemmParams {
 
 // DBUF: two LDS stage buffers and one barrier per stage (2 workgroups per CU), or one buffer and two
 // barriers per stage (3 workgroups per CU = 3 waves per SIMD to cover the barriers and LDS latency).
-template <int NT, bool PADDED, bool DBUF>
+// DBG (timing-only ablations, results are wrong): 1 = no MFMA, 2 = no LDS stores, 8 = no LDS fragment
+// reads, 16 = no barriers.  DBG = 0 is the product kernel.
+template <int NT, bool PADDED, bool DBUF, int DBG = 0>
 __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XIgemmParams p) {
   constexpr int BN = NT * 16;
   constexpr int NJ = (BN + 31) / 32;
@@ -182,6 +184,13 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
   };
   const int wslot = (vq ^ ((prow >> 1) & 3)) * 8;       // swizzled 16-byte slot of this thread's vector
   auto store_chunk = [&](int buf, const u32x4* ra, const u32x4* rb) {
+    if (DBG & 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(ra[j]));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(rb[j]));
+      return;
+    }
     u16* a = smem16 + buf * BUF + pl * A_LO + wslot;
     u16* b = smem16 + buf * BUF + A_ELEMS + pl * B_LO + wslot;
 #pragma unroll
@@ -205,17 +214,32 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
     // every fragment read of the stage is issued before the first MFMA (hipcc otherwise emits
     // read -> lgkmcnt(0) -> 6 MFMAs per cout tile and exposes the LDS latency seven times per stage)
     bf16x8 ah[2], al[2], wh[NT], wl[NT];
+    if (DBG & 8) {
+      const bf16x8 z = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, 0u, 0u, 0u});
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      ah[i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * XROW);
-      al[i] = *reinterpret_cast<const bf16x8*>(a + A_LO + i * 16 * XROW);
-    }
+      for (int i = 0; i < 2; ++i) { ah[i] = z; al[i] = z; }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      wh[j] = *reinterpret_cast<const bf16x8*>(b + j * 16 * XROW);
-      wl[j] = *reinterpret_cast<const bf16x8*>(b + B_LO + j * 16 * XROW);
+      for (int j = 0; j < NT; ++j) { wh[j] = z; wl[j] = z; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * XROW);
+        al[i] = *reinterpret_cast<const bf16x8*>(a + A_LO + i * 16 * XROW);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        wh[j] = *reinterpret_cast<const bf16x8*>(b + j * 16 * XROW);
+        wl[j] = *reinterpret_cast<const bf16x8*>(b + B_LO + j * 16 * XROW);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (DBG & 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { asm volatile("" ::"v"(ah[i])); asm volatile("" ::"v"(al[i])); }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { asm volatile("" ::"v"(wh[j])); asm volatile("" ::"v"(wl[j])); }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -240,11 +264,11 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
       load_chunk(c + 2, ra0, rb0);          // set 0 is free; set 1 holds stage c+1
       compute(0);                           // stage c from LDS buffer 0
       store_chunk(1, ra1, rb1);
-      __syncthreads();
+      if (!(DBG & 16)) __syncthreads();
       load_chunk(c + 3, ra1, rb1);          // set 1 is free; set 0 holds stage c+2
       compute(1);                           // stage c+1 from LDS buffer 1
       store_chunk(0, ra0, rb0);
-      __syncthreads();
+      if (!(DBG & 16)) __syncthreads();
     }
   } else {
     for (int c = 0; c < nchunks; c += 2) {
@@ -658,8 +682,30 @@ static int launch_xigemm3(const XIgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3");
 }
+template <int DBG>
+static int launch_xigemm_dbg(const XIgemmParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)2 * (2 * XBM * XROW + 64 + 2 * 7 * 16 * XROW + 64) * sizeof(u16);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<7, false, true, DBG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const dim3 grid((unsigned)ceil_div64(p.M, XBM), (unsigned)((p.Np / 16 + 6) / 7));
+  hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<7, false, true, DBG>), grid, dim3(256), lds, stream, p);
+  return check_launch("conv2d_igemm_bf16x3(ablation)");
+}
 template <int NT, bool PADDED>
 static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
+  if (NT == 7 && !PADDED) {       // WCMC_DEBUG_ABLATE=<mask>: timing-only ablation builds of the 5x5 forward GEMM
+    static int ab = -1;
+    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    switch (ab) {
+      case 1: return launch_xigemm_dbg<1>(p, stream);
+      case 2: return launch_xigemm_dbg<2>(p, stream);
+      case 8: return launch_xigemm_dbg<8>(p, stream);
+      case 16: return launch_xigemm_dbg<16>(p, stream);
+      case 10: return launch_xigemm_dbg<10>(p, stream);
+      case 26: return launch_xigemm_dbg<26>(p, stream);
+      default: break;
+    }
+  }
   if (g_xigemm_dbuf < 0) {
     const char* e = getenv("WCMC_IGEMM_DBUF");
     g_xigemm_dbuf = (e && e[0] == '0') ? 0 : 1;
