@@ -420,10 +420,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
   const int cob = tileid / p.ciBlocks, cib = tileid - cob * p.ciBlocks;
   const int co0 = cob * YC, ci0 = cib * XC;
   const int tdy = tap / p.ks - p.pad, tdx = tap % p.ks - p.pad;
-  const int tm_valid = min(TM, (p.Np - co0) / 16);
-  const int wk = wave >> 1, wn = wave & 1;         // k-step (pixel half) and cin half of this wave
-  const int tn_valid = min(2, max(0, (p.Cq - ci0) / 16 - wn * 2));
-
+  // waves: 2 (pixel halves = MFMA k-steps) x 2 (cout halves); every wave covers the 4 cin tiles, so a
+  // stage costs it 8 + 2*MT transposing fragment loads for 12*MT MFMAs (was 36 for 42).
+  constexpr int MT = (TM + 1) / 2;                 // cout tiles per wave (the second half may hold one less)
+  const int wk = wave >> 1, wm = wave & 1;
+  const int tm_valid = min(MT, max(0, min(TM, (p.Np - co0) / 16) - wm * MT));
+  const int tn_valid = min(4, max(0, (p.Cq - ci0) / 16));
   const int64_t pstart = (int64_t)s * p.pix_per_split;
   const int64_t pend = min(p.M, pstart + p.pix_per_split);
   const int nstages = (int)((pend - pstart + PK - 1) / PK);
@@ -478,9 +480,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
     for (int j = 0; j < NV; ++j) *reinterpret_cast<u32x4*>(smem16 + lds_off[j]) = rv[j];
   };
 
-  f32x4 acc[TM][2];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // transposing read: lane (group g = lane>>4, i = lane&15, q = i>>2, pp = i&3) addresses pixel row
   // 4g + q (first read) / 16 + 4g + q (second read) and channels 4pp..4pp+3 of a 16-channel tile;
@@ -504,24 +508,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
     store_stage();
     __syncthreads();
     if (st + 1 < nstages) load_stage();
-    bf16x8 xh[2], xl[2];
+    bf16x8 xh[4], xl[4], yh[MT], yl[MT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      tr_read(Xs, SB, (wn * 2 + j) * 16, xh[j]);
-      tr_read(Xs + PK * SB, SB, (wn * 2 + j) * 16, xl[j]);
+    for (int j = 0; j < 4; ++j) {
+      tr_read(Xs, SB, j * 16, xh[j]);
+      tr_read(Xs + PK * SB, SB, j * 16, xl[j]);
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if (i < tm_valid) {
-        bf16x8 yh, yl;
-        tr_read(Ys, SA, i * 16, yh);
-        tr_read(Ys + PK * SA, SA, i * 16, yl);
+    for (int i = 0; i < MT; ++i) {
+      tr_read(Ys, SA, (wm * MT + i) * 16, yh[i]);            // (a tile past TM reads the X region: unused)
+      tr_read(Ys + PK * SA, SA, (wm * MT + i) * 16, yl[i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+    for (int i = 0; i < MT; ++i) {
+      if (i < tm_valid) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
           if (j < tn_valid) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl[i], xh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xh[j], acc[i][j], 0, 0, 0);
           }
         }
       }
@@ -536,14 +543,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
   for (int h = 0; h < 2; ++h) {
     if (wk == h) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < MT; ++i) {
+        if (wm * MT + i < TM) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* q = red + (i * 16 + fq + r) * RS + (wn * 2 + j) * 16 + fcol;
-            *q = (h == 0 ? 0.f : *q) + acc[i][j][r];
-          }
+            for (int r = 0; r < 4; ++r) {
+              float* q = red + ((wm * MT + i) * 16 + fq + r) * RS + j * 16 + fcol;
+              *q = (h == 0 ? 0.f : *q) + acc[i][j][r];
+            }
+        }
+      }
     }
     __syncthreads();
   }
