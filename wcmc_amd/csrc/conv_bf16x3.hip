@@ -174,11 +174,14 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
         const int iy = aiy[j] + tdy, ix = aix[j] + tdx;
         off = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? off : XOOB;
       }
-      ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+      if (DBG & 4) ra[j] = u32x4{off, 0u, 0u, 0u};             // ablation: no A-operand load instruction at all
+      else ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (wbase[j] + (unsigned)(c * XKC * 2)) | kill, 0, 0);
+    for (int j = 0; j < NJ; ++j) {
+      if (DBG & 32) rb[j] = u32x4{wbase[j], 0u, 0u, 0u};       // ablation: no B-operand load instruction
+      else rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (wbase[j] + (unsigned)(c * XKC * 2)) | kill, 0, 0);
+    }
     ci += XKC;
     while (ci >= p.Kp) { ci -= p.Kp; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
   };
@@ -713,6 +716,10 @@ static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
       case 16: return launch_xigemm_dbg<16>(p, stream);
       case 10: return launch_xigemm_dbg<10>(p, stream);
       case 26: return launch_xigemm_dbg<26>(p, stream);
+      case 4: return launch_xigemm_dbg<4>(p, stream);
+      case 32: return launch_xigemm_dbg<32>(p, stream);
+      case 36: return launch_xigemm_dbg<36>(p, stream);
+      case 62: return launch_xigemm_dbg<62>(p, stream);
       default: break;
     }
   }
