@@ -626,7 +626,9 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
   const int64_t M = (int64_t)N * Ho * Wo;
   const int taps = ks * ks;
   const int64_t tiles = (int64_t)taps * pl.coBlocks * pl.ciBlocks;
-  int64_t S = 1024 / tiles;                           // ~2 waves of 512 co-resident blocks; fewer, larger slabs
+  // ~2 waves of 512 co-resident blocks for the multi-tap convs; one wave for the HBM-bound 1x1 layers,
+  // whose slab traffic (S x Np x Cq floats, written and re-read) otherwise rivals the operand stream
+  int64_t S = (ks == 1 ? 512 : 1024) / tiles;
   const int64_t maxS = M / 512 > 0 ? M / 512 : 1;     // >= 8 stages of 64 pixels per block
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
