@@ -222,6 +222,7 @@ def main():
         step()
     prof = EventProfiler()
     if args.eager:
+        ops.USE_SIDE_STREAM = False        # per-launch events need one stream
         ops.set_profiler(prof)
     if world > 1:
         torch.distributed.barrier()
@@ -243,6 +244,7 @@ def main():
         itf.loss_funcs["l_manif"].static_perms = None
         itf.loss_funcs["l_manif"].check_finite = True
         nprof = max(2, min(5, args.steps))
+        ops.USE_SIDE_STREAM = False        # one stream: every event pair brackets exactly one kernel class
         eager_step()
         ops.set_profiler(prof)
         torch.cuda.synchronize()
