@@ -248,11 +248,18 @@ def main():
         eager_step()
         ops.set_profiler(prof)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        prof_elapsed = 0.0
         for _ in range(nprof):
+            # The eager host needs ~40 ms to enqueue a step, longer than the GPU needs to run it: park the
+            # stream behind a spin kernel while the step is enqueued, so that the event pairs bracket
+            # kernels that run back to back instead of a GPU waiting for Python.
+            torch.cuda._sleep(int(2.0e8))
+            pe0.record()
             eager_step()
-        torch.cuda.synchronize()
-        prof_elapsed = time.perf_counter() - t1
+            pe1.record()
+            torch.cuda.synchronize()
+            prof_elapsed += pe0.elapsed_time(pe1) * 1e-3
         ops.set_profiler(None)
 
     if rank == 0:
