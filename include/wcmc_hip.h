@@ -126,10 +126,12 @@ int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              int ks, int pad, int act, float slope,
                              const void* gate_split, int gate_act, float gate_slope, void* stream);
 size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks);
+/* phase: 0 = everything; 1 = the split-K GEMM into the workspace only; 2 = the slab reduction and
+ * bias gradient only (1 then 2 == 0; lets a profiler bracket the GEMM launch alone). */
 int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              const void* dy_split, int Cout, int ks, int pad,
                              float* dw_oihw, float* db, void* workspace, size_t workspace_bytes,
-                             void* stream);
+                             int phase, void* stream);
 
 /* dx = dy * act'(y) from the post-activation value y (NHWC views of equal geometry). */
 int wcmc_act_backward(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw,

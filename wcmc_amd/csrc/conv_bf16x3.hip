@@ -800,7 +800,7 @@ static int launch_xwgrad(const XWgradParams& p, hipStream_t stream) {
 
 extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W, int Cin, const void* dy_split,
                                         int Cout, int ks, int pad, float* dw, float* db, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
+                                        size_t workspace_bytes, int phase, void* stream) {
   WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ks > 0 && pad >= 0 && dw && workspace &&
                    x_split && dy_split,
                WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: bad argument");
@@ -821,8 +821,10 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
   WCMC_REQUIRE(xb < 0x7ff00000u && yb < 0x7ff00000u, WCMC_ERR_BAD_ARG,
                "conv2d_wgrad_bf16x3: operand larger than 2 GiB (split the batch)");
   p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
-  int rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
-  if (rc) return rc;
+  WCMC_REQUIRE(phase >= 0 && phase <= 2, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: phase must be 0, 1 or 2");
+  int rc = 0;
+  if (phase != 2) rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
+  if (rc || phase == 1) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + WR_CI - 1) / WR_CI), (unsigned)Cout), dim3(256),
                      (size_t)WR_CI * (ks * ks + 1) * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq);
   rc = check_launch("conv2d_wgrad_bf16x3_reduce");

@@ -319,9 +319,14 @@ def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape):
     ws = torch.empty((nbytes + 3) // 4, device=xs.device, dtype=torch.float32)
     dw = torch.empty(weight_shape, device=xs.device, dtype=torch.float32)
     db = torch.empty(cout, device=xs.device, dtype=torch.float32)
-    with _Timed("conv_wgrad", 2.0 * n * ho * wo * cout * cin * ks * ks, "flop"):
-        check(lib().wcmc_conv2d_wgrad_bf16x3(_ptr(xs), n, h, w, cin, _ptr(dys), cout, ks, pad, _ptr(dw), _ptr(db),
-                                             _ptr(ws), ws.numel() * 4, _stream()), "conv2d_wgrad_bf16x3")
+    args = (_ptr(xs), n, h, w, cin, _ptr(dys), cout, ks, pad, _ptr(dw), _ptr(db), _ptr(ws), ws.numel() * 4)
+    if _PROFILER is None:
+        check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 0, _stream()), "conv2d_wgrad_bf16x3")
+    else:       # bracket the split-K GEMM launch alone; the slab reduce + bias gradient is its own class
+        with _Timed("conv_wgrad", 2.0 * n * ho * wo * cout * cin * ks * ks, "flop"):
+            check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, _stream()), "conv2d_wgrad_bf16x3")
+        with _Timed("conv_wgrad_finish", 0.0, "flop"):
+            check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 2, _stream()), "conv2d_wgrad_bf16x3")
     return dw, db
 
 
