@@ -277,8 +277,13 @@ def main():
                 ach, unit = rate / 1e12, "TFLOP/s"
             else:
                 ach, peak, unit = rate / 1e9, PEAK_HBM_GBS, "GB/s"
+            extra = {}
+            if bound == "mfma" and ops.PRECISION == "bf16x3":
+                # 3 bf16 MFMAs per algorithmic multiply-add (+12 % cout and 5 % k padding): the MFMA pipe does
+                # ~3.5x the counted FLOPs; for scale, the exact-fp32 MFMA peak is 157.3 TFLOP/s
+                extra = {"mfma_flops_per_algorithmic_flop": 3.0, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 3)}
             return {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": None, "launches": d["launches"],
+                    "frac": round(ach / peak, 4), "traffic": None, "launches": d["launches"], **extra,
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "share_of_profiled_region": round(d["ms"] / (prof_elapsed * 1e3), 4)}
 
