@@ -253,9 +253,11 @@ int wcmc_grs_bwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t 
  * train_kpcn.py:274-277: default betas/eps, no weight decay, no amsgrad) fused
  * over one flat parameter buffer.  grad is clamped IN PLACE (the reference leaves
  * clipped .grad behind), then m,v,param are updated.  step is the 1-based count. */
+/* guard (optional device float): when *guard == 0 the launch is a no-op (the host raises the
+ * reference's non-finite-loss error, interfaces.py:254-257, without having to sync before enqueuing). */
 int wcmc_clip_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float clip, double lr, double beta1, double beta2, double eps, int step,
-                   float grad_scale, void* stream);
+                   float grad_scale, const float* guard, void* stream);
 
 #ifdef __cplusplus
 }

@@ -273,3 +273,33 @@ def test_graphed_step_equals_eager_step():
         assert torch.equal(p0, p1)
     finally:
         ops.set_precision(old)
+
+
+def test_nonfinite_loss_raises_and_skips_the_update():
+    """interfaces.py:254-257: a non-finite loss raises RuntimeError; with the fused optimiser the raise comes
+    after the (guarded, hence skipped) update has been enqueued -- parameters must be untouched."""
+    from wcmc_amd import KPCN
+    from wcmc_amd.optim import FusedClipAdam
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import RelativeMSE
+    from wcmc_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    models = {"dncnn": KPCN(34, ksize=5, depth=2, width=8).to(DEV)}
+    optims = {"optim_dncnn": torch.optim.Adam(models["dncnn"].parameters(), lr=1e-3)}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+          "l_test": RelativeMSE()}
+    itf = KPCNInterface(models, optims, lf, types.SimpleNamespace(model_name="n"))
+    itf.fused_optim = FusedClipAdam(models, optims)
+    itf.to_train_mode()
+    batch = make_batch(1, 2, 32, seed=1, device=DEV, use_llpm=False)
+    itf.preprocess(batch)
+    itf.train_batch(batch)                                   # a healthy step first
+    before = torch.cat([p.detach().reshape(-1).clone() for p in models["dncnn"].parameters()])
+    bad = dict(batch)
+    bad["target_diffuse"] = batch["target_diffuse"].clone()
+    bad["target_diffuse"][0, 0, 16, 16] = float("nan")
+    itf.preprocess(bad)
+    with pytest.raises(RuntimeError, match="l_diffuse: Non-finite loss at train time."):
+        itf.train_batch(bad)
+    after = torch.cat([p.detach().reshape(-1) for p in models["dncnn"].parameters()])
+    assert torch.equal(before, after)

@@ -360,3 +360,9 @@ def test_clip_adam_matches_torch():
     st = opt.state[pr]
     assert_close(m, st["exp_avg"], tol=1e-6, what="exp_avg")
     assert_close(v, st["exp_avg_sq"], tol=1e-6, what="exp_avg_sq")
+    # a zero guard makes the launch a no-op (non-finite loss upstream)
+    before = (p.clone(), m.clone(), v.clone())
+    o.clip_adam_(p, (g0 * 7).to(DEV), m, v, 4, 1e-3, guard=torch.zeros((), device=DEV))
+    assert torch.equal(p, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
+    o.clip_adam_(p, (g0 * 7).to(DEV), m, v, 4, 1e-3, guard=torch.ones((), device=DEV))
+    assert not torch.equal(p, before[0])

@@ -49,7 +49,7 @@ SIGNATURES = {
     "wcmc_feature_mse_bwd": (I, [P, L, L, L, L, L, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "wcmc_grs_fwd": (I, [P, L, L, L, L, L, P, L, L, L, L, P, P, F, P, P, Z, I, I, I, I, I, P]),
     "wcmc_grs_bwd": (I, [P, L, L, L, L, L, P, P, P, P, P, Z, I, I, I, I, I, P]),
-    "wcmc_clip_adam": (I, [P, P, P, P, L, F, D, D, D, D, I, F, P]),
+    "wcmc_clip_adam": (I, [P, P, P, P, L, F, D, D, D, D, I, F, P, P]),
 }
 
 _lib = None

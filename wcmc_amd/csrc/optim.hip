@@ -11,7 +11,8 @@ namespace wcmc {
 __global__ void clip_adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float clip, float step_size, float beta1,
                                  float beta2, float omb1, float omb2, float eps, float inv_bc2_sqrt,
-                                 float grad_scale) {
+                                 float grad_scale, const float* __restrict__ guard) {
+  if (guard && guard[0] == 0.f) return;        // non-finite loss upstream: leave parameters and moments untouched
   const int64_t n4 = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 g = reinterpret_cast<float4*>(grad)[i];
@@ -51,7 +52,7 @@ using namespace wcmc;
 
 extern "C" int wcmc_clip_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float clip,
                               double lr, double beta1, double beta2, double eps, int step, float grad_scale,
-                              void* stream) {
+                              const float* guard, void* stream) {
   WCMC_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, WCMC_ERR_BAD_ARG,
                "clip_adam: bad argument (n=%lld step=%d)", (long long)n, step);
   WCMC_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), WCMC_ERR_ALIGNMENT,
@@ -65,6 +66,6 @@ extern "C" int wcmc_clip_adam(float* param, float* grad, float* exp_avg, float* 
   const int64_t blocks = ceil_div64(n / 4 > 0 ? n / 4 : 1, 256);
   hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
                      (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, clip, step_size, (float)beta1,
-                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, inv_bc2_sqrt, grad_scale);
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, inv_bc2_sqrt, grad_scale, guard);
   return check_launch("clip_adam");
 }

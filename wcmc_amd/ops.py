@@ -679,8 +679,10 @@ def feature_mse(p, ref, idx_patch, idx_batch):
 
 # ------------------------------------------------------------------------ optimiser
 def clip_adam_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0,
-               grad_scale=1.0):
-    """In-place fused clip_grad_value_ + Adam over flat fp32 buffers."""
-    _need_cuda(param, grad, exp_avg, exp_avg_sq)
+               grad_scale=1.0, guard=None):
+    """In-place fused clip_grad_value_ + Adam over flat fp32 buffers (no-op when the device float
+    ``guard`` is 0)."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq, guard)
     check(lib().wcmc_clip_adam(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
-                               clip, lr, beta1, beta2, eps, int(step), grad_scale, _stream()), "clip_adam")
+                               clip, lr, beta1, beta2, eps, int(step), grad_scale, _ptr(guard), _stream()),
+          "clip_adam")

@@ -72,7 +72,8 @@ class FusedClipAdam:
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.flats = {name: _Flat(models[name], optims["optim_" + name]) for name in models}
 
-    def step(self, models, optims):
+    def step(self, models, optims, guard=None):
+        """guard: optional device float; 0 turns every update of this step into a no-op."""
         for name, fl in self.flats.items():
             optim = optims["optim_" + name]
             if not fl.bound(optim):
@@ -84,7 +85,8 @@ class FusedClipAdam:
             g0 = optim.param_groups[0]
             fl.steps += 1
             ops.clip_adam_(fl.flat, flat_g, fl.m, fl.v, fl.steps, float(g0["lr"]), float(g0["betas"][0]),
-                           float(g0["betas"][1]), float(g0["eps"]), clip=self.clip, grad_scale=1.0 / self.world)
+                           float(g0["betas"][1]), float(g0["eps"]), clip=self.clip, grad_scale=1.0 / self.world,
+                           guard=guard)
             # leave the (averaged, clipped) gradients behind as the reference does
             if self.leave_grads:
                 for p, gv in zip(fl.params, fl._views(flat_g)):

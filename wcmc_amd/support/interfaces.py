@@ -261,10 +261,13 @@ class KPCNInterface(BaseInterface):
     def _logging(self, loss_dict):
         """ error handling """
         keys = list(loss_dict)
-        finite = torch.isfinite(torch.stack([loss_dict[k].reshape(()) for k in keys])).tolist()   # one sync
-        for key, ok in zip(keys, finite):
-            if not ok:
-                raise RuntimeError("%s: Non-finite loss at train time." % (key))
+        finite = torch.isfinite(torch.stack([loss_dict[k].reshape(()) for k in keys]))
+        if self.fused_optim is not None:
+            # Deferred: the fused optimiser is enqueued behind a device-side guard (no update when a
+            # loss is non-finite) and the host check -- the only sync of the step -- comes after it.
+            self._pending_finite = (keys, finite)
+        else:
+            self._raise_if_nonfinite(keys, finite)
 
         if self.grad_sync is not None:
             self.grad_sync(self.models)
@@ -279,9 +282,18 @@ class KPCNInterface(BaseInterface):
                 self.m_losses['m_' + key] = torch.tensor(0.0, device=loss_dict[key].device)
             self.m_losses['m_' + key] += loss_dict[key]
 
+    @staticmethod
+    def _raise_if_nonfinite(keys, finite):
+        for key, ok in zip(keys, finite.tolist()):                   # one sync
+            if not ok:
+                raise RuntimeError("%s: Non-finite loss at train time." % (key))
+
     def _optimization(self):
         if self.fused_optim is not None:
-            self.fused_optim.step(self.models, self.optims)      # clip_grad_value_(1.0) + Adam, fused
+            keys, finite = self._pending_finite
+            guard = finite.all().to(torch.float32)
+            self.fused_optim.step(self.models, self.optims, guard=guard)   # clip_grad_value_(1.0) + Adam, fused
+            self._raise_if_nonfinite(keys, finite)
             return
         for model_name in self.models:
             self.optims['optim_' + model_name].step()
