@@ -162,6 +162,18 @@ int wcmc_kernel_apply_bwd(const float* logits, int64_t lsn, int64_t lsh, int64_t
                           float* d_logits, int64_t qsn, int64_t qsh, int64_t qsw,
                           float* d_data, int N, int C, int h, int w, int k, void* stream);
 
+/* Tail of sbmc.KPCN.forward (result keys consumed at support/interfaces.py:207-211):
+ *   radiance = albedo * r_diffuse + exp(r_specular) - 1.
+ * Inputs (N,C,H,W) with arbitrary element strides; out / grad_out / d_* contiguous (N,C,H,W). */
+int wcmc_recombine_fwd(const float* albedo, int64_t asn, int64_t asc, int64_t ash, int64_t asw,
+                       const float* r_diffuse, int64_t dsn, int64_t dsc, int64_t dsh, int64_t dsw,
+                       const float* r_specular, int64_t ssn, int64_t ssc, int64_t ssh, int64_t ssw,
+                       float* out, int N, int C, int H, int W, void* stream);
+int wcmc_recombine_bwd(const float* grad_out,
+                       const float* albedo, int64_t asn, int64_t asc, int64_t ash, int64_t asw,
+                       const float* r_specular, int64_t ssn, int64_t ssc, int64_t ssh, int64_t ssw,
+                       float* d_diffuse, float* d_specular, int N, int C, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- U-Net glue
  * F.max_pool2d(x,2,2) / F.interpolate(x, scale_factor=2, 'bilinear',
  * align_corners=False) inside sbmc.modules.Autoencoder (support/networks.py:20-22). */

@@ -260,6 +260,37 @@ __global__ void pbuffer_cat_bwd_kernel(const float* __restrict__ g, int64_t gsn,
   }
 }
 
+// ------------------------------------------------------------------ KPCN recombination
+// radiance = albedo * r_diffuse + exp(r_specular) - 1   (tail of sbmc.KPCN.forward; consumed at
+// support/interfaces.py:207-211).  All tensors (N,C,H,W) with arbitrary element strides.
+struct S4 { int64_t n, c, h, w; };
+__global__ void recombine_fwd_kernel(const float* __restrict__ alb, S4 sa, const float* __restrict__ rd, S4 sd,
+                                     const float* __restrict__ rs, S4 ss, float* __restrict__ out, int C, int H, int W,
+                                     int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W); int64_t t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C); const int n = (int)(t / C);
+    const float a = alb[n * sa.n + c * sa.c + y * sa.h + x * sa.w];
+    const float d = rd[n * sd.n + c * sd.c + y * sd.h + x * sd.w];
+    const float s = rs[n * ss.n + c * ss.c + y * ss.h + x * ss.w];
+    out[i] = a * d + expf(s) - 1.f;
+  }
+}
+// g (contiguous) -> d r_diffuse = g * albedo ; d r_specular = g * exp(r_specular)   (contiguous outputs)
+__global__ void recombine_bwd_kernel(const float* __restrict__ g, const float* __restrict__ alb, S4 sa,
+                                     const float* __restrict__ rs, S4 ss, float* __restrict__ dd,
+                                     float* __restrict__ ds, int C, int H, int W, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W); int64_t t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C); const int n = (int)(t / C);
+    const float gv = g[i];
+    dd[i] = gv * alb[n * sa.n + c * sa.c + y * sa.h + x * sa.w];
+    ds[i] = gv * expf(rs[n * ss.n + c * ss.c + y * ss.h + x * ss.w]);
+  }
+}
+
 static unsigned grid_for(int64_t total) {
   const int64_t g = ceil_div64(total, 256);
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -389,4 +420,29 @@ extern "C" int wcmc_pbuffer_cat_bwd(const float* g, int64_t gsn, int64_t gsh, in
   hipLaunchKernelGGL(pbuffer_cat_bwd_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, g,
                      gsn, gsh, gsw, dp, psb, pss, psc, psh, psw, B, S, Cb, Cp, H, W);
   return check_launch("pbuffer_cat_bwd");
+}
+
+extern "C" int wcmc_recombine_fwd(const float* albedo, int64_t asn, int64_t asc, int64_t ash, int64_t asw,
+                                  const float* r_diffuse, int64_t dsn, int64_t dsc, int64_t dsh, int64_t dsw,
+                                  const float* r_specular, int64_t ssn, int64_t ssc, int64_t ssh, int64_t ssw,
+                                  float* out, int N, int C, int H, int W, void* stream) {
+  WCMC_REQUIRE(albedo && r_diffuse && r_specular && out && N > 0 && C > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG,
+               "recombine_fwd: bad argument");
+  const int64_t total = (int64_t)N * C * H * W;
+  hipLaunchKernelGGL(recombine_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, albedo,
+                     S4{asn, asc, ash, asw}, r_diffuse, S4{dsn, dsc, dsh, dsw}, r_specular, S4{ssn, ssc, ssh, ssw}, out,
+                     C, H, W, total);
+  return check_launch("recombine_fwd");
+}
+
+extern "C" int wcmc_recombine_bwd(const float* grad_out, const float* albedo, int64_t asn, int64_t asc, int64_t ash,
+                                  int64_t asw, const float* r_specular, int64_t ssn, int64_t ssc, int64_t ssh,
+                                  int64_t ssw, float* d_diffuse, float* d_specular, int N, int C, int H, int W,
+                                  void* stream) {
+  WCMC_REQUIRE(grad_out && albedo && r_specular && d_diffuse && d_specular && N > 0 && C > 0 && H > 0 && W > 0,
+               WCMC_ERR_BAD_ARG, "recombine_bwd: bad argument");
+  const int64_t total = (int64_t)N * C * H * W;
+  hipLaunchKernelGGL(recombine_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, grad_out, albedo,
+                     S4{asn, asc, ash, asw}, r_specular, S4{ssn, ssc, ssh, ssw}, d_diffuse, d_specular, C, H, W, total);
+  return check_launch("recombine_bwd");
 }

@@ -1,8 +1,8 @@
 """MI355X-native ``sbmc.KPCN`` (constructed at ``train_kpcn.py:213,229``; result keys consumed
 at ``support/interfaces.py:207-211``).  Same specification as ``oracle/models.py``."""
-import torch
 import torch.nn as nn
 
+from . import ops
 from .modules import ConvChain, KernelApply
 from .support.utils import crop_like
 
@@ -25,6 +25,5 @@ class KPCN(nn.Module):
         r_diffuse = self.kernel_apply(b_diffuse, k_diffuse)
         r_specular = self.kernel_apply(b_specular, k_specular)
         albedo = crop_like(data["kpcn_albedo"], r_diffuse)
-        # (B,3,92,92) recombination on 200 KB tensors
-        radiance = albedo * r_diffuse + torch.exp(r_specular) - 1
+        radiance = ops.recombine(albedo, r_diffuse, r_specular)
         return dict(radiance=radiance, diffuse=r_diffuse, specular=r_specular)

@@ -454,6 +454,35 @@ def kernel_apply(data, logits):
     return _KernelApply.apply(data, as_nhwc(logits))
 
 
+class _Recombine(torch.autograd.Function):
+    """radiance = albedo * r_diffuse + exp(r_specular) - 1 (albedo is data: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, albedo, r_d, r_s):
+        _need_cuda(albedo, r_d, r_s)
+        n, c, h, w = r_d.shape
+        out = torch.empty((n, c, h, w), device=r_d.device, dtype=torch.float32)
+        check(lib().wcmc_recombine_fwd(_ptr(albedo), *albedo.stride(), _ptr(r_d), *r_d.stride(), _ptr(r_s),
+                                       *r_s.stride(), _ptr(out), n, c, h, w, _stream()), "recombine_fwd")
+        ctx.save_for_backward(albedo, r_s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        albedo, r_s = ctx.saved_tensors
+        n, c, h, w = r_s.shape
+        g = g.contiguous()
+        dd = torch.empty((n, c, h, w), device=g.device, dtype=torch.float32)
+        ds = torch.empty((n, c, h, w), device=g.device, dtype=torch.float32)
+        check(lib().wcmc_recombine_bwd(_ptr(g), _ptr(albedo), *albedo.stride(), _ptr(r_s), *r_s.stride(), _ptr(dd),
+                                       _ptr(ds), n, c, h, w, _stream()), "recombine_bwd")
+        return None, dd, ds
+
+
+def recombine(albedo, r_diffuse, r_specular):
+    return _Recombine.apply(albedo, r_diffuse, r_specular)
+
+
 # ------------------------------------------------------------------------ U-Net glue
 class _MaxPool2(torch.autograd.Function):
     @staticmethod
