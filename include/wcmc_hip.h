@@ -124,7 +124,13 @@ int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              const void* wp, const float* bias,
                              float* y, int64_t ysn, int64_t ysh, int64_t ysw, void* y_split, int Cout,
                              int ks, int pad, int act, float slope,
-                             const void* gate_split, int gate_act, float gate_slope, void* stream);
+                             const void* gate_split, int gate_act, float gate_slope,
+                             float* colsum_partial, void* stream);
+/* colsum_partial (optional, with y_split): [wcmc_conv2d_igemm_colsum_elems] floats that receive the
+ * per-pixel-tile column sums of the result -- the bias gradient of the layer that consumes this
+ * data gradient, finished by wcmc_colsum_finish (saves a pass over dy per layer). */
+size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout);
+int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, int Cout, float* db, void* stream);
 size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks);
 /* phase: 0 = everything; 1 = the split-K GEMM into the workspace only; 2 = the slab reduction and
  * bias gradient only (1 then 2 == 0; lets a profiler bracket the GEMM launch alone). */

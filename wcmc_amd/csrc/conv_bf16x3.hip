@@ -104,6 +104,7 @@ struct XIgemmParams {
   int Kp, Kt, Np;
   int64_t M;
   unsigned x_bytes, wp_bytes;
+  float* colsum;                          // optional [pixel tiles][Np] per-tile column sums of the split output
 };
 
 // DBUF: two LDS stage buffers and one barrier per stage (2 workgroups per CU), or one buffer and two
@@ -338,6 +339,13 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
       if (m < p.M && co < p.Cpo)
         *reinterpret_cast<u32x4*>(p.ys + (int64_t)m * 2 * p.Cpo + plane * p.Cpo + co) =
             *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+    }
+    if (p.colsum && tid < BN) {
+      // bias gradient of the consumer layer for free: column sums of this tile (hi + lo) while it is in LDS
+      const int rows = (int)min((int64_t)XBM, p.M - m0);
+      float acc = 0.f;
+      for (int r = 0; r < rows; ++r) acc += bf2f(so[r * OLD + tid]) + bf2f(so[r * OLD + BN + tid]);
+      if (n0 + tid < p.Np) p.colsum[(int64_t)tile * p.Np + n0 + tid] = acc;
     }
   } else {
     constexpr int OLD = BN + 4;                          // floats per LDS pixel row
@@ -739,9 +747,12 @@ static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
 extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin, const void* wp,
                                         const float* bias, float* y, int64_t ysn, int64_t ysh, int64_t ysw,
                                         void* y_split, int Cout, int ks, int pad, int act, float slope,
-                                        const void* gate_split, int gate_act, float gate_slope, void* stream) {
+                                        const void* gate_split, int gate_act, float gate_slope,
+                                        float* colsum_partial, void* stream) {
   WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ks > 0 && pad >= 0 && x_split && wp,
                WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: bad argument");
+  WCMC_REQUIRE(!colsum_partial || y_split, WCMC_ERR_BAD_ARG,
+               "conv2d_igemm_bf16x3: column sums are produced with the split output only");
   WCMC_REQUIRE((y != nullptr) != (y_split != nullptr), WCMC_ERR_BAD_ARG,
                "conv2d_igemm_bf16x3: exactly one of y (fp32 view) and y_split must be given");
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
@@ -767,6 +778,7 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   WCMC_REQUIRE(xb < 0x7ff00000u && wb < 0x7ff00000u, WCMC_ERR_BAD_ARG,
                "conv2d_igemm_bf16x3: operand larger than 2 GiB (split the batch)");
   p.x_bytes = (unsigned)xb; p.wp_bytes = (unsigned)wb;
+  p.colsum = colsum_partial;
   {  // timing-only experiments (guide section 7: zero-record descriptors drop one operand's traffic)
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("WCMC_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
@@ -780,6 +792,20 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
     case 2: return launch_xigemm<2>(p, st);
     default: return launch_xigemm<1>(p, st);
   }
+}
+
+extern "C" size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return 0;
+  return (size_t)ceil_div64((int64_t)N * Ho * Wo, XBM) * round_up(Cout, 16);
+}
+
+extern "C" int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, int Cout, float* db, void* stream) {
+  WCMC_REQUIRE(partial && db && N > 0 && Ho > 0 && Wo > 0 && Cout > 0, WCMC_ERR_BAD_ARG, "colsum_finish: bad argument");
+  const int G = (int)ceil_div64((int64_t)N * Ho * Wo, XBM), Np = round_up(Cout, 16);
+  // partial rows are Np wide: reduce the first Cout columns of each
+  hipLaunchKernelGGL(colsum_final_strided_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(1024), 0,
+                     (hipStream_t)stream, partial, G, Np, Cout, db);
+  return check_launch("colsum_finish");
 }
 
 extern "C" size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks) {

@@ -58,4 +58,23 @@ static __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* 
   }
 }
 
+// same with a row pitch (partial[g][ld], first C columns)
+static __global__ __launch_bounds__(1024) void colsum_final_strided_kernel(const float* __restrict__ partial, int G,
+                                                                           int ld, int C, float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, gg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (c < C)
+    for (int g = gg; g < G; g += 16) acc += partial[(int64_t)g * ld + c];
+  red[gg][cl] = acc;
+  __syncthreads();
+  if (gg == 0 && c < C) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][cl];
+    out[c] = t;
+  }
+}
+
 }  // namespace wcmc

@@ -293,9 +293,10 @@ def _pack_x(weight, mode):
     return wp
 
 
-def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, gate_act="linear"):
+def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, gate_act="linear", colsum=False):
     """One split-bf16 implicit-GEMM launch.  xs: split tensor of dims (n,cin,h,w).
-    Returns a split tensor when out_split else an fp32 NHWC view."""
+    Returns a split tensor when out_split else an fp32 NHWC view; with colsum=True also the per-tile
+    column sums of the result (the consumer layer's bias gradient, see colsum_finish_raw)."""
     n, cin, h, w = dims
     ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
     dev = xs.device
@@ -305,20 +306,31 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
         yf = nhwc_empty(n, cout, ho, wo, dev)
         ysp, yv = None, _v(yf)
     pix = min(ho * wo, h * w)
+    part = None
+    if colsum:
+        part = torch.empty(lib().wcmc_conv2d_igemm_colsum_elems(n, ho, wo, cout), device=dev, dtype=torch.float32)
     with _Timed("conv_igemm", 2.0 * n * pix * cout * cin * ks * ks, "flop"):
         check(lib().wcmc_conv2d_igemm_bf16x3(_ptr(xs), n, h, w, cin, _ptr(wp), _ptr(bias), *yv, _ptr(ysp), cout,
                                              ks, pad, ACT[act], LEAKY_SLOPE, _ptr(gate), ACT[gate_act], LEAKY_SLOPE,
-                                             _stream()), "conv2d_igemm_bf16x3")
-    return ysp if out_split else yf
+                                             _ptr(part), _stream()), "conv2d_igemm_bf16x3")
+    out = ysp if out_split else yf
+    return (out, part) if colsum else out
 
 
-def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape):
+def colsum_finish_raw(part, dims):
+    n, c, h, w = dims
+    db = torch.empty(c, device=part.device, dtype=torch.float32)
+    check(lib().wcmc_colsum_finish(_ptr(part), n, h, w, c, _ptr(db), _stream()), "colsum_finish")
+    return db
+
+
+def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=True):
     n, cin, h, w = xdims
     ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
     nbytes = lib().wcmc_conv2d_wgrad_bf16x3_workspace_bytes(n, ho, wo, cout, cin, ks)
     ws = torch.empty((nbytes + 3) // 4, device=xs.device, dtype=torch.float32)
     dw = torch.empty(weight_shape, device=xs.device, dtype=torch.float32)
-    db = torch.empty(cout, device=xs.device, dtype=torch.float32)
+    db = torch.empty(cout, device=xs.device, dtype=torch.float32) if want_bias else None
     args = (_ptr(xs), n, h, w, cin, _ptr(dys), cout, ks, pad, _ptr(dw), _ptr(db), _ptr(ws), ws.numel() * 4)
     if _PROFILER is None:
         check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 0, _stream()), "conv2d_wgrad_bf16x3")
@@ -377,6 +389,7 @@ class _ConvChainX(torch.autograd.Function):
             off += 1
         ws = saved[off:]
         dys = split_raw(dy)
+        part = None                     # per-tile column sums of dys when the dgrad GEMM produced them
         grads = [None] * (2 * nl)
         dx = None
         main = torch.cuda.current_stream()
@@ -388,17 +401,22 @@ class _ConvChainX(torch.autograd.Function):
             if side is not None:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape)
+                    dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None)
+                    if part is not None:
+                        db = colsum_finish_raw(part, dims[l + 1])
                 dw.record_stream(main)
                 db.record_stream(main)
                 keep.append(dys)
+                keep.append(part)
             else:
-                dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape)
+                dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None)
+                if part is not None:
+                    db = colsum_finish_raw(part, dims[l + 1])
             grads[2 * l], grads[2 * l + 1] = dw, db
             if l > 0:
                 wpt = _pack_x(wt, 1)
-                dys = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
-                                   out_split=True, gate=xs[l], gate_act=acts[l - 1])
+                dys, part = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
+                                         out_split=True, gate=xs[l], gate_act=acts[l - 1], colsum=True)
             elif ctx.needs_input_grad[0]:
                 wpt = _pack_x(wt, 1)
                 dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
