@@ -93,6 +93,19 @@ class _OracleOps:
     def pbuffer_cat(base, p):
         return assemble_input(base, p)
 
+    class on_branch:                     # stream fork/join is a no-op on the host
+        def __init__(self, device):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def join(self, *tensors):
+            pass
+
 
 class _OracleFeatureMSE(torch.nn.Module):
     def __init__(self):

@@ -18,12 +18,14 @@ class KPCN(nn.Module):
         self.kernel_apply = KernelApply(softmax=True, splat=False)
 
     def forward(self, data):
+        with ops.on_branch(data["kpcn_specular_in"].device) as br:      # specular half on the branch stream
+            k_specular = self.specular(data["kpcn_specular_in"])
+            b_specular = crop_like(data["kpcn_specular_buffer"], k_specular)
+            r_specular = self.kernel_apply(b_specular, k_specular)
         k_diffuse = self.diffuse(data["kpcn_diffuse_in"])
-        k_specular = self.specular(data["kpcn_specular_in"])
         b_diffuse = crop_like(data["kpcn_diffuse_buffer"], k_diffuse)
-        b_specular = crop_like(data["kpcn_specular_buffer"], k_specular)
         r_diffuse = self.kernel_apply(b_diffuse, k_diffuse)
-        r_specular = self.kernel_apply(b_specular, k_specular)
+        br.join(r_specular)
         albedo = crop_like(data["kpcn_albedo"], r_diffuse)
         radiance = ops.recombine(albedo, r_diffuse, r_specular)
         return dict(radiance=radiance, diffuse=r_diffuse, specular=r_specular)

@@ -189,10 +189,57 @@ USE_SIDE_STREAM = True      # weight-gradient GEMMs run beside the data-gradient
 
 
 def _side_stream(device):
-    key = (device.type, device.index)
+    """The weight-gradient stream that belongs to the CURRENT stream (one per forked branch)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
+
+
+# Branch-level concurrency: the diffuse and specular halves of the step (PathNet backbones, KPCN conv
+# stacks + kernel apply, their losses and backward passes) are independent until the optimiser.
+# Running the specular half on a second stream lets its kernels fill the CUs that the tail of a
+# diffuse launch leaves idle (a conv launch is a whole number of 512-workgroup waves); autograd
+# replays each half's backward on the stream its forward ran on.
+USE_BRANCH_STREAM = True
+_BRANCH_STREAMS = {}
+
+
+def branch_stream(device):
+    key = (device.type, device.index)
+    if key not in _BRANCH_STREAMS:
+        _BRANCH_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _BRANCH_STREAMS[key]
+
+
+class on_branch:
+    """``with on_branch(device) as br: y = f(x)`` runs f on the branch stream after everything enqueued
+    so far on the current stream; ``br.join(y, ...)`` makes the current stream wait for it."""
+
+    def __init__(self, device):
+        self.enabled = USE_BRANCH_STREAM and torch.device(device).type == "cuda"
+        if self.enabled:
+            self.main = torch.cuda.current_stream(device)
+            self.stream = branch_stream(torch.device(device))
+            self.ctx = torch.cuda.stream(self.stream)
+
+    def __enter__(self):
+        if self.enabled:
+            self.stream.wait_stream(self.main)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.enabled:
+            self.main.wait_stream(self.stream)
+            for t in tensors:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(self.main)
 
 
 class _ConvChain(torch.autograd.Function):

@@ -200,10 +200,14 @@ class KPCNInterface(BaseInterface):
         self._optimization()
 
     def _manifold_forward(self, batch):
-        return {
-            'diffuse': self.models['backbone_diffuse'](batch),
-            'specular': self.models['backbone_specular'](batch),
-        }
+        pre = getattr(self.models['backbone_diffuse'], '_paths_nhwc', None)
+        if pre is not None:
+            pre(batch)                       # shared NHWC copy of `paths`, made before the streams fork
+        with _ops.on_branch(batch['paths'].device) as br:
+            p_specular = self.models['backbone_specular'](batch)
+        p_diffuse = self.models['backbone_diffuse'](batch)
+        br.join(p_specular)
+        return {'diffuse': p_diffuse, 'specular': p_specular}
 
     def _regress_forward(self, batch):
         return self.models['dncnn'](batch)
