@@ -212,6 +212,17 @@ def branch_stream(device):
     return _BRANCH_STREAMS[key]
 
 
+def join_all_streams(device):
+    """Make the current stream wait for the branch stream and every weight-gradient stream (end of a
+    step: a stream capture must not end with forked work outstanding)."""
+    if torch.device(device).type != "cuda":
+        return
+    cur = torch.cuda.current_stream(device)
+    for s in list(_BRANCH_STREAMS.values()) + list(_SIDE_STREAMS.values()):
+        if s.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(s)
+
+
 class on_branch:
     """``with on_branch(device) as br: y = f(x)`` runs f on the branch stream after everything enqueued
     so far on the current stream; ``br.join(y, ...)`` makes the current stream wait for it."""

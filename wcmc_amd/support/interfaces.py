@@ -187,7 +187,9 @@ class KPCNInterface(BaseInterface):
         self.models['dncnn'].zero_grad()
         out = self._regress_forward(batch)
 
-        return self._backward(batch, out, out_manif)
+        loss_dict = self._backward(batch, out, out_manif)
+        _ops.join_all_streams(out['radiance'].device)
+        return loss_dict
 
     def train_batch(self, batch, grad_hook_mode=False):
         loss_dict = self._forward_backward(batch)
