@@ -97,6 +97,10 @@ class _OracleOps:
     def join_all_streams(device):
         pass
 
+    @staticmethod
+    def fork_all_streams(device):
+        pass
+
     class on_branch:                     # stream fork/join is a no-op on the host
         def __init__(self, device):
             pass

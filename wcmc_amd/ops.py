@@ -188,9 +188,11 @@ _SIDE_STREAMS = {}
 USE_SIDE_STREAM = True      # weight-gradient GEMMs run beside the data-gradient GEMMs
 
 
-def _side_stream(device):
-    """The weight-gradient stream that belongs to the CURRENT stream (one per forked branch)."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+def _side_stream(device, of=None):
+    """The weight-gradient stream that belongs to stream `of` (default: the CURRENT stream) -- one per
+    forked branch."""
+    of = torch.cuda.current_stream(device) if of is None else of
+    key = (device.type, device.index, of.cuda_stream)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
@@ -212,15 +214,40 @@ def branch_stream(device):
     return _BRANCH_STREAMS[key]
 
 
-def join_all_streams(device):
-    """Make the current stream wait for the branch stream and every weight-gradient stream (end of a
-    step: a stream capture must not end with forked work outstanding)."""
+def _step_streams(device):
+    """The streams one step forks work onto from the current stream."""
+    device = torch.device(device)
+    cur = torch.cuda.current_stream(device)
+    out = []
+    if USE_SIDE_STREAM:
+        out.append(_side_stream(device, cur))
+    if USE_BRANCH_STREAM:
+        br = branch_stream(device)
+        out.append(br)
+        if USE_SIDE_STREAM:
+            out.append(_side_stream(device, br))
+    return cur, out
+
+
+def fork_all_streams(device):
+    """Fork every stream the step uses directly from the current stream.  Under HIP stream capture this
+    makes them all first-level children of the capturing stream: hipStreamEndCapture (ROCm 7.0)
+    overflows its stack on a stream that joined the capture through another forked stream."""
     if torch.device(device).type != "cuda":
         return
-    cur = torch.cuda.current_stream(device)
-    for s in list(_BRANCH_STREAMS.values()) + list(_SIDE_STREAMS.values()):
-        if s.cuda_stream != cur.cuda_stream:
-            cur.wait_stream(s)
+    cur, streams = _step_streams(device)
+    for s in streams:
+        s.wait_stream(cur)
+
+
+def join_all_streams(device):
+    """Make the current stream wait for every stream the step forked work onto (a stream capture must
+    not end with forked work outstanding)."""
+    if torch.device(device).type != "cuda":
+        return
+    cur, streams = _step_streams(device)
+    for s in streams:
+        cur.wait_stream(s)
 
 
 class on_branch:

@@ -172,6 +172,8 @@ class KPCNInterface(BaseInterface):
         """Everything of ``train_batch`` up to (not including) ``_logging``: no host sync inside, so
         ``wcmc_amd.graph.GraphedTrainStep`` can capture it into one hipGraph."""
         out_manif = None
+        dev = batch['kpcn_diffuse_in'].device
+        _ops.fork_all_streams(dev)
 
         if self.use_llpm_buf:
             self.models['backbone_diffuse'].zero_grad()
@@ -188,7 +190,7 @@ class KPCNInterface(BaseInterface):
         out = self._regress_forward(batch)
 
         loss_dict = self._backward(batch, out, out_manif)
-        _ops.join_all_streams(out['radiance'].device)
+        _ops.join_all_streams(dev)
         return loss_dict
 
     def train_batch(self, batch, grad_hook_mode=False):
