@@ -189,9 +189,19 @@ USE_SIDE_STREAM = True      # weight-gradient GEMMs run beside the data-gradient
 
 
 def _side_stream(device, of=None):
-    """The weight-gradient stream that belongs to stream `of` (default: the CURRENT stream) -- one per
-    forked branch."""
+    """The weight-gradient stream that belongs to stream `of` (default: the CURRENT stream), or None when
+    weight gradients should stay on that stream.
+
+    The forked specular branch keeps its weight gradients on its own stream: hipStreamEndCapture (ROCm
+    7.0) recurses without end when two forked (non-origin) streams of a capture wait on each other
+    (each wait registers the waiter as a child of the other), so only the step's origin stream forks
+    and joins a weight-gradient stream."""
+    if not USE_SIDE_STREAM:
+        return None
     of = torch.cuda.current_stream(device) if of is None else of
+    br = _BRANCH_STREAMS.get((device.type, device.index))
+    if br is not None and br.cuda_stream == of.cuda_stream:
+        return None
     key = (device.type, device.index, of.cuda_stream)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -218,21 +228,15 @@ def _step_streams(device):
     """The streams one step forks work onto from the current stream."""
     device = torch.device(device)
     cur = torch.cuda.current_stream(device)
-    out = []
-    if USE_SIDE_STREAM:
-        out.append(_side_stream(device, cur))
+    out = [_side_stream(device, cur)]
     if USE_BRANCH_STREAM:
-        br = branch_stream(device)
-        out.append(br)
-        if USE_SIDE_STREAM:
-            out.append(_side_stream(device, br))
-    return cur, out
+        out.append(branch_stream(device))
+    return cur, [s for s in out if s is not None and s.cuda_stream != cur.cuda_stream]
 
 
 def fork_all_streams(device):
-    """Fork every stream the step uses directly from the current stream.  Under HIP stream capture this
-    makes them all first-level children of the capturing stream: hipStreamEndCapture (ROCm 7.0)
-    overflows its stack on a stream that joined the capture through another forked stream."""
+    """Fork every stream the step uses directly from the current stream (under HIP stream capture: make
+    them first-level children of the capturing stream before anything else touches them)."""
     if torch.device(device).type != "cuda":
         return
     cur, streams = _step_streams(device)
@@ -319,7 +323,7 @@ class _ConvChain(torch.autograd.Function):
         grads = [None] * (2 * nl)
         dx = None
         main = torch.cuda.current_stream()
-        side = _side_stream(dy.device) if USE_SIDE_STREAM else None
+        side = _side_stream(dy.device)
         keep = []                       # every dy stays allocated until the side stream has joined
         for l in range(nl - 1, -1, -1):
             w = ws[l]
@@ -478,7 +482,7 @@ class _ConvChainX(torch.autograd.Function):
         grads = [None] * (2 * nl)
         dx = None
         main = torch.cuda.current_stream()
-        side = _side_stream(dy.device) if USE_SIDE_STREAM else None
+        side = _side_stream(dy.device)
         keep = []
         for l in range(nl - 1, -1, -1):
             wt = ws[l]
