@@ -1,0 +1,30 @@
+"""Phase shares of the split-bf16 implicit-GEMM main loop from in-kernel stamps (WCMC_DEBUG_ABLATE=64).
+   WCMC_DEBUG_ABLATE=64 python3 scripts/stamp_igemm.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from wcmc_amd import ops as o
+assert os.environ.get("WCMC_DEBUG_ABLATE") == "64"
+dev = "cuda"
+n, cin, h, cout, ks = 8, 100, 116, 100, 5
+x = o.to_nhwc_raw(torch.randn(n, cin, h, h, device=dev))
+w = torch.randn(cout, cin, ks, ks, device=dev) * 0.02
+b = torch.zeros(cout, device=dev)
+xs = o.split_raw(x); wp = o._pack_x(w, 0)
+for _ in range(3):
+    y, part = o.conv2d_x_raw(xs, (n, cin, h, h), wp, b, cout, ks, 0, "relu", out_split=True, colsum=True)
+torch.cuda.synchronize()
+ho = h - ks + 1
+tiles = (n * ho * ho + 127) // 128
+st = part.cpu().numpy().view(np.uint64)[: tiles * 4 * 8].reshape(tiles, 4, 8).astype(np.float64)
+names = ["load issue", "frag reads+wait", "mfma issue", "vmcnt+lds store", "barrier"]
+tot = st[:, :, :5].sum(axis=2)
+print("tiles", tiles, "stages/tile", (ks * ks * 104 + 31) // 32)
+print("cycles per tile (s_memtime ticks = 100 MHz?): mean %.0f min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
+for i, nm in enumerate(names):
+    print("  %-18s %5.1f %%   (per stage %.0f ticks)" % (nm, 100 * st[:, :, i].sum() / tot.sum(), st[:, :, i].mean() / 82))
+end = st[:, :, 5]
+print("end stamps: span %.0f ticks; first-round tiles end at ~%.0f, all at %.0f" %
+      (end.max() - end.min(), np.median(np.sort(end[:, 0])[:512]) - end.min(), end.max() - end.min()))
+for wv in range(4):
+    print("  wave %d:" % wv, " ".join("%5.1f" % (100 * st[:, wv, i].sum() / tot[:, wv].sum()) for i in range(5)))

@@ -210,6 +210,20 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
 #pragma unroll
   for (int j = 0; j < NT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+  // DBG & 64: in-kernel stamps (s_memtime) accumulate per-phase cycles of every wave into p.colsum
+  // reinterpreted as u64 [tile][wave][8] (diagnostic build: read the shares, not the run time).
+  unsigned long long st_prev = 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int i) {
+    if (DBG & 64) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (i >= 0) st_acc[i] += t - st_prev;
+      st_prev = t;
+    }
+  };
+
   const int frow = lane & 15;
   const int fslot = ((lane >> 4) ^ ((frow >> 1) & 3)) * 8;   // MFMA 16x16x32: lane holds k = 8*(lane>>4) .. +7
   auto compute = [&](int buf) {
@@ -237,6 +251,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    stamp(1);                                // fragment reads issued and returned
     if (DBG & 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) { asm volatile("" ::"v"(ah[i])); asm volatile("" ::"v"(al[i])); }
@@ -264,15 +279,31 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
   if (DBUF) {
     // Straight-line body, two stages per trip (a stage past the end multiplies zeros): no branch
     // between a load and its use, so hipcc's vmcnt bookkeeping keeps both register sets in flight.
+    stamp(-1);
     for (int c = 0; c < nchunks; c += 2) {
       load_chunk(c + 2, ra0, rb0);          // set 0 is free; set 1 holds stage c+1
+      stamp(0);                             // global loads issued
       compute(0);                           // stage c from LDS buffer 0
+      stamp(2);                             // MFMAs issued
       store_chunk(1, ra1, rb1);
+      stamp(3);                             // vmcnt wait + LDS stores
       if (!(DBG & 16)) __syncthreads();
+      stamp(4);                             // barrier
       load_chunk(c + 3, ra1, rb1);          // set 1 is free; set 0 holds stage c+2
+      stamp(0);
       compute(1);                           // stage c+1 from LDS buffer 1
+      stamp(2);
       store_chunk(0, ra0, rb0);
+      stamp(3);
       if (!(DBG & 16)) __syncthreads();
+      stamp(4);
+    }
+    if (DBG & 64) {
+      if (lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * 4 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = st_acc[i];
+        o[5] = st_prev; o[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID
+      }
     }
   } else {
     for (int c = 0; c < nchunks; c += 2) {
@@ -340,7 +371,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
         *reinterpret_cast<u32x4*>(p.ys + (int64_t)m * 2 * p.Cpo + plane * p.Cpo + co) =
             *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
     }
-    if (p.colsum && tid < BN) {
+    if (!(DBG & 64) && p.colsum && tid < BN) {
       // bias gradient of the consumer layer for free: column sums of this tile (hi + lo) while it is in LDS
       const int rows = (int)min((int64_t)XBM, p.M - m0);
       float acc = 0.f;
@@ -730,6 +761,7 @@ static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
       case 32: return launch_xigemm_dbg<32>(p, stream);
       case 36: return launch_xigemm_dbg<36>(p, stream);
       case 62: return launch_xigemm_dbg<62>(p, stream);
+      case 64: return launch_xigemm_dbg<64>(p, stream);
       default: break;
     }
   }
