@@ -59,12 +59,16 @@ __global__ void split_kernel(const float* __restrict__ x, int64_t xsn, int64_t x
   }
 }
 
+// K order of the packed weights: k = slab*Ks + tap*CS + cl, channel = slab*CS + cl.  The streaming
+// kernel uses one slab of all (padded) channels (CS = Kp, Ks = Kt); the halo kernel cuts the channels into
+// slabs of CS <= 64 that fit in LDS with their halo (x_plan_k below decides, from (kchan, ks) alone).
 __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int Cin,
-                                         int ks, int mode, int rows, int Np, int Kp, int Kt) {
+                                         int ks, int mode, int rows, int Np, int CS, int Ks, int Kt) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)Np * Kt) return;
   const int n = (int)(idx / Kt), k = (int)(idx - (int64_t)n * Kt);
-  const int tap = k / Kp, c = k - tap * Kp;
+  const int slab = k / Ks, kk = k - slab * Ks;
+  const int tap = kk / CS, c = slab * CS + (kk - tap * CS);
   const int taps = ks * ks;
   const int kchan = mode == 0 ? Cin : Cout;
   float v = 0.f;
@@ -76,6 +80,32 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __res
   split1(v, hi, lo);
   wp[((int64_t)n * 2) * Kt + k] = hi;
   wp[((int64_t)n * 2 + 1) * Kt + k] = lo;
+}
+
+struct XKPlan { bool halo; int Kp, CS, nslabs, Ks, Kt, PXS; };
+static XKPlan x_plan_k(int kchan, int ks) {
+  static int enable = -1;
+  if (enable < 0) { const char* e = getenv("WCMC_IGEMM_HALO"); enable = (e && e[0] == '0') ? 0 : 1; }
+  XKPlan q;
+  q.Kp = round_up(kchan, 8);
+  q.halo = enable && ks >= 3 && ks <= 5 && q.Kp >= 32;
+  if (q.halo) {
+    q.nslabs = (q.Kp + 63) / 64;
+    q.CS = round_up((q.Kp + q.nslabs - 1) / q.nslabs, 8);
+    q.PXS = q.CS <= 56 ? 224 : 288;           // halo pixel stride: 16 B x (2 or 14 mod 16) -> conflict-free b128 reads
+    q.Ks = round_up(ks * ks * q.CS, 32);
+  } else {
+    q.nslabs = 1; q.CS = q.Kp; q.PXS = 0;
+    q.Ks = round_up(ks * ks * q.Kp, 32);
+  }
+  q.Kt = q.nslabs * q.Ks;
+  return q;
+}
+// rows of the per-tile column-sum buffer: enough for either kernel's tiling of (N, Ho, Wo)
+static int x_colsum_rows(int N, int Ho, int Wo) {
+  const int64_t gl = ceil_div64((int64_t)N * Ho * Wo, 128);
+  const int64_t gh = (int64_t)N * ((Ho + 15) / 16) * ((Wo + 15) / 16);
+  return (int)(gl > gh ? gl : gh);
 }
 
 // ------------------------------------------------------------------ implicit GEMM (fwd + dgrad)
@@ -104,7 +134,9 @@ struct XIgemmParams {
   int Kp, Kt, Np;
   int64_t M;
   unsigned x_bytes, wp_bytes;
-  float* colsum;                          // optional [pixel tiles][Np] per-tile column sums of the split output
+  float* colsum;                          // optional [G][Np] per-tile column sums of the split output
+  int G;                                  // rows of colsum (tiles past the kernel's own are zero-filled)
+  int CS, nslabs, SPS, PXS, tilesX, tilesY;   // halo kernel: channel slab, stages per slab, halo pixel stride
 };
 
 // DBUF: two LDS stage buffers and one barrier per stage (2 workgroups per CU), or one buffer and two
@@ -376,7 +408,10 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
       const int rows = (int)min((int64_t)XBM, p.M - m0);
       float acc = 0.f;
       for (int r = 0; r < rows; ++r) acc += bf2f(so[r * OLD + tid]) + bf2f(so[r * OLD + BN + tid]);
-      if (n0 + tid < p.Np) p.colsum[(int64_t)tile * p.Np + n0 + tid] = acc;
+      if (n0 + tid < p.Np) {
+        p.colsum[(int64_t)tile * p.Np + n0 + tid] = acc;
+        for (int r = (int)gridDim.x + tile; r < p.G; r += (int)gridDim.x) p.colsum[(int64_t)r * p.Np + n0 + tid] = 0.f;
+      }
     }
   } else {
     constexpr int OLD = BN + 4;                          // floats per LDS pixel row
@@ -413,6 +448,276 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
         *reinterpret_cast<float4*>(p.yf + (int64_t)n * p.ysn + (int64_t)oy * p.ysh + (int64_t)ox * p.ysw + co) =
             *reinterpret_cast<const float4*>(so + pr * OLD + vec * 4);
       }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------ implicit GEMM, halo-resident (ks 3..5)
+// Stamps of the streaming kernel above (scripts/stamp_igemm.py): per 32-k stage a wave spends 830 cycles
+// issuing its 8 buffer loads and 540 storing them to LDS, against 770 issuing MFMAs -- the L1/TA path and
+// L2 bandwidth (23 B/clk/CU sustained), not the matrix pipe, set the pace, and 53 % of those bytes are
+// the A operand re-read once per filter tap.  This kernel keeps the input pixels of a 16x16 output
+// tile with their (ks-1) halo resident in LDS for one channel slab (CS <= 64 channels, both planes) and
+// reads every tap's A fragments from there with shifted addresses; only the weights stream (14 KB per
+// stage for 256 pixels instead of 30 KB for 128).  512 threads = 8 waves, each 32 pixels (two tile rows)
+// x all NT*16 couts; one workgroup per CU (LDS: halo 90-115 KB + two weight stages).
+// K order: slab-major (pack_weight_split_kernel); stages never straddle slabs (Ks % 32 == 0).
+template <int NT, int TH, int TW>
+__global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p) {
+  constexpr int BN = NT * 16;
+  constexpr int NJ = (BN + 63) / 64;
+  constexpr int NTHR = 512;
+  constexpr int TPR = TW / 16;                 // MFMA pixel tiles per tile row
+  static_assert(TH * TW == 256 && TW % 16 == 0, "8 waves x 2 pixel tiles of 16");
+  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
+  constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
+  const int HWd = TW + p.ks - 1, HHt = TH + p.ks - 1, HP = HWd * HHt;
+  char* const halo = reinterpret_cast<char*>(smem16);
+  u16* const bsm = smem16 + ((HP * p.PXS + 127) & ~127) / 2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tile;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tpi = p.tilesX * p.tilesY;
+  const int img = tile / tpi, trem = tile - img * tpi;
+  const int oy0 = (trem / p.tilesX) * TH, ox0 = (trem % p.tilesX) * TW;
+  const int n0 = blockIdx.y * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  const int pixb = 4 * p.Cpi;
+
+  // ---- halo: [pixel][hi CS][lo CS] at stride PXS; out-of-image pixels and channels >= Cpi read zeros
+  const int V = p.CS / 4;                      // 16-byte vectors per halo pixel (2 planes x CS/8)
+  const int hvecs = HP * V;
+  auto load_halo = [&](int slab) {
+    constexpr int HL = 6;
+    for (int base = 0; base < hvecs; base += NTHR * HL) {
+      u32x4 r[HL]; int so[HL];
+#pragma unroll
+      for (int j = 0; j < HL; ++j) {
+        const int idx = base + j * NTHR + tid;
+        unsigned off = XOOB; so[j] = -1;
+        if (idx < hvecs) {
+          const int px = idx / V, v = idx - px * V;
+          const int hy = px / HWd, hx = px - hy * HWd;
+          const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+          const int plane = v >= (V >> 1), vec = v - plane * (V >> 1);
+          const int ch = slab * p.CS + vec * 8;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Cpi)
+            off = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb + plane * 2 * p.Cpi + ch * 2);
+          so[j] = px * p.PXS + v * 16;
+        }
+        r[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < HL; ++j)
+        if (so[j] >= 0) *reinterpret_cast<u32x4*>(halo + so[j]) = r[j];
+    }
+  };
+
+  // ---- weights: 8 consecutive threads = one cout row's 2 planes x 4 vectors of 8 bf16 (as the streaming kernel)
+  const int vq = tid & 3, pl = (tid >> 2) & 1, prow = tid >> 3;
+  unsigned wbase[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int nrow = prow + 64 * j;
+    wbase[j] = (nrow < BN && n0 + nrow < p.Np) ? (unsigned)((((n0 + nrow) * 2 + pl) * p.Kt + vq * 8) * 2) : XOOB;
+  }
+  const int nstages = p.Kt / XKC;
+  auto load_b = [&](int g, u32x4* rb) {
+    const unsigned kill = g < nstages ? 0u : XOOB;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (wbase[j] + (unsigned)(g * XKC * 2)) | kill, 0, 0);
+  };
+  const int wslot = (vq ^ ((prow >> 1) & 3)) * 8;
+  auto store_b = [&](int buf, const u32x4* rb) {
+    u16* b = bsm + buf * B_ELEMS + pl * B_LO + wslot;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int nrow = prow + 64 * j;
+      if (nrow < BN) *reinterpret_cast<u32x4*>(b + nrow * XROW) = rb[j];
+    }
+  };
+
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // ---- fragments: lane = pixel (lane & 15) of a 16-pixel row segment, k group kg = lane >> 4 (8 k each)
+  const int frow = lane & 15, kg = lane >> 4;
+  const int fslot = (kg ^ ((frow >> 1) & 3)) * 8;
+  int abase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pt = wave * 2 + i;
+    abase[i] = ((pt / TPR) * HWd + (pt % TPR) * 16 + frow) * p.PXS;
+  }
+  int cl = kg * 8, tdx = 0, tdy = 0, aoff = cl * 2;      // this lane's (channel, tap) inside the slab
+  const int lo_off = p.CS * 2;
+  auto compute = [&](int buf) {
+    const u16* b = bsm + buf * B_ELEMS + frow * XROW + fslot;
+    bf16x8 ah[2], al[2], wh[NT], wl[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
+      al[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      wh[j] = *reinterpret_cast<const bf16x8*>(b + j * 16 * XROW);
+      wl[j] = *reinterpret_cast<const bf16x8*>(b + B_LO + j * 16 * XROW);
+    }
+    // next stage's tap / channel of this lane (CS >= 32: at most one wrap); taps past ks*ks (slab padding,
+    // zero weights) read the tile's first pixels
+    cl += XKC;
+    if (cl >= p.CS) { cl -= p.CS; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
+    aoff = tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
+      }
+    }
+  };
+
+  u32x4 rb0[NJ], rb1[NJ];
+  load_b(0, rb0);
+  load_b(1, rb1);
+  load_halo(0);
+  store_b(0, rb0);
+  __syncthreads();
+  int s_in = 0, slab = 0;
+  auto boundary = [&]() {                      // called after a stage's barrier: nobody is reading the halo
+    if (++s_in == p.SPS) {
+      s_in = 0;
+      if (++slab < p.nslabs) {
+        load_halo(slab);
+        cl = kg * 8; tdx = 0; tdy = 0; aoff = cl * 2;
+        __syncthreads();
+      }
+    }
+  };
+  for (int g = 0; g < nstages; g += 2) {
+    load_b(g + 2, rb0);
+    compute(0);
+    store_b(1, rb1);
+    __syncthreads();
+    boundary();
+    load_b(g + 3, rb1);
+    compute(1);
+    store_b(0, rb0);
+    __syncthreads();
+    boundary();
+  }
+
+  // ---- epilogue (as the streaming kernel; pixels of the tile outside the image are written as zeros to LDS
+  // and skipped on the way out).  Tile-local pixel pr = 16 * pixel-tile + column.
+  const int fq = kg * 4;
+  auto pix_of = [&](int pr, int& oy, int& ox) {
+    const int pt = pr >> 4;
+    oy = oy0 + pt / TPR; ox = ox0 + (pt % TPR) * 16 + (pr & 15);
+    return oy < p.Ho && ox < p.Wo;
+  };
+  if (p.ys) {
+    constexpr int OLD = 2 * BN + 8;
+    u16* so = smem16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pr = wave * 32 + i * 16 + frow;
+      int oy, ox;
+      const bool ok = pix_of(pr, oy, ox);
+      const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+      const u16* gp = (p.gate && ok) ? p.gate + m * 2 * p.Cpo : nullptr;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + fq;
+        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ok && co + e < p.Cout) {
+            if (p.bias) v[e] += p.bias[co + e];
+            v[e] = act_apply(v[e], p.act, p.slope);
+          } else {
+            v[e] = 0.f;
+          }
+        }
+        if (gp && co < p.Cpo) {
+          const uint2 g2 = *reinterpret_cast<const uint2*>(gp + co);
+          const u16 g[4] = {(u16)(g2.x & 0xffff), (u16)(g2.x >> 16), (u16)(g2.y & 0xffff), (u16)(g2.y >> 16)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= act_gate(bf2f(g[e]), p.gate_act, p.gate_slope);
+        }
+        u16 hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split1(v[e], hi[e], lo[e]);
+        *reinterpret_cast<uint2*>(so + pr * OLD + j * 16 + fq) =
+            make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+        *reinterpret_cast<uint2*>(so + pr * OLD + BN + j * 16 + fq) =
+            make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+      }
+    }
+    __syncthreads();
+    constexpr int VPP = BN / 8;
+    for (int v = tid; v < 256 * 2 * VPP; v += NTHR) {
+      const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
+      const int plane = q >= VPP, vec = q - plane * VPP;
+      const int co = n0 + vec * 8;
+      int oy, ox;
+      if (pix_of(pr, oy, ox) && co < p.Cpo) {
+        const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+        *reinterpret_cast<u32x4*>(p.ys + m * 2 * p.Cpo + plane * p.Cpo + co) =
+            *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+      }
+    }
+    if (p.colsum && tid < BN) {
+      float a = 0.f;
+      for (int r = 0; r < 256; ++r) a += bf2f(so[r * OLD + tid]) + bf2f(so[r * OLD + BN + tid]);
+      if (n0 + tid < p.Np) {
+        p.colsum[(int64_t)tile * p.Np + n0 + tid] = a;
+        for (int r = (int)gridDim.x + tile; r < p.G; r += (int)gridDim.x) p.colsum[(int64_t)r * p.Np + n0 + tid] = 0.f;
+      }
+    }
+  } else {
+    constexpr int OLD = BN + 4;
+    float* so = reinterpret_cast<float*>(smem16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pr = wave * 32 + i * 16 + frow;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + fq;
+        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (co + e < p.Cout) {
+            if (p.bias) v[e] += p.bias[co + e];
+            v[e] = act_apply(v[e], p.act, p.slope);
+          } else {
+            v[e] = 0.f;
+          }
+        }
+        *reinterpret_cast<float4*>(so + pr * OLD + j * 16 + fq) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();
+    constexpr int VPP = BN / 4;
+    for (int v = tid; v < 256 * VPP; v += NTHR) {
+      const int pr = v / VPP, vec = v - pr * VPP;
+      const int co = n0 + vec * 4;
+      int oy, ox;
+      if (pix_of(pr, oy, ox) && co < p.Cpo)
+        *reinterpret_cast<float4*>(p.yf + (int64_t)img * p.ysn + (int64_t)oy * p.ysh + (int64_t)ox * p.ysw + co) =
+            *reinterpret_cast<const float4*>(so + pr * OLD + vec * 4);
     }
   }
 }
@@ -705,7 +1010,7 @@ extern "C" int wcmc_split_bf16(const float* x, int64_t xsn, int64_t xsh, int64_t
 
 extern "C" size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks) {
   if (rows <= 0 || kchan <= 0 || ks <= 0) return 0;
-  return (size_t)round_up(rows, 16) * 2 * round_up(ks * ks * round_up(kchan, 8), 32);
+  return (size_t)round_up(rows, 16) * 2 * x_plan_k(kchan, ks).Kt;
 }
 
 extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout, int Cin, int ks, int mode,
@@ -713,10 +1018,11 @@ extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout
   WCMC_REQUIRE(w && wp && Cout > 0 && Cin > 0 && ks > 0 && (mode == 0 || mode == 1), WCMC_ERR_BAD_ARG,
                "conv2d_pack_weight_bf16x3: bad argument");
   const int rows = mode == 0 ? Cout : Cin, kchan = mode == 0 ? Cin : Cout;
-  const int Np = round_up(rows, 16), Kp = round_up(kchan, 8), Kt = round_up(ks * ks * Kp, 32);
-  const int64_t total = (int64_t)Np * Kt;
+  const int Np = round_up(rows, 16);
+  const XKPlan q = x_plan_k(kchan, ks);
+  const int64_t total = (int64_t)Np * q.Kt;
   hipLaunchKernelGGL(pack_weight_split_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, mode, rows, Np, Kp, Kt);
+                     (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, mode, rows, Np, q.CS, q.Ks, q.Kt);
   return check_launch("conv2d_pack_weight_bf16x3");
 }
 
@@ -772,7 +1078,26 @@ static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
   return g_xigemm_dbuf ? launch_xigemm3<NT, PADDED, true>(p, stream) : launch_xigemm3<NT, PADDED, false>(p, stream);
 }
 template <int NT>
+static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
+  constexpr int TH = 16, TW = 16;
+  const int HP = (TH + p.ks - 1) * (TW + p.ks - 1);
+  const size_t lds_main = (size_t)((HP * p.PXS + 127) & ~127) + (size_t)2 * (2 * NT * 16 * XROW + 64) * sizeof(u16);
+  const size_t lds_out = p.ys ? (size_t)256 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)256 * (NT * 16 + 4) * sizeof(float);
+  const size_t lds = lds_main > lds_out ? lds_main : lds_out;
+  WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
+  static size_t attr = 0;
+  if (lds > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH, TW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = lds;
+  }
+  const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
+  hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW>), grid, dim3(512), lds, stream, p);
+  return check_launch("conv2d_igemm_bf16x3(halo)");
+}
+template <int NT>
 static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
+  if (p.PXS) return launch_xhalo<NT>(p, stream);
   return p.pad > 0 ? launch_xigemm2<NT, true>(p, stream) : launch_xigemm2<NT, false>(p, stream);
 }
 
@@ -804,7 +1129,11 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.gate = (const u16*)gate_split; p.gate_act = gate_act; p.gate_slope = gate_slope;
   p.ks = ks; p.pad = pad; p.act = act; p.slope = slope;
-  p.Kp = p.Cpi; p.Kt = round_up(ks * ks * p.Kp, 32); p.Np = round_up(Cout, 16);
+  const XKPlan q = x_plan_k(Cin, ks);
+  p.Kp = p.Cpi; p.Kt = q.Kt; p.Np = round_up(Cout, 16);
+  p.CS = q.CS; p.nslabs = q.nslabs; p.SPS = q.Ks / 32; p.PXS = q.halo ? q.PXS : 0;
+  p.tilesY = (Ho + 15) / 16; p.tilesX = (Wo + 15) / 16;
+  p.G = x_colsum_rows(N, Ho, Wo);
   p.M = (int64_t)N * Ho * Wo;
   const size_t xb = wcmc_split_elems(N, H, W, Cin) * sizeof(u16), wb = (size_t)p.Np * 2 * p.Kt * sizeof(u16);
   WCMC_REQUIRE(xb < 0x7ff00000u && wb < 0x7ff00000u, WCMC_ERR_BAD_ARG,
@@ -828,12 +1157,12 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
 
 extern "C" size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout) {
   if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return 0;
-  return (size_t)ceil_div64((int64_t)N * Ho * Wo, XBM) * round_up(Cout, 16);
+  return (size_t)x_colsum_rows(N, Ho, Wo) * round_up(Cout, 16);
 }
 
 extern "C" int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, int Cout, float* db, void* stream) {
   WCMC_REQUIRE(partial && db && N > 0 && Ho > 0 && Wo > 0 && Cout > 0, WCMC_ERR_BAD_ARG, "colsum_finish: bad argument");
-  const int G = (int)ceil_div64((int64_t)N * Ho * Wo, XBM), Np = round_up(Cout, 16);
+  const int G = x_colsum_rows(N, Ho, Wo), Np = round_up(Cout, 16);
   // partial rows are Np wide: reduce the first Cout columns of each
   hipLaunchKernelGGL(colsum_final_strided_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(1024), 0,
                      (hipStream_t)stream, partial, G, Np, Cout, db);
