@@ -15,16 +15,18 @@ for _ in range(3):
     y, part = o.conv2d_x_raw(xs, (n, cin, h, h), wp, b, cout, ks, 0, "relu", out_split=True, colsum=True)
 torch.cuda.synchronize()
 ho = h - ks + 1
-tiles = (n * ho * ho + 127) // 128
-st = part.cpu().numpy().view(np.uint64)[: tiles * 4 * 8].reshape(tiles, 4, 8).astype(np.float64)
-names = ["load issue", "frag reads+wait", "mfma issue", "vmcnt+lds store", "barrier"]
-tot = st[:, :, :5].sum(axis=2)
-print("tiles", tiles, "stages/tile", (ks * ks * 104 + 31) // 32)
+halo = os.environ.get("WCMC_IGEMM_HALO", "1") != "0"
+if halo:
+    tiles, nw, nstage = n * ((ho + 15) // 16) ** 2, 8, 2 * ((ks * ks * 56 + 31) // 32)
+else:
+    tiles, nw, nstage = (n * ho * ho + 127) // 128, 4, (ks * ks * 104 + 31) // 32
+st = part.cpu().numpy().view(np.uint64)[: tiles * nw * 8].reshape(tiles, nw, 8).astype(np.float64)
+names = ["load issue", "frag reads+wait", "mfma issue", "vmcnt+lds store", "barrier", "slab boundary"]
+NB = 6 if halo else 5
+tot = st[:, :, :NB].sum(axis=2)
+print("tiles", tiles, "stages/tile", nstage)
 print("cycles per tile (s_memtime ticks = 100 MHz?): mean %.0f min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
-for i, nm in enumerate(names):
-    print("  %-18s %5.1f %%   (per stage %.0f ticks)" % (nm, 100 * st[:, :, i].sum() / tot.sum(), st[:, :, i].mean() / 82))
-end = st[:, :, 5]
-print("end stamps: span %.0f ticks; first-round tiles end at ~%.0f, all at %.0f" %
-      (end.max() - end.min(), np.median(np.sort(end[:, 0])[:512]) - end.min(), end.max() - end.min()))
-for wv in range(4):
-    print("  wave %d:" % wv, " ".join("%5.1f" % (100 * st[:, wv, i].sum() / tot[:, wv].sum()) for i in range(5)))
+for i, nm in enumerate(names[:NB]):
+    print("  %-18s %5.1f %%   (per stage %.0f ticks)" % (nm, 100 * st[:, :, i].sum() / tot.sum(), st[:, :, i].mean() / nstage))
+for wv in range(nw):
+    print("  wave %d:" % wv, " ".join("%5.1f" % (100 * st[:, wv, i].sum() / tot[:, wv].sum()) for i in range(NB)))

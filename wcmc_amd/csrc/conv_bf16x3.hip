@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
 // stage for 256 pixels instead of 30 KB for 128).  512 threads = 8 waves, each 32 pixels (two tile rows)
 // x all NT*16 couts; one workgroup per CU (LDS: halo 90-115 KB + two weight stages).
 // K order: slab-major (pack_weight_split_kernel); stages never straddle slabs (Ks % 32 == 0).
-template <int NT, int TH, int TW>
+template <int NT, int TH, int TW, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p) {
   constexpr int BN = NT * 16;
   constexpr int NJ = (BN + 63) / 64;
@@ -549,6 +549,18 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
 #pragma unroll
   for (int j = 0; j < NT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+  unsigned long long st_prev = 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int i) {
+    if (DBG & 64) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (i >= 0) st_acc[i] += t - st_prev;
+      st_prev = t;
+    }
+  };
+
   // ---- fragments: lane = pixel (lane & 15) of a 16-pixel row segment, k group kg = lane >> 4 (8 k each)
   const int frow = lane & 15, kg = lane >> 4;
   const int fslot = (kg ^ ((frow >> 1) & 3)) * 8;
@@ -579,6 +591,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     if (cl >= p.CS) { cl -= p.CS; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
     aoff = tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0;
     __builtin_amdgcn_sched_barrier(0);
+    stamp(1);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -607,17 +620,35 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
       }
     }
   };
+  stamp(-1);
   for (int g = 0; g < nstages; g += 2) {
     load_b(g + 2, rb0);
+    stamp(0);
     compute(0);
+    stamp(2);
     store_b(1, rb1);
+    stamp(3);
     __syncthreads();
+    stamp(4);
     boundary();
+    stamp(5);
     load_b(g + 3, rb1);
+    stamp(0);
     compute(1);
+    stamp(2);
     store_b(0, rb0);
+    stamp(3);
     __syncthreads();
+    stamp(4);
     boundary();
+    stamp(5);
+  }
+  if (DBG & 64) {
+    if (lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * 8 + wave) * 8;
+      for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
+      o[6] = st_prev;
+    }
   }
 
   // ---- epilogue (as the streaming kernel; pixels of the tile outside the image are written as zeros to LDS
@@ -679,7 +710,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
             *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
       }
     }
-    if (p.colsum && tid < BN) {
+    if (!(DBG & 64) && p.colsum && tid < BN) {
       float a = 0.f;
       for (int r = 0; r < 256; ++r) a += bf2f(so[r * OLD + tid]) + bf2f(so[r * OLD + BN + tid]);
       if (n0 + tid < p.Np) {
@@ -1092,6 +1123,16 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
     attr = lds;
   }
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
+  if (NT == 7) {
+    static int ab = -1;
+    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    if (ab == 64) {      // stamp build (scripts/stamp_igemm.py)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<7, TH, TW, 64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((conv_halo_bf16x3_kernel<7, TH, TW, 64>), grid, dim3(512), lds, stream, p);
+      return check_launch("conv2d_igemm_bf16x3(halo, stamps)");
+    }
+  }
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
