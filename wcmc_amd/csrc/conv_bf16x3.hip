@@ -572,9 +572,16 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   }
   int cl = kg * 8, tdx = 0, tdy = 0, aoff = cl * 2;      // this lane's (channel, tap) inside the slab
   const int lo_off = p.CS * 2;
-  auto compute = [&](int buf) {
-    const u16* b = bsm + buf * B_ELEMS + frow * XROW + fslot;
-    bf16x8 ah[2], al[2], wh[NT], wl[NT];
+  // Ping-pong: waves 0-3 (group 0) and waves 4-7 (group 1) share the four SIMDs pairwise and run half a
+  // stage apart -- while one group issues its 42 MFMAs the other stores the next weight stage, issues the
+  // loads of the one after and reads its fragments, so the matrix pipe always has a wave to serve (in
+  // lock step both waves of a SIMD read, then both multiply: stamps showed 53 % MFMA issue occupancy).
+  bf16x8 ah[2], al[2], wh[NT], wl[NT];
+  u32x4 rb[NJ];
+  auto mem = [&](int g) {                      // memory half of stage g
+    store_b((g + 1) & 1, rb);                  // weights of stage g+1 (loaded during stage g-1)
+    load_b(g + 2, rb);
+    const u16* b = bsm + (g & 1) * B_ELEMS + frow * XROW + fslot;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       ah[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
@@ -590,8 +597,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     cl += XKC;
     if (cl >= p.CS) { cl -= p.CS; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
     aoff = tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0;
-    __builtin_amdgcn_sched_barrier(0);
-    stamp(1);
+  };
+  auto mma = [&]() {                           // matrix half: fragments are in registers
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -601,17 +609,22 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
-  u32x4 rb0[NJ], rb1[NJ];
-  load_b(0, rb0);
-  load_b(1, rb1);
+  load_b(0, rb);
   load_halo(0);
-  store_b(0, rb0);
+  store_b(0, rb);
+  load_b(1, rb);
   __syncthreads();
+  const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= 4;
   int s_in = 0, slab = 0;
-  auto boundary = [&]() {                      // called after a stage's barrier: nobody is reading the halo
-    if (++s_in == p.SPS) {
+  for (int g = 0; g < nstages; ++g) {
+    if (!g1) mem(g); else if (g > 0) mma();
+    __syncthreads();
+    if (!g1) mma(); else mem(g);
+    __syncthreads();
+    if (++s_in == p.SPS) {                     // slab boundary: every fragment of the old slab is in registers
       s_in = 0;
       if (++slab < p.nslabs) {
         load_halo(slab);
@@ -619,37 +632,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
         __syncthreads();
       }
     }
-  };
-  stamp(-1);
-  for (int g = 0; g < nstages; g += 2) {
-    load_b(g + 2, rb0);
-    stamp(0);
-    compute(0);
-    stamp(2);
-    store_b(1, rb1);
-    stamp(3);
-    __syncthreads();
-    stamp(4);
-    boundary();
-    stamp(5);
-    load_b(g + 3, rb1);
-    stamp(0);
-    compute(1);
-    stamp(2);
-    store_b(0, rb0);
-    stamp(3);
-    __syncthreads();
-    stamp(4);
-    boundary();
-    stamp(5);
   }
-  if (DBG & 64) {
-    if (lane == 0) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * 8 + wave) * 8;
-      for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
-      o[6] = st_prev;
-    }
-  }
+  if (g1) mma();
+  __syncthreads();
 
   // ---- epilogue (as the streaming kernel; pixels of the tile outside the image are written as zeros to LDS
   // and skipped on the way out).  Tile-local pixel pr = 16 * pixel-tile + column.
