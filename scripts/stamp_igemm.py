@@ -22,11 +22,13 @@ else:
     tiles, nw, nstage = (n * ho * ho + 127) // 128, 4, (ks * ks * 104 + 31) // 32
 st = part.cpu().numpy().view(np.uint64)[: tiles * nw * 8].reshape(tiles, nw, 8).astype(np.float64)
 names = ["load issue", "frag reads+wait", "mfma issue", "vmcnt+lds store", "barrier", "slab boundary"]
-NB = 6 if halo else 5
+if halo:
+    names = ["mem phase (store/load/frag reads)", "barrier after phase 1", "mfma issue", "barrier after phase 2", "slab boundary"]
+NB = 5
 tot = st[:, :, :NB].sum(axis=2)
 print("tiles", tiles, "stages/tile", nstage)
 print("cycles per tile (s_memtime ticks = 100 MHz?): mean %.0f min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
 for i, nm in enumerate(names[:NB]):
-    print("  %-18s %5.1f %%   (per stage %.0f ticks)" % (nm, 100 * st[:, :, i].sum() / tot.sum(), st[:, :, i].mean() / nstage))
+    print("  %-34s %5.1f %%   (per stage %.0f ticks)" % (nm, 100 * st[:, :, i].sum() / tot.sum(), st[:, :, i].mean() / nstage))
 for wv in range(nw):
     print("  wave %d:" % wv, " ".join("%5.1f" % (100 * st[:, wv, i].sum() / tot[:, wv].sum()) for i in range(NB)))

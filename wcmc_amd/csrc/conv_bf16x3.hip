@@ -619,11 +619,14 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   __syncthreads();
   const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= 4;
   int s_in = 0, slab = 0;
+  stamp(-1);
   for (int g = 0; g < nstages; ++g) {
-    if (!g1) mem(g); else if (g > 0) mma();
+    if (!g1) { mem(g); stamp(0); } else { if (g > 0) mma(); stamp(2); }
     __syncthreads();
-    if (!g1) mma(); else mem(g);
+    stamp(1);
+    if (!g1) { mma(); stamp(2); } else { mem(g); stamp(0); }
     __syncthreads();
+    stamp(3);
     if (++s_in == p.SPS) {                     // slab boundary: every fragment of the old slab is in registers
       s_in = 0;
       if (++slab < p.nslabs) {
@@ -632,9 +635,17 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
         __syncthreads();
       }
     }
+    stamp(4);
   }
   if (g1) mma();
   __syncthreads();
+  if (DBG & 64) {
+    if (lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * 8 + wave) * 8;
+      for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
+      o[6] = st_prev;
+    }
+  }
 
   // ---- epilogue (as the streaming kernel; pixels of the tile outside the image are written as zeros to LDS
   // and skipped on the way out).  Tile-local pixel pr = 16 * pixel-tile + column.
