@@ -572,34 +572,49 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   }
   int cl = kg * 8, tdx = 0, tdy = 0, aoff = cl * 2;      // this lane's (channel, tap) inside the slab
   const int lo_off = p.CS * 2;
-  // Ping-pong: waves 0-3 (group 0) and waves 4-7 (group 1) share the four SIMDs pairwise and run half a
-  // stage apart -- while one group issues its 42 MFMAs the other stores the next weight stage, issues the
-  // loads of the one after and reads its fragments, so the matrix pipe always has a wave to serve (in
-  // lock step both waves of a SIMD read, then both multiply: stamps showed 53 % MFMA issue occupancy).
+  // Software pipeline inside every wave (stamps of the first version: all eight waves read fragments,
+  // then all multiply -- 53 % MFMA issue occupancy; a two-group ping-pong did no better): the fragments of
+  // stage g+1 are read WHILE the MFMAs of stage g issue, cout tile by cout tile into the registers the
+  // tile's MFMAs have just consumed, so no wave ever waits for LDS with an idle matrix pipe.  Three weight
+  // buffers: stage g+1 must be complete in LDS (stored during stage g-1, published by the barrier at the
+  // top of stage g) while stage g+2 is being stored.
   bf16x8 ah[2], al[2], wh[NT], wl[NT];
   u32x4 rb[NJ];
-  auto mem = [&](int g) {                      // memory half of stage g
-    store_b((g + 1) & 1, rb);                  // weights of stage g+1 (loaded during stage g-1)
-    load_b(g + 2, rb);
-    const u16* b = bsm + (g & 1) * B_ELEMS + frow * XROW + fslot;
+  auto read_a = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       ah[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
       al[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
     }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      wh[j] = *reinterpret_cast<const bf16x8*>(b + j * 16 * XROW);
-      wl[j] = *reinterpret_cast<const bf16x8*>(b + B_LO + j * 16 * XROW);
-    }
-    // next stage's tap / channel of this lane (CS >= 32: at most one wrap); taps past ks*ks (slab padding,
-    // zero weights) read the tile's first pixels
+    // the following stage's tap / channel of this lane (CS >= 32: at most one wrap); taps past ks*ks (slab
+    // padding, zero weights) read the tile's first pixels
     cl += XKC;
     if (cl >= p.CS) { cl -= p.CS; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
     aoff = tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0;
   };
-  auto mma = [&]() {                           // matrix half: fragments are in registers
-    __builtin_amdgcn_s_setprio(1);
+  const u16* const bfrag = bsm + frow * XROW + fslot;
+  auto read_b = [&](int buf, int j) {
+    wh[j] = *reinterpret_cast<const bf16x8*>(bfrag + buf * B_ELEMS + j * 16 * XROW);
+    wl[j] = *reinterpret_cast<const bf16x8*>(bfrag + buf * B_ELEMS + B_LO + j * 16 * XROW);
+  };
+
+  load_b(0, rb); store_b(0, rb);
+  load_b(1, rb); store_b(1, rb);
+  load_b(2, rb);
+  load_halo(0);
+  __syncthreads();
+  read_a();
+#pragma unroll
+  for (int j = 0; j < NT; ++j) read_b(0, j);
+  int s_in = 0, slab = 0;
+  int b1 = 1, b2 = 2, b0 = 0;                    // buffers of stage g+1, g+2, g
+  for (int g = 0; g < nstages; ++g) {
+    __syncthreads();                             // stage g+1's weights are visible; buffer b2 (stage g-1) is free
+    store_b(b2, rb);
+    load_b(g + 3, rb);
+    const bool last_of_slab = (s_in + 1 == p.SPS);
+    bf16x8 ahn[2], aln[2];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -608,44 +623,35 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
       }
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  load_b(0, rb);
-  load_halo(0);
-  store_b(0, rb);
-  load_b(1, rb);
-  __syncthreads();
-  const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= 4;
-  int s_in = 0, slab = 0;
-  stamp(-1);
-  for (int g = 0; g < nstages; ++g) {
-    if (!g1) { mem(g); stamp(0); } else { if (g > 0) mma(); stamp(2); }
-    __syncthreads();
-    stamp(1);
-    if (!g1) { mma(); stamp(2); } else { mem(g); stamp(0); }
-    __syncthreads();
-    stamp(3);
-    if (++s_in == p.SPS) {                     // slab boundary: every fragment of the old slab is in registers
-      s_in = 0;
-      if (++slab < p.nslabs) {
-        load_halo(slab);
-        cl = kg * 8; tdx = 0; tdy = 0; aoff = cl * 2;
-        __syncthreads();
+      read_b(b1, j);                             // stage g+1, same cout tile, into the registers just consumed
+      if (j == 0 && !last_of_slab) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ahn[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
+          aln[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    stamp(4);
+    if (!last_of_slab) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { ah[i] = ahn[i]; al[i] = aln[i]; }
+      cl += XKC;
+      if (cl >= p.CS) { cl -= p.CS; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
+      aoff = tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0;
+      ++s_in;
+    } else {                                     // slab boundary: the next A fragments come from the next halo
+      s_in = 0;
+      ++slab;
+      __syncthreads();                           // every wave has consumed its fragments of the old halo
+      if (slab < p.nslabs) load_halo(slab);
+      cl = kg * 8; tdx = 0; tdy = 0; aoff = cl * 2;
+      __syncthreads();
+      read_a();
+    }
+    const int t = b0; b0 = b1; b1 = b2; b2 = t;
   }
-  if (g1) mma();
   __syncthreads();
-  if (DBG & 64) {
-    if (lane == 0) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * 8 + wave) * 8;
-      for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
-      o[6] = st_prev;
-    }
-  }
 
   // ---- epilogue (as the streaming kernel; pixels of the tile outside the image are written as zeros to LDS
   // and skipped on the way out).  Tile-local pixel pr = 16 * pixel-tile + column.
@@ -1108,7 +1114,7 @@ template <int NT>
 static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   constexpr int TH = 16, TW = 16;
   const int HP = (TH + p.ks - 1) * (TW + p.ks - 1);
-  const size_t lds_main = (size_t)((HP * p.PXS + 127) & ~127) + (size_t)2 * (2 * NT * 16 * XROW + 64) * sizeof(u16);
+  const size_t lds_main = (size_t)((HP * p.PXS + 127) & ~127) + (size_t)3 * (2 * NT * 16 * XROW + 64) * sizeof(u16);
   const size_t lds_out = p.ys ? (size_t)256 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)256 * (NT * 16 + 4) * sizeof(float);
   const size_t lds = lds_main > lds_out ? lds_main : lds_out;
   WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
