@@ -23,8 +23,8 @@ else:
 st = part.cpu().numpy().view(np.uint64)[: tiles * nw * 8].reshape(tiles, nw, 8).astype(np.float64)
 names = ["load issue", "frag reads+wait", "mfma issue", "vmcnt+lds store", "barrier", "slab boundary"]
 if halo:
-    names = ["mem phase (store/load/frag reads)", "barrier after phase 1", "mfma issue", "barrier after phase 2", "slab boundary"]
-NB = 5
+    names = ["barrier", "weight store + load issue", "mfma + fragment reads (drained)", "stage tail / slab boundary"]
+NB = 4 if halo else 5
 tot = st[:, :, :NB].sum(axis=2)
 print("tiles", tiles, "stages/tile", nstage)
 print("cycles per tile (s_memtime ticks = 100 MHz?): mean %.0f min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))

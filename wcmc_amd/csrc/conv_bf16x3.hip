@@ -608,10 +608,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   for (int j = 0; j < NT; ++j) read_b(0, j);
   int s_in = 0, slab = 0;
   int b1 = 1, b2 = 2, b0 = 0;                    // buffers of stage g+1, g+2, g
+  stamp(-1);
   for (int g = 0; g < nstages; ++g) {
     __syncthreads();                             // stage g+1's weights are visible; buffer b2 (stage g-1) is free
+    stamp(0);
     store_b(b2, rb);
     load_b(g + 3, rb);
+    stamp(1);
     const bool last_of_slab = (s_in + 1 == p.SPS);
     bf16x8 ahn[2], aln[2];
     __builtin_amdgcn_sched_barrier(0);
@@ -633,6 +636,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(2);
     if (!last_of_slab) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) { ah[i] = ahn[i]; al[i] = aln[i]; }
@@ -650,8 +654,16 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
       read_a();
     }
     const int t = b0; b0 = b1; b1 = b2; b2 = t;
+    stamp(3);
   }
   __syncthreads();
+  if (DBG & 64) {
+    if (lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * 8 + wave) * 8;
+      for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
+      o[6] = st_prev;
+    }
+  }
 
   // ---- epilogue (as the streaming kernel; pixels of the tile outside the image are written as zeros to LDS
   // and skipped on the way out).  Tile-local pixel pr = 16 * pixel-tile + column.
