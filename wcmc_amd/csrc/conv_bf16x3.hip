@@ -494,35 +494,29 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   // ---- halo: [pixel][hi CS][lo CS] at stride PXS; out-of-image pixels and channels >= Cpi read zeros
   const int V = p.CS / 4;                      // 16-byte vectors per halo pixel (2 planes x CS/8)
   const int hvecs = HP * V;
-  // one batch of loads, then one batch of LDS stores (prefetching the next slab during the previous stage
-  // would need 52 more live VGPRs than the 256 two waves per SIMD allow)
-  constexpr int HLM = 13;                      // ceil(20*20 pixels * 16 vectors / 512 threads)
-  u32x4 hr[HLM];
-  auto halo_fetch = [&](int slab) {
+  auto load_halo = [&](int slab) {
+    constexpr int HL = 6;
+    for (int base = 0; base < hvecs; base += NTHR * HL) {
+      u32x4 r[HL]; int so[HL];
 #pragma unroll
-    for (int j = 0; j < HLM; ++j) {
-      const int idx = j * NTHR + tid;
-      unsigned off = XOOB;
-      if (idx < hvecs) {
-        const int px = idx / V, v = idx - px * V;
-        const int hy = px / HWd, hx = px - hy * HWd;
-        const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
-        const int plane = v >= (V >> 1), vec = v - plane * (V >> 1);
-        const int ch = slab * p.CS + vec * 8;
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Cpi)
-          off = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb + plane * 2 * p.Cpi + ch * 2);
+      for (int j = 0; j < HL; ++j) {
+        const int idx = base + j * NTHR + tid;
+        unsigned off = XOOB; so[j] = -1;
+        if (idx < hvecs) {
+          const int px = idx / V, v = idx - px * V;
+          const int hy = px / HWd, hx = px - hy * HWd;
+          const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+          const int plane = v >= (V >> 1), vec = v - plane * (V >> 1);
+          const int ch = slab * p.CS + vec * 8;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Cpi)
+            off = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb + plane * 2 * p.Cpi + ch * 2);
+          so[j] = px * p.PXS + v * 16;
+        }
+        r[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
       }
-      hr[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-    }
-  };
-  auto halo_commit = [&]() {
 #pragma unroll
-    for (int j = 0; j < HLM; ++j) {
-      const int idx = j * NTHR + tid;
-      if (idx < hvecs) {
-        const int px = idx / V, v = idx - px * V;
-        *reinterpret_cast<u32x4*>(halo + px * p.PXS + v * 16) = hr[j];
-      }
+      for (int j = 0; j < HL; ++j)
+        if (so[j] >= 0) *reinterpret_cast<u32x4*>(halo + so[j]) = r[j];
     }
   };
 
@@ -607,8 +601,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   load_b(0, rb); store_b(0, rb);
   load_b(1, rb); store_b(1, rb);
   load_b(2, rb);
-  halo_fetch(0);
-  halo_commit();
+  load_halo(0);
   __syncthreads();
   read_a();
 #pragma unroll
@@ -619,8 +612,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   for (int g = 0; g < nstages; ++g) {
     __syncthreads();                             // stage g+1's weights are visible; buffer b2 (stage g-1) is free
     stamp(0);
-    const bool last_of_slab = (s_in + 1 == p.SPS);
+    store_b(b2, rb);
+    load_b(g + 3, rb);
     stamp(1);
+    const bool last_of_slab = (s_in + 1 == p.SPS);
     bf16x8 ahn[2], aln[2];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -632,10 +627,6 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
       }
       read_b(b1, j);                             // stage g+1, same cout tile, into the registers just consumed
-      if (j == (NT > 1 ? 1 : 0)) {               // weights of stage g+2 -> LDS, stage g+3 -> registers, behind queued MFMAs
-        store_b(b2, rb);
-        load_b(g + 3, rb);
-      }
       if (j == 0 && !last_of_slab) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -657,7 +648,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
       s_in = 0;
       ++slab;
       __syncthreads();                           // every wave has consumed its fragments of the old halo
-      if (slab < p.nslabs) { halo_fetch(slab); halo_commit(); }
+      if (slab < p.nslabs) load_halo(slab);
       cl = kg * 8; tdx = 0; tdy = 0; aoff = cl * 2;
       __syncthreads();
       read_a();
