@@ -778,7 +778,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
 // the pixel fragments of the 16 tile rows from the halo, three MFMAs per pair of ds_read_b128.  There is
 // no barrier inside a channel slab, so the waves of a SIMD drift apart and fill each other's gaps.
 // NW = waves (= cout tiles) per block: 7 for 112 couts (KPCN hidden layers; 441 = 4 blocks), 8 otherwise.
-template <int NW>
+template <int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64, 1) void conv_halo_ws_bf16x3_kernel(XIgemmParams p) {
   constexpr int BN = NW * 16, NTHR = NW * 64, TH = 16, TW = 16, PD = 4;
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
@@ -839,6 +839,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_halo_ws_bf16x3_kernel(XIgemmP
   const int nstages = p.Kt / XKC;
   auto load_w = [&](int g, bf16x8& h, bf16x8& l) {
     const unsigned kill = g < nstages ? 0u : XOOB;
+    if (DBG & 32) { h = __builtin_bit_cast(bf16x8, u32x4{wb_hi, 0u, 0u, 0u}); l = h; return; }
     h = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, (wb_hi + (unsigned)(g * XKC * 2)) | kill, 0, 0));
     l = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, (wb_lo + (unsigned)(g * XKC * 2)) | kill, 0, 0));
   };
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_halo_ws_bf16x3_kernel(XIgemmP
   };
   bf16x8 fh[PD], fl[PD];
   auto read_px = [&](int slot, int t, int off) {
+    if (DBG & 8) { fh[slot] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)off, 0u, 0u, 0u}); fl[slot] = fh[slot]; return; }
     fh[slot] = *reinterpret_cast<const bf16x8*>(halo + off + t * rowb);
     fl[slot] = *reinterpret_cast<const bf16x8*>(halo + off + t * rowb + lo_off);
   };
@@ -877,9 +879,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_halo_ws_bf16x3_kernel(XIgemmP
     const int aoff_n = next_aoff();
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, fh[t % PD], acc[t], 0, 0, 0);   // small terms first
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fl[t % PD], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fh[t % PD], acc[t], 0, 0, 0);
+      if (DBG & 1) {
+        asm volatile("" ::"v"(fh[t % PD]), "v"(fl[t % PD]), "v"(wh), "v"(wl));
+      } else {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, fh[t % PD], acc[t], 0, 0, 0);   // small terms first
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fl[t % PD], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fh[t % PD], acc[t], 0, 0, 0);
+      }
       if (t + PD < 16) read_px(t % PD, t + PD, aoff);
       else if (!last_of_slab) read_px(t % PD, t + PD - 16, aoff_n);
       __builtin_amdgcn_sched_barrier(0);
@@ -892,7 +898,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_halo_ws_bf16x3_kernel(XIgemmP
       s_in = 0;
       ++slab;
       __syncthreads();                                   // every wave is done with the old halo
-      if (slab < p.nslabs) load_halo(slab);
+      if (slab < p.nslabs && !(DBG & 128)) load_halo(slab);
       cl = kg * 8; tdx = 0; tdy = 0; aoff = pbase + cl * 2;
       __syncthreads();
 #pragma unroll
@@ -1390,6 +1396,19 @@ static int launch_xhalo_ws(const XIgemmParams& p, hipStream_t stream) {
     attr = lds;
   }
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NW - 1) / NW));
+  if (NW == 7) {       // WCMC_DEBUG_ABLATE=<mask>: timing-only builds (wrong results)
+    static int ab = -1;
+    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+#define WS_ABL(M)                                                                                       \
+    if (ab == M) {                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_ws_bf16x3_kernel<7, M>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+      hipLaunchKernelGGL((conv_halo_ws_bf16x3_kernel<7, M>), grid, dim3(448), lds, stream, p);          \
+      return check_launch("conv2d_igemm_bf16x3(ws ablation)");                                         \
+    }
+    WS_ABL(1) WS_ABL(8) WS_ABL(32) WS_ABL(128) WS_ABL(9) WS_ABL(40) WS_ABL(168) WS_ABL(169)
+#undef WS_ABL
+  }
   hipLaunchKernelGGL((conv_halo_ws_bf16x3_kernel<NW>), grid, dim3(NW * 64), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo, weights in registers)");
 }
