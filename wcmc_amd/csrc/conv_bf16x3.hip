@@ -494,6 +494,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   // ---- halo: [pixel][hi CS][lo CS] at stride PXS; out-of-image pixels and channels >= Cpi read zeros
   const int V = p.CS / 4;                      // 16-byte vectors per halo pixel (2 planes x CS/8)
   const int hvecs = HP * V;
+  const float invV = 1.0f / (float)V, invHW = 1.0f / (float)HWd;
   auto load_halo = [&](int slab) {
     constexpr int HL = 6;
     for (int base = 0; base < hvecs; base += NTHR * HL) {
@@ -503,8 +504,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
         const int idx = base + j * NTHR + tid;
         unsigned off = XOOB; so[j] = -1;
         if (idx < hvecs) {
-          const int px = idx / V, v = idx - px * V;
-          const int hy = px / HWd, hx = px - hy * HWd;
+          const int px = (int)(((float)idx + 0.5f) * invV), v = idx - px * V;      // exact: idx < 2^13
+          const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
           const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
           const int plane = v >= (V >> 1), vec = v - plane * (V >> 1);
           const int ch = slab * p.CS + vec * 8;
@@ -803,6 +804,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_halo_ws_bf16x3_kernel(XIgemmP
   // ---- halo (layout as conv_halo_bf16x3_kernel): one batch of loads, one batch of LDS stores
   const int V = p.CS / 4;
   const int hvecs = HP * V;
+  const float invV = 1.0f / (float)V, invHW = 1.0f / (float)HWd;
   constexpr int HLM = (400 * 16 + NTHR - 1) / NTHR;
   auto load_halo = [&](int slab) {
     u32x4 hr[HLM];
@@ -811,8 +813,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_halo_ws_bf16x3_kernel(XIgemmP
       const int idx = j * NTHR + tid;
       unsigned off = XOOB;
       if (idx < hvecs) {
-        const int px = idx / V, v = idx - px * V;
-        const int hy = px / HWd, hx = px - hy * HWd;
+        const int px = (int)(((float)idx + 0.5f) * invV), v = idx - px * V;      // exact: idx < 2^13
+        const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
         const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
         const int plane = v >= (V >> 1), vec = v - plane * (V >> 1);
         const int ch = slab * p.CS + vec * 8;
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_halo_ws_bf16x3_kernel(XIgemmP
     for (int j = 0; j < HLM; ++j) {
       const int idx = j * NTHR + tid;
       if (idx < hvecs) {
-        const int px = idx / V, v = idx - px * V;
+        const int px = (int)(((float)idx + 0.5f) * invV), v = idx - px * V;      // exact: idx < 2^13
         *reinterpret_cast<u32x4*>(halo + px * p.PXS + v * 16) = hr[j];
       }
     }
@@ -1415,8 +1417,8 @@ static int launch_xhalo_ws(const XIgemmParams& p, hipStream_t stream) {
 template <int NT>
 static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
   if (p.PXS) {
-    static int ws = -1;      // WCMC_IGEMM_WS=0: A/B switch back to the shared-weight-stage halo kernel
-    if (ws < 0) { const char* e = getenv("WCMC_IGEMM_WS"); ws = (e && e[0] == '0') ? 0 : 1; }
+    static int ws = -1;      // WCMC_IGEMM_WS=1: A/B switch to the weights-in-registers variant (slower today)
+    if (ws < 0) { const char* e = getenv("WCMC_IGEMM_WS"); ws = (e && e[0] == '1') ? 1 : 0; }
     const int tiles = p.Np / 16;
     if (ws && tiles % 7 == 0) return launch_xhalo_ws<7>(p, stream);
     if (ws && tiles % 8 == 0) return launch_xhalo_ws<8>(p, stream);
