@@ -1191,6 +1191,159 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
   }
 }
 
+
+// ------------------------------------------------------------------ weight gradient, one filter row per block
+// The kernel above runs one tap per block: every 64-pixel stage (44 KB of dy and x) feeds 168 MFMAs, i.e.
+// 65 B per clock and CU from L2 -- the load path, not the matrix pipe, sets its pace (120-150 TF/s).
+// Here a block owns a whole filter ROW (KS taps) of one 112-cout block and keeps all KS x 7 x 7
+// accumulator tiles in registers (wave w = cin tile w: KS x 7 tiles = 140 VGPRs at KS = 5): a stage is
+// 64 pixels of one output row, dy [64][112] and the x row segment [64 + KS - 1][112] (both planes),
+// and feeds 2 x KS x 49 x 3 = 1470 MFMAs -- 8.6 B per clock.  The KS taps read the same x rows at shifted
+// pixel offsets (the transposing LDS read addresses pixel rows per lane, so any shift is free), dy
+// fragments are shared by all taps.  Stages are filled by LDS-DMA (buffer_load ... lds, no staging
+// registers) into two buffers; one barrier per stage of ~3400 MFMA cycles per wave.
+struct XWRowsParams {
+  const u16* x; int N, H, W, Cpi;
+  const u16* dy; int Ho, Wo, Cpo;
+  int pad;
+  float* slabs; int S, rps, R;
+  int Np, Cq, coBlocks;
+  unsigned x_bytes, dy_bytes;
+};
+
+template <int KS, int TM>
+__global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsParams p) {
+  constexpr int NW = 7, CH = 112, PK = 64, XR = PK + KS - 1;
+  constexpr int VPR = CH / 8;                               // 16-byte vectors per row and plane
+  constexpr int YV = PK * VPR, XV = XR * VPR;
+  constexpr int NVEC = 2 * YV + 2 * XV;
+  constexpr int NI = (NVEC + NW * 64 - 1) / (NW * 64);      // LDS-DMA instructions per wave and stage
+  constexpr int BUF = NI * NW * 64 * 8;                     // u16 per buffer (whole instructions)
+  static_assert(TM == 7, "one 112-cout block per workgroup");
+  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per_split = KS * p.coBlocks;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int s = (local / per_split) * 8 + xcd;
+  if (s >= p.S) return;
+  const int within = local - (local / per_split) * per_split;
+  const int trow = within % KS, cob = within / KS;
+  const int co0 = cob * CH;
+  const int r0 = s * p.rps, r1 = min(p.R, r0 + p.rps);
+  const int nch = (p.Wo + PK - 1) / PK;
+  const int nst = (r1 - r0) * nch;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+
+  // ---- stage fill: the buffer is one linear run of 16-byte vectors [Yh | Yl | Xh | Xl], rows of 224 B;
+  // instruction i of wave w writes vectors (i*NW + w)*64 + lane (lane-linear destination), the per-lane
+  // SOURCE picks the pixel / plane / channel; invalid sources use an out-of-range offset and land as zeros.
+  auto issue = [&](int st, int buf) {
+    const int rr = st / nch, c = st - rr * nch;
+    const int r = r0 + rr;
+    const int n = r / p.Ho, oy = r - n * p.Ho;
+    const int ox0 = c * PK;
+    const int iy = oy + trow - p.pad;
+    const bool rowok = (unsigned)iy < (unsigned)p.H;
+    const unsigned ybase = (unsigned)(((n * p.Ho + oy) * p.Wo + ox0) * 4 * p.Cpo);
+    const int xpix0 = (n * p.H + iy) * p.W + ox0 - p.pad;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int v = (i * NW + wave) * 64 + lane;
+      unsigned off = XOOB;
+      if (v < 2 * YV) {
+        const int plane = v >= YV, vv = v - plane * YV;
+        const int row = vv / VPR, vec = vv - row * VPR;
+        const int co = co0 + vec * 8;
+        if (ox0 + row < p.Wo && co < p.Cpo) off = ybase + (unsigned)(row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (__attribute__((address_space(3))) void*)(smem16 + buf * BUF + (i * NW + wave) * 512),
+                                                 16, off, 0, 0, 0);
+      } else {
+        const int u = v - 2 * YV;
+        const int plane = u >= XV, uu = u - plane * XV;
+        const int row = uu / VPR, vec = uu - row * VPR;
+        const int ix = ox0 - p.pad + row, ci = vec * 8;
+        if (u < 2 * XV && rowok && (unsigned)ix < (unsigned)p.W && ci < p.Cpi)
+          off = (unsigned)((xpix0 + row) * 4 * p.Cpi + plane * 2 * p.Cpi + ci * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(smem16 + buf * BUF + (i * NW + wave) * 512),
+                                                 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[KS][TM];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposing read (see conv_wgrad_bf16x3_kernel): lane addresses pixel row 4g + q (+16) and channels
+  // 4pp..4pp+3 of a 16-channel tile and receives channel (lane & 15) of pixels {4g..4g+3, 16+4g..16+4g+3}
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  auto tr_read = [&](const u16* base, int prow, int col0, bf16x8& out) {
+    const u16* a0 = base + prow * CH + col0 + 4 * tp;
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 16 * CH));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 cat = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    out = __builtin_bit_cast(bf16x8, cat);
+  };
+
+  if (nst > 0) issue(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of stage st has landed
+    __syncthreads();                                      // ... everyone's; and everyone is done with stage st-1
+    if (st + 1 < nst) issue(st + 1, (st + 1) & 1);
+    const u16* Yh = smem16 + (st & 1) * BUF;
+    const u16* Yl = Yh + PK * CH;
+    const u16* Xh = Yh + 2 * PK * CH;
+    const u16* Xl = Xh + XR * CH;
+    const int c = st % nch;
+    const int nk = (min(PK, p.Wo - c * PK) + 31) / 32;    // 32-pixel MFMA k-steps with any valid pixel
+    for (int kk = 0; kk < nk; ++kk) {
+      const int prow = kk * 32 + 4 * g + tq;
+      bf16x8 yh[TM], yl[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        tr_read(Yh, prow, i * 16, yh[i]);
+        tr_read(Yl, prow, i * 16, yl[i]);
+      }
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        bf16x8 xh, xl;
+        tr_read(Xh, prow + t, wave * 16, xh);
+        tr_read(Xl, prow + t, wave * 16, xl);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl[i], xh, acc[t][i], 0, 0, 0);
+          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xl, acc[t][i], 0, 0, 0);
+          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xh, acc[t][i], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- slab write: lane holds D[co = 4*(lane>>4) + r][ci = lane & 15] of each tile
+  const int fcol = lane & 15, fq = (lane >> 4) * 4;
+  const int ci = wave * 16 + fcol;
+  if (wave * 16 < p.Cq) {
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      float* slab = p.slabs + ((int64_t)s * KS * KS + trow * KS + t) * p.Np * p.Cq;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int co = co0 + i * 16 + fq;
+        if (co < p.Np) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) slab[(int64_t)(co + r) * p.Cq + ci] = acc[t][i][r];
+        }
+      }
+    }
+  }
+}
+
 // bias gradient from a split tensor: partial[g][c] = sum over the block's pixels of hi + lo.
 // One thread = 8 channels (two 16-byte loads per pixel), 256/V pixel lanes, LDS tree across them.
 __global__ __launch_bounds__(256) void colsum_split_kernel(const u16* __restrict__ dy, int Cp, int C, int64_t M,
@@ -1237,7 +1390,7 @@ static int x_pick_nt(int tiles) {
   return best;
 }
 
-struct XWgradPlan { int TM, coBlocks, ciBlocks, S, Np, Cq, G; int64_t pix_per_split, per_block; size_t slab_elems, bytes; };
+struct XWgradPlan { int rows, rps, R; int TM, coBlocks, ciBlocks, S, Np, Cq, G; int64_t pix_per_split, per_block; size_t slab_elems, bytes; };
 static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks) {
   XWgradPlan pl;
   pl.Np = round_up(Cout, 16); pl.Cq = round_up(Cin, 16);
@@ -1247,6 +1400,18 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
   pl.ciBlocks = (ciT + 3) / 4;
   const int64_t M = (int64_t)N * Ho * Wo;
   const int taps = ks * ks;
+  static int rows_on = -1;            // WCMC_WGRAD_ROWS=0: A/B switch back to the one-tap-per-block kernel
+  if (rows_on < 0) { const char* e = getenv("WCMC_WGRAD_ROWS"); rows_on = (e && e[0] == '0') ? 0 : 1; }
+  pl.rows = rows_on && ks == 5 && pl.Cq == 112 && coT % 7 == 0 && (int64_t)N * Ho >= 64;
+  pl.R = N * Ho; pl.rps = 0;
+  if (pl.rows) {
+    // one block per (split, filter row, cout block); one round of the 256 CUs
+    int S = 256 / (ks * pl.coBlocks);
+    if (S < 1) S = 1;
+    pl.rps = (pl.R + S - 1) / S;
+    pl.S = (pl.R + pl.rps - 1) / pl.rps;
+    pl.pix_per_split = 0;
+  }
   const int64_t tiles = (int64_t)taps * pl.coBlocks * pl.ciBlocks;
   // ~2 waves of 512 co-resident blocks for the multi-tap convs; one wave for the HBM-bound 1x1 layers,
   // whose slab traffic (S x Np x Cq floats, written and re-read) otherwise rivals the operand stream
@@ -1254,8 +1419,10 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
   const int64_t maxS = M / 512 > 0 ? M / 512 : 1;     // >= 8 stages of 64 pixels per block
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
-  pl.pix_per_split = ceil_div64(ceil_div64(M, S), 64) * 64;
-  pl.S = (int)ceil_div64(M, pl.pix_per_split);
+  if (!pl.rows) {
+    pl.pix_per_split = ceil_div64(ceil_div64(M, S), 64) * 64;
+    pl.S = (int)ceil_div64(M, pl.pix_per_split);
+  }
   pl.slab_elems = (size_t)pl.S * taps * pl.Np * pl.Cq;
   pl.G = (int)(M / 64 > 0 ? (M / 64 < 1024 ? M / 64 : 1024) : 1);
   pl.per_block = ceil_div64(M, pl.G);
@@ -1536,7 +1703,25 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
   p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
   WCMC_REQUIRE(phase >= 0 && phase <= 2, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: phase must be 0, 1 or 2");
   int rc = 0;
-  if (phase != 2) rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
+  if (phase != 2 && pl.rows) {
+    XWRowsParams q;
+    q.x = p.x; q.N = N; q.H = H; q.W = W; q.Cpi = p.Cpi; q.dy = p.dy; q.Ho = Ho; q.Wo = Wo; q.Cpo = p.Cpo;
+    q.pad = pad; q.slabs = p.slabs; q.S = pl.S; q.rps = pl.rps; q.R = pl.R; q.Np = pl.Np; q.Cq = pl.Cq;
+    q.coBlocks = pl.coBlocks; q.x_bytes = p.x_bytes; q.dy_bytes = p.dy_bytes;
+    constexpr int NVEC = 2 * 64 * 14 + 2 * 68 * 14, NI = (NVEC + 447) / 448;
+    const size_t lds = (size_t)2 * NI * 448 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<5, 7>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    const dim3 grid((unsigned)(((pl.S + 7) / 8) * 8 * 5 * pl.coBlocks));
+    hipLaunchKernelGGL((conv_wgrad_rows_bf16x3_kernel<5, 7>), grid, dim3(448), lds, st, q);
+    rc = check_launch("conv2d_wgrad_bf16x3(rows)");
+  } else if (phase != 2) {
+    rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
+  }
   if (rc || phase == 1) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + WR_CI - 1) / WR_CI), (unsigned)Cout), dim3(256),
                      (size_t)WR_CI * (ks * ks + 1) * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq);
