@@ -1232,7 +1232,8 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
   const int co0 = cob * CH;
   const int r0 = s * p.rps, r1 = min(p.R, r0 + p.rps);
   const int nch = (p.Wo + PK - 1) / PK;
-  const int nst = (r1 - r0) * nch;
+  const int nrows = r1 - r0;
+  const int nst = nrows * nch;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
@@ -1241,8 +1242,13 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
   // instruction i of wave w writes vectors (i*NW + w)*64 + lane (lane-linear destination), the per-lane
   // SOURCE picks the pixel / plane / channel; invalid sources use an out-of-range offset and land as zeros.
   auto issue = [&](int st, int buf) {
+    // Row order skewed by the filter row: at step j the KS blocks of a split (same XCD, same time) read
+    // the SAME x row r0 + j and dy rows one step apart, so the second reader of every line still finds
+    // it in the XCD's L2 (unskewed, x rows were re-read two stages later and 4 MB of other stages in between).
     const int rr = st / nch, c = st - rr * nch;
-    const int r = r0 + rr;
+    int rs = rr - trow;
+    rs = rs < 0 ? rs + ((trow + nrows - 1) / nrows) * nrows : rs;
+    const int r = r0 + rs % nrows;
     const int n = r / p.Ho, oy = r - n * p.Ho;
     const int ox0 = c * PK;
     const int iy = oy + trow - p.pad;
