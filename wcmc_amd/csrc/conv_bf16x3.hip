@@ -1207,11 +1207,12 @@ struct XWRowsParams {
   const u16* dy; int Ho, Wo, Cpo;
   int pad;
   float* slabs; int S, rps, R;
+  float* dbg;                       // clock-probe build only
   int Np, Cq, coBlocks;
   unsigned x_bytes, dy_bytes;
 };
 
-template <int KS, int TM>
+template <int KS, int TM, int DBG = 0>
 __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsParams p) {
   constexpr int NW = 7, CH = 112, PK = 64, XR = PK + KS - 1;
   constexpr int VPR = CH / 8;                               // 16-byte vectors per row and plane
@@ -1297,11 +1298,13 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
     out = __builtin_bit_cast(bf16x8, cat);
   };
 
+  unsigned long long tc0 = 0, tr0 = 0;
+  if (DBG & 4) { tc0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
   if (nst > 0) issue(0, 0);
   for (int st = 0; st < nst; ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of stage st has landed
     __syncthreads();                                      // ... everyone's; and everyone is done with stage st-1
-    if (st + 1 < nst) issue(st + 1, (st + 1) & 1);
+    if (st + 1 < nst && !((DBG & 2) && st > 0)) issue(st + 1, (st + 1) & 1);
     const u16* Yh = smem16 + (st & 1) * BUF;
     const u16* Yl = Yh + PK * CH;
     const u16* Xh = Yh + 2 * PK * CH;
@@ -1323,6 +1326,7 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
         tr_read(Xl, prow + t, wave * 16, xl);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+          if (DBG & 1) { asm volatile("" ::"v"(yl[i]), "v"(yh[i]), "v"(xh), "v"(xl)); continue; }
           acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl[i], xh, acc[t][i], 0, 0, 0);
           acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xl, acc[t][i], 0, 0, 0);
           acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xh, acc[t][i], 0, 0, 0);
@@ -1331,22 +1335,34 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
     }
   }
 
-  // ---- slab write: lane holds D[co = 4*(lane>>4) + r][ci = lane & 15] of each tile
-  const int fcol = lane & 15, fq = (lane >> 4) * 4;
-  const int ci = wave * 16 + fcol;
-  if (wave * 16 < p.Cq) {
-#pragma unroll
-    for (int t = 0; t < KS; ++t) {
-      float* slab = p.slabs + ((int64_t)s * KS * KS + trow * KS + t) * p.Np * p.Cq;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int co = co0 + i * 16 + fq;
-        if (co < p.Np) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) slab[(int64_t)(co + r) * p.Cq + ci] = acc[t][i][r];
-        }
-      }
+  if (DBG & 4) {     // clock probe: shader-clock ticks and 100 MHz ticks over the main loop
+    const unsigned long long tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.dbg) + (int64_t)blockIdx.x * 4;
+      o[0] = tc1 - tc0; o[1] = tr1 - tr0; o[2] = (unsigned long long)nst;
     }
+  }
+  // ---- slab write: lane holds D[co = 4*(lane>>4) + r][ci = 16*wave + (lane & 15)] of each tile.  Each tap's
+  // [112][Cq = 112] tile is one contiguous 50 KB run of the slab: transpose through LDS and copy it out in
+  // whole 16-byte vectors (direct stores are 64-byte fragments of 128-byte lines: 0.4 TB/s measured).
+  __syncthreads();
+  constexpr int RS = CH + 4;
+  float* red = reinterpret_cast<float*>(smem16);           // [112][RS]
+  const int fcol = lane & 15, fq = (lane >> 4) * 4;
+#pragma unroll
+  for (int t = 0; t < KS; ++t) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(i * 16 + fq + r) * RS + wave * 16 + fcol] = acc[t][i][r];
+    __syncthreads();
+    float* slab = p.slabs + (((int64_t)s * KS * KS + trow * KS + t) * p.Np + co0) * p.Cq;
+    for (int idx = tid; idx < CH * (CH / 4); idx += NW * 64) {
+      const int row = idx / (CH / 4), v = idx - row * (CH / 4);
+      if (co0 + row < p.Np)
+        *reinterpret_cast<float4*>(slab + (int64_t)row * p.Cq + v * 4) = *reinterpret_cast<const float4*>(red + row * RS + v * 4);
+    }
+    __syncthreads();
   }
 }
 
@@ -1712,6 +1728,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
   if (phase != 2 && pl.rows) {
     XWRowsParams q;
     q.x = p.x; q.N = N; q.H = H; q.W = W; q.Cpi = p.Cpi; q.dy = p.dy; q.Ho = Ho; q.Wo = Wo; q.Cpo = p.Cpo;
+    q.dbg = (float*)workspace + pl.slab_elems;
     q.pad = pad; q.slabs = p.slabs; q.S = pl.S; q.rps = pl.rps; q.R = pl.R; q.Np = pl.Np; q.Cq = pl.Cq;
     q.coBlocks = pl.coBlocks; q.x_bytes = p.x_bytes; q.dy_bytes = p.dy_bytes;
     constexpr int NVEC = 2 * 64 * 14 + 2 * 68 * 14, NI = (NVEC + 447) / 448;
@@ -1723,6 +1740,15 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
       attr_set = true;
     }
     const dim3 grid((unsigned)(((pl.S + 7) / 8) * 8 * 5 * pl.coBlocks));
+    static int ab = -1;                 // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills)
+    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    if (ab == 1 || ab == 2 || ab == 3 || ab == 4) {
+      auto kfn = ab == 1 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 1> : ab == 2 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 2>
+                 : ab == 3 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 3> : &conv_wgrad_rows_bf16x3_kernel<5, 7, 4>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, grid, dim3(448), lds, st, q);
+      return check_launch("conv2d_wgrad_bf16x3(rows ablation)");
+    }
     hipLaunchKernelGGL((conv_wgrad_rows_bf16x3_kernel<5, 7>), grid, dim3(448), lds, st, q);
     rc = check_launch("conv2d_wgrad_bf16x3(rows)");
   } else if (phase != 2) {
