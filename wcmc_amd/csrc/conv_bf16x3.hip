@@ -1224,12 +1224,13 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int per_split = KS * p.coBlocks;
+  // unit = (split, cout block); its KS filter-row blocks run side by side on one XCD (blockIdx & 7) and share
+  // the unit's dy rows and x rows in that XCD's L2.  The plan keeps units <= 8 * (32 / KS): one round.
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int s = (local / per_split) * 8 + xcd;
-  if (s >= p.S) return;
-  const int within = local - (local / per_split) * per_split;
-  const int trow = within % KS, cob = within / KS;
+  const int unit = (local / KS) * 8 + xcd;
+  if (unit >= p.S * p.coBlocks) return;
+  const int trow = local % KS;
+  const int s = unit / p.coBlocks, cob = unit - s * p.coBlocks;
   const int co0 = cob * CH;
   const int r0 = s * p.rps, r1 = min(p.R, r0 + p.rps);
   const int nch = (p.Wo + PK - 1) / PK;
@@ -1427,8 +1428,9 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
   pl.rows = rows_on && ks == 5 && pl.Cq == 112 && coT % 7 == 0 && (int64_t)N * Ho >= 64;
   pl.R = N * Ho; pl.rps = 0;
   if (pl.rows) {
-    // one block per (split, filter row, cout block); one round of the 256 CUs
-    int S = 256 / (ks * pl.coBlocks);
+    // one block per (split, cout block, filter row); the ks blocks of a (split, cout block) unit share an XCD
+    // (32 CUs): at most 32 / ks units per XCD keeps the launch to one round of the 256 CUs
+    int S = 8 * (32 / ks) / pl.coBlocks;
     if (S < 1) S = 1;
     pl.rps = (pl.R + S - 1) / S;
     pl.S = (pl.R + pl.rps - 1) / pl.rps;
@@ -1739,7 +1741,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
-    const dim3 grid((unsigned)(((pl.S + 7) / 8) * 8 * 5 * pl.coBlocks));
+    const dim3 grid((unsigned)(((pl.S * pl.coBlocks + 7) / 8) * 8 * 5));
     static int ab = -1;                 // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills)
     if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
     if (ab == 1 || ab == 2 || ab == 3 || ab == 4) {
