@@ -73,6 +73,11 @@ CONV_CASES = [
     (2, 128, 6, 6, 3, 1, 0, "relu"),
     (1, 7, 6, 5, 5, 3, 1, "linear"),
     (1, 256, 8, 8, 256, 3, 1, "relu"),
+    # several 16x16 halo tiles per image with ragged edges; N*Ho >= 64 selects the filter-row weight-gradient kernel
+    (2, 100, 40, 37, 100, 5, 0, "relu"),       # Wo = 33: one 64-pixel chunk per row, second k-step nearly empty
+    (1, 100, 70, 75, 441, 5, 0, "linear"),     # Wo = 71: two chunks per row, four cout blocks
+    (2, 100, 36, 36, 100, 5, 4, "linear"),     # full correlation (the data-gradient geometry), padded halo
+    (1, 128, 37, 21, 128, 3, 1, "relu"),       # 3x3, 128-channel slabs (PXS 288), weights-in-registers candidates
 ]
 
 
@@ -139,6 +144,12 @@ def test_conv_wgrad_is_bitwise_reproducible():
     xs, dys = o.split_raw(x), o.split_raw(dy)
     a = o.conv2d_wgrad_x_raw(xs, (2, 100, 24, 24), dys, 100, 5, 0, (100, 100, 5, 5))
     b = o.conv2d_wgrad_x_raw(xs, (2, 100, 24, 24), dys, 100, 5, 0, (100, 100, 5, 5))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # filter-row kernel (N*Ho >= 64): fixed slab order as well
+    xs = o.split_raw(o.to_nhwc_raw(gen(4, 100, 24, 24, seed=22).to(DEV)))
+    dys = o.split_raw(o.to_nhwc_raw(gen(4, 100, 20, 20, seed=23).to(DEV)))
+    a = o.conv2d_wgrad_x_raw(xs, (4, 100, 24, 24), dys, 100, 5, 0, (100, 100, 5, 5))
+    b = o.conv2d_wgrad_x_raw(xs, (4, 100, 24, 24), dys, 100, 5, 0, (100, 100, 5, 5))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
