@@ -1208,30 +1208,38 @@ struct XWRowsParams {
   int pad;
   float* slabs; int S, rps, R;
   float* dbg;                       // clock-probe build only
-  int Np, Cq, coBlocks;
+  int Np, Cq, coBlocks, ciBlocks;
   unsigned x_bytes, dy_bytes;
 };
 
-template <int KS, int TM, int DBG = 0>
-__global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsParams p) {
-  constexpr int NW = 7, CH = 112, PK = 64, XR = PK + KS - 1;
-  constexpr int VPR = CH / 8;                               // 16-byte vectors per row and plane
-  constexpr int YV = PK * VPR, XV = XR * VPR;
+// LDS row stride (u16) of a CH-channel tile: bytes = odd multiple of 32 (conflict-free transposing reads);
+// the pad vectors of a row are filled by DMA lanes with an out-of-range source (zeros).
+constexpr int xwr_stride(int ch) { return ((ch / 16) | 1) * 16; }
+
+// KS = filter size, TM = cout tiles (16) per block, NW = waves = cin tiles per block.
+template <int KS, int TM, int NW, int DBG = 0>
+__global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf16x3_kernel(XWRowsParams p) {
+  constexpr int CHY = TM * 16, CHX = NW * 16, PK = 64, XR = PK + KS - 1;
+  constexpr int SY = xwr_stride(CHY), SX = xwr_stride(CHX);
+  constexpr int VY = SY / 8, VX = SX / 8;                   // 16-byte vectors per row and plane (with pad)
+  constexpr int YV = PK * VY, XV = XR * VX;
   constexpr int NVEC = 2 * YV + 2 * XV;
   constexpr int NI = (NVEC + NW * 64 - 1) / (NW * 64);      // LDS-DMA instructions per wave and stage
   constexpr int BUF = NI * NW * 64 * 8;                     // u16 per buffer (whole instructions)
-  static_assert(TM == 7, "one 112-cout block per workgroup");
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // unit = (split, cout block); its KS filter-row blocks run side by side on one XCD (blockIdx & 7) and share
-  // the unit's dy rows and x rows in that XCD's L2.  The plan keeps units <= 8 * (32 / KS): one round.
+  // unit = (split, cout block, cin block); its KS filter-row blocks run side by side on one XCD
+  // (blockIdx & 7) and share the unit's dy rows and x rows in that XCD's L2.  The plan keeps the units of
+  // an XCD within its 32 CUs: one round.
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int unit = (local / KS) * 8 + xcd;
-  if (unit >= p.S * p.coBlocks) return;
+  const int upb = p.coBlocks * p.ciBlocks;
+  if (unit >= p.S * upb) return;
   const int trow = local % KS;
-  const int s = unit / p.coBlocks, cob = unit - s * p.coBlocks;
-  const int co0 = cob * CH;
+  const int s = unit / upb, ub = unit - s * upb;
+  const int cob = ub / p.ciBlocks, cib = ub - cob * p.ciBlocks;
+  const int co0 = cob * CHY, ci0 = cib * CHX;
   const int r0 = s * p.rps, r1 = min(p.R, r0 + p.rps);
   const int nch = (p.Wo + PK - 1) / PK;
   const int nrows = r1 - r0;
@@ -1240,13 +1248,12 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
 
-  // ---- stage fill: the buffer is one linear run of 16-byte vectors [Yh | Yl | Xh | Xl], rows of 224 B;
+  // ---- stage fill: the buffer is one linear run of 16-byte vectors [Yh | Yl | Xh | Xl];
   // instruction i of wave w writes vectors (i*NW + w)*64 + lane (lane-linear destination), the per-lane
   // SOURCE picks the pixel / plane / channel; invalid sources use an out-of-range offset and land as zeros.
   auto issue = [&](int st, int buf) {
-    // Row order skewed by the filter row: at step j the KS blocks of a split (same XCD, same time) read
-    // the SAME x row r0 + j and dy rows one step apart, so the second reader of every line still finds
-    // it in the XCD's L2 (unskewed, x rows were re-read two stages later and 4 MB of other stages in between).
+    // Row order skewed by the filter row: at step j the KS blocks of a unit read the SAME x row r0 + j and
+    // dy rows one step apart.
     const int rr = st / nch, c = st - rr * nch;
     int rs = rr - trow;
     rs = rs < 0 ? rs + ((trow + nrows - 1) / nrows) * nrows : rs;
@@ -1257,26 +1264,29 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
     const bool rowok = (unsigned)iy < (unsigned)p.H;
     const unsigned ybase = (unsigned)(((n * p.Ho + oy) * p.Wo + ox0) * 4 * p.Cpo);
     const int xpix0 = (n * p.H + iy) * p.W + ox0 - p.pad;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));        // keep the per-vector decode inside the stage (hoisted, it costs ~4 VGPRs per vector)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int v = (i * NW + wave) * 64 + lane;
+      const int v = (i * NW + wave) * 64 + ln;
       unsigned off = XOOB;
+      __attribute__((address_space(3))) void* dst =
+          (__attribute__((address_space(3))) void*)(smem16 + buf * BUF + (i * NW + wave) * 512);
       if (v < 2 * YV) {
         const int plane = v >= YV, vv = v - plane * YV;
-        const int row = vv / VPR, vec = vv - row * VPR;
+        const int row = vv / VY, vec = vv - row * VY;
         const int co = co0 + vec * 8;
-        if (ox0 + row < p.Wo && co < p.Cpo) off = ybase + (unsigned)(row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (__attribute__((address_space(3))) void*)(smem16 + buf * BUF + (i * NW + wave) * 512),
-                                                 16, off, 0, 0, 0);
+        if (vec * 8 < CHY && ox0 + row < p.Wo && co < p.Cpo)
+          off = ybase + (unsigned)(row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, dst, 16, off, 0, 0, 0);
       } else {
         const int u = v - 2 * YV;
         const int plane = u >= XV, uu = u - plane * XV;
-        const int row = uu / VPR, vec = uu - row * VPR;
-        const int ix = ox0 - p.pad + row, ci = vec * 8;
-        if (u < 2 * XV && rowok && (unsigned)ix < (unsigned)p.W && ci < p.Cpi)
+        const int row = uu / VX, vec = uu - row * VX;
+        const int ix = ox0 - p.pad + row, ci = ci0 + vec * 8;
+        if (u < 2 * XV && vec * 8 < CHX && rowok && (unsigned)ix < (unsigned)p.W && ci < p.Cpi)
           off = (unsigned)((xpix0 + row) * 4 * p.Cpi + plane * 2 * p.Cpi + ci * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(smem16 + buf * BUF + (i * NW + wave) * 512),
-                                                 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, off, 0, 0, 0);
       }
     }
   };
@@ -1290,10 +1300,10 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
   // transposing read (see conv_wgrad_bf16x3_kernel): lane addresses pixel row 4g + q (+16) and channels
   // 4pp..4pp+3 of a 16-channel tile and receives channel (lane & 15) of pixels {4g..4g+3, 16+4g..16+4g+3}
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  auto tr_read = [&](const u16* base, int prow, int col0, bf16x8& out) {
-    const u16* a0 = base + prow * CH + col0 + 4 * tp;
+  auto tr_read = [&](const u16* base, int stride, int prow, int col0, bf16x8& out) {
+    const u16* a0 = base + prow * stride + col0 + 4 * tp;
     const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
-    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 16 * CH));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 16 * stride));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 cat = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     out = __builtin_bit_cast(bf16x8, cat);
@@ -1307,9 +1317,9 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
     __syncthreads();                                      // ... everyone's; and everyone is done with stage st-1
     if (st + 1 < nst && !((DBG & 2) && st > 0)) issue(st + 1, (st + 1) & 1);
     const u16* Yh = smem16 + (st & 1) * BUF;
-    const u16* Yl = Yh + PK * CH;
-    const u16* Xh = Yh + 2 * PK * CH;
-    const u16* Xl = Xh + XR * CH;
+    const u16* Yl = Yh + PK * SY;
+    const u16* Xh = Yh + 2 * PK * SY;
+    const u16* Xl = Xh + XR * SX;
     const int c = st % nch;
     const int nk = (min(PK, p.Wo - c * PK) + 31) / 32;    // 32-pixel MFMA k-steps with any valid pixel
     for (int kk = 0; kk < nk; ++kk) {
@@ -1317,14 +1327,14 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
       bf16x8 yh[TM], yl[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        tr_read(Yh, prow, i * 16, yh[i]);
-        tr_read(Yl, prow, i * 16, yl[i]);
+        tr_read(Yh, SY, prow, i * 16, yh[i]);
+        tr_read(Yl, SY, prow, i * 16, yl[i]);
       }
 #pragma unroll
       for (int t = 0; t < KS; ++t) {
         bf16x8 xh, xl;
-        tr_read(Xh, prow + t, wave * 16, xh);
-        tr_read(Xl, prow + t, wave * 16, xl);
+        tr_read(Xh, SX, prow + t, wave * 16, xh);
+        tr_read(Xl, SX, prow + t, wave * 16, xl);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           if (DBG & 1) { asm volatile("" ::"v"(yl[i]), "v"(yh[i]), "v"(xh), "v"(xl)); continue; }
@@ -1343,12 +1353,12 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
       o[0] = tc1 - tc0; o[1] = tr1 - tr0; o[2] = (unsigned long long)nst;
     }
   }
-  // ---- slab write: lane holds D[co = 4*(lane>>4) + r][ci = 16*wave + (lane & 15)] of each tile.  Each tap's
-  // [112][Cq = 112] tile is one contiguous 50 KB run of the slab: transpose through LDS and copy it out in
-  // whole 16-byte vectors (direct stores are 64-byte fragments of 128-byte lines: 0.4 TB/s measured).
+  // ---- slab write: lane holds D[co = 4*(lane>>4) + r][ci = 16*wave + (lane & 15)] of each tile.  The tile
+  // goes through LDS and leaves as whole 16-byte vectors, CHX*4-byte row segments (direct stores are
+  // 64-byte fragments of 128-byte lines: 0.4 TB/s measured).
   __syncthreads();
-  constexpr int RS = CH + 4;
-  float* red = reinterpret_cast<float*>(smem16);           // [112][RS]
+  constexpr int RS = CHX + 4;
+  float* red = reinterpret_cast<float*>(smem16);           // [CHY][RS]
   const int fcol = lane & 15, fq = (lane >> 4) * 4;
 #pragma unroll
   for (int t = 0; t < KS; ++t) {
@@ -1357,14 +1367,54 @@ __global__ __launch_bounds__(448, 1) void conv_wgrad_rows_bf16x3_kernel(XWRowsPa
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(i * 16 + fq + r) * RS + wave * 16 + fcol] = acc[t][i][r];
     __syncthreads();
-    float* slab = p.slabs + (((int64_t)s * KS * KS + trow * KS + t) * p.Np + co0) * p.Cq;
-    for (int idx = tid; idx < CH * (CH / 4); idx += NW * 64) {
-      const int row = idx / (CH / 4), v = idx - row * (CH / 4);
-      if (co0 + row < p.Np)
+    float* slab = p.slabs + (((int64_t)s * KS * KS + trow * KS + t) * p.Np + co0) * p.Cq + ci0;
+    for (int idx = tid; idx < CHY * (CHX / 4); idx += NW * 64) {
+      const int row = idx / (CHX / 4), v = idx - row * (CHX / 4);
+      if (co0 + row < p.Np && ci0 + v * 4 < p.Cq)
         *reinterpret_cast<float4*>(slab + (int64_t)row * p.Cq + v * 4) = *reinterpret_cast<const float4*>(red + row * RS + v * 4);
     }
     __syncthreads();
   }
+}
+
+template <int KS, int TM, int NW>
+static constexpr size_t xwr_lds_bytes() {
+  constexpr int NVEC = 2 * 64 * (xwr_stride(TM * 16) / 8) + 2 * (64 + KS - 1) * (xwr_stride(NW * 16) / 8);
+  constexpr int NI = (NVEC + NW * 64 - 1) / (NW * 64);
+  constexpr size_t stage = (size_t)2 * NI * NW * 64 * 16;
+  constexpr size_t red = (size_t)TM * 16 * (NW * 16 + 4) * sizeof(float);
+  return stage > red ? stage : red;
+}
+static size_t xwr_lds_bytes_rt(int ks, int tm, int nw) {
+  const int nvec = 2 * 64 * (xwr_stride(tm * 16) / 8) + 2 * (64 + ks - 1) * (xwr_stride(nw * 16) / 8);
+  const int ni = (nvec + nw * 64 - 1) / (nw * 64);
+  const size_t stage = (size_t)2 * ni * nw * 64 * 16, red = (size_t)tm * 16 * (nw * 16 + 4) * sizeof(float);
+  return stage > red ? stage : red;
+}
+
+template <int KS, int TM, int NW>
+static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
+  constexpr size_t lds = xwr_lds_bytes<KS, TM, NW>();
+  const dim3 grid((unsigned)(((q.S * q.coBlocks * q.ciBlocks + 7) / 8) * 8 * KS));
+  if (KS == 5 && TM == 7 && NW == 7) {
+    static int ab = -1;                 // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills, 4 = clock probe)
+    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    if (ab == 1 || ab == 2 || ab == 3 || ab == 4) {
+      auto kfn = ab == 1 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 1> : ab == 2 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 2>
+                 : ab == 3 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 3> : &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 4>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, grid, dim3(448), lds, st, q);
+      return check_launch("conv2d_wgrad_bf16x3(rows ablation)");
+    }
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<KS, TM, NW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_rows_bf16x3_kernel<KS, TM, NW>), grid, dim3(NW * 64), lds, st, q);
+  return check_launch("conv2d_wgrad_bf16x3(rows)");
 }
 
 // bias gradient from a split tensor: partial[g][c] = sum over the block's pixels of hi + lo.
@@ -1413,7 +1463,7 @@ static int x_pick_nt(int tiles) {
   return best;
 }
 
-struct XWgradPlan { int rows, rps, R; int TM, coBlocks, ciBlocks, S, Np, Cq, G; int64_t pix_per_split, per_block; size_t slab_elems, bytes; };
+struct XWgradPlan { int rows, rps, R, rTM, rNW; int TM, coBlocks, ciBlocks, S, Np, Cq, G; int64_t pix_per_split, per_block; size_t slab_elems, bytes; };
 static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks) {
   XWgradPlan pl;
   pl.Np = round_up(Cout, 16); pl.Cq = round_up(Cin, 16);
@@ -1425,16 +1475,31 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
   const int taps = ks * ks;
   static int rows_on = -1;            // WCMC_WGRAD_ROWS=0: A/B switch back to the one-tap-per-block kernel
   if (rows_on < 0) { const char* e = getenv("WCMC_WGRAD_ROWS"); rows_on = (e && e[0] == '0') ? 0 : 1; }
-  pl.rows = rows_on && ks == 5 && pl.Cq == 112 && coT % 7 == 0 && (int64_t)N * Ho >= 64;
-  pl.R = N * Ho; pl.rps = 0;
-  if (pl.rows) {
-    // one block per (split, cout block, filter row); the ks blocks of a (split, cout block) unit share an XCD
-    // (32 CUs): at most 32 / ks units per XCD keeps the launch to one round of the 256 CUs
-    int S = 8 * (32 / ks) / pl.coBlocks;
-    if (S < 1) S = 1;
-    pl.rps = (pl.R + S - 1) / S;
-    pl.S = (pl.R + pl.rps - 1) / pl.rps;
-    pl.pix_per_split = 0;
+  // filter-row kernel: (KS, TM, NW) instances below; TM / NW must divide the tile counts
+  pl.R = N * Ho; pl.rps = 0; pl.rows = 0; pl.rTM = pl.rNW = 0;
+  if (rows_on && (ks == 5 || ks == 3) && (int64_t)N * Ho >= 64) {
+    const int tm = ks == 5 ? (coT % 7 == 0 ? 7 : 0) : (coT % 8 == 0 ? 8 : coT % 4 == 0 ? 4 : 0);
+    int nw = 0;
+    if (ks == 5) nw = ciT % 7 == 0 ? 7 : ciT == 3 ? 3 : 0;
+    else if (tm == 8) nw = ciT % 8 == 0 ? 8 : ciT % 4 == 0 ? 4 : 0;
+    else if (tm == 4) nw = ciT % 8 == 0 ? 8 : ciT % 6 == 0 ? 6 : ciT % 4 == 0 ? 4 : 0;
+    if (tm && nw) {
+      pl.rows = 1; pl.rTM = tm; pl.rNW = nw;
+      pl.coBlocks = coT / tm; pl.ciBlocks = ciT / nw;
+      // one block per (unit, filter row); the ks blocks of a unit share an XCD (32 CUs x resident blocks
+      // per CU): at most that many per XCD keeps the launch to one round
+      const size_t lds = xwr_lds_bytes_rt(ks, tm, nw);
+      int wpc = (int)((160 * 1024) / lds);
+      const int wcap = nw <= 4 ? 2 : 1;               // as the kernel's __launch_bounds__
+      if (wpc > wcap) wpc = wcap;
+      if (wpc < 1) wpc = 1;
+      int S = 8 * ((32 * wpc) / ks) / (pl.coBlocks * pl.ciBlocks);
+      if (S > pl.R / 4) S = pl.R / 4;                 // at least 4 rows per block
+      if (S < 1) S = 1;
+      pl.rps = (pl.R + S - 1) / S;
+      pl.S = (pl.R + pl.rps - 1) / pl.rps;
+      pl.pix_per_split = 0;
+    }
   }
   const int64_t tiles = (int64_t)taps * pl.coBlocks * pl.ciBlocks;
   // ~2 waves of 512 co-resident blocks for the multi-tap convs; one wave for the HBM-bound 1x1 layers,
@@ -1732,27 +1797,18 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
     q.x = p.x; q.N = N; q.H = H; q.W = W; q.Cpi = p.Cpi; q.dy = p.dy; q.Ho = Ho; q.Wo = Wo; q.Cpo = p.Cpo;
     q.dbg = (float*)workspace + pl.slab_elems;
     q.pad = pad; q.slabs = p.slabs; q.S = pl.S; q.rps = pl.rps; q.R = pl.R; q.Np = pl.Np; q.Cq = pl.Cq;
-    q.coBlocks = pl.coBlocks; q.x_bytes = p.x_bytes; q.dy_bytes = p.dy_bytes;
-    constexpr int NVEC = 2 * 64 * 14 + 2 * 68 * 14, NI = (NVEC + 447) / 448;
-    const size_t lds = (size_t)2 * NI * 448 * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<5, 7>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
+    q.coBlocks = pl.coBlocks; q.ciBlocks = pl.ciBlocks; q.x_bytes = p.x_bytes; q.dy_bytes = p.dy_bytes;
+    const int key = ks * 100 + pl.rTM * 10 + pl.rNW;
+    switch (key) {
+      case 577: rc = launch_xwgrad_rows<5, 7, 7>(q, st); break;
+      case 573: rc = launch_xwgrad_rows<5, 7, 3>(q, st); break;
+      case 388: rc = launch_xwgrad_rows<3, 8, 8>(q, st); break;
+      case 384: rc = launch_xwgrad_rows<3, 8, 4>(q, st); break;
+      case 348: rc = launch_xwgrad_rows<3, 4, 8>(q, st); break;
+      case 346: rc = launch_xwgrad_rows<3, 4, 6>(q, st); break;
+      case 344: rc = launch_xwgrad_rows<3, 4, 4>(q, st); break;
+      default: WCMC_REQUIRE(false, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: no filter-row instance for the plan");
     }
-    const dim3 grid((unsigned)(((pl.S * pl.coBlocks + 7) / 8) * 8 * 5));
-    static int ab = -1;                 // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills)
-    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
-    if (ab == 1 || ab == 2 || ab == 3 || ab == 4) {
-      auto kfn = ab == 1 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 1> : ab == 2 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 2>
-                 : ab == 3 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 3> : &conv_wgrad_rows_bf16x3_kernel<5, 7, 4>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kfn, grid, dim3(448), lds, st, q);
-      return check_launch("conv2d_wgrad_bf16x3(rows ablation)");
-    }
-    hipLaunchKernelGGL((conv_wgrad_rows_bf16x3_kernel<5, 7>), grid, dim3(448), lds, st, q);
-    rc = check_launch("conv2d_wgrad_bf16x3(rows)");
   } else if (phase != 2) {
     rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
   }
