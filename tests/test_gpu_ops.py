@@ -100,8 +100,11 @@ def test_conv_chain_single_layer_fwd_bwd(case, precision):
     b = gen(cout, seed=4, scale=0.2)
     # oracle in fp64
     xr, wr, br = (t.double().requires_grad_(True) for t in (x, wt, b))
-    yr = om._activation(F.conv2d(xr, wr, br, padding=pad), act)
-    gy = gen(*yr.shape, seed=5)
+    pre = F.conv2d(xr, wr, br, padding=pad)
+    yr = om._activation(pre, act)
+    # no upstream gradient where the pre-activation is within rounding of the activation's kink: there the two
+    # implementations may legitimately pick different slopes (a whole dy * w row of difference per unit)
+    gy = gen(*yr.shape, seed=5) * (pre.detach().abs() > 1e-4).float()
     yr.backward(gy.double())
     xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, wt, b))
     y = o.conv_chain(xd, ks, pad, [act], [wd, bd])
