@@ -1251,6 +1251,29 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
   // ---- stage fill: the buffer is one linear run of 16-byte vectors [Yh | Yl | Xh | Xl];
   // instruction i of wave w writes vectors (i*NW + w)*64 + lane (lane-linear destination), the per-lane
   // SOURCE picks the pixel / plane / channel; invalid sources use an out-of-range offset and land as zeros.
+  // What a lane fetches for instruction i is the same in every stage up to the stage's base address and
+  // edge tests: one packed word per instruction -- bits 0..19 byte offset / 2 relative to the stage's first
+  // pixel, 20..26 pixel row of the tile, 27 operand (1 = x), 28 never valid (row pad, tail of the buffer).
+  unsigned vdesc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int v = (i * NW + wave) * 64 + lane;
+    unsigned d = 1u << 28;
+    if (v < 2 * YV) {
+      const int plane = v >= YV, vv = v - plane * YV;
+      const int row = vv / VY, vec = vv - row * VY;
+      const int co = co0 + vec * 8;
+      if (vec * 8 < CHY && co < p.Cpo) d = (unsigned)((row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2) >> 1) | ((unsigned)row << 20);
+    } else if (v < NVEC) {
+      const int u = v - 2 * YV;
+      const int plane = u >= XV, uu = u - plane * XV;
+      const int row = uu / VX, vec = uu - row * VX;
+      const int ci = ci0 + vec * 8;
+      if (vec * 8 < CHX && ci < p.Cpi)
+        d = (unsigned)((row * 4 * p.Cpi + plane * 2 * p.Cpi + ci * 2) >> 1) | ((unsigned)row << 20) | (1u << 27);
+    }
+    vdesc[i] = d;
+  }
   auto issue = [&](int st, int buf) {
     // Row order skewed by the filter row: at step j the KS blocks of a unit read the SAME x row r0 + j and
     // dy rows one step apart.
@@ -1263,31 +1286,22 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
     const int iy = oy + trow - p.pad;
     const bool rowok = (unsigned)iy < (unsigned)p.H;
     const unsigned ybase = (unsigned)(((n * p.Ho + oy) * p.Wo + ox0) * 4 * p.Cpo);
-    const int xpix0 = (n * p.H + iy) * p.W + ox0 - p.pad;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));        // keep the per-vector decode inside the stage (hoisted, it costs ~4 VGPRs per vector)
+    const unsigned xbase = (unsigned)(((n * p.H + iy) * p.W + ox0 - p.pad) * 4 * p.Cpi);   // may wrap: only used when valid
+    const int yrows = p.Wo - ox0;                              // dy rows [0, yrows) exist
+    const int xlo = p.pad - ox0, xhi = p.W + p.pad - ox0;      // x rows [xlo, xhi) are inside the image
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int v = (i * NW + wave) * 64 + ln;
-      unsigned off = XOOB;
+      const unsigned d = vdesc[i];
+      const int row = (int)((d >> 20) & 127u);
+      const unsigned rel = (d & 0xfffffu) << 1;
+      const bool isx = (d >> 27) & 1u;
+      const bool ok = !(d >> 28) && (isx ? (rowok && row >= xlo && row < xhi) : (row < yrows));
+      const unsigned off = ok ? (isx ? xbase : ybase) + rel : XOOB;
       __attribute__((address_space(3))) void* dst =
           (__attribute__((address_space(3))) void*)(smem16 + buf * BUF + (i * NW + wave) * 512);
-      if (v < 2 * YV) {
-        const int plane = v >= YV, vv = v - plane * YV;
-        const int row = vv / VY, vec = vv - row * VY;
-        const int co = co0 + vec * 8;
-        if (vec * 8 < CHY && ox0 + row < p.Wo && co < p.Cpo)
-          off = ybase + (unsigned)(row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, dst, 16, off, 0, 0, 0);
-      } else {
-        const int u = v - 2 * YV;
-        const int plane = u >= XV, uu = u - plane * XV;
-        const int row = uu / VX, vec = uu - row * VX;
-        const int ix = ox0 - p.pad + row, ci = ci0 + vec * 8;
-        if (u < 2 * XV && vec * 8 < CHX && rowok && (unsigned)ix < (unsigned)p.W && ci < p.Cpi)
-          off = (unsigned)((xpix0 + row) * 4 * p.Cpi + plane * 2 * p.Cpi + ci * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, off, 0, 0, 0);
-      }
+      // 2*YV is a multiple of 64: a wave-instruction is all dy or all x (wave-uniform choice of descriptor)
+      if ((i * NW + wave) * 64 < 2 * YV) __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, dst, 16, off, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, off, 0, 0, 0);
     }
   };
 
@@ -1399,9 +1413,10 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
   if (KS == 5 && TM == 7 && NW == 7) {
     static int ab = -1;                 // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills, 4 = clock probe)
     if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
-    if (ab == 1 || ab == 2 || ab == 3 || ab == 4) {
+    if (ab == 1 || ab == 2 || ab == 3 || ab == 4 || ab == 8) {
       auto kfn = ab == 1 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 1> : ab == 2 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 2>
-                 : ab == 3 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 3> : &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 4>;
+                 : ab == 3 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 3> : ab == 4 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 4>
+                 : &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 8>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kfn, grid, dim3(448), lds, st, q);
       return check_launch("conv2d_wgrad_bf16x3(rows ablation)");
