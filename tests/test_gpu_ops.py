@@ -80,11 +80,8 @@ CONV_CASES = [
     (1, 128, 37, 21, 128, 3, 1, "relu"),       # 3x3, 128-channel slabs (PXS 288), weights-in-registers candidates
     # filter-row weight-gradient instances (KS, cout tiles, cin tiles per block)
     (2, 39, 40, 37, 100, 5, 0, "relu"),        # (5,7,3)
-    (2, 64, 40, 37, 64, 3, 1, "relu"),         # (3,4,4)
-    (1, 128, 70, 75, 128, 3, 1, "leaky_relu"), # (3,8,8)
-    (1, 192, 66, 20, 64, 3, 1, "relu"),        # (3,4,6)
-    (1, 64, 64, 20, 128, 3, 1, "relu"),        # (3,8,4)
-    (1, 128, 64, 20, 64, 3, 1, "relu"),        # (3,4,8)
+    (2, 64, 40, 37, 64, 3, 1, "relu"),         # 3x3 below 256 input channels: one-tap kernel
+    (1, 256, 70, 35, 128, 3, 1, "leaky_relu"), # (3,8,8), two cin blocks
     (1, 384, 64, 18, 128, 3, 1, "relu"),       # (3,8,8), three cin blocks
 ]
 

@@ -1493,11 +1493,11 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
   // filter-row kernel: (KS, TM, NW) instances below; TM / NW must divide the tile counts
   pl.R = N * Ho; pl.rps = 0; pl.rows = 0; pl.rTM = pl.rNW = 0;
   if (rows_on && (ks == 5 || ks == 3) && (int64_t)N * Ho >= 64) {
-    const int tm = ks == 5 ? (coT % 7 == 0 ? 7 : 0) : (coT % 8 == 0 ? 8 : coT % 4 == 0 ? 4 : 0);
-    int nw = 0;
-    if (ks == 5) nw = ciT % 7 == 0 ? 7 : ciT == 3 ? 3 : 0;
-    else if (tm == 8) nw = ciT % 8 == 0 ? 8 : ciT % 4 == 0 ? 4 : 0;
-    else if (tm == 4) nw = ciT % 8 == 0 ? 8 : ciT % 6 == 0 ? 6 : ciT % 4 == 0 ? 4 : 0;
+    // measured against the one-tap kernel (scripts/profile_layers.py): the 5x5 layers gain 1.9-2.7x; of the
+    // 3x3 U-Net layers only those with >= 256 input channels gain (a filter row is 3 taps of reuse, not 5)
+    int tm = 0, nw = 0;
+    if (ks == 5) { tm = coT % 7 == 0 ? 7 : 0; nw = ciT % 7 == 0 ? 7 : ciT == 3 ? 3 : 0; }
+    else if (coT % 8 == 0 && ciT % 8 == 0 && ciT >= 16) { tm = 8; nw = 8; }
     if (tm && nw) {
       pl.rows = 1; pl.rTM = tm; pl.rNW = nw;
       pl.coBlocks = coT / tm; pl.ciBlocks = ciT / nw;
@@ -1818,10 +1818,6 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
       case 577: rc = launch_xwgrad_rows<5, 7, 7>(q, st); break;
       case 573: rc = launch_xwgrad_rows<5, 7, 3>(q, st); break;
       case 388: rc = launch_xwgrad_rows<3, 8, 8>(q, st); break;
-      case 384: rc = launch_xwgrad_rows<3, 8, 4>(q, st); break;
-      case 348: rc = launch_xwgrad_rows<3, 4, 8>(q, st); break;
-      case 346: rc = launch_xwgrad_rows<3, 4, 6>(q, st); break;
-      case 344: rc = launch_xwgrad_rows<3, 4, 4>(q, st); break;
       default: WCMC_REQUIRE(false, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: no filter-row instance for the plan");
     }
   } else if (phase != 2) {
