@@ -14,7 +14,8 @@ b = torch.zeros(100, device=dev)
 dy = o.to_nhwc_raw(torch.randn(n, 100, h - 4, h - 4, device=dev))
 xs, dys = o.split_raw(x), o.split_raw(dy)
 wp, wpt = o._pack_x(w, 0), o._pack_x(w, 1)
-wpf, wptf = o._pack(w, 0), o._pack(w, 1)
+x1s = o.split_raw(o.to_nhwc_raw(torch.randn(64, 64, 128, 128, device=dev)))
+w1p, b1 = o._pack_x(torch.randn(64, 64, 1, 1, device=dev) * 0.1, 0), torch.zeros(64, device=dev)
 logits = o.to_nhwc_raw(torch.randn(8, 441, 92, 92, device=dev))
 data = torch.rand(8, 3, 92, 92, device=dev)
 g = torch.randn(8, 3, 92, 92, device=dev)
@@ -22,8 +23,7 @@ def run():
     y = o.conv2d_x_raw(xs, (n, c, h, h), wp, b, 100, 5, 0, "relu", out_split=True)          # bf16x3 fwd
     o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu")
     o.conv2d_wgrad_x_raw(xs, (n, c, h, h), dys, 100, 5, 0, (100, 100, 5, 5))
-    o.conv2d_raw(x, wpf, b, 100, 5, 0, "relu")                                               # fp32 fwd
-    o.conv2d_wgrad_raw(x, dy, 5, 0, (100, 100, 5, 5))
+    o.conv2d_x_raw(x1s, (64, 64, 128, 128), w1p, b1, 64, 1, 0, "relu", out_split=True)       # PathNet 1x1 layer (HBM-bound)
     ld = logits.clone().requires_grad_(True)
     out = o.kernel_apply(data, ld)
     out.backward(g)
