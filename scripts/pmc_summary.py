@@ -52,5 +52,5 @@ for k, d in sorted(acc.items()):
 # MFMA-busy fraction needs GRBM_GUI_ACTIVE from another pass: combine here
 for k, e in out.items():
     if e.get("mfma_busy_cycles_per_simd") is not None and e.get("gui_active_cycles"):
-        e["mfma_busy_frac"] = e["mfma_busy_cycles_per_simd"] / e["gui_active_cycles"]
+        e["mfma_busy_frac"] = e["mfma_busy_cycles_per_simd"] / (e["gui_active_cycles"] / 8.0)   # GUI_ACTIVE sums the 8 XCDs
 json.dump(out, sys.stdout, indent=1)
