@@ -131,7 +131,7 @@ def pmc_traffic():
         d = json.load(f)
     pick = {}
     for k, v in d.items():
-        for tag, key in (("conv_igemm_bf16x3_kernel<7, false", "conv_igemm"), ("conv_wgrad_bf16x3_kernel<7>", "conv_wgrad"),
+        for tag, key in (("conv_halo_bf16x3_kernel<7", "conv_igemm"), ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad"),
                          ("kernel_apply_kernel<false", "kernel_apply_fwd"), ("kernel_apply_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
                 pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"],
