@@ -65,8 +65,17 @@ static __global__ __launch_bounds__(1024) void colsum_final_strided_kernel(const
   const int cl = threadIdx.x & 63, gg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float acc = 0.f;
-  if (c < C)
-    for (int g = gg; g < G; g += 16) acc += partial[(int64_t)g * ld + c];
+  if (c < C) {
+    // eight independent loads in flight per thread (one block reduces up to 8192 tile rows: latency-bound)
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int g = gg;
+    for (; g + 7 * 16 < G; g += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += partial[(int64_t)(g + u * 16) * ld + c];
+    }
+    for (; g < G; g += 16) a[0] += partial[(int64_t)g * ld + c];
+    acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
   red[gg][cl] = acc;
   __syncthreads();
   if (gg == 0 && c < C) {
