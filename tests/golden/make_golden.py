@@ -245,8 +245,102 @@ def gen_interface(ref_losses, ref_itf):
         print("G5", case, {k: float(v) for k, v in itf.m_losses.items()})
 
 
+# ---------------------------------------------------------------------------------- G5b
+VARIANT_CASES = {
+    # name: (class, manif_learn, train_branches)
+    "ref_vanilla": ("KPCNRefInterface", False, True),         # interfaces.py:526-585
+    "pre_manifold": ("KPCNPreInterface", True, True),         # interfaces.py:588-750, PathNet pre-training
+    "pre_regress": ("KPCNPreInterface", False, True),         # ... KPCN on frozen PathNets
+}
+
+
+def build_variant_models(case, seed):
+    from oracle.models import KPCN
+    from oracle.networks import PathNet
+    kind, manif, tb = VARIANT_CASES[case]
+    torch.manual_seed(seed)
+    G = G5_GEOM
+    if kind == "KPCNRefInterface":
+        models = {"dncnn": KPCN(G["BASE_IN"] + 3, ksize=G["KS"], depth=G["DEPTH"], width=G["WIDTH"])}
+    else:
+        models = {"dncnn": KPCN(G["BASE_IN"] + 1 + 3 + 1, ksize=G["KS"], depth=G["DEPTH"], width=G["WIDTH"]),
+                  "backbone_diffuse": PathNet(36, intermc=G["INTERMC"], outc=3),
+                  "backbone_specular": PathNet(36, intermc=G["INTERMC"], outc=3)}
+    with torch.no_grad():
+        for m in models.values():
+            for n, p in m.named_parameters():
+                if n.endswith("bias"):
+                    p.uniform_(-0.1, 0.1)
+    return models
+
+
+def gen_interface_variants(ref_losses, ref_itf):
+    from oracle.step import draw_perms
+    for ci, case in enumerate(VARIANT_CASES):
+        kind, manif, tb = VARIANT_CASES[case]
+        models = build_variant_models(case, 600 + ci)
+        init_state = {"%s/%s" % (mn, k): np_(v) for mn, m in models.items() for k, v in m.state_dict().items()}
+        optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+                  for mn, m in models.items()}
+        loss_funcs = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(),
+                      "l_recon": torch.nn.L1Loss(), "l_test": ref_losses.RelativeMSE()}
+        if manif:
+            loss_funcs["l_manif"] = ref_losses.FeatureMSE(non_local=True)
+        args = types.SimpleNamespace(model_name="golden")
+        if kind == "KPCNRefInterface":
+            itf = ref_itf.KPCNRefInterface(models, optims, loss_funcs, args, train_branches=tb)
+        else:
+            itf = ref_itf.KPCNPreInterface(models, optims, loss_funcs, args, manif_learn=manif, w_manif=0.1,
+                                           train_branches=tb)
+        itf.iters = 1
+        use_llpm = kind != "KPCNRefInterface"
+        batch = small_batch(700 + ci, use_llpm)
+        if not use_llpm:                       # the Ref interface takes the vanilla 11-channel inputs
+            pass
+        out = {"batch/" + k: np_(v) for k, v in batch.items()}
+        out.update({"init/" + k: v for k, v in init_state.items()})
+        B, S, H = G5_GEOM["B"], G5_GEOM["S"], G5_GEOM["H"]
+        seed = 800 + ci
+        torch.manual_seed(seed)
+        perms = [draw_perms(B, S, H, H), draw_perms(B, S, H, H)]      # pre-training pairs FULL-size P-buffers
+        for i, br in enumerate(("diffuse", "specular")):
+            out["perm/%s_patch" % br] = np_(perms[i][0])
+            out["perm/%s_batch" % br] = np_(perms[i][1])
+        out["seed"] = np.array(seed)
+        itf.to_train_mode()
+        out["train_flags"] = np.array([int(m.training) for m in models.values()])
+        torch.manual_seed(seed)
+        itf.preprocess(batch)
+        itf.train_batch(batch)
+        for k, v in itf.m_losses.items():
+            out["m_losses/" + k] = np_(v)
+        for mn, m in models.items():
+            for k, v in m.state_dict().items():
+                out["after/%s/%s" % (mn, k)] = np_(v)
+            for k, p in m.named_parameters():
+                out["grad/%s/%s" % (mn, k)] = np_(p.grad) if p.grad is not None else np.zeros(0, np.float32)
+        itf.to_eval_mode()
+        with torch.no_grad():
+            rad, pb = itf.validate_batch(batch)
+        out["val/radiance"] = np_(rad)
+        if pb is not None:
+            out["val/p_diffuse"], out["val/p_specular"] = np_(pb["diffuse"]), np_(pb["specular"])
+        out["val/summary"] = np.array(itf.get_epoch_summary(mode="eval", norm=1))
+        np.savez_compressed(os.path.join(HERE, "interface_%s.npz" % case), **out)
+        print("G5b", case, {k: float(v) for k, v in itf.m_losses.items()})
+
+
 def main():
     ref_losses, ref_utils, ref_itf = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":          # only the rank-1 "next" interfaces
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                gen_interface_variants(ref_losses, ref_itf)
+            finally:
+                os.chdir(cwd)
+        return
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:
         os.chdir(tmp)
@@ -256,6 +350,7 @@ def main():
             gen_grs(ref_losses)
             gen_image_losses(ref_losses)
             gen_interface(ref_losses, ref_itf)
+            gen_interface_variants(ref_losses, ref_itf)
         finally:
             os.chdir(cwd)
     print("goldens written to", HERE)

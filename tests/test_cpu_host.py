@@ -94,6 +94,10 @@ class _OracleOps:
         return assemble_input(base, p)
 
     @staticmethod
+    def cat_channels(a, b):
+        return torch.cat([a, b], 1)
+
+    @staticmethod
     def join_all_streams(device):
         pass
 
@@ -167,6 +171,60 @@ def test_interface_host_logic_against_reference_golden(golden_dir, case, monkeyp
     np.testing.assert_allclose(itf.get_epoch_summary("eval", 1), d["val/summary"], rtol=1e-5)
     assert itf.get_epoch_summary("train", 1) == -1.0
     assert all(float(v) == 0.0 for k, v in itf.m_losses.items() if k != "m_val")
+
+
+@pytest.mark.parametrize("case", list(mg.VARIANT_CASES))
+def test_ref_and_pre_interfaces_host_logic_against_reference_golden(golden_dir, case, monkeypatch):
+    """KPCNRefInterface / KPCNPreInterface == the real reference classes: which models
+    train, clip and step in each phase, batch assembly, loss keys, validation."""
+    from wcmc_amd.support import interfaces as itf_mod
+    monkeypatch.setattr(itf_mod, "_ops", _OracleOps)
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    kind, manif, tb = mg.VARIANT_CASES[case]
+    models = mg.build_variant_models(case, 0)
+    for mn, m in models.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+          "l_test": ol.RelativeMSE()}
+    if manif:
+        lf["l_manif"] = _OracleFeatureMSE()
+    args = types.SimpleNamespace(model_name="g")
+    if kind == "KPCNRefInterface":
+        itf = itf_mod.KPCNRefInterface(models, optims, lf, args, train_branches=tb)
+        with pytest.raises(AssertionError):
+            itf_mod.KPCNRefInterface(models, optims, lf, args, use_llpm_buf=True)
+    else:
+        itf = itf_mod.KPCNPreInterface(models, optims, lf, args, manif_learn=manif, w_manif=0.1, train_branches=tb)
+        assert itf.use_llpm_buf
+    assert str(itf) == kind
+    itf.iters = 1
+    batch = {k[len("batch/"):]: T(d[k]) for k in d.files if k.startswith("batch/")}
+    itf.to_train_mode()
+    assert [int(m.training) for m in models.values()] == list(d["train_flags"])
+    torch.manual_seed(int(d["seed"]))
+    itf.preprocess(batch)
+    itf.train_batch(batch)
+    assert set("m_losses/" + k for k in itf.m_losses) == set(k for k in d.files if k.startswith("m_losses/")) - {"m_losses/m_val"}
+    for k, v in itf.m_losses.items():
+        np.testing.assert_allclose(v.item(), d["m_losses/" + k], rtol=2e-5, err_msg=k)
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            want = d["grad/%s/%s" % (mn, k)]
+            if want.size == 0:
+                assert p.grad is None, (mn, k)         # the pre-training phase never touches KPCN
+            else:
+                np.testing.assert_allclose(p.grad.numpy(), want, rtol=1e-4, atol=1e-7, err_msg="%s %s" % (mn, k))
+        for k, v in m.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), d["after/%s/%s" % (mn, k)], rtol=1e-4, atol=2e-6,
+                                       err_msg="after %s %s" % (mn, k))
+    itf.to_eval_mode()
+    with torch.no_grad():
+        rad, pb = itf.validate_batch(batch)
+    np.testing.assert_allclose(rad.numpy(), d["val/radiance"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(itf.get_epoch_summary("eval", 1), d["val/summary"], rtol=1e-5)
+    assert (pb is None) == ("val/p_diffuse" not in d.files)
 
 
 def test_interface_asserts_like_reference():

@@ -181,6 +181,72 @@ def test_interface_step_against_reference_golden(golden_dir, case, fused, precis
         assert_close(pb["diffuse"], T(d["val/p_diffuse"]), tol=5e-3, what="validate p_buffer")
 
 
+@pytest.mark.parametrize("case", list(mg.VARIANT_CASES))
+def test_ref_and_pre_interfaces_against_reference_golden(golden_dir, case, precision):
+    """KPCNRefInterface / KPCNPreInterface on the GPU vs the real reference classes."""
+    from wcmc_amd import KPCN
+    from wcmc_amd.support import interfaces as itf_mod
+    from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
+    from wcmc_amd.support.networks import PathNet
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    kind, manif, tb = mg.VARIANT_CASES[case]
+    G = mg.G5_GEOM
+    if kind == "KPCNRefInterface":
+        models = {"dncnn": KPCN(G["BASE_IN"] + 3, ksize=G["KS"], depth=G["DEPTH"], width=G["WIDTH"])}
+    else:
+        models = {"dncnn": KPCN(G["BASE_IN"] + 5, ksize=G["KS"], depth=G["DEPTH"], width=G["WIDTH"]),
+                  "backbone_diffuse": PathNet(36, intermc=G["INTERMC"], outc=3),
+                  "backbone_specular": PathNet(36, intermc=G["INTERMC"], outc=3)}
+    for mn, m in models.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+        m.to(DEV)
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+          "l_test": RelativeMSE()}
+    if manif:
+        lf["l_manif"] = FeatureMSE(non_local=True)
+    args = types.SimpleNamespace(model_name="golden")
+    if kind == "KPCNRefInterface":
+        itf = itf_mod.KPCNRefInterface(models, optims, lf, args, train_branches=tb)
+    else:
+        itf = itf_mod.KPCNPreInterface(models, optims, lf, args, manif_learn=manif, w_manif=0.1, train_branches=tb)
+    itf.iters = 1
+    batch = {k[len("batch/"):]: T(d[k]).to(DEV) for k in d.files if k.startswith("batch/")}
+    itf.to_train_mode()
+    assert [int(m.training) for m in models.values()] == list(d["train_flags"])
+    torch.manual_seed(int(d["seed"]))
+    itf.preprocess(batch)
+    itf.train_batch(batch)
+    if manif:
+        assert np.array_equal(lf["l_manif"].last_perms[0].numpy(), d["perm/specular_patch"])
+    for k in d.files:
+        if k.startswith("m_losses/") and k != "m_losses/m_val":
+            np.testing.assert_allclose(itf.m_losses[k[len("m_losses/"):]].item(), d[k], rtol=1e-3, err_msg=k)
+    loose = 1e-1 if precision == "fp32" else 0.5      # tiny golden networks: see the main interface test
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            want = d["grad/%s/%s" % (mn, k)]
+            if want.size == 0:
+                assert p.grad is None
+                continue
+            assert_close(p.grad, T(want), tol=loose, what="post-clip grad %s %s" % (mn, k))
+        for k, v in m.state_dict().items():
+            want, got = d["after/%s/%s" % (mn, k)], v.cpu().numpy()
+            g = np.abs(d["grad/%s/%s" % (mn, k)])
+            if g.size == 0 or not itf_mod.KPCNPreInterface._trained(itf, mn) if kind != "KPCNRefInterface" else False:
+                np.testing.assert_array_equal(got, d["init/%s/%s" % (mn, k)], err_msg="frozen %s %s" % (mn, k))
+                continue
+            big = g > 1e-4
+            np.testing.assert_allclose(got[big], want[big], rtol=1e-3, atol=5e-5, err_msg="after %s %s" % (mn, k))
+            np.testing.assert_allclose(got[~big], want[~big], atol=4.1e-3)
+    itf.to_eval_mode()
+    with torch.no_grad():
+        rad, pb = itf.validate_batch(batch)
+    assert_close(rad, T(d["val/radiance"]), tol=5e-3, what="validate radiance")
+    np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=5e-3)
+
+
 def test_full_size_step_against_oracle(precision):
     """One KPCN-Manifold step at the benchmark geometry (128x128, S=8, pnet_out 3) with B=1 against the
     CPU oracle: same weights, inputs and permutations."""

@@ -344,3 +344,142 @@ class KPCNInterface(BaseInterface):
             return -1.0
         else:
             return self.m_losses['m_val'].item() / (norm * 2)
+
+
+class KPCNRefInterface(KPCNInterface):
+    """``interfaces.py:526-585``: vanilla KPCN whose inputs are extended by the clean per-branch targets
+    (the "reference features" upper bound of the paper).  Same kernels as ``KPCNInterface``; only the batch
+    assembly differs."""
+
+    def __init__(self, models, optims, loss_funcs, args, visual=False, use_llpm_buf=False, manif_learn=False,
+                 w_manif=0.1, train_branches=True):
+        assert not use_llpm_buf
+        assert not manif_learn
+        super(KPCNRefInterface, self).__init__(models, optims, loss_funcs, args, visual, use_llpm_buf,
+                                               manif_learn, w_manif, train_branches)
+
+    def __str__(self):
+        return 'KPCNRefInterface'
+
+    @staticmethod
+    def _with_targets(batch):
+        new_batch = {k: batch[k] for k in _BATCH_KEYS}
+        new_batch['kpcn_diffuse_in'] = _ops.cat_channels(batch['kpcn_diffuse_in'], batch['target_diffuse'])
+        new_batch['kpcn_specular_in'] = _ops.cat_channels(batch['kpcn_specular_in'], batch['target_specular'])
+        return new_batch
+
+    def _forward_backward(self, batch):
+        dev = batch['kpcn_diffuse_in'].device
+        _ops.fork_all_streams(dev)
+        batch = self._with_targets(batch)
+        self.models['dncnn'].zero_grad()
+        out = self._regress_forward(batch)
+        loss_dict = self._backward(batch, out, None)
+        _ops.join_all_streams(dev)
+        return loss_dict
+
+    def validate_batch(self, batch):
+        batch = self._with_targets(batch)
+        out = self._regress_forward(batch)
+        tgt_total = crop_like(batch['target_total'], out['radiance'])
+        L_total = self.loss_funcs['l_test'](out['radiance'], tgt_total)
+        if self.m_losses['m_val'] == 0.0 and self.m_losses['m_val'].device != L_total.device:
+            self.m_losses['m_val'] = torch.tensor(0.0, device=L_total.device)
+        self.m_losses['m_val'] += L_total.detach()
+        return out['radiance'], None
+
+
+class KPCNPreInterface(KPCNInterface):
+    """``interfaces.py:588-750``: two-phase training.  ``manif_learn=True`` pre-trains the two PathNets on the
+    manifold loss alone (full-size P-buffers against the full-size targets, no KPCN forward);
+    ``manif_learn=False`` trains KPCN on top of the frozen PathNets (their gradients are still produced,
+    as in the reference, but neither clipped nor stepped)."""
+
+    def __init__(self, models, optims, loss_funcs, args, visual=False, manif_learn=False, w_manif=0.1,
+                 train_branches=True):
+        super(KPCNPreInterface, self).__init__(models, optims, loss_funcs, args, visual, True, manif_learn,
+                                               w_manif, train_branches)
+
+    def __str__(self):
+        return 'KPCNPreInterface'
+
+    def _trained(self, model_name):
+        return ('backbone' in model_name) if self.manif_learn else ('dncnn' in model_name)
+
+    def to_train_mode(self):
+        for model_name in self.models:
+            if 'dncnn' in model_name or 'backbone' in model_name:
+                self.models[model_name].train(self._trained(model_name))
+            assert 'optim_' + model_name in self.optims, \
+                '`optim_%s`: an optimization algorithm is not defined.' % (model_name)
+
+    def _forward_backward(self, batch):
+        dev = batch['kpcn_diffuse_in'].device
+        _ops.fork_all_streams(dev)
+        self.models['backbone_diffuse'].zero_grad()
+        self.models['backbone_specular'].zero_grad()
+        if self.manif_learn:
+            p_buffers = self._manifold_forward(batch)
+            if self.iters % 1000 == 1 and not torch.cuda.is_current_stream_capturing():
+                self._dump_pbuffers(p_buffers)
+            loss_dict = self._backward(batch, None, p_buffers)
+        else:
+            self.models['dncnn'].zero_grad()
+            p_buffers = self._manifold_forward(batch)
+            batch = self._assemble(batch, p_buffers)           # interfaces.py:647-663 (no disentanglement here)
+            out = self._regress_forward(batch)
+            loss_dict = self._backward(batch, out, None)
+        _ops.join_all_streams(dev)
+        return loss_dict
+
+    def _backward(self, batch, out, p_buffers):
+        assert not out or 'radiance' in out
+        assert not out or 'diffuse' in out
+        assert not out or 'specular' in out
+        loss_dict = {}
+        if out:
+            total, diffuse, specular = out['radiance'], out['diffuse'], out['specular']
+            tgt_total = crop_like(batch['target_total'], total)
+
+        if self.manif_learn:
+            L_manif_diffuse = self.loss_funcs['l_manif'](p_buffers['diffuse'], batch['target_diffuse']) * self.w_manif
+            L_manif_specular = self.loss_funcs['l_manif'](p_buffers['specular'], batch['target_specular']) * self.w_manif
+            loss_dict['l_manif_diffuse'] = L_manif_diffuse.detach() / self.w_manif
+            loss_dict['l_manif_specular'] = L_manif_specular.detach() / self.w_manif
+            L_manif_diffuse.backward()
+            L_manif_specular.backward()
+        elif self.train_branches:
+            tgt_diffuse = crop_like(batch['target_diffuse'], diffuse)
+            L_diffuse = self.loss_funcs['l_diffuse'](diffuse, tgt_diffuse)
+            tgt_specular = crop_like(batch['target_specular'], specular)
+            L_specular = self.loss_funcs['l_specular'](specular, tgt_specular)
+            loss_dict['l_diffuse'] = L_diffuse.detach()
+            loss_dict['l_specular'] = L_specular.detach()
+            L_diffuse.backward()
+            L_specular.backward()
+            with torch.no_grad():
+                loss_dict['l_total'] = self.loss_funcs['l_recon'](total, tgt_total).detach()
+        else:
+            L_total = self.loss_funcs['l_recon'](total, tgt_total)
+            loss_dict['l_total'] = L_total.detach()
+            L_total.backward()
+        return loss_dict
+
+    def _logging(self, loss_dict):
+        keys = list(loss_dict)
+        finite = torch.isfinite(torch.stack([loss_dict[k].reshape(()) for k in keys]))
+        self._raise_if_nonfinite(keys, finite)
+        if self.grad_sync is not None:
+            self.grad_sync({n: m for n, m in self.models.items() if self._trained(n)})
+        for model_name in self.models:                       # interfaces.py:729-735: only the phase's models
+            if self._trained(model_name):
+                nn.utils.clip_grad_value_(self.models[model_name].parameters(), clip_value=1.0)
+        for key in loss_dict:
+            if 'm_' + key not in self.m_losses:
+                self.m_losses['m_' + key] = torch.tensor(0.0, device=loss_dict[key].device)
+            self.m_losses['m_' + key] += loss_dict[key]
+
+    def _optimization(self):
+        for model_name in self.models:
+            if self._trained(model_name):
+                self.optims['optim_' + model_name].step()
