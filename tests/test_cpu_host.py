@@ -94,10 +94,6 @@ class _OracleOps:
         return assemble_input(base, p)
 
     @staticmethod
-    def cat_channels(a, b):
-        return torch.cat([a, b], 1)
-
-    @staticmethod
     def join_all_streams(device):
         pass
 
