@@ -466,7 +466,6 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
 template <int NT, int TH, int TW, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p) {
   constexpr int BN = NT * 16;
-  constexpr int NJ = (BN + 63) / 64;
   constexpr int NTHR = 512;
   constexpr int TPR = TW / 16;                 // MFMA pixel tiles per tile row
   static_assert(TH * TW == 256 && TW % 16 == 0, "8 waves x 2 pixel tiles of 16");
@@ -521,28 +520,21 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     }
   };
 
-  // ---- weights: 8 consecutive threads = one cout row's 2 planes x 4 vectors of 8 bf16 (as the streaming kernel)
-  const int vq = tid & 3, pl = (tid >> 2) & 1, prow = tid >> 3;
-  unsigned wbase[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int nrow = prow + 64 * j;
-    wbase[j] = (nrow < BN && n0 + nrow < p.Np) ? (unsigned)((((n0 + nrow) * 2 + pl) * p.Kt + vq * 8) * 2) : XOOB;
-  }
+  // ---- weights: LDS-DMA (buffer_load ... lds), no staging registers and no ds_write pass.  One wave
+  // instruction fills 16 cout rows x 64 B of one plane (1 KB, lane-linear destination: row 16*wave + lane/4,
+  // 16-byte slot lane%4); the XOR swizzle of the slot goes on the per-lane SOURCE column.
   const int nstages = p.Kt / XKC;
-  auto load_b = [&](int g, u32x4* rb) {
-    const unsigned kill = g < nstages ? 0u : XOOB;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (wbase[j] + (unsigned)(g * XKC * 2)) | kill, 0, 0);
-  };
-  const int wslot = (vq ^ ((prow >> 1) & 3)) * 8;
-  auto store_b = [&](int buf, const u32x4* rb) {
-    u16* b = bsm + buf * B_ELEMS + pl * B_LO + wslot;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int nrow = prow + 64 * j;
-      if (nrow < BN) *reinterpret_cast<u32x4*>(b + nrow * XROW) = rb[j];
+  const int drow = 16 * wave + (lane >> 2);
+  const int dvq = (lane & 3) ^ ((drow >> 1) & 3);
+  const unsigned dbase = (16 * wave < BN && n0 + drow < p.Np) ? (unsigned)(((n0 + drow) * 2 * p.Kt + dvq * 8) * 2) : XOOB;
+  auto dma_b = [&](int g, int buf) {
+    if (16 * wave < BN) {
+      const unsigned kill = g < nstages ? 0u : XOOB;
+      const unsigned off = (dbase + (unsigned)(g * XKC * 2)) | kill;
+      u16* d = bsm + buf * B_ELEMS + 16 * wave * XROW;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16,
+                                               dbase >= XOOB ? XOOB : (off + (unsigned)(p.Kt * 2)) | kill, 0, 0, 0);
     }
   };
 
@@ -576,11 +568,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   // Software pipeline inside every wave (stamps of the first version: all eight waves read fragments,
   // then all multiply -- 53 % MFMA issue occupancy; a two-group ping-pong did no better): the fragments of
   // stage g+1 are read WHILE the MFMAs of stage g issue, cout tile by cout tile into the registers the
-  // tile's MFMAs have just consumed, so no wave ever waits for LDS with an idle matrix pipe.  Three weight
-  // buffers: stage g+1 must be complete in LDS (stored during stage g-1, published by the barrier at the
-  // top of stage g) while stage g+2 is being stored.
+  // tile's MFMAs have just consumed, so no wave ever waits for LDS with an idle matrix pipe.  Two weight
+  // buffers: while stage g multiplies (its fragments are in registers), stage g+1 is read from one buffer
+  // and the DMA of stage g+2 lands in the other; each wave waits for its own DMA before the stage barrier.
   bf16x8 ah[2], al[2], wh[NT], wl[NT];
-  u32x4 rb[NJ];
   auto read_a = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -599,22 +590,22 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     wl[j] = *reinterpret_cast<const bf16x8*>(bfrag + buf * B_ELEMS + B_LO + j * 16 * XROW);
   };
 
-  load_b(0, rb); store_b(0, rb);
-  load_b(1, rb); store_b(1, rb);
-  load_b(2, rb);
+  dma_b(0, 0);
+  dma_b(1, 1);
   load_halo(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   read_a();
 #pragma unroll
   for (int j = 0; j < NT; ++j) read_b(0, j);
   int s_in = 0, slab = 0;
-  int b1 = 1, b2 = 2, b0 = 0;                    // buffers of stage g+1, g+2, g
   stamp(-1);
   for (int g = 0; g < nstages; ++g) {
-    __syncthreads();                             // stage g+1's weights are visible; buffer b2 (stage g-1) is free
+    const int b1 = (g + 1) & 1;                  // buffer of stage g+1; stage g's fragments are in registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage g+1 has landed
+    __syncthreads();                             // ... everyone's; and everyone has read stage g's fragments
     stamp(0);
-    store_b(b2, rb);
-    load_b(g + 3, rb);
+    dma_b(g + 2, g & 1);
     stamp(1);
     const bool last_of_slab = (s_in + 1 == p.SPS);
     bf16x8 ahn[2], aln[2];
@@ -654,7 +645,6 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
       __syncthreads();
       read_a();
     }
-    const int t = b0; b0 = b1; b1 = b2; b2 = t;
     stamp(3);
   }
   __syncthreads();
@@ -1630,7 +1620,7 @@ template <int NT>
 static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   constexpr int TH = 16, TW = 16;
   const int HP = (TH + p.ks - 1) * (TW + p.ks - 1);
-  const size_t lds_main = (size_t)((HP * p.PXS + 127) & ~127) + (size_t)3 * (2 * NT * 16 * XROW + 64) * sizeof(u16);
+  const size_t lds_main = (size_t)((HP * p.PXS + 127) & ~127) + (size_t)2 * (2 * NT * 16 * XROW + 64) * sizeof(u16);
   const size_t lds_out = p.ys ? (size_t)256 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)256 * (NT * 16 + 4) * sizeof(float);
   const size_t lds = lds_main > lds_out ? lds_main : lds_out;
   WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
