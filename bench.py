@@ -251,10 +251,12 @@ def main():
         pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         prof_elapsed = 0.0
         for _ in range(nprof):
-            # The eager host needs ~40 ms to enqueue a step, longer than the GPU needs to run it: park the
-            # stream behind a spin kernel while the step is enqueued, so that the event pairs bracket
-            # kernels that run back to back instead of a GPU waiting for Python.
-            torch.cuda._sleep(int(2.0e8))
+            # The eager host needs ~40 ms to enqueue a step, longer than the GPU needs to run it: keep the
+            # stream busy with replays of the captured step meanwhile, so that the event pairs bracket
+            # kernels that run back to back (and at the clocks of the timed region: behind a 100 ms spin
+            # kernel the same launches measured 2-3x longer) instead of a GPU waiting for Python.
+            for _ in range(3):
+                graphed.graph.replay()
             pe0.record()
             eager_step()
             pe1.record()
