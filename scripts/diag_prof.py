@@ -25,3 +25,25 @@ s = prof.summary()
 for k, d in sorted(s.items(), key=lambda kv: -kv[1]["ms"])[:8]:
     print("   %-22s %5d launches %8.2f ms/step  avg %.3f ms" % (k, d["launches"], d["ms"] / 3, d["ms"] / d["launches"]))
 ops.set_profiler(None)
+# --- as bench.py: captured step, then the eager step behind replays
+from wcmc_amd.graph import GraphedTrainStep
+graphed = GraphedTrainStep(itf, batch)
+for _ in range(3): graphed(batch)
+itf.fused_optim.leave_grads = True
+itf.loss_funcs["l_manif"].static_perms = None
+itf.loss_funcs["l_manif"].check_finite = True
+ops.USE_SIDE_STREAM = False
+step()
+for mode in ("replays", "none"):
+    prof = bench.EventProfiler(); ops.set_profiler(prof)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        if mode == "replays":
+            for _ in range(3): graphed.graph.replay()
+        step()
+        torch.cuda.synchronize()
+    ops.set_profiler(None)
+    s = prof.summary()
+    print("after GraphedTrainStep, eager step behind", mode)
+    for k, d in sorted(s.items(), key=lambda kv: -kv[1]["ms"])[:4]:
+        print("   %-22s %5d launches %8.2f ms/step  avg %.3f ms" % (k, d["launches"], d["ms"] / 3, d["ms"] / d["launches"]))
