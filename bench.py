@@ -266,6 +266,11 @@ def main():
 
     if rank == 0:
         summ = prof.summary()
+        if os.environ.get("WCMC_BENCH_DEBUG"):
+            for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                print("  [profile] %-22s %5d launches %9.3f ms total  avg %.4f ms" %
+                      (k, d["launches"], d["ms"], d["ms"] / d["launches"]), file=sys.stderr)
+            print("  [profile] eager region %.1f ms over the profiled steps" % (prof_elapsed * 1e3), file=sys.stderr)
         global_batch = B_PER_GPU * world
         value = global_batch * args.steps / elapsed
 
