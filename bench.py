@@ -36,19 +36,34 @@ B_PER_GPU, SPP, PATCH = 8, 8, 128
 
 
 class EventProfiler:
+    """HIP-event pairs around op launches (wcmc_amd.ops._Timed).  Per class the summary takes the MEDIAN
+    profiled step times the number of steps: one bracket in a few thousand straddles a host stall (the queue
+    of an eagerly enqueued step running dry) and would otherwise add ~100 ms to its class."""
+
     def __init__(self):
         self.rows = []
+        self.step = 0
+
+    def next_step(self):
+        self.step += 1
 
     def add(self, name, work, unit, e0, e1):
-        self.rows.append((name, work, unit, e0, e1))
+        self.rows.append((name, work, unit, e0, e1, self.step))
 
     def summary(self):
+        per = {}
+        for name, work, unit, e0, e1, st in self.rows:
+            d = per.setdefault(name, {"unit": unit, "steps": {}})
+            a = d["steps"].setdefault(st, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += work
         out = {}
-        for name, work, unit, e0, e1 in self.rows:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})
-            d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["work"] += work
+        for name, d in per.items():
+            steps = sorted(d["steps"].values(), key=lambda a: a[1])
+            med = steps[len(steps) // 2]
+            n = len(steps)
+            out[name] = {"launches": med[0] * n, "ms": med[1] * n, "work": med[2] * n, "unit": d["unit"]}
         return out
 
 
@@ -131,7 +146,7 @@ def pmc_traffic():
         d = json.load(f)
     pick = {}
     for k, v in d.items():
-        for tag, key in (("conv_halo_bf16x3_kernel<7", "conv_igemm"), ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad"),
+        for tag, key in (("conv_halo_bf16x3_kernel<7", "conv_halo7"), ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
                          ("kernel_apply_kernel<false", "kernel_apply_fwd"), ("kernel_apply_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
                 pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"],
@@ -211,8 +226,14 @@ def main():
         itf.preprocess(batch)
         itf.train_batch(batch)
 
+    prof = EventProfiler()
+
+    def eager_profiled_step():
+        prof.next_step()
+        eager_step()
+
     if args.eager:
-        step = eager_step
+        step = eager_profiled_step
     else:
         from wcmc_amd.graph import GraphedTrainStep
         graphed = GraphedTrainStep(itf, batch)
@@ -220,7 +241,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    prof = EventProfiler()
     if args.eager:
         ops.USE_SIDE_STREAM = False        # per-launch events need one stream
         ops.set_profiler(prof)
@@ -255,6 +275,7 @@ def main():
             # stream busy with replays of the captured step meanwhile, so that the event pairs bracket
             # kernels that run back to back (and at the clocks of the timed region: behind a 100 ms spin
             # kernel the same launches measured 2-3x longer) instead of a GPU waiting for Python.
+            prof.next_step()
             for _ in range(3):
                 graphed.graph.replay()
             pe0.record()
@@ -289,12 +310,16 @@ def main():
                 # 3 bf16 MFMAs per algorithmic multiply-add (+12 % cout and 5 % k padding): the MFMA pipe does
                 # ~3.5x the counted FLOPs; for scale, the exact-fp32 MFMA peak is 157.3 TFLOP/s
                 extra = {"mfma_flops_per_algorithmic_flop": 3.0, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 3)}
-            return {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+            rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 16, 16, 0>",
+                            "conv_wgrad_rows": "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>"}.get(name, name + " (several kernels)")
+            return {"kernel": rocprof_name, "class": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": None, "launches": d["launches"], **extra,
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "share_of_profiled_region": round(d["ms"] / (prof_elapsed * 1e3), 4)}
 
-        conv_keys = [k for k in ("conv_igemm", "conv_wgrad") if k in summ]
+        # classes = kernels: conv_halo7 is conv_halo_bf16x3_kernel<7,16,16> (KPCN 5x5 fwd + dgrad), conv_wgrad_rows
+        # is conv_wgrad_rows_bf16x3_kernel<5,7,7>; conv_igemm / conv_wgrad collect the other GEMM kernels
+        conv_keys = [k for k in ("conv_halo7", "conv_wgrad_rows", "conv_igemm", "conv_wgrad") if k in summ]
         dominant = max(conv_keys, key=lambda k: summ[k]["ms"]) if conv_keys else None
         ka = kernel_apply_probe(device)
         traffic = pmc_traffic()
@@ -318,9 +343,7 @@ def main():
                                      "the dense bf16 MFMA peak, so frac <= 1/3); everything else fp32")
                        if ops.PRECISION == "bf16x3" else "fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate"},
             "roofline": dict(roof(dominant, "mfma"), traffic=traffic.get(dominant)) if dominant else None,
-            "roofline_other_conv": dict(roof([k for k in conv_keys if k != dominant][0], "mfma"),
-                                        traffic=traffic.get([k for k in conv_keys if k != dominant][0]))
-            if len(conv_keys) > 1 else None,
+            "roofline_other_conv": [dict(roof(k, "mfma"), traffic=traffic.get(k)) for k in conv_keys if k != dominant],
             "roofline_kernel_apply": ka,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -152,7 +152,7 @@ def conv2d_raw(x, wp, bias, cout, ks, pad, act, gate=None, gate_act="linear", ou
     g = _v(gate) if gate is not None else (_ptr(None), 0, 0, 0)
     # algorithmic FLOPs: 2 * pixels * Cout * Cin * ks^2 of the (smaller) valid-conv side
     pix = min(ho * wo, h * w)
-    with _Timed("conv_igemm", 2.0 * n * pix * cout * cin * ks * ks, "flop"):
+    with _Timed(_igemm_class(cin, cout, ks), 2.0 * n * pix * cout * cin * ks * ks, "flop"):
         check(lib().wcmc_conv2d_igemm(*_v(x), n, h, w, cin, _ptr(wp), _ptr(bias), *_v(out), cout, ks, pad,
                                       ACT[act], LEAKY_SLOPE, *g, ACT[gate_act], LEAKY_SLOPE, _stream()),
               "conv2d_igemm")
@@ -382,6 +382,20 @@ def _pack_x(weight, mode):
     return wp
 
 
+def _igemm_class(cin, cout, ks):
+    """Profiler class of a split-bf16 GEMM launch = the kernel the library's plan picks for it
+    (csrc/conv_bf16x3.hip: x_plan_k, x_pick_nt), so that a class average is one kernel's average."""
+    tiles = (cout + 15) // 16
+    nt = min((7, 4, 2, 1), key=lambda t: (-(-tiles // t)) * (t + 2))
+    halo = 3 <= ks <= 5 and (cin + 7) // 8 * 8 >= 32
+    return "conv_halo7" if halo and nt == 7 else "conv_igemm"
+
+
+def _wgrad_class(n, ho, cin, cout, ks):
+    rows = ks == 5 and (cin + 15) // 16 == 7 and ((cout + 15) // 16) % 7 == 0 and n * ho >= 64
+    return "conv_wgrad_rows" if rows else "conv_wgrad"
+
+
 def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, gate_act="linear", colsum=False):
     """One split-bf16 implicit-GEMM launch.  xs: split tensor of dims (n,cin,h,w).
     Returns a split tensor when out_split else an fp32 NHWC view; with colsum=True also the per-tile
@@ -398,7 +412,7 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     part = None
     if colsum:
         part = torch.empty(lib().wcmc_conv2d_igemm_colsum_elems(n, ho, wo, cout), device=dev, dtype=torch.float32)
-    with _Timed("conv_igemm", 2.0 * n * pix * cout * cin * ks * ks, "flop"):
+    with _Timed(_igemm_class(cin, cout, ks), 2.0 * n * pix * cout * cin * ks * ks, "flop"):
         check(lib().wcmc_conv2d_igemm_bf16x3(_ptr(xs), n, h, w, cin, _ptr(wp), _ptr(bias), *yv, _ptr(ysp), cout,
                                              ks, pad, ACT[act], LEAKY_SLOPE, _ptr(gate), ACT[gate_act], LEAKY_SLOPE,
                                              _ptr(part), _stream()), "conv2d_igemm_bf16x3")
@@ -424,7 +438,7 @@ def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=Tr
     if _PROFILER is None:
         check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 0, _stream()), "conv2d_wgrad_bf16x3")
     else:       # bracket the split-K GEMM launch alone; the slab reduce + bias gradient is its own class
-        with _Timed("conv_wgrad", 2.0 * n * ho * wo * cout * cin * ks * ks, "flop"):
+        with _Timed(_wgrad_class(n, ho, cin, cout, ks), 2.0 * n * ho * wo * cout * cin * ks * ks, "flop"):
             check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, _stream()), "conv2d_wgrad_bf16x3")
         with _Timed("conv_wgrad_finish", 0.0, "flop"):
             check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 2, _stream()), "conv2d_wgrad_bf16x3")
