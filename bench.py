@@ -233,7 +233,8 @@ def main():
         eager_step()
 
     if args.eager:
-        step = eager_profiled_step
+        ops.USE_SIDE_STREAM = False        # per-launch events need one stream (warm-up included: the rocprofv3
+        step = eager_profiled_step         # averages of `bench.py --eager` are then single-stream durations too)
     else:
         from wcmc_amd.graph import GraphedTrainStep
         graphed = GraphedTrainStep(itf, batch)
