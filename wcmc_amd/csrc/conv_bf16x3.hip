@@ -759,237 +759,6 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
 }
 
 
-// ------------------------------------------------------------------ implicit GEMM, halo-resident, weights in registers
-// The kernel above still meets at one workgroup barrier per 32-k stage (shared weight stages in LDS);
-// its stamps show the matrix pipe saturated only while the slower wave of each SIMD multiplies (1360 of
-// 2340 cycles per stage) -- barrier, weight staging and the stage tail run with the pipe idle because
-// the barrier keeps both waves of a SIMD in phase.  Here nothing is shared but the (read-only) halo:
-// wave w owns cout tile w of the block for ALL 256 pixels of the tile, loads its own 16 x 32 weight
-// fragments (hi, lo) straight from global memory into registers (no LDS, one stage ahead) and streams
-// the pixel fragments of the 16 tile rows from the halo, three MFMAs per pair of ds_read_b128.  There is
-// no barrier inside a channel slab, so the waves of a SIMD drift apart and fill each other's gaps.
-// NW = waves (= cout tiles) per block: 7 for 112 couts (KPCN hidden layers; 441 = 4 blocks), 8 otherwise.
-template <int NW, int DBG = 0>
-__global__ __launch_bounds__(NW * 64, 1) void conv_halo_ws_bf16x3_kernel(XIgemmParams p) {
-  constexpr int BN = NW * 16, NTHR = NW * 64, TH = 16, TW = 16, PD = 4;
-  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
-  const int HWd = TW + p.ks - 1, HHt = TH + p.ks - 1, HP = HWd * HHt;
-  char* const halo = reinterpret_cast<char*>(smem16);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int tile;
-  {
-    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
-  const int tpi = p.tilesX * p.tilesY;
-  const int img = tile / tpi, trem = tile - img * tpi;
-  const int oy0 = (trem / p.tilesX) * TH, ox0 = (trem % p.tilesX) * TW;
-  const int n0 = blockIdx.y * BN;
-
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
-  const int pixb = 4 * p.Cpi;
-
-  // ---- halo (layout as conv_halo_bf16x3_kernel): one batch of loads, one batch of LDS stores
-  const int V = p.CS / 4;
-  const int hvecs = HP * V;
-  const float invV = 1.0f / (float)V, invHW = 1.0f / (float)HWd;
-  constexpr int HLM = (400 * 16 + NTHR - 1) / NTHR;
-  auto load_halo = [&](int slab) {
-    u32x4 hr[HLM];
-#pragma unroll
-    for (int j = 0; j < HLM; ++j) {
-      const int idx = j * NTHR + tid;
-      unsigned off = XOOB;
-      if (idx < hvecs) {
-        const int px = (int)(((float)idx + 0.5f) * invV), v = idx - px * V;      // exact: idx < 2^13
-        const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
-        const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
-        const int plane = v >= (V >> 1), vec = v - plane * (V >> 1);
-        const int ch = slab * p.CS + vec * 8;
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Cpi)
-          off = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb + plane * 2 * p.Cpi + ch * 2);
-      }
-      hr[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < HLM; ++j) {
-      const int idx = j * NTHR + tid;
-      if (idx < hvecs) {
-        const int px = (int)(((float)idx + 0.5f) * invV), v = idx - px * V;      // exact: idx < 2^13
-        *reinterpret_cast<u32x4*>(halo + px * p.PXS + v * 16) = hr[j];
-      }
-    }
-  };
-
-  // ---- this wave's weights: lane = cout row (lane & 15) of tile `wave`, k group kg = lane >> 4
-  const int frow = lane & 15, kg = lane >> 4;
-  const int wrow = n0 + wave * 16 + frow;
-  const unsigned wb_hi = wrow < p.Np ? (unsigned)(((wrow * 2) * p.Kt + kg * 8) * 2) : XOOB;
-  const unsigned wb_lo = wrow < p.Np ? wb_hi + (unsigned)(p.Kt * 2) : XOOB;
-  const int nstages = p.Kt / XKC;
-  auto load_w = [&](int g, bf16x8& h, bf16x8& l) {
-    const unsigned kill = g < nstages ? 0u : XOOB;
-    if (DBG & 32) { h = __builtin_bit_cast(bf16x8, u32x4{wb_hi, 0u, 0u, 0u}); l = h; return; }
-    h = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, (wb_hi + (unsigned)(g * XKC * 2)) | kill, 0, 0));
-    l = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, (wb_lo + (unsigned)(g * XKC * 2)) | kill, 0, 0));
-  };
-
-  f32x4 acc[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- pixel fragments: tile row t, pixel (lane & 15), k group kg, from the halo at the lane's (tap, channel)
-  const int rowb = HWd * p.PXS;                           // bytes per halo row
-  const int pbase = frow * p.PXS;
-  const int lo_off = p.CS * 2;
-  int cl = kg * 8, tdx = 0, tdy = 0;
-  int aoff = pbase + cl * 2;                              // current stage
-  auto next_aoff = [&]() {                                // CS >= 32: at most one wrap per 32-k stage
-    cl += XKC;
-    if (cl >= p.CS) { cl -= p.CS; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
-    return pbase + (tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0);   // slab padding: zero weights
-  };
-  bf16x8 fh[PD], fl[PD];
-  auto read_px = [&](int slot, int t, int off) {
-    if (DBG & 8) { fh[slot] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)off, 0u, 0u, 0u}); fl[slot] = fh[slot]; return; }
-    fh[slot] = *reinterpret_cast<const bf16x8*>(halo + off + t * rowb);
-    fl[slot] = *reinterpret_cast<const bf16x8*>(halo + off + t * rowb + lo_off);
-  };
-
-  bf16x8 wh, wl, whn, wln;
-  load_w(0, wh, wl);
-  load_halo(0);
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < PD; ++t) read_px(t, t, aoff);
-  int s_in = 0, slab = 0;
-  for (int g = 0; g < nstages; ++g) {
-    load_w(g + 1, whn, wln);
-    const bool last_of_slab = (s_in + 1 == p.SPS);
-    const int aoff_n = next_aoff();
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      if (DBG & 1) {
-        asm volatile("" ::"v"(fh[t % PD]), "v"(fl[t % PD]), "v"(wh), "v"(wl));
-      } else {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, fh[t % PD], acc[t], 0, 0, 0);   // small terms first
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fl[t % PD], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fh[t % PD], acc[t], 0, 0, 0);
-      }
-      if (t + PD < 16) read_px(t % PD, t + PD, aoff);
-      else if (!last_of_slab) read_px(t % PD, t + PD - 16, aoff_n);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    wh = whn; wl = wln;
-    aoff = aoff_n;
-    if (!last_of_slab) {
-      ++s_in;
-    } else {
-      s_in = 0;
-      ++slab;
-      __syncthreads();                                   // every wave is done with the old halo
-      if (slab < p.nslabs && !(DBG & 128)) load_halo(slab);
-      cl = kg * 8; tdx = 0; tdy = 0; aoff = pbase + cl * 2;
-      __syncthreads();
-#pragma unroll
-      for (int t = 0; t < PD; ++t) read_px(t, t, aoff);
-    }
-  }
-  __syncthreads();
-
-  // ---- epilogue: lane holds couts n0 + wave*16 + 4*kg + {0..3} of pixel (tile row t, column frow)
-  const int fq = kg * 4;
-  const int co = n0 + wave * 16 + fq;
-  auto pix_of = [&](int pr, int& oy, int& ox) {
-    oy = oy0 + (pr >> 4); ox = ox0 + (pr & 15);
-    return oy < p.Ho && ox < p.Wo;
-  };
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) if (co + e < p.Cout) bv[e] = p.bias[co + e];
-  }
-  if (p.ys) {
-    constexpr int OLD = 2 * BN + 8;
-    u16* so = smem16;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int pr = t * 16 + frow;
-      int oy, ox;
-      const bool ok = pix_of(pr, oy, ox);
-      const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
-      float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (ok && co + e < p.Cout) ? act_apply(v[e] + bv[e], p.act, p.slope) : 0.f;
-      if (p.gate && ok && co < p.Cpo) {
-        const uint2 g2 = *reinterpret_cast<const uint2*>(p.gate + m * 2 * p.Cpo + co);
-        const u16 gg[4] = {(u16)(g2.x & 0xffff), (u16)(g2.x >> 16), (u16)(g2.y & 0xffff), (u16)(g2.y >> 16)};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_gate(bf2f(gg[e]), p.gate_act, p.gate_slope);
-      }
-      u16 hi[4], lo[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) split1(v[e], hi[e], lo[e]);
-      *reinterpret_cast<uint2*>(so + pr * OLD + wave * 16 + fq) =
-          make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
-      *reinterpret_cast<uint2*>(so + pr * OLD + BN + wave * 16 + fq) =
-          make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
-    }
-    __syncthreads();
-    constexpr int VPP = BN / 8;
-    for (int v = tid; v < 256 * 2 * VPP; v += NTHR) {
-      const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
-      const int plane = q >= VPP, vec = q - plane * VPP;
-      const int c8 = n0 + vec * 8;
-      int oy, ox;
-      if (pix_of(pr, oy, ox) && c8 < p.Cpo) {
-        const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
-        *reinterpret_cast<u32x4*>(p.ys + m * 2 * p.Cpo + plane * p.Cpo + c8) =
-            *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
-      }
-    }
-    if (p.colsum) {
-      // column sums of the tile (bias gradient of the consumer): 4 row groups per column, combined through LDS
-      float* red = reinterpret_cast<float*>(so + 256 * OLD);
-      constexpr int RG = NTHR / BN;                      // 4
-      const int c = tid % BN, rg = tid / BN;
-      float a = 0.f;
-      if (rg < RG)
-        for (int r = rg; r < 256; r += RG) a += bf2f(so[r * OLD + c]) + bf2f(so[r * OLD + BN + c]);
-      if (rg > 0 && rg < RG) red[(rg - 1) * BN + c] = a;
-      __syncthreads();
-      if (rg == 0 && n0 + c < p.Np) {
-        for (int q = 0; q < RG - 1; ++q) a += red[q * BN + c];
-        p.colsum[(int64_t)tile * p.Np + n0 + c] = a;
-        for (int r = (int)gridDim.x + tile; r < p.G; r += (int)gridDim.x) p.colsum[(int64_t)r * p.Np + n0 + c] = 0.f;
-      }
-    }
-  } else {
-    constexpr int OLD = BN + 4;
-    float* so = reinterpret_cast<float*>(smem16);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int pr = t * 16 + frow;
-      float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (co + e < p.Cout) ? act_apply(v[e] + bv[e], p.act, p.slope) : 0.f;
-      *reinterpret_cast<float4*>(so + pr * OLD + wave * 16 + fq) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    __syncthreads();
-    constexpr int VPP = BN / 4;
-    for (int v = tid; v < 256 * VPP; v += NTHR) {
-      const int pr = v / VPP, vec = v - pr * VPP;
-      const int c4 = n0 + vec * 4;
-      int oy, ox;
-      if (pix_of(pr, oy, ox) && c4 < p.Cpo)
-        *reinterpret_cast<float4*>(p.yf + (int64_t)img * p.ysn + (int64_t)oy * p.ysh + (int64_t)ox * p.ysw + c4) =
-            *reinterpret_cast<const float4*>(so + pr * OLD + vec * 4);
-    }
-  }
-}
-
 // ------------------------------------------------------------------ weight gradient
 // D[co][ci] (per tap) = sum_pix dy[pix][co] * x[pix+tap][ci]; both operands are read with the
 // transposing LDS load (ds_read_b64_tr_b16): the tiles sit in LDS as [pixel][channel] exactly as
@@ -1644,47 +1413,9 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
-template <int NW>
-static int launch_xhalo_ws(const XIgemmParams& p, hipStream_t stream) {
-  const int HP = (16 + p.ks - 1) * (16 + p.ks - 1);
-  const size_t lds_main = (size_t)HP * p.PXS;
-  const size_t lds_out = p.ys ? (size_t)256 * (2 * NW * 16 + 8) * sizeof(u16) + (size_t)3 * NW * 16 * sizeof(float)
-                              : (size_t)256 * (NW * 16 + 4) * sizeof(float);
-  const size_t lds = lds_main > lds_out ? lds_main : lds_out;
-  WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
-  static size_t attr = 0;
-  if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_ws_bf16x3_kernel<NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
-  const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NW - 1) / NW));
-  if (NW == 7) {       // WCMC_DEBUG_ABLATE=<mask>: timing-only builds (wrong results)
-    static int ab = -1;
-    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
-#define WS_ABL(M)                                                                                       \
-    if (ab == M) {                                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_ws_bf16x3_kernel<7, M>),       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
-      hipLaunchKernelGGL((conv_halo_ws_bf16x3_kernel<7, M>), grid, dim3(448), lds, stream, p);          \
-      return check_launch("conv2d_igemm_bf16x3(ws ablation)");                                         \
-    }
-    WS_ABL(1) WS_ABL(8) WS_ABL(32) WS_ABL(128) WS_ABL(9) WS_ABL(40) WS_ABL(168) WS_ABL(169)
-#undef WS_ABL
-  }
-  hipLaunchKernelGGL((conv_halo_ws_bf16x3_kernel<NW>), grid, dim3(NW * 64), lds, stream, p);
-  return check_launch("conv2d_igemm_bf16x3(halo, weights in registers)");
-}
 template <int NT>
 static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
-  if (p.PXS) {
-    static int ws = -1;      // WCMC_IGEMM_WS=1: A/B switch to the weights-in-registers variant (slower today)
-    if (ws < 0) { const char* e = getenv("WCMC_IGEMM_WS"); ws = (e && e[0] == '1') ? 1 : 0; }
-    const int tiles = p.Np / 16;
-    if (ws && tiles % 7 == 0) return launch_xhalo_ws<7>(p, stream);
-    if (ws && tiles % 8 == 0) return launch_xhalo_ws<8>(p, stream);
-    return launch_xhalo<NT>(p, stream);
-  }
+  if (p.PXS) return launch_xhalo<NT>(p, stream);
   return p.pad > 0 ? launch_xigemm2<NT, true>(p, stream) : launch_xigemm2<NT, false>(p, stream);
 }
 
