@@ -490,33 +490,27 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
   const int pixb = 4 * p.Cpi;
 
-  // ---- halo: [pixel][hi CS][lo CS] at stride PXS; out-of-image pixels and channels >= Cpi read zeros
-  const int V = p.CS / 4;                      // 16-byte vectors per halo pixel (2 planes x CS/8)
-  const int hvecs = HP * V;
-  const float invV = 1.0f / (float)V, invHW = 1.0f / (float)HWd;
-  auto load_halo = [&](int slab) {
-    constexpr int HL = 6;
-    for (int base = 0; base < hvecs; base += NTHR * HL) {
-      u32x4 r[HL]; int so[HL];
-#pragma unroll
-      for (int j = 0; j < HL; ++j) {
-        const int idx = base + j * NTHR + tid;
-        unsigned off = XOOB; so[j] = -1;
-        if (idx < hvecs) {
-          const int px = (int)(((float)idx + 0.5f) * invV), v = idx - px * V;      // exact: idx < 2^13
-          const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
-          const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
-          const int plane = v >= (V >> 1), vec = v - plane * (V >> 1);
-          const int ch = slab * p.CS + vec * 8;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Cpi)
-            off = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb + plane * 2 * p.Cpi + ch * 2);
-          so[j] = px * p.PXS + v * 16;
-        }
-        r[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+  // ---- halo: [pixel][hi CS][lo CS] at stride PXS; out-of-image pixels and channels >= Cpi read zeros.
+  // Filled by LDS-DMA as one linear run of 16-byte vectors (PXS / 16 per pixel, the last ones pad): wave
+  // instruction ii writes vectors [64 ii, 64 ii + 64), the per-lane source picks pixel / plane / channel.
+  const int V = p.CS / 4;                      // data vectors per halo pixel (2 planes x CS/8)
+  const int VP = p.PXS / 16;                   // vectors per halo pixel with pad
+  const int hvecs = HP * VP;
+  const float invVP = 1.0f / (float)VP, invHW = 1.0f / (float)HWd;
+  auto dma_halo = [&](int slab) {
+    for (int ii = wave; ii * 64 < hvecs; ii += NTHR / 64) {
+      const int v = ii * 64 + lane;
+      if (v < hvecs) {
+        const int px = (int)(((float)v + 0.5f) * invVP), part = v - px * VP;     // exact: v < 2^13
+        const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
+        const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+        const int plane = part >= (V >> 1), vec = part - plane * (V >> 1);
+        const int ch = slab * p.CS + vec * 8;
+        unsigned off = XOOB;
+        if (part < V && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Cpi)
+          off = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb + plane * 2 * p.Cpi + ch * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(halo + ii * 1024), 16, off, 0, 0, 0);
       }
-#pragma unroll
-      for (int j = 0; j < HL; ++j)
-        if (so[j] >= 0) *reinterpret_cast<u32x4*>(halo + so[j]) = r[j];
     }
   };
 
@@ -592,7 +586,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
 
   dma_b(0, 0);
   dma_b(1, 1);
-  load_halo(0);
+  dma_halo(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   read_a();
@@ -606,8 +600,11 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     __syncthreads();                             // ... everyone's; and everyone has read stage g's fragments
     stamp(0);
     dma_b(g + 2, g & 1);
-    stamp(1);
     const bool last_of_slab = (s_in + 1 == p.SPS);
+    // the fragments of a slab's last stage are in registers and the barrier above retired every read of the
+    // halo: the next slab's halo lands while this stage multiplies
+    if (last_of_slab && slab + 1 < p.nslabs) dma_halo(slab + 1);
+    stamp(1);
     bf16x8 ahn[2], aln[2];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -639,15 +636,15 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     } else {                                     // slab boundary: the next A fragments come from the next halo
       s_in = 0;
       ++slab;
-      __syncthreads();                           // every wave has consumed its fragments of the old halo
-      if (slab < p.nslabs) load_halo(slab);
       cl = kg * 8; tdx = 0; tdy = 0; aoff = cl * 2;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the new halo (and of stage g+2)
       __syncthreads();
       read_a();
     }
     stamp(3);
   }
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (zero) weight stages past the end have landed:
+  __syncthreads();                                     // LDS is free for the epilogue staging
   if (DBG & 64) {
     if (lane == 0) {
       unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * 8 + wave) * 8;
