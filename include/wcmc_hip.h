@@ -277,6 +277,19 @@ int wcmc_clip_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                    float clip, double lr, double beta1, double beta2, double eps, int step,
                    float grad_scale, const float* guard, void* stream);
 
+/* ---------------------------------------------------------------- per-image preprocessing (data step before the path)
+ * support/datasets.py: DenoiseDataset._preprocess_llpm :302-361, ._preprocess_kpcn :487-582,
+ * ._gradients :286-300; raw channel map :223-267 (C >= 38 + 11*(max_depth+1); the reference's MAX_DEPTH is 5,
+ * C = 104).  Dense, contiguous fp32 device buffers in the reference's numpy layouts:
+ *   raw (h, w, s, C);  llpm out (h, w, s, 7 + 5*(max_depth+1)) = 37;  kpcn out (h, w, 44);
+ *   gradients: buf (h, w, c) -> out (h, w, 2c) = [d/dx (c), d/dy (c)], zero first column / row. */
+int wcmc_preprocess_llpm(const float* raw, int64_t nsamples /* h*w*s */, int C, int max_depth, float* out,
+                         void* stream);
+size_t wcmc_preprocess_kpcn_workspace_bytes(int h, int w);
+int wcmc_preprocess_kpcn(const float* raw, int h, int w, int s, int C, int max_depth, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int wcmc_gradients(const float* buf, int h, int w, int c, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -330,8 +330,50 @@ def gen_interface_variants(ref_losses, ref_itf):
         print("G5b", case, {k: float(v) for k, v in itf.m_losses.items()})
 
 
+# ---------------------------------------------------------------------------------- G6
+def raw_samples(h, w, s, seed, zero_depth=False):
+    """Random raw renderer output (h, w, s, 104) with the value ranges the preprocessors care about:
+    signed radiance (exercises the max(., 0) clamps), throughputs / intensities spanning decades with exact
+    zeros (path ended), roughness in [0, 1], bounce-type codes."""
+    rng = np.random.RandomState(seed)
+    x = rng.rand(h, w, s, 104).astype(np.float32)
+    x[..., 2:8] = (rng.randn(h, w, s, 6) * 2.0).astype(np.float32)                  # radiance, diffuse: signed
+    x[..., 66:69] = rng.rand(h, w, s, 3).astype(np.float32)                         # albedo at first diffuse
+    x[..., 69:72] = (rng.randn(h, w, s, 3)).astype(np.float32)                      # normal
+    x[..., 72:73] = 0.0 if zero_depth else (rng.rand(h, w, s, 1) * 40.0).astype(np.float32)
+    x[..., 73:74] = np.exp(rng.randn(h, w, s, 1) * 3.0).astype(np.float32)          # path weight
+    x[..., 74:77] = np.exp(rng.randn(h, w, s, 3) * 2.0).astype(np.float32)
+    x[..., 77:80] = (rng.rand(h, w, s, 3) * 1e4).astype(np.float32)
+    thr = np.exp(rng.randn(h, w, s, 18) * 2.0).astype(np.float32)
+    thr[rng.rand(h, w, s, 18) < 0.3] = 0.0
+    x[..., 80:98] = thr
+    x[..., 60:66] = rng.randint(0, 20, size=(h, w, s, 6)).astype(np.float32)        # bounce types
+    return x
+
+
+def gen_preprocess(ref_datasets):
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "train", "gt"))
+        ds = ref_datasets.DenoiseDataset(tmp, 4, base_model="kpcn", mode="train", use_llpm_buf=True)
+        out = {}
+        for name, (h, w, s, seed, zd) in {"a": (12, 10, 4, 901, False), "b": (9, 17, 8, 902, False),
+                                          "zero_depth": (6, 5, 2, 903, True)}.items():
+            x = raw_samples(h, w, s, seed, zd)
+            out[name + "/raw"] = x
+            out[name + "/llpm"] = ds._preprocess_llpm(x.copy())
+            out[name + "/kpcn"] = ds._preprocess_kpcn(x.copy())
+        buf = np.random.RandomState(904).randn(7, 9, 5).astype(np.float32)
+        out["grad/buf"], out["grad/out"] = buf, ds._gradients(buf)
+        np.savez_compressed(os.path.join(HERE, "preprocess.npz"), **out)
+        print("G6", {k: v.shape for k, v in out.items()})
+
+
 def main():
     ref_losses, ref_utils, ref_itf = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "preprocess":          # only the data-step functions
+        import support.datasets as ref_datasets
+        gen_preprocess(ref_datasets)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "variants":          # only the rank-1 "next" interfaces
         cwd = os.getcwd()
         with tempfile.TemporaryDirectory() as tmp:
@@ -351,6 +393,8 @@ def main():
             gen_image_losses(ref_losses)
             gen_interface(ref_losses, ref_itf)
             gen_interface_variants(ref_losses, ref_itf)
+            import support.datasets as ref_datasets
+            gen_preprocess(ref_datasets)
         finally:
             os.chdir(cwd)
     print("goldens written to", HERE)

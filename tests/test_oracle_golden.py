@@ -121,3 +121,16 @@ def test_interface_step_golden(golden_dir, case):
     np.testing.assert_allclose(losses["val"].item() / 2, d["val/summary"], rtol=1e-5)
     if p_regress is not None:
         np.testing.assert_allclose(p_regress["diffuse"].numpy(), d["val/p_diffuse"], rtol=1e-4, atol=1e-6)
+
+
+def test_preprocess_golden(golden_dir):
+    """G6: oracle/datasets.py == DenoiseDataset._preprocess_llpm / _preprocess_kpcn / _gradients (bit-exact:
+    the same numpy operations in the same order)."""
+    from oracle import datasets as od
+    d = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    for name in ("a", "b", "zero_depth"):
+        raw = d[name + "/raw"]
+        np.testing.assert_array_equal(od.preprocess_llpm(raw), d[name + "/llpm"])
+        np.testing.assert_array_equal(od.preprocess_kpcn(raw), d[name + "/kpcn"])
+    np.testing.assert_array_equal(od.gradients(d["grad/buf"]), d["grad/out"])
+    assert d["a/llpm"].shape[-1] == 37 and d["a/kpcn"].shape[-1] == 44

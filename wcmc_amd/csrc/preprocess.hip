@@ -1,0 +1,207 @@
+// Per-image preprocessing of raw renderer samples (the step before the KPCN-Manifold path).
+//
+// Replaces the numpy code of the reference's support/datasets.py:
+//   DenoiseDataset._preprocess_llpm :302-361   raw (h,w,s,C) -> (h,w,s,37) path descriptors (log / sqrt transforms)
+//   DenoiseDataset._preprocess_kpcn :487-582   raw (h,w,s,C) -> (h,w,44) per-pixel statistics over the spp axis,
+//                                              albedo factorisation, log transform, depth normalisation, gradients
+//   DenoiseDataset._gradients       :286-300   backward differences with a zero first column / row
+// Raw channel map: datasets.py:223-267 (C = 38 + 11 * (MAX_DEPTH + 1) = 104 at MAX_DEPTH = 5).
+// All three are streaming, HBM-bound kernels: the raw buffer (416 B per sample) is read once per function.
+#include "common.h"
+
+namespace wcmc {
+
+struct PPMap { int radiance, diffuse, bounce, albedo, normal, depth, pweight, rwow, light, thr, rough, d; };
+
+static PPMap pp_map(int max_depth) {
+  const int d = max_depth + 1;
+  PPMap m;
+  m.radiance = 2; m.diffuse = 5; m.bounce = 24 + d * 6; m.albedo = 24 + d * 7; m.normal = 27 + d * 7;
+  m.depth = 30 + d * 7; m.pweight = 31 + d * 7; m.rwow = 32 + d * 7; m.light = 35 + d * 7;
+  m.thr = 38 + d * 7; m.rough = 38 + d * 10; m.d = d;
+  return m;
+}
+
+// one thread per (sample, output channel); consecutive threads = consecutive output channels of a sample
+__global__ __launch_bounds__(256) void pp_llpm_kernel(const float* __restrict__ raw, float* __restrict__ out, int64_t n,
+                                                      int C, PPMap m) {
+  const int OC = 7 + 5 * m.d;                       // 1 + 3 + 3 + 3d + d + d
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * OC;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / OC;
+    const int c = (int)(idx - i * OC);
+    const float* r = raw + i * C;
+    float v;
+    if (c < 1) v = logf(r[m.pweight] + 1e-6f) / 90.0f;
+    else if (c < 4) v = logf(r[m.rwow + c - 1] + 1e-6f) / 30.0f;
+    else if (c < 7) v = logf(r[m.light + c - 4] + 1e-8f) / 10.0f;
+    else if (c < 7 + 3 * m.d) v = logf(r[m.thr + c - 7] + 1e-6f) / 30.0f;
+    else if (c < 7 + 4 * m.d) v = r[m.bounce + c - 7 - 3 * m.d] / 19.0f;
+    else v = sqrtf(r[m.rough + c - 7 - 4 * m.d]);
+    out[idx] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pp_gradients_kernel(const float* __restrict__ buf, float* __restrict__ out, int h,
+                                                           int w, int c) {
+  const int64_t total = (int64_t)h * w * c;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % c);
+    const int64_t p = idx / c;
+    const int x = (int)(p % w), y = (int)(p / w);
+    const float v = buf[idx];
+    out[p * 2 * c + ch] = x > 0 ? v - buf[idx - c] : 0.f;
+    out[p * 2 * c + c + ch] = y > 0 ? v - buf[idx - (int64_t)w * c] : 0.f;
+  }
+}
+
+// mean and population variance over the s samples of one raw channel group (numpy .mean(2) / .var(2))
+template <int NC, class F>
+__device__ __forceinline__ void pp_mean_var(const float* __restrict__ px, int s, int C, F f, float* mean, float* var) {
+  float sum[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) sum[c] = 0.f;
+  for (int k = 0; k < s; ++k)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sum[c] += f(px + (int64_t)k * C, c);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { mean[c] = sum[c] / (float)s; sum[c] = 0.f; }
+  for (int k = 0; k < s; ++k)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { const float d = f(px + (int64_t)k * C, c) - mean[c]; sum[c] += d * d; }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) var[c] = sum[c] / (float)s;
+}
+
+// output channel offsets of the 44-channel KPCN buffer
+constexpr int KP_DIFF = 0, KP_SPEC = 10, KP_NORM = 20, KP_DEPTH = 30, KP_ALB = 34, KP_C = 44;
+
+// pass 1: everything that needs only the pixel's own samples; depth stays raw in the workspace
+__global__ __launch_bounds__(256) void pp_kpcn_stats_kernel(const float* __restrict__ raw, float* __restrict__ out,
+                                                            float* __restrict__ ws, int64_t npix, int s, int C, PPMap m) {
+  const float eps = 0.00316f;
+  float bmax = 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    const float* px = raw + p * s * C;
+    float* o = out + p * KP_C;
+    float mean[3], var[3];
+    const float spp = (float)s;
+    pp_mean_var<3>(px, s, C, [&](const float* r, int c) { return r[m.normal + c]; }, mean, var);
+    o[KP_NORM + 0] = mean[0]; o[KP_NORM + 1] = mean[1]; o[KP_NORM + 2] = mean[2];
+    o[KP_NORM + 3] = ((var[0] + var[1] + var[2]) / 3.0f) / spp;
+    float dm[1], dv[1];
+    pp_mean_var<1>(px, s, C, [&](const float* r, int) { return r[m.depth]; }, dm, dv);
+    ws[2 * p] = dm[0]; ws[2 * p + 1] = dv[0];
+    bmax = fmaxf(bmax, dm[0]);
+    float alb[3];
+    pp_mean_var<3>(px, s, C, [&](const float* r, int c) { return r[m.albedo + c]; }, alb, var);
+    o[KP_ALB + 0] = alb[0]; o[KP_ALB + 1] = alb[1]; o[KP_ALB + 2] = alb[2];
+    o[KP_ALB + 3] = ((var[0] + var[1] + var[2]) / 3.0f) / spp;
+    const float a0 = alb[0] + eps, a1 = alb[1] + eps, a2 = alb[2] + eps;
+    const float albedo_sqr = (a0 * a0 + a1 * a1 + a2 * a2) / 3.0f;
+    pp_mean_var<3>(px, s, C, [&](const float* r, int c) { return fmaxf(r[m.diffuse + c], 0.f); }, mean, var);
+    const float diffuse_v = ((var[0] + var[1] + var[2]) / 3.0f) / spp;
+    o[KP_DIFF + 0] = mean[0] / a0; o[KP_DIFF + 1] = mean[1] / a1; o[KP_DIFF + 2] = mean[2] / a2;
+    o[KP_DIFF + 3] = diffuse_v / albedo_sqr;
+    pp_mean_var<3>(px, s, C,
+                   [&](const float* r, int c) {
+                     return fmaxf(fmaxf(r[m.radiance + c], 0.f) - fmaxf(r[m.diffuse + c], 0.f), 0.f);
+                   },
+                   mean, var);
+    const float specular_v = ((var[0] + var[1] + var[2]) / 3.0f) / spp;
+    const float s0 = 1.0f + mean[0], s1 = 1.0f + mean[1], s2 = 1.0f + mean[2];
+    const float specular_sqr = (s0 * s0 + s1 * s1 + s2 * s2) / 3.0f;
+    o[KP_SPEC + 0] = logf(s0); o[KP_SPEC + 1] = logf(s1); o[KP_SPEC + 2] = logf(s2);
+    o[KP_SPEC + 3] = specular_v / specular_sqr;
+  }
+  // image maximum of the mean depth (only its positive part matters: datasets.py:517-520 scales when max > 0)
+  bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(ws + 2 * npix), __float_as_int(bmax));
+}
+
+// pass 2: depth normalisation + clip, and the backward differences of the five feature groups
+__global__ __launch_bounds__(256) void pp_kpcn_finish_kernel(float* __restrict__ out, const float* __restrict__ ws, int h,
+                                                             int w, int s) {
+  const int64_t npix = (int64_t)h * w;
+  const float maxd = ws[2 * npix];
+  auto depth_of = [&](int64_t p) {
+    float d = ws[2 * p];
+    if (maxd > 0.f) d = d / maxd;
+    return fminf(fmaxf(d, 0.f), 1.f);
+  };
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(p % w), y = (int)(p / w);
+    float* o = out + p * KP_C;
+    const float* l = o - KP_C;                 // left neighbour (x > 0)
+    const float* u = o - (int64_t)w * KP_C;    // upper neighbour (y > 0)
+    const float d = depth_of(p);
+    float dv = ws[2 * p + 1];
+    if (maxd > 0.f) dv = dv / (maxd * maxd * (float)s);
+    o[KP_DEPTH] = d; o[KP_DEPTH + 1] = dv;
+    o[KP_DEPTH + 2] = x > 0 ? d - depth_of(p - 1) : 0.f;
+    o[KP_DEPTH + 3] = y > 0 ? d - depth_of(p - w) : 0.f;
+    const int grp[4] = {KP_DIFF, KP_SPEC, KP_NORM, KP_ALB};
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = o[grp[g] + c];
+        o[grp[g] + 4 + c] = x > 0 ? v - l[grp[g] + c] : 0.f;
+        o[grp[g] + 7 + c] = y > 0 ? v - u[grp[g] + c] : 0.f;
+      }
+  }
+}
+
+static unsigned pp_grid(int64_t work) {
+  const int64_t b = ceil_div64(work, 256);
+  return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace wcmc
+
+using namespace wcmc;
+
+extern "C" int wcmc_preprocess_llpm(const float* raw, int64_t nsamples, int C, int max_depth, float* out, void* stream) {
+  WCMC_REQUIRE(raw && out && nsamples > 0 && max_depth >= 0 && C >= 38 + 11 * (max_depth + 1), WCMC_ERR_BAD_ARG,
+               "preprocess_llpm: bad argument (raw needs >= 38 + 11*(max_depth+1) channels)");
+  const PPMap m = pp_map(max_depth);
+  hipLaunchKernelGGL(pp_llpm_kernel, dim3(pp_grid(nsamples * (7 + 5 * m.d))), dim3(256), 0, (hipStream_t)stream, raw, out,
+                     nsamples, C, m);
+  return check_launch("preprocess_llpm");
+}
+
+extern "C" int wcmc_gradients(const float* buf, int h, int w, int c, float* out, void* stream) {
+  WCMC_REQUIRE(buf && out && h > 0 && w > 0 && c > 0, WCMC_ERR_BAD_ARG, "gradients: bad argument");
+  hipLaunchKernelGGL(pp_gradients_kernel, dim3(pp_grid((int64_t)h * w * c)), dim3(256), 0, (hipStream_t)stream, buf, out, h,
+                     w, c);
+  return check_launch("gradients");
+}
+
+extern "C" size_t wcmc_preprocess_kpcn_workspace_bytes(int h, int w) {
+  if (h <= 0 || w <= 0) return 0;
+  return ((size_t)2 * h * w + 4) * sizeof(float);
+}
+
+extern "C" int wcmc_preprocess_kpcn(const float* raw, int h, int w, int s, int C, int max_depth, float* out,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  WCMC_REQUIRE(raw && out && workspace && h > 0 && w > 0 && s > 0 && max_depth >= 0 && C >= 38 + 11 * (max_depth + 1),
+               WCMC_ERR_BAD_ARG, "preprocess_kpcn: bad argument");
+  WCMC_REQUIRE(workspace_bytes >= wcmc_preprocess_kpcn_workspace_bytes(h, w), WCMC_ERR_WORKSPACE,
+               "preprocess_kpcn: workspace too small");
+  const PPMap m = pp_map(max_depth);
+  const int64_t npix = (int64_t)h * w;
+  float* ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws + 2 * npix, 0, sizeof(float), st) != hipSuccess) {
+    set_error("preprocess_kpcn: memset failed");
+    return WCMC_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(pp_kpcn_stats_kernel, dim3(pp_grid(npix)), dim3(256), 0, st, raw, out, ws, npix, s, C, m);
+  int rc = check_launch("preprocess_kpcn(stats)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(pp_kpcn_finish_kernel, dim3(pp_grid(npix)), dim3(256), 0, st, out, ws, h, w, s);
+  return check_launch("preprocess_kpcn(finish)");
+}

@@ -836,3 +836,40 @@ def clip_adam_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.99
     check(lib().wcmc_clip_adam(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
                                clip, lr, beta1, beta2, eps, int(step), grad_scale, _ptr(guard), _stream()),
           "clip_adam")
+
+
+# ---------------------------------------------------------------------------------- data step
+def _need_dense(t, ndim):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != ndim or not t.is_contiguous():
+        raise RuntimeError("wcmc_amd preprocessing takes contiguous fp32 CUDA tensors in the reference's numpy "
+                           "layout (got %s %s %s); there is no CPU path" % (t.device, t.dtype, tuple(t.shape)))
+
+
+def preprocess_llpm(sample, max_depth=5):
+    """``DenoiseDataset._preprocess_llpm`` (datasets.py:302-361): raw (h,w,s,C) -> (h,w,s,37)."""
+    _need_dense(sample, 4)
+    h, w, s, c = sample.shape
+    out = torch.empty((h, w, s, 7 + 5 * (max_depth + 1)), device=sample.device, dtype=torch.float32)
+    check(lib().wcmc_preprocess_llpm(_ptr(sample), h * w * s, c, max_depth, _ptr(out), _stream()), "preprocess_llpm")
+    return out
+
+
+def preprocess_kpcn(sample, max_depth=5):
+    """``DenoiseDataset._preprocess_kpcn`` (datasets.py:487-582): raw (h,w,s,C) -> (h,w,44)."""
+    _need_dense(sample, 4)
+    h, w, s, c = sample.shape
+    out = torch.empty((h, w, 44), device=sample.device, dtype=torch.float32)
+    nbytes = lib().wcmc_preprocess_kpcn_workspace_bytes(h, w)
+    ws = torch.empty((nbytes + 3) // 4, device=sample.device, dtype=torch.float32)
+    check(lib().wcmc_preprocess_kpcn(_ptr(sample), h, w, s, c, max_depth, _ptr(out), _ptr(ws), ws.numel() * 4, _stream()),
+          "preprocess_kpcn")
+    return out
+
+
+def gradients(buf):
+    """``DenoiseDataset._gradients`` (datasets.py:286-300): (h,w,c) -> (h,w,2c)."""
+    _need_dense(buf, 3)
+    h, w, c = buf.shape
+    out = torch.empty((h, w, 2 * c), device=buf.device, dtype=torch.float32)
+    check(lib().wcmc_gradients(_ptr(buf), h, w, c, _ptr(out), _stream()), "gradients")
+    return out
