@@ -51,6 +51,18 @@ def test_preprocess_full_patch_against_oracle():
     assert torch.equal(kp[:, 0, 4:7], torch.zeros_like(kp[:, 0, 4:7]))                  # zero first column of d/dx
 
 
+@pytest.mark.parametrize("spp", [1, 3, 6, 16])
+def test_preprocess_kpcn_other_sample_counts(spp):
+    """spp 3 and 6 take the one-lane-per-pixel statistics kernel, 1 and 16 the lane-per-sample one."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    from oracle import datasets as od
+    raw = mg.raw_samples(21, 19, spp, 80 + spp)
+    got = _pre()._preprocess_kpcn(torch.from_numpy(raw).to(DEV))
+    _close(got, od.preprocess_kpcn(raw), 5e-5, 2e-6, "kpcn spp %d" % spp)
+
+
 def test_preprocess_rejects_host_tensors():
     with pytest.raises(RuntimeError, match="no CPU path"):
         _pre()._preprocess_llpm(torch.zeros(2, 2, 2, 104))

@@ -22,23 +22,51 @@ static PPMap pp_map(int max_depth) {
   return m;
 }
 
-// one thread per (sample, output channel); consecutive threads = consecutive output channels of a sample
+// generic form: one thread per (sample, output channel)
+__device__ __forceinline__ float pp_llpm_value(const float* r, int c, const PPMap& m, int base) {
+  // r: the sample's raw record shifted by `base` channels (0 for a global pointer, m.bounce for the LDS tile)
+  if (c < 1) return logf(r[m.pweight - base] + 1e-6f) / 90.0f;
+  if (c < 4) return logf(r[m.rwow + c - 1 - base] + 1e-6f) / 30.0f;
+  if (c < 7) return logf(r[m.light + c - 4 - base] + 1e-8f) / 10.0f;
+  if (c < 7 + 3 * m.d) return logf(r[m.thr + c - 7 - base] + 1e-6f) / 30.0f;
+  if (c < 7 + 4 * m.d) return r[m.bounce + c - 7 - 3 * m.d - base] / 19.0f;
+  return sqrtf(r[m.rough + c - 7 - 4 * m.d - base]);
+}
+
 __global__ __launch_bounds__(256) void pp_llpm_kernel(const float* __restrict__ raw, float* __restrict__ out, int64_t n,
                                                       int C, PPMap m) {
   const int OC = 7 + 5 * m.d;                       // 1 + 3 + 3 + 3d + d + d
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * OC;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx / OC;
-    const int c = (int)(idx - i * OC);
-    const float* r = raw + i * C;
-    float v;
-    if (c < 1) v = logf(r[m.pweight] + 1e-6f) / 90.0f;
-    else if (c < 4) v = logf(r[m.rwow + c - 1] + 1e-6f) / 30.0f;
-    else if (c < 7) v = logf(r[m.light + c - 4] + 1e-8f) / 10.0f;
-    else if (c < 7 + 3 * m.d) v = logf(r[m.thr + c - 7] + 1e-6f) / 30.0f;
-    else if (c < 7 + 4 * m.d) v = r[m.bounce + c - 7 - 3 * m.d] / 19.0f;
-    else v = sqrtf(r[m.rough + c - 7 - 4 * m.d]);
-    out[idx] = v;
+    out[idx] = pp_llpm_value(raw + i * C, (int)(idx - i * OC), m, 0);
+  }
+}
+
+// Tiled form (16-byte aligned records): every channel the function reads lies in [bounce, C) -- 44 of the 104
+// channels at MAX_DEPTH 5.  A block stages that range of 256 consecutive samples in LDS with 16-byte loads
+// (176-byte runs per record; the first 240 bytes of a record are never requested), then writes the 256 x 37
+// outputs as one contiguous run.
+__global__ __launch_bounds__(256) void pp_llpm_tiled_kernel(const float* __restrict__ raw, float* __restrict__ out,
+                                                            int64_t n, int C, PPMap m) {
+  extern __shared__ __attribute__((aligned(16))) float pp_tile[];
+  const int W4 = (C - m.bounce) / 4;                // float4 per record (11)
+  const int LD = W4 * 4 + 1;                        // odd row pitch: conflict-free column reads
+  const int OC = 7 + 5 * m.d;
+  for (int64_t s0 = (int64_t)blockIdx.x * 256; s0 < n; s0 += (int64_t)gridDim.x * 256) {
+    const int cnt = (int)min((int64_t)256, n - s0);
+    for (int t = threadIdx.x; t < cnt * W4; t += 256) {
+      const int j = t / W4, q = t - j * W4;
+      const float4 v = *reinterpret_cast<const float4*>(raw + (s0 + j) * C + m.bounce + q * 4);
+      float* d = pp_tile + j * LD + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * OC; t += 256) {
+      const int j = t / OC, c = t - j * OC;
+      out[s0 * OC + t] = pp_llpm_value(pp_tile + j * LD, c, m, m.bounce);
+    }
+    __syncthreads();
   }
 }
 
@@ -122,6 +150,68 @@ __global__ __launch_bounds__(256) void pp_kpcn_stats_kernel(const float* __restr
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(ws + 2 * npix), __float_as_int(bmax));
 }
 
+// pass 1, one lane per (pixel, sample) for power-of-two spp <= 64: the s lanes of a pixel sit side by side, so a
+// wave reads 64 consecutive raw records (26 KB of contiguous memory) and the statistics are xor-shuffle trees
+// (the per-pixel form above walks each pixel's records from a single lane, 3.3 KB apart across the wave).
+__global__ __launch_bounds__(256) void pp_kpcn_stats_lanes_kernel(const float* __restrict__ raw, float* __restrict__ out,
+                                                                  float* __restrict__ ws, int64_t npix, int s, int C,
+                                                                  PPMap m) {
+  const float eps = 0.00316f, spp = (float)s;
+  const int ppw = 64 / s;                                       // pixels per wave
+  const int lane = threadIdx.x & 63, k = lane & (s - 1), pl = lane / s;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float bmax = 0.f;
+  for (int64_t p0 = wave * ppw; p0 < npix; p0 += nwaves * ppw) {
+    const int64_t p = p0 + pl;
+    const bool ok = p < npix;
+    const float* r = raw + ((ok ? p : npix - 1) * s + k) * C;
+    // v: normal(3) depth(1) albedo(3) diffuse+(3) specular+(3)
+    float v[13];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      v[c] = r[m.normal + c];
+      v[4 + c] = r[m.albedo + c];
+      const float df = fmaxf(r[m.diffuse + c], 0.f);
+      v[7 + c] = df;
+      v[10 + c] = fmaxf(fmaxf(r[m.radiance + c], 0.f) - df, 0.f);
+    }
+    v[3] = r[m.depth];
+    float mean[13], var[13];
+#pragma unroll
+    for (int c = 0; c < 13; ++c) {
+      float a = v[c];
+      for (int o = 1; o < s; o <<= 1) a += __shfl_xor(a, o, 64);
+      mean[c] = a / spp;
+      const float d = v[c] - mean[c];
+      float q = d * d;
+      for (int o = 1; o < s; o <<= 1) q += __shfl_xor(q, o, 64);
+      var[c] = q / spp;
+    }
+    if (ok && k == 0) {
+      float* o = out + p * KP_C;
+      o[KP_NORM + 0] = mean[0]; o[KP_NORM + 1] = mean[1]; o[KP_NORM + 2] = mean[2];
+      o[KP_NORM + 3] = ((var[0] + var[1] + var[2]) / 3.0f) / spp;
+      ws[2 * p] = mean[3]; ws[2 * p + 1] = var[3];
+      bmax = fmaxf(bmax, mean[3]);
+      o[KP_ALB + 0] = mean[4]; o[KP_ALB + 1] = mean[5]; o[KP_ALB + 2] = mean[6];
+      o[KP_ALB + 3] = ((var[4] + var[5] + var[6]) / 3.0f) / spp;
+      const float a0 = mean[4] + eps, a1 = mean[5] + eps, a2 = mean[6] + eps;
+      const float albedo_sqr = (a0 * a0 + a1 * a1 + a2 * a2) / 3.0f;
+      o[KP_DIFF + 0] = mean[7] / a0; o[KP_DIFF + 1] = mean[8] / a1; o[KP_DIFF + 2] = mean[9] / a2;
+      o[KP_DIFF + 3] = (((var[7] + var[8] + var[9]) / 3.0f) / spp) / albedo_sqr;
+      const float s0 = 1.0f + mean[10], s1 = 1.0f + mean[11], s2 = 1.0f + mean[12];
+      const float specular_sqr = (s0 * s0 + s1 * s1 + s2 * s2) / 3.0f;
+      o[KP_SPEC + 0] = logf(s0); o[KP_SPEC + 1] = logf(s1); o[KP_SPEC + 2] = logf(s2);
+      o[KP_SPEC + 3] = (((var[10] + var[11] + var[12]) / 3.0f) / spp) / specular_sqr;
+    }
+  }
+  bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
+  if (lane == 0) atomicMax(reinterpret_cast<int*>(ws + 2 * npix), __float_as_int(bmax));
+}
+
 // pass 2: depth normalisation + clip, and the backward differences of the five feature groups
 __global__ __launch_bounds__(256) void pp_kpcn_finish_kernel(float* __restrict__ out, const float* __restrict__ ws, int h,
                                                              int w, int s) {
@@ -168,8 +258,15 @@ extern "C" int wcmc_preprocess_llpm(const float* raw, int64_t nsamples, int C, i
   WCMC_REQUIRE(raw && out && nsamples > 0 && max_depth >= 0 && C >= 38 + 11 * (max_depth + 1), WCMC_ERR_BAD_ARG,
                "preprocess_llpm: bad argument (raw needs >= 38 + 11*(max_depth+1) channels)");
   const PPMap m = pp_map(max_depth);
-  hipLaunchKernelGGL(pp_llpm_kernel, dim3(pp_grid(nsamples * (7 + 5 * m.d))), dim3(256), 0, (hipStream_t)stream, raw, out,
-                     nsamples, C, m);
+  if (C % 4 == 0 && m.bounce % 4 == 0 && aligned16(raw)) {
+    const size_t lds = (size_t)256 * (C - m.bounce + 1) * sizeof(float);
+    const int64_t blocks = ceil_div64(nsamples, 256);
+    hipLaunchKernelGGL(pp_llpm_tiled_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), lds,
+                       (hipStream_t)stream, raw, out, nsamples, C, m);
+  } else {
+    hipLaunchKernelGGL(pp_llpm_kernel, dim3(pp_grid(nsamples * (7 + 5 * m.d))), dim3(256), 0, (hipStream_t)stream, raw,
+                       out, nsamples, C, m);
+  }
   return check_launch("preprocess_llpm");
 }
 
@@ -199,7 +296,10 @@ extern "C" int wcmc_preprocess_kpcn(const float* raw, int h, int w, int s, int C
     set_error("preprocess_kpcn: memset failed");
     return WCMC_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(pp_kpcn_stats_kernel, dim3(pp_grid(npix)), dim3(256), 0, st, raw, out, ws, npix, s, C, m);
+  if (s <= 64 && (s & (s - 1)) == 0)
+    hipLaunchKernelGGL(pp_kpcn_stats_lanes_kernel, dim3(pp_grid(npix * s)), dim3(256), 0, st, raw, out, ws, npix, s, C, m);
+  else
+    hipLaunchKernelGGL(pp_kpcn_stats_kernel, dim3(pp_grid(npix)), dim3(256), 0, st, raw, out, ws, npix, s, C, m);
   int rc = check_launch("preprocess_kpcn(stats)");
   if (rc) return rc;
   hipLaunchKernelGGL(pp_kpcn_finish_kernel, dim3(pp_grid(npix)), dim3(256), 0, st, out, ws, h, w, s);
