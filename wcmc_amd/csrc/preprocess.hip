@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void pp_kpcn_stats_kernel(const float* __restr
 // pass 1, one lane per (pixel, sample) for power-of-two spp <= 64: the s lanes of a pixel sit side by side, so a
 // wave reads 64 consecutive raw records (26 KB of contiguous memory) and the statistics are xor-shuffle trees
 // (the per-pixel form above walks each pixel's records from a single lane, 3.3 KB apart across the wave).
+template <bool VEC>
 __global__ __launch_bounds__(256) void pp_kpcn_stats_lanes_kernel(const float* __restrict__ raw, float* __restrict__ out,
                                                                   float* __restrict__ ws, int64_t npix, int s, int C,
                                                                   PPMap m) {
@@ -167,16 +168,29 @@ __global__ __launch_bounds__(256) void pp_kpcn_stats_lanes_kernel(const float* _
     const bool ok = p < npix;
     const float* r = raw + ((ok ? p : npix - 1) * s + k) * C;
     // v: normal(3) depth(1) albedo(3) diffuse+(3) specular+(3)
-    float v[13];
+    float v[13], in[13];       // in: radiance(3) diffuse(3) albedo(3) normal(3) depth(1)
+    if (VEC) {                 // 16-byte aligned records, albedo at an even channel with albedo+2 a multiple of 4
+      const float2 a = *reinterpret_cast<const float2*>(r + 2), b = *reinterpret_cast<const float2*>(r + 4),
+                   c2 = *reinterpret_cast<const float2*>(r + 6), d2 = *reinterpret_cast<const float2*>(r + m.albedo);
+      const float4 e = *reinterpret_cast<const float4*>(r + m.albedo + 2);
+      in[0] = a.x; in[1] = a.y; in[2] = b.x; in[3] = b.y; in[4] = c2.x; in[5] = c2.y;
+      in[6] = d2.x; in[7] = d2.y; in[8] = e.x; in[9] = e.y; in[10] = e.z; in[11] = e.w; in[12] = r[m.depth];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        in[c] = r[m.radiance + c]; in[3 + c] = r[m.diffuse + c]; in[6 + c] = r[m.albedo + c]; in[9 + c] = r[m.normal + c];
+      }
+      in[12] = r[m.depth];
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      v[c] = r[m.normal + c];
-      v[4 + c] = r[m.albedo + c];
-      const float df = fmaxf(r[m.diffuse + c], 0.f);
+      v[c] = in[9 + c];
+      v[4 + c] = in[6 + c];
+      const float df = fmaxf(in[3 + c], 0.f);
       v[7 + c] = df;
-      v[10 + c] = fmaxf(fmaxf(r[m.radiance + c], 0.f) - df, 0.f);
+      v[10 + c] = fmaxf(fmaxf(in[c], 0.f) - df, 0.f);
     }
-    v[3] = r[m.depth];
+    v[3] = in[12];
     float mean[13], var[13];
 #pragma unroll
     for (int c = 0; c < 13; ++c) {
@@ -212,7 +226,8 @@ __global__ __launch_bounds__(256) void pp_kpcn_stats_lanes_kernel(const float* _
   if (lane == 0) atomicMax(reinterpret_cast<int*>(ws + 2 * npix), __float_as_int(bmax));
 }
 
-// pass 2: depth normalisation + clip, and the backward differences of the five feature groups
+// pass 2: depth normalisation + clip, and the backward differences of the five feature groups.  One thread per
+// (pixel, output channel): a wave touches consecutive floats of the 176-byte pixel records.
 __global__ __launch_bounds__(256) void pp_kpcn_finish_kernel(float* __restrict__ out, const float* __restrict__ ws, int h,
                                                              int w, int s) {
   const int64_t npix = (int64_t)h * w;
@@ -222,26 +237,27 @@ __global__ __launch_bounds__(256) void pp_kpcn_finish_kernel(float* __restrict__
     if (maxd > 0.f) d = d / maxd;
     return fminf(fmaxf(d, 0.f), 1.f);
   };
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < npix * KP_C;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = idx / KP_C;
+    const int c = (int)(idx - p * KP_C);
     const int x = (int)(p % w), y = (int)(p / w);
-    float* o = out + p * KP_C;
-    const float* l = o - KP_C;                 // left neighbour (x > 0)
-    const float* u = o - (int64_t)w * KP_C;    // upper neighbour (y > 0)
-    const float d = depth_of(p);
-    float dv = ws[2 * p + 1];
-    if (maxd > 0.f) dv = dv / (maxd * maxd * (float)s);
-    o[KP_DEPTH] = d; o[KP_DEPTH + 1] = dv;
-    o[KP_DEPTH + 2] = x > 0 ? d - depth_of(p - 1) : 0.f;
-    o[KP_DEPTH + 3] = y > 0 ? d - depth_of(p - w) : 0.f;
-    const int grp[4] = {KP_DIFF, KP_SPEC, KP_NORM, KP_ALB};
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float v = o[grp[g] + c];
-        o[grp[g] + 4 + c] = x > 0 ? v - l[grp[g] + c] : 0.f;
-        o[grp[g] + 7 + c] = y > 0 ? v - u[grp[g] + c] : 0.f;
-      }
+    if (c >= KP_DEPTH && c < KP_ALB) {
+      float v;
+      if (c == KP_DEPTH) v = depth_of(p);
+      else if (c == KP_DEPTH + 1) { v = ws[2 * p + 1]; if (maxd > 0.f) v = v / (maxd * maxd * (float)s); }
+      else if (c == KP_DEPTH + 2) v = x > 0 ? depth_of(p) - depth_of(p - 1) : 0.f;
+      else v = y > 0 ? depth_of(p) - depth_of(p - w) : 0.f;
+      out[idx] = v;
+      continue;
+    }
+    const int g0 = c < KP_SPEC ? KP_DIFF : c < KP_NORM ? KP_SPEC : c < KP_DEPTH ? KP_NORM : KP_ALB;
+    const int j = c - g0;
+    if (j < 4) continue;                                  // values and variance: final since pass 1
+    const int src = g0 + (j < 7 ? j - 4 : j - 7);
+    const float v = out[p * KP_C + src];
+    if (j < 7) out[idx] = x > 0 ? v - out[(p - 1) * KP_C + src] : 0.f;
+    else out[idx] = y > 0 ? v - out[(p - w) * KP_C + src] : 0.f;
   }
 }
 
@@ -296,12 +312,16 @@ extern "C" int wcmc_preprocess_kpcn(const float* raw, int h, int w, int s, int C
     set_error("preprocess_kpcn: memset failed");
     return WCMC_ERR_LAUNCH;
   }
-  if (s <= 64 && (s & (s - 1)) == 0)
-    hipLaunchKernelGGL(pp_kpcn_stats_lanes_kernel, dim3(pp_grid(npix * s)), dim3(256), 0, st, raw, out, ws, npix, s, C, m);
+  const bool vec = C % 4 == 0 && aligned16(raw) && m.radiance == 2 && m.diffuse == 5 && m.albedo % 2 == 0 &&
+                   (m.albedo + 2) % 4 == 0 && m.normal == m.albedo + 3 && m.depth == m.albedo + 6;
+  if (s <= 64 && (s & (s - 1)) == 0 && vec)
+    hipLaunchKernelGGL(pp_kpcn_stats_lanes_kernel<true>, dim3(pp_grid(npix * s)), dim3(256), 0, st, raw, out, ws, npix, s, C, m);
+  else if (s <= 64 && (s & (s - 1)) == 0)
+    hipLaunchKernelGGL(pp_kpcn_stats_lanes_kernel<false>, dim3(pp_grid(npix * s)), dim3(256), 0, st, raw, out, ws, npix, s, C, m);
   else
     hipLaunchKernelGGL(pp_kpcn_stats_kernel, dim3(pp_grid(npix)), dim3(256), 0, st, raw, out, ws, npix, s, C, m);
   int rc = check_launch("preprocess_kpcn(stats)");
   if (rc) return rc;
-  hipLaunchKernelGGL(pp_kpcn_finish_kernel, dim3(pp_grid(npix)), dim3(256), 0, st, out, ws, h, w, s);
+  hipLaunchKernelGGL(pp_kpcn_finish_kernel, dim3(pp_grid(npix * KP_C)), dim3(256), 0, st, out, ws, h, w, s);
   return check_launch("preprocess_kpcn(finish)");
 }
