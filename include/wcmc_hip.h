@@ -114,6 +114,11 @@ int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
 size_t wcmc_split_elems(int N, int H, int W, int C);
 int wcmc_split_bf16(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, void* out_split,
                     int N, int H, int W, int C, void* stream);
+/* cat([flat (B*S,C1,H,W), repeat_S(prop (B,C2,H,W))], 1) (support/networks.py:39-40) written directly as a
+ * split tensor of B*S images with C1 + C2 channels; C1 % 8 == 0. */
+int wcmc_cat_broadcast_split(const float* flat, int64_t fsn, int64_t fsh, int64_t fsw,
+                             const float* prop, int64_t psn, int64_t psh, int64_t psw,
+                             void* out_split, int B, int S, int H, int W, int C1, int C2, void* stream);
 size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks);
 int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
                                    void* stream);

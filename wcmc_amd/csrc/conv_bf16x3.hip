@@ -59,6 +59,41 @@ __global__ void split_kernel(const float* __restrict__ x, int64_t xsn, int64_t x
   }
 }
 
+// ------------------------------------------------------------------ cat([flat, repeat_S(prop)], 1) -> split
+// support/networks.py:39-40 feeding the `final` ConvChain: the 128-channel concatenation of the per-sample
+// embedding (B*S images) and the spp-broadcast U-Net output (B images) is written once, directly as the
+// chain's split-bf16 input (separately: copy 268 MB + broadcast 268 MB into an fp32 tensor, then read its
+// 537 MB and write 537 MB of split planes).  One thread = 8 channels of one pixel.
+__global__ void cat_broadcast_split_kernel(const float* __restrict__ flat, int64_t fsn, int64_t fsh, int64_t fsw,
+                                           const float* __restrict__ prop, int64_t psn, int64_t psh, int64_t psw,
+                                           u16* __restrict__ out, int S, int H, int W, int C1, int C2, int Cp,
+                                           int64_t total) {
+  const int V = Cp / 8;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % V); int64_t t = idx / V;
+    const int xx = (int)(t % W); t /= W;
+    const int y = (int)(t % H); const int n = (int)(t / H);
+    const int c0 = v * 8;
+    float f[8];
+    if (c0 < C1) {                                   // C1 % 8 == 0: a vector never straddles the two sources
+      const float* src = flat + n * fsn + y * fsh + xx * fsw + c0;
+      const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+      f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+      const float* src = prop + (n / S) * psn + y * psh + xx * psw + (c0 - C1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (c0 - C1 + e < C2) ? src[e] : 0.f;
+    }
+    u16 hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split1(f[e], hi[e], lo[e]);
+    u16* o = out + (((int64_t)n * H + y) * W + xx) * 2 * Cp + c0;
+    *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(hi);
+    *reinterpret_cast<uint4*>(o + Cp) = *reinterpret_cast<const uint4*>(lo);
+  }
+}
+
 // K order of the packed weights: k = slab*Ks + tap*CS + cl, channel = slab*CS + cl.  The streaming
 // kernel uses one slab of all (padded) channels (CS = Kp, Ks = Kt); the halo kernel cuts the channels into
 // slabs of CS <= 64 that fit in LDS with their halo (x_plan_k below decides, from (kchan, ks) alone).
@@ -1311,6 +1346,23 @@ extern "C" int wcmc_split_bf16(const float* x, int64_t xsn, int64_t xsh, int64_t
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
                      x, xsn, xsh, xsw, (u16*)out, H, W, C, Cp, total);
   return check_launch("split_bf16");
+}
+
+extern "C" int wcmc_cat_broadcast_split(const float* flat, int64_t fsn, int64_t fsh, int64_t fsw, const float* prop,
+                                       int64_t psn, int64_t psh, int64_t psw, void* out_split, int B, int S, int H,
+                                       int W, int C1, int C2, void* stream) {
+  WCMC_REQUIRE(flat && prop && out_split && B > 0 && S > 0 && H > 0 && W > 0 && C1 > 0 && C2 > 0, WCMC_ERR_BAD_ARG,
+               "cat_broadcast_split: bad argument");
+  WCMC_REQUIRE(C1 % 8 == 0, WCMC_ERR_BAD_ARG, "cat_broadcast_split: the first operand needs a multiple of 8 channels");
+  WCMC_REQUIRE(nhwc_view_ok(flat, fsn, fsh, fsw, C1) && nhwc_view_ok(prop, psn, psh, psw, C2) && aligned16(out_split),
+               WCMC_ERR_ALIGNMENT, "cat_broadcast_split: a view violates the NHWC-view contract");
+  const int Cp = round_up(C1 + C2, 8);
+  const int64_t total = (int64_t)B * S * H * W * (Cp / 8);
+  const int64_t blocks = ceil_div64(total, 256);
+  hipLaunchKernelGGL(cat_broadcast_split_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, flat, fsn, fsh, fsw, prop, psn, psh, psw, (u16*)out_split, S, H, W, C1, C2, Cp,
+                     total);
+  return check_launch("cat_broadcast_split");
 }
 
 extern "C" size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks) {

@@ -38,12 +38,21 @@ class ConvChain(nn.Module):
             nn.init.xavier_uniform_(conv.weight, gain=gain)
             nn.init.zeros_(conv.bias)
 
-    def forward(self, x):
+    def _acts_params(self):
         acts = ["relu"] * (self.depth - 1) + [self.output_type]
         params = []
         for conv in self.layers:
             params += [conv.weight, conv.bias]
+        return acts, params
+
+    def forward(self, x):
+        acts, params = self._acts_params()
         return ops.conv_chain(x, self.ksize, self.padding, acts, params)
+
+    def forward_cat_broadcast(self, flat, prop, s):
+        """``self(cat([flat, repeat_S(prop)], 1))`` (support/networks.py:39-42) without the fp32 concatenation."""
+        acts, params = self._acts_params()
+        return ops.cat_broadcast_chain(flat, prop, s, self.ksize, self.padding, acts, params)
 
 
 class _Level(nn.Module):

@@ -445,94 +445,143 @@ def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=Tr
     return dw, db
 
 
+def _chainx_forward(ctx, xs0, dims0, spec, params):
+    """Shared forward of the split-bf16 chains: xs0 is the chain input as a split tensor of dims0."""
+    ks, pad, acts = spec
+    nl = len(acts)
+    n = dims0[0]
+    dims = [dims0]
+    xs = [xs0]
+    y = None
+    for l in range(nl):
+        wt, b = params[2 * l], params[2 * l + 1]
+        cout = wt.shape[0]
+        wp = _pack_x(wt, 0)
+        out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=(l < nl - 1))
+        hh, ww = dims[l][2] + 2 * pad - ks + 1, dims[l][3] + 2 * pad - ks + 1
+        dims.append((n, cout, hh, ww))
+        if l < nl - 1:
+            xs.append(out)
+        else:
+            y = out
+    ctx.spec, ctx.dims = spec, dims
+    keep_y = [y] if acts[-1] != "linear" else []
+    ctx.save_for_backward(*xs, *keep_y, *[params[2 * l] for l in range(nl)])
+    if DEBUG_ACTS is not None:
+        DEBUG_ACTS.extend(unsplit_debug(xs[l + 1], *dims[l + 1]) for l in range(nl - 1))
+        if acts[-1] != "linear":
+            DEBUG_ACTS.append(y)
+    return y
+
+
+def _chainx_backward(ctx, dy, need_dx):
+    """Shared backward: returns (dx as an fp32 NHWC view or None, [dw0, db0, dw1, db1, ...])."""
+    ks, pad, acts = ctx.spec
+    dims = ctx.dims
+    nl = len(acts)
+    saved = ctx.saved_tensors
+    xs = saved[:nl]
+    off = nl
+    dy = _as_nhwc_nograd(dy)
+    if acts[-1] != "linear":
+        dy = act_backward_raw(dy, saved[off], acts[-1])
+        off += 1
+    ws = saved[off:]
+    dys = split_raw(dy)
+    part = None                     # per-tile column sums of dys when the dgrad GEMM produced them
+    grads = [None] * (2 * nl)
+    dx = None
+    main = torch.cuda.current_stream()
+    side = _side_stream(dy.device)
+    keep = []
+    for l in range(nl - 1, -1, -1):
+        wt = ws[l]
+        cout = wt.shape[0]
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None)
+                if part is not None:
+                    db = colsum_finish_raw(part, dims[l + 1])
+            dw.record_stream(main)
+            db.record_stream(main)
+            keep.append(dys)
+            keep.append(part)
+        else:
+            dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None)
+            if part is not None:
+                db = colsum_finish_raw(part, dims[l + 1])
+        grads[2 * l], grads[2 * l + 1] = dw, db
+        if l > 0:
+            wpt = _pack_x(wt, 1)
+            dys, part = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
+                                     out_split=True, gate=xs[l], gate_act=acts[l - 1], colsum=True)
+        elif need_dx:
+            wpt = _pack_x(wt, 1)
+            dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
+                              out_split=False)
+    if side is not None:
+        main.wait_stream(side)
+    del keep
+    return dx, grads
+
+
 class _ConvChainX(torch.autograd.Function):
     """``_ConvChain`` on the split-bf16 GEMMs: intermediates live as split tensors (same bytes as
     fp32), only the chain's input and output are fp32 NHWC views."""
 
     @staticmethod
     def forward(ctx, x, spec, *params):
-        ks, pad, acts = spec
         _need_cuda(x, *params)
-        nl = len(acts)
-        n, c, h, w = x.shape
-        dims = [(n, c, h, w)]
-        xs = [split_raw(x)]
-        y = None
-        for l in range(nl):
-            wt, b = params[2 * l], params[2 * l + 1]
-            cout = wt.shape[0]
-            wp = _pack_x(wt, 0)
-            out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=(l < nl - 1))
-            hh, ww = dims[l][2] + 2 * pad - ks + 1, dims[l][3] + 2 * pad - ks + 1
-            dims.append((n, cout, hh, ww))
-            if l < nl - 1:
-                xs.append(out)
-            else:
-                y = out
-        ctx.spec, ctx.dims = spec, dims
-        keep_y = [y] if acts[-1] != "linear" else []
-        ctx.save_for_backward(*xs, *keep_y, *[params[2 * l] for l in range(nl)])
-        if DEBUG_ACTS is not None:
-            DEBUG_ACTS.extend(unsplit_debug(xs[l + 1], *dims[l + 1]) for l in range(nl - 1))
-            if acts[-1] != "linear":
-                DEBUG_ACTS.append(y)
-        return y
+        return _chainx_forward(ctx, split_raw(x), tuple(x.shape), spec, params)
 
     @staticmethod
     def backward(ctx, dy):
-        ks, pad, acts = ctx.spec
-        dims = ctx.dims
-        nl = len(acts)
-        saved = ctx.saved_tensors
-        xs = saved[:nl]
-        off = nl
-        dy = _as_nhwc_nograd(dy)
-        if acts[-1] != "linear":
-            dy = act_backward_raw(dy, saved[off], acts[-1])
-            off += 1
-        ws = saved[off:]
-        dys = split_raw(dy)
-        part = None                     # per-tile column sums of dys when the dgrad GEMM produced them
-        grads = [None] * (2 * nl)
-        dx = None
-        main = torch.cuda.current_stream()
-        side = _side_stream(dy.device)
-        keep = []
-        for l in range(nl - 1, -1, -1):
-            wt = ws[l]
-            cout = wt.shape[0]
-            if side is not None:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None)
-                    if part is not None:
-                        db = colsum_finish_raw(part, dims[l + 1])
-                dw.record_stream(main)
-                db.record_stream(main)
-                keep.append(dys)
-                keep.append(part)
-            else:
-                dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None)
-                if part is not None:
-                    db = colsum_finish_raw(part, dims[l + 1])
-            grads[2 * l], grads[2 * l + 1] = dw, db
-            if l > 0:
-                wpt = _pack_x(wt, 1)
-                dys, part = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
-                                         out_split=True, gate=xs[l], gate_act=acts[l - 1], colsum=True)
-            elif ctx.needs_input_grad[0]:
-                wpt = _pack_x(wt, 1)
-                dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
-                                  out_split=False)
-        if side is not None:
-            main.wait_stream(side)
-        del keep
+        dx, grads = _chainx_backward(ctx, dy, ctx.needs_input_grad[0])
         return (dx, None, *grads)
+
+
+class _CatBroadcastChainX(torch.autograd.Function):
+    """``chain(cat([flat, repeat_S(prop)], 1))`` (networks.py:39-42) with the concatenation written once,
+    directly as the chain's split input (``wcmc_cat_broadcast_split``); the backward splits the chain's
+    input gradient into the per-sample half (a view) and the spp-summed half."""
+
+    @staticmethod
+    def forward(ctx, flat, prop, s, spec, *params):
+        _need_cuda(flat, prop, *params)
+        bs, c1, h, w = flat.shape
+        b, c2 = prop.shape[0], prop.shape[1]
+        assert bs == b * s and c1 % 8 == 0 and prop.shape[2:] == flat.shape[2:]
+        xs0 = _split_empty(bs, c1 + c2, h, w, flat.device)
+        check(lib().wcmc_cat_broadcast_split(*_v(flat), *_v(prop), _ptr(xs0), b, s, h, w, c1, c2, _stream()),
+              "cat_broadcast_split")
+        ctx.cat = (b, s, c1, c2)
+        return _chainx_forward(ctx, xs0, (bs, c1 + c2, h, w), spec, params)
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, s, c1, c2 = ctx.cat
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dx, grads = _chainx_backward(ctx, dy, need)
+        dflat = dprop = None
+        if need:
+            _, _, h, w = dx.shape
+            dflat = dx[:, :c1]
+            dprop = nhwc_empty(b, c2, h, w, dx.device)
+            check(lib().wcmc_spp_reduce(*_v(dx[:, c1:]), *_v(dprop), b, s, h, w, c2, 1.0, _stream()), "spp_reduce")
+        return (dflat, dprop, None, None, *grads)
 
 
 def conv_chain(x, ksize, pad, acts, params):
     fn = _ConvChainX if PRECISION == "bf16x3" else _ConvChain
     return fn.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
+
+
+def cat_broadcast_chain(flat, prop, s, ksize, pad, acts, params):
+    """``conv_chain(cat_broadcast(flat, prop, s), ...)``; fused into one autograd node on the split-bf16 path."""
+    if PRECISION == "bf16x3" and flat.shape[1] % 8 == 0:
+        return _CatBroadcastChainX.apply(as_nhwc(flat), as_nhwc(prop), s, (ksize, pad, tuple(acts)), *params)
+    return conv_chain(cat_broadcast(flat, prop, s), ksize, pad, acts, params)
 
 
 # ------------------------------------------------------------------------ kernel apply

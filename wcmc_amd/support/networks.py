@@ -47,6 +47,5 @@ class PathNet(nn.Module):
         flat = self.embedding(self._paths_nhwc(samples))            # (B*S, intermc, H, W)
         reduced = ops.spp_mean(flat, spp)                           # networks.py:36
         propagated = self.propagation(reduced)
-        flat = ops.cat_broadcast(flat, propagated, spp)             # networks.py:39-40
-        out = self.final(flat)                                      # (B*S, outc, H, W)
+        out = self.final.forward_cat_broadcast(flat, propagated, spp)   # networks.py:39-42, (B*S, outc, H, W)
         return out.unflatten(0, (bs, spp))
