@@ -119,6 +119,12 @@ int wcmc_split_bf16(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, void*
 int wcmc_cat_broadcast_split(const float* flat, int64_t fsn, int64_t fsh, int64_t fsw,
                              const float* prop, int64_t psn, int64_t psh, int64_t psw,
                              void* out_split, int B, int S, int H, int W, int C1, int C2, void* stream);
+/* split(g (B*S,C,H,W) + repeat_S(gm (B,C,H,W)) * scale): the gradient of a chain output that feeds both the
+ * concatenation and the spp mean (support/networks.py:35-40), as the split dy of the chain's backward.  Either
+ * gradient may be null. */
+int wcmc_add_broadcast_split(const float* g, int64_t gsn, int64_t gsh, int64_t gsw,
+                             const float* gm, int64_t msn, int64_t msh, int64_t msw, float scale,
+                             void* out_split, int B, int S, int H, int W, int C, void* stream);
 size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks);
 int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
                                    void* stream);

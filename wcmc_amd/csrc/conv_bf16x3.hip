@@ -94,6 +94,41 @@ __global__ void cat_broadcast_split_kernel(const float* __restrict__ flat, int64
   }
 }
 
+// ------------------------------------------------------------------ split(g + repeat_S(gm) * scale)
+// Gradient of the embedding chain's output (support/networks.py:35-40): the per-sample gradient from the
+// concatenation plus the spp-broadcast gradient of the mean, written once as the split dy of the chain's
+// backward (separately: broadcast into 268 MB, an elementwise add over 3 x 268 MB, then the split pass).
+// g may be null (only the mean path carries gradient).  One thread = 8 channels of one pixel.
+__global__ void add_broadcast_split_kernel(const float* __restrict__ g, int64_t gsn, int64_t gsh, int64_t gsw,
+                                           const float* __restrict__ gm, int64_t msn, int64_t msh, int64_t msw,
+                                           float scale, u16* __restrict__ out, int S, int H, int W, int C, int Cp,
+                                           int64_t total) {
+  const int V = Cp / 8;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % V); int64_t t = idx / V;
+    const int xx = (int)(t % W); t /= W;
+    const int y = (int)(t % H); const int n = (int)(t / H);
+    const int c0 = v * 8;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = 0.f;
+      if (c0 + e < C) {
+        if (g) a = g[n * gsn + y * gsh + xx * gsw + c0 + e];
+        if (gm) a += gm[(n / S) * msn + y * msh + xx * msw + c0 + e] * scale;
+      }
+      f[e] = a;
+    }
+    u16 hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split1(f[e], hi[e], lo[e]);
+    u16* o = out + (((int64_t)n * H + y) * W + xx) * 2 * Cp + c0;
+    *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(hi);
+    *reinterpret_cast<uint4*>(o + Cp) = *reinterpret_cast<const uint4*>(lo);
+  }
+}
+
 // K order of the packed weights: k = slab*Ks + tap*CS + cl, channel = slab*CS + cl.  The streaming
 // kernel uses one slab of all (padded) channels (CS = Kp, Ks = Kt); the halo kernel cuts the channels into
 // slabs of CS <= 64 that fit in LDS with their halo (x_plan_k below decides, from (kchan, ks) alone).
@@ -1363,6 +1398,23 @@ extern "C" int wcmc_cat_broadcast_split(const float* flat, int64_t fsn, int64_t 
                      (hipStream_t)stream, flat, fsn, fsh, fsw, prop, psn, psh, psw, (u16*)out_split, S, H, W, C1, C2, Cp,
                      total);
   return check_launch("cat_broadcast_split");
+}
+
+extern "C" int wcmc_add_broadcast_split(const float* g, int64_t gsn, int64_t gsh, int64_t gsw, const float* gm,
+                                       int64_t msn, int64_t msh, int64_t msw, float scale, void* out_split, int B,
+                                       int S, int H, int W, int C, void* stream) {
+  WCMC_REQUIRE((g || gm) && out_split && B > 0 && S > 0 && H > 0 && W > 0 && C > 0, WCMC_ERR_BAD_ARG,
+               "add_broadcast_split: bad argument");
+  WCMC_REQUIRE((!g || nhwc_view_ok(g, gsn, gsh, gsw, C)) && (!gm || nhwc_view_ok(gm, msn, msh, msw, C)) &&
+                   aligned16(out_split),
+               WCMC_ERR_ALIGNMENT, "add_broadcast_split: a view violates the NHWC-view contract");
+  const int Cp = round_up(C, 8);
+  const int64_t total = (int64_t)B * S * H * W * (Cp / 8);
+  const int64_t blocks = ceil_div64(total, 256);
+  hipLaunchKernelGGL(add_broadcast_split_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, g, gsn, gsh, gsw, gm, msn, msh, msw, scale, (u16*)out_split, S, H, W, C, Cp,
+                     total);
+  return check_launch("add_broadcast_split");
 }
 
 extern "C" size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks) {

@@ -49,6 +49,11 @@ class ConvChain(nn.Module):
         acts, params = self._acts_params()
         return ops.conv_chain(x, self.ksize, self.padding, acts, params)
 
+    def forward_spp_mean(self, x, s):
+        """``y = self(x); return y, y.view(B, s, ...).mean(1)`` (support/networks.py:33-36) as one node."""
+        acts, params = self._acts_params()
+        return ops.conv_chain_spp_mean(x, s, self.ksize, self.padding, acts, params)
+
     def forward_cat_broadcast(self, flat, prop, s):
         """``self(cat([flat, repeat_S(prop)], 1))`` (support/networks.py:39-42) without the fp32 concatenation."""
         acts, params = self._acts_params()

@@ -474,25 +474,29 @@ def _chainx_forward(ctx, xs0, dims0, spec, params):
     return y
 
 
-def _chainx_backward(ctx, dy, need_dx):
-    """Shared backward: returns (dx as an fp32 NHWC view or None, [dw0, db0, dw1, db1, ...])."""
+def _chainx_backward(ctx, dy, need_dx, dys=None):
+    """Shared backward: returns (dx as an fp32 NHWC view or None, [dw0, db0, dw1, db1, ...]).
+    dys: the output gradient already as a split tensor (linear output layers only)."""
     ks, pad, acts = ctx.spec
     dims = ctx.dims
     nl = len(acts)
     saved = ctx.saved_tensors
     xs = saved[:nl]
     off = nl
-    dy = _as_nhwc_nograd(dy)
-    if acts[-1] != "linear":
-        dy = act_backward_raw(dy, saved[off], acts[-1])
-        off += 1
+    if dys is None:
+        dy = _as_nhwc_nograd(dy)
+        if acts[-1] != "linear":
+            dy = act_backward_raw(dy, saved[off], acts[-1])
+            off += 1
+        dys = split_raw(dy)
+    else:
+        assert acts[-1] == "linear"
     ws = saved[off:]
-    dys = split_raw(dy)
     part = None                     # per-tile column sums of dys when the dgrad GEMM produced them
     grads = [None] * (2 * nl)
     dx = None
     main = torch.cuda.current_stream()
-    side = _side_stream(dy.device)
+    side = _side_stream(dys.device)
     keep = []
     for l in range(nl - 1, -1, -1):
         wt = ws[l]
@@ -541,6 +545,37 @@ class _ConvChainX(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+class _ChainSppMeanX(torch.autograd.Function):
+    """``y = chain(x); m = y.view(B,S,...).mean(1)`` (networks.py:33-36) as one node.  y feeds the concatenation
+    and m the U-Net, so y's gradient is ``g_y + repeat_S(g_m) / S``: formed once, directly as the split dy of
+    the chain's backward (``wcmc_add_broadcast_split``) instead of broadcast + add + split."""
+
+    @staticmethod
+    def forward(ctx, x, s, spec, *params):
+        _need_cuda(x, *params)
+        assert spec[2][-1] == "linear"
+        y = _chainx_forward(ctx, split_raw(x), tuple(x.shape), spec, params)
+        bs, c, h, w = y.shape
+        m = nhwc_empty(bs // s, c, h, w, y.device)
+        check(lib().wcmc_spp_reduce(*_v(y), *_v(m), bs // s, s, h, w, c, 1.0 / s, _stream()), "spp_reduce")
+        ctx.s = s
+        return y, m
+
+    @staticmethod
+    def backward(ctx, gy, gm):
+        s = ctx.s
+        bs, c, h, w = ctx.dims[-1]
+        gy = _as_nhwc_nograd(gy) if gy is not None else None
+        gm = _as_nhwc_nograd(gm) if gm is not None else None
+        dev = (gy if gy is not None else gm).device
+        dys = _split_empty(bs, c, h, w, dev)
+        z = (_ptr(None), 0, 0, 0)
+        check(lib().wcmc_add_broadcast_split(*(_v(gy) if gy is not None else z), *(_v(gm) if gm is not None else z),
+                                             1.0 / s, _ptr(dys), bs // s, s, h, w, c, _stream()), "add_broadcast_split")
+        dx, grads = _chainx_backward(ctx, None, ctx.needs_input_grad[0], dys=dys)
+        return (dx, None, None, *grads)
+
+
 class _CatBroadcastChainX(torch.autograd.Function):
     """``chain(cat([flat, repeat_S(prop)], 1))`` (networks.py:39-42) with the concatenation written once,
     directly as the chain's split input (``wcmc_cat_broadcast_split``); the backward splits the chain's
@@ -575,6 +610,14 @@ class _CatBroadcastChainX(torch.autograd.Function):
 def conv_chain(x, ksize, pad, acts, params):
     fn = _ConvChainX if PRECISION == "bf16x3" else _ConvChain
     return fn.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
+
+
+def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
+    """``y = conv_chain(x, ...); return y, spp_mean(y, s)``; one autograd node on the split-bf16 path."""
+    if PRECISION == "bf16x3" and acts[-1] == "linear":
+        return _ChainSppMeanX.apply(as_nhwc(x), s, (ksize, pad, tuple(acts)), *params)
+    y = conv_chain(x, ksize, pad, acts, params)
+    return y, spp_mean(y, s)
 
 
 def cat_broadcast_chain(flat, prop, s, ksize, pad, acts, params):

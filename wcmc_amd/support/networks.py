@@ -44,8 +44,7 @@ class PathNet(nn.Module):
 
     def forward(self, samples):
         bs, spp, nf, h, w = samples["paths"].shape
-        flat = self.embedding(self._paths_nhwc(samples))            # (B*S, intermc, H, W)
-        reduced = ops.spp_mean(flat, spp)                           # networks.py:36
+        flat, reduced = self.embedding.forward_spp_mean(self._paths_nhwc(samples), spp)   # networks.py:33-36
         propagated = self.propagation(reduced)
         out = self.final.forward_cat_broadcast(flat, propagated, spp)   # networks.py:39-42, (B*S, outc, H, W)
         return out.unflatten(0, (bs, spp))
