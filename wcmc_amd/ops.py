@@ -612,9 +612,13 @@ def conv_chain(x, ksize, pad, acts, params):
     return fn.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
 
 
+# A/B switch for the two PathNet glue fusions below (WCMC_FUSE_CHAIN_GLUE=0: separate spp-mean / concat nodes)
+FUSE_CHAIN_GLUE = os.environ.get("WCMC_FUSE_CHAIN_GLUE", "1") != "0"
+
+
 def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
     """``y = conv_chain(x, ...); return y, spp_mean(y, s)``; one autograd node on the split-bf16 path."""
-    if PRECISION == "bf16x3" and acts[-1] == "linear":
+    if FUSE_CHAIN_GLUE and PRECISION == "bf16x3" and acts[-1] == "linear":
         return _ChainSppMeanX.apply(as_nhwc(x), s, (ksize, pad, tuple(acts)), *params)
     y = conv_chain(x, ksize, pad, acts, params)
     return y, spp_mean(y, s)
@@ -622,7 +626,7 @@ def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
 
 def cat_broadcast_chain(flat, prop, s, ksize, pad, acts, params):
     """``conv_chain(cat_broadcast(flat, prop, s), ...)``; fused into one autograd node on the split-bf16 path."""
-    if PRECISION == "bf16x3" and flat.shape[1] % 8 == 0:
+    if FUSE_CHAIN_GLUE and PRECISION == "bf16x3" and flat.shape[1] % 8 == 0:
         return _CatBroadcastChainX.apply(as_nhwc(flat), as_nhwc(prop), s, (ksize, pad, tuple(acts)), *params)
     return conv_chain(cat_broadcast(flat, prop, s), ksize, pad, acts, params)
 
