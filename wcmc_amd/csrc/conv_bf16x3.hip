@@ -111,14 +111,30 @@ __global__ void add_broadcast_split_kernel(const float* __restrict__ g, int64_t 
     const int y = (int)(t % H); const int n = (int)(t / H);
     const int c0 = v * 8;
     float f[8];
+    if (c0 + 8 <= C) {                               // whole vector: two 16-byte loads per operand
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float a = 0.f;
-      if (c0 + e < C) {
-        if (g) a = g[n * gsn + y * gsh + xx * gsw + c0 + e];
-        if (gm) a += gm[(n / S) * msn + y * msh + xx * msw + c0 + e] * scale;
+      for (int e = 0; e < 8; ++e) f[e] = 0.f;
+      if (g) {
+        const float* q = g + n * gsn + y * gsh + xx * gsw + c0;
+        const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
       }
-      f[e] = a;
+      if (gm) {
+        const float* q = gm + (n / S) * msn + y * msh + xx * msw + c0;
+        const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+        f[0] += a.x * scale; f[1] += a.y * scale; f[2] += a.z * scale; f[3] += a.w * scale;
+        f[4] += b.x * scale; f[5] += b.y * scale; f[6] += b.z * scale; f[7] += b.w * scale;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = 0.f;
+        if (c0 + e < C) {
+          if (g) a = g[n * gsn + y * gsh + xx * gsw + c0 + e];
+          if (gm) a += gm[(n / S) * msn + y * msh + xx * msw + c0 + e] * scale;
+        }
+        f[e] = a;
+      }
     }
     u16 hi[8], lo[8];
 #pragma unroll
