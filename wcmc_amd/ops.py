@@ -545,6 +545,20 @@ class _ConvChainX(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+def _split_shared(x):
+    """split_raw, remembered ON the tensor object: the two PathNets embed the SAME converted ``paths`` tensor
+    (interfaces.py:195-196; PathNet._paths_nhwc keeps that object in the batch dictionary for one step), so its
+    168 MB split is made once per step.  Valid for the version and stream it was made on."""
+    tag = (x._version, torch.cuda.current_stream().cuda_stream)
+    cached = getattr(x, "_wcmc_split", None)
+    if cached is not None and cached[0] == tag:
+        return cached[1]
+    xs = split_raw(x)
+    if not x.requires_grad:
+        x._wcmc_split = (tag, xs)
+    return xs
+
+
 class _ChainSppMeanX(torch.autograd.Function):
     """``y = chain(x); m = y.view(B,S,...).mean(1)`` (networks.py:33-36) as one node.  y feeds the concatenation
     and m the U-Net, so y's gradient is ``g_y + repeat_S(g_m) / S``: formed once, directly as the split dy of
@@ -554,7 +568,7 @@ class _ChainSppMeanX(torch.autograd.Function):
     def forward(ctx, x, s, spec, *params):
         _need_cuda(x, *params)
         assert spec[2][-1] == "linear"
-        y = _chainx_forward(ctx, split_raw(x), tuple(x.shape), spec, params)
+        y = _chainx_forward(ctx, _split_shared(x), tuple(x.shape), spec, params)
         bs, c, h, w = y.shape
         m = nhwc_empty(bs // s, c, h, w, y.device)
         check(lib().wcmc_spp_reduce(*_v(y), *_v(m), bs // s, s, h, w, c, 1.0 / s, _stream()), "spp_reduce")
