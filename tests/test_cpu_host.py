@@ -223,6 +223,52 @@ def test_ref_and_pre_interfaces_host_logic_against_reference_golden(golden_dir, 
     assert (pb is None) == ("val/p_diffuse" not in d.files)
 
 
+def test_tiled_inference_stitches_every_pixel_once():
+    """Rank-4 host logic (test_models.py:49-101, datasets.py:1276-1299): with a network that returns the centre
+    crop of its input, the stitched image equals the input wherever tiles own pixels from their valid interior,
+    and replicate-padded values on the outer ring."""
+    from wcmc_amd.support import inference as inf
+    H, W, P, PAD = 192, 256, 128, 32
+    coords = inf.tile_coords(H, W, P, PAD)
+    assert len(coords) == ((H - 2 * PAD) // (P - 2 * PAD)) * ((W - 2 * PAD) // (P - 2 * PAD))
+    cover = torch.zeros(H, W)
+    for i0, j0, i1, j1, i, j in coords:
+        cover[i0:i1, j0:j1] += 1
+    assert torch.equal(cover, torch.ones(H, W))                 # a partition of the image
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(3, H, W, generator=g)
+    pbuf = torch.rand(2, 4, H, W, generator=g)
+
+    class FakeItf:
+        def to_eval_mode(self):
+            self.eval_called = True
+
+        def validate_batch(self, batch):
+            x = batch["kpcn_diffuse_buffer"]                    # (B,3,128,128) -> valid 5x5 x9 geometry: 92x92
+            return x[..., 18:110, 18:110], {"diffuse": batch["p"], "specular": batch["p"] * 2}
+
+    def loader():
+        for k in range(0, len(coords), 2):
+            cs = coords[k:k + 2]
+            batch = {"kpcn_diffuse_buffer": torch.stack([img[:, c[4]:c[4] + P, c[5]:c[5] + P] for c in cs]),
+                     "p": torch.stack([pbuf[:, :, c[4]:c[4] + P, c[5]:c[5] + P] for c in cs])}
+            yield (batch, *[torch.tensor([c[q] for c in cs]) for q in range(6)])
+
+    itf = FakeItf()
+    rad, path = inf.inference(itf, loader(), H, W, P)
+    assert itf.eval_called
+    inner = (slice(None), slice(18, H - 18), slice(18, W - 18))
+    assert torch.equal(rad[inner], img[inner])                  # interior pixels come straight from the network
+    assert torch.equal(rad[:, 0, 40], img[:, 18, 40])           # outer ring: replicate padding of the 92x92 output
+    assert torch.equal(path["diffuse"], pbuf) and torch.equal(path["specular"], pbuf * 2)
+    hit = (torch.rand(H, W, 1, generator=g) > 0.3).float()
+    noisy = torch.rand(H, W, 3, generator=g)
+    comp = inf.crop_and_composite(rad.permute(1, 2, 0), noisy, hit)
+    assert comp.shape == (H - 56, W - 56, 3)
+    want = torch.where(hit[28:-28, 28:-28] == 0, noisy[28:-28, 28:-28], rad.permute(1, 2, 0)[28:-28, 28:-28])
+    assert torch.equal(comp, want)
+
+
 def test_interface_asserts_like_reference():
     from wcmc_amd.support.interfaces import KPCNInterface
     lf = {"l_recon": None, "l_test": None}
