@@ -431,7 +431,7 @@ class packed_weights:
     def __enter__(self):
         global _PACKED
         self.prev = _PACKED
-        if PRECISION != "bf16x3" or os.environ.get("WCMC_PACK_BATCHED", "1") == "0":     # (A/B switch)
+        if PRECISION != "bf16x3":
             return self
         table = {}
         for m in self.models:
