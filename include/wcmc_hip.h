@@ -128,11 +128,6 @@ int wcmc_add_broadcast_split(const float* g, int64_t gsn, int64_t gsh, int64_t g
 size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks);
 int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
                                    void* stream);
-/* The same for many layers in one launch: an array of opaque jobs (wcmc_conv2d_pack_job_bytes() each), filled on
- * the host by wcmc_conv2d_pack_job_fill and copied to the device by the caller; wp as for the single form. */
-size_t wcmc_conv2d_pack_job_bytes(void);
-int wcmc_conv2d_pack_job_fill(void* job_host, const float* w, void* wp, int Cout, int Cin, int ks, int mode);
-int wcmc_conv2d_pack_weights_bf16x3(const void* jobs_device, int njobs, void* stream);
 /* Exactly one of y (fp32 NHWC view) and y_split (dense split tensor) receives the result.
  * gate_split (optional, geometry of the output, requires y_split): fused activation-derivative
  * mask evaluated from the hi plane of the post-activation tensor. */

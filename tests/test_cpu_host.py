@@ -101,16 +101,6 @@ class _OracleOps:
     def fork_all_streams(device):
         pass
 
-    class packed_weights:                # the batched weight packing is GPU-only
-        def __init__(self, models):
-            pass
-
-        def __enter__(self):
-            return self
-
-        def __exit__(self, *exc):
-            return False
-
     class on_branch:                     # stream fork/join is a no-op on the host
         def __init__(self, device):
             pass

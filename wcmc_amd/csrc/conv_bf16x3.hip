@@ -168,32 +168,6 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __res
   wp[((int64_t)n * 2 + 1) * Kt + k] = lo;
 }
 
-// All conv weights of a model in one launch (both orientations): the per-layer form above is ~4 us of launch
-// per call, 114 calls in the serial chain of a KPCN-Manifold step.  One descriptor per (layer, mode), grid.y
-// picks the descriptor, grid.x strides over its elements.
-struct XPackJob { const float* w; u16* wp; int Cout, Cin, ks, mode, rows, Np, CS, Ks, Kt, pad_; };
-__global__ void pack_weight_split_batched_kernel(const XPackJob* __restrict__ jobs) {
-  const XPackJob j = jobs[blockIdx.y];
-  const int taps = j.ks * j.ks;
-  const int kchan = j.mode == 0 ? j.Cin : j.Cout;
-  const int64_t total = (int64_t)j.Np * j.Kt;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int n = (int)(idx / j.Kt), k = (int)(idx - (int64_t)n * j.Kt);
-    const int slab = k / j.Ks, kk = k - slab * j.Ks;
-    const int tap = kk / j.CS, c = slab * j.CS + (kk - tap * j.CS);
-    float v = 0.f;
-    if (n < j.rows && tap < taps && c < kchan) {
-      if (j.mode == 0) v = j.w[((int64_t)n * j.Cin + c) * taps + tap];
-      else             v = j.w[((int64_t)c * j.Cin + n) * taps + (taps - 1 - tap)];
-    }
-    u16 hi, lo;
-    split1(v, hi, lo);
-    j.wp[((int64_t)n * 2) * j.Kt + k] = hi;
-    j.wp[((int64_t)n * 2 + 1) * j.Kt + k] = lo;
-  }
-}
-
 struct XKPlan { bool halo; int Kp, CS, nslabs, Ks, Kt, PXS; };
 static XKPlan x_plan_k(int kchan, int ks) {
   static int enable = -1;
@@ -1457,27 +1431,6 @@ extern "C" int wcmc_add_broadcast_split(const float* g, int64_t gsn, int64_t gsh
                      (hipStream_t)stream, g, gsn, gsh, gsw, gm, msn, msh, msw, scale, (u16*)out_split, S, H, W, C, Cp,
                      total);
   return check_launch("add_broadcast_split");
-}
-
-extern "C" size_t wcmc_conv2d_pack_job_bytes(void) { return sizeof(XPackJob); }
-
-extern "C" int wcmc_conv2d_pack_job_fill(void* job_host, const float* w, void* wp, int Cout, int Cin, int ks, int mode) {
-  WCMC_REQUIRE(job_host && w && wp && Cout > 0 && Cin > 0 && ks > 0 && (mode == 0 || mode == 1), WCMC_ERR_BAD_ARG,
-               "conv2d_pack_job_fill: bad argument");
-  const int rows = mode == 0 ? Cout : Cin, kchan = mode == 0 ? Cin : Cout;
-  const XKPlan q = x_plan_k(kchan, ks);
-  XPackJob j;
-  j.w = w; j.wp = (u16*)wp; j.Cout = Cout; j.Cin = Cin; j.ks = ks; j.mode = mode; j.rows = rows;
-  j.Np = round_up(rows, 16); j.CS = q.CS; j.Ks = q.Ks; j.Kt = q.Kt; j.pad_ = 0;
-  *reinterpret_cast<XPackJob*>(job_host) = j;
-  return 0;
-}
-
-extern "C" int wcmc_conv2d_pack_weights_bf16x3(const void* jobs_device, int njobs, void* stream) {
-  WCMC_REQUIRE(jobs_device && njobs > 0 && njobs <= 65535, WCMC_ERR_BAD_ARG, "conv2d_pack_weights_bf16x3: bad argument");
-  hipLaunchKernelGGL(pack_weight_split_batched_kernel, dim3(64, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream,
-                     (const XPackJob*)jobs_device);
-  return check_launch("conv2d_pack_weights_bf16x3");
 }
 
 extern "C" size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks) {

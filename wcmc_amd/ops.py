@@ -370,14 +370,7 @@ def unsplit_debug(t, n, c, h, w):
     return (v[:, :, :, 0] + v[:, :, :, 1])[..., :c].permute(0, 3, 1, 2)
 
 
-_PACKED = None          # data_ptr of a conv weight -> (wp forward, wp transposed); only inside packed_weights()
-
-
 def _pack_x(weight, mode):
-    if _PACKED is not None:
-        hit = _PACKED.get(weight.data_ptr())
-        if hit is not None:
-            return hit[mode]
     cout, cin, ks, _ = weight.shape
     rows, kch = (cout, cin) if mode == 0 else (cin, cout)
     wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks), device=weight.device, dtype=torch.int16)
@@ -387,65 +380,6 @@ def _pack_x(weight, mode):
     check(lib().wcmc_conv2d_pack_weight_bf16x3(_ptr(w), _ptr(wp), cout, cin, ks, mode, _stream()),
           "pack_weight_bf16x3")
     return wp
-
-
-class packed_weights:
-    """``with packed_weights(models): step`` -- every conv weight of the models is packed for the split-bf16 GEMMs
-    (both orientations) by ONE launch per model at the top of the step instead of one ~4 us launch per layer and
-    orientation inside the serial chain (114 per KPCN-Manifold step).  The packs are valid only inside the scope:
-    the weights must not change in it (they do not between a step's forward and its backward)."""
-
-    _plans = {}
-
-    def __init__(self, models):
-        self.models = list(models)
-
-    @staticmethod
-    def _plan(model):
-        convs = [m.weight for m in model.modules()
-                 if isinstance(m, torch.nn.Conv2d) and m.weight.is_cuda and m.weight.shape[2] == m.weight.shape[3]]
-        key = tuple(w.data_ptr() for w in convs)
-        plan = packed_weights._plans.get(id(model))
-        if plan is not None and plan[0] == key:
-            return plan
-        sz = lib().wcmc_conv2d_pack_job_bytes()
-        host = (ctypes.c_ubyte * (sz * 2 * len(convs)))()
-        base = ctypes.addressof(host)
-        table = {}
-        for i, w in enumerate(convs):
-            cout, cin, ks, _ = w.shape
-            assert w.is_contiguous()
-            wps = []
-            for mode in (0, 1):
-                rows, kch = (cout, cin) if mode == 0 else (cin, cout)
-                wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks), device=w.device, dtype=torch.int16)
-                check(lib().wcmc_conv2d_pack_job_fill(ctypes.c_void_p(base + (2 * i + mode) * sz), _ptr(w), _ptr(wp),
-                                                      cout, cin, ks, mode), "pack_job_fill")
-                wps.append(wp)
-            table[w.data_ptr()] = tuple(wps)
-        jobs = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(convs[0].device) if convs else None
-        plan = (key, jobs, 2 * len(convs), table)
-        packed_weights._plans[id(model)] = plan
-        return plan
-
-    def __enter__(self):
-        global _PACKED
-        self.prev = _PACKED
-        if PRECISION != "bf16x3":
-            return self
-        table = {}
-        for m in self.models:
-            key, jobs, n, t = self._plan(m)
-            if n:
-                check(lib().wcmc_conv2d_pack_weights_bf16x3(_ptr(jobs), n, _stream()), "pack_weights_bf16x3")
-                table.update(t)
-        _PACKED = table
-        return self
-
-    def __exit__(self, *exc):
-        global _PACKED
-        _PACKED = self.prev
-        return False
 
 
 def _igemm_class(cin, cout, ks):

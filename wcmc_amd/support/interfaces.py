@@ -171,10 +171,6 @@ class KPCNInterface(BaseInterface):
     def _forward_backward(self, batch):
         """Everything of ``train_batch`` up to (not including) ``_logging``: no host sync inside, so
         ``wcmc_amd.graph.GraphedTrainStep`` can capture it into one hipGraph."""
-        with _ops.packed_weights(self.models.values()):      # all conv weights packed once per step
-            return self._forward_backward_packed(batch)
-
-    def _forward_backward_packed(self, batch):
         out_manif = None
         dev = batch['kpcn_diffuse_in'].device
         _ops.fork_all_streams(dev)
@@ -373,7 +369,7 @@ class KPCNRefInterface(KPCNInterface):
         new_batch['kpcn_specular_in'] = torch.cat([batch['kpcn_specular_in'], batch['target_specular']], 1)
         return new_batch
 
-    def _forward_backward_packed(self, batch):
+    def _forward_backward(self, batch):
         dev = batch['kpcn_diffuse_in'].device
         _ops.fork_all_streams(dev)
         batch = self._with_targets(batch)
@@ -418,7 +414,7 @@ class KPCNPreInterface(KPCNInterface):
             assert 'optim_' + model_name in self.optims, \
                 '`optim_%s`: an optimization algorithm is not defined.' % (model_name)
 
-    def _forward_backward_packed(self, batch):
+    def _forward_backward(self, batch):
         dev = batch['kpcn_diffuse_in'].device
         _ops.fork_all_streams(dev)
         self.models['backbone_diffuse'].zero_grad()
