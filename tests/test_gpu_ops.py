@@ -289,6 +289,37 @@ def test_spp_mean_and_cat_broadcast():
     assert_close(pd.grad, pr.grad, tol=1e-6, what="d prop")
 
 
+@pytest.mark.parametrize("geom", [(2, 3, 8, 5, 6, 10), (1, 1, 16, 12, 7, 9), (2, 4, 64, 64, 9, 33)])
+def test_fused_chain_glue_matches_the_separate_ops(geom):
+    """The PathNet glue fusions (embedding chain + spp mean as one node, concatenation written as the final chain's
+    split input) against the separate autograd ops they replace: same outputs, same parameter and input gradients
+    up to the bf16x2 split of the fused gradient (2^-17 relative per element)."""
+    o = ops()
+    if o.PRECISION != "bf16x3":
+        pytest.skip("fusions exist on the split-bf16 path only")
+    b, s, c1, c2, h, w = geom
+    x = gen(b * s, 20, h, w, seed=60)
+    prop_in = gen(b, c2, h, w, seed=61)
+    w1, b1 = gen(c1, 20, 1, 1, seed=62, scale=0.3), gen(c1, seed=63, scale=0.1)
+    w2, b2 = gen(5, c1 + c2, 1, 1, seed=64, scale=0.2), gen(5, seed=65, scale=0.1)
+    g_out, g_mean = gen(b * s, 5, h, w, seed=66), gen(b, c1, h, w, seed=67)
+    res = []
+    for fused in (False, True):
+        o.FUSE_CHAIN_GLUE = fused
+        try:
+            ts = [t.to(DEV).requires_grad_(True) for t in (x, prop_in, w1, b1, w2, b2)]
+            xd, pd, w1d, b1d, w2d, b2d = ts
+            flat, mean = o.conv_chain_spp_mean(xd, s, 1, 0, ["linear"], [w1d, b1d])
+            out = o.cat_broadcast_chain(flat, pd, s, 1, 0, ["relu"], [w2d, b2d])
+            ((out * g_out.to(DEV)).sum() + (mean * g_mean.to(DEV)).sum()).backward()
+            res.append([out.detach(), mean.detach()] + [t.grad for t in ts])
+        finally:
+            o.FUSE_CHAIN_GLUE = True
+    names = ["final out", "spp mean", "d x", "d prop", "d w1", "d b1", "d w2", "d b2"]
+    for a, bb, nm in zip(res[0], res[1], names):
+        assert_close(bb, a, tol=2e-5, what="fused vs separate: " + nm)
+
+
 @pytest.mark.parametrize("cp", [3, 2, 6])
 def test_pbuffer_cat(cp):
     o = ops()
