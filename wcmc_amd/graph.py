@@ -8,8 +8,6 @@ Python -- as long as the MI355X needs to run them -- so the step is captured onc
 talks to the host or other ranks: drawing the FeatureMSE pairings, the non-finite-loss check
 (``interfaces.py:254-257``), loss bookkeeping, the RCCL gradient all-reduce and the fused clip + Adam.
 """
-import os
-
 import torch
 
 from . import ops
@@ -23,7 +21,6 @@ class GraphedTrainStep:
         self.static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
         self.keys = list(self.static)                     # (PathNet stashes a converted copy of `paths` in the dict)
         self.fm = itf.loss_funcs.get('l_manif') if itf.manif_learn and itf.train_branches else None
-        self._ahead, self._draw_stream = None, None
         dev = next(iter(self.static.values())).device
         cur = torch.cuda.current_stream()
         s = torch.cuda.Stream(device=dev)
@@ -56,39 +53,12 @@ class GraphedTrainStep:
             itf.fused_optim.leave_grads = False           # .grad must keep pointing at the captured buffers
 
     def _draw(self):
-        """Fresh pairings, in the reference's call order (diffuse: patch, batch; specular: patch, batch).
-
-        rng='cpu' (the reference's generator stream): drawn on the host, now.  rng='device': the four sorts behind
-        ``torch.randperm`` cost ~0.5 ms of GPU time, so the pairings of step t+1 are drawn on a second stream while
-        the graph of step t runs, and only copied (17 MB) into the captured buffers at the top of step t+1."""
-        if self.fm.rng != 'device' or os.environ.get("WCMC_PERM_AHEAD", "1") == "0":      # (env: A/B switch)
-            dev = self.perms[0][0].device if self.fm.rng == 'device' else None
-            for ip, ib in self.perms:
-                ip.copy_(torch.randperm(self.perm_sizes[0], device=dev), non_blocking=True)
-                if ib is not None:
-                    ib.copy_(torch.randperm(self.perm_sizes[1], device=dev), non_blocking=True)
-            return
-        main = torch.cuda.current_stream()
-        if self._ahead is None:                           # first step: nothing drawn ahead yet
-            self._ahead = [(torch.empty_like(ip), torch.empty_like(ib) if ib is not None else None)
-                           for ip, ib in self.perms]
-            self._draw_stream = torch.cuda.Stream(device=self.perms[0][0].device)
-            self._prefetch(main)
-        main.wait_stream(self._draw_stream)
-        for (ip, ib), (np_, nb) in zip(self.perms, self._ahead):
-            ip.copy_(np_, non_blocking=True)
+        """Fresh pairings, in the reference's call order (diffuse: patch, batch; specular: patch, batch)."""
+        dev = self.perms[0][0].device if self.fm.rng == 'device' else None
+        for ip, ib in self.perms:
+            ip.copy_(torch.randperm(self.perm_sizes[0], device=dev), non_blocking=True)
             if ib is not None:
-                ib.copy_(nb, non_blocking=True)
-        self._prefetch(main)
-
-    def _prefetch(self, main):
-        dev = self.perms[0][0].device
-        self._draw_stream.wait_stream(main)               # the copies out of the look-ahead buffers are ordered first
-        with torch.cuda.stream(self._draw_stream):
-            for np_, nb in self._ahead:
-                torch.randperm(self.perm_sizes[0], device=dev, out=np_)
-                if nb is not None:
-                    torch.randperm(self.perm_sizes[1], device=dev, out=nb)
+                ib.copy_(torch.randperm(self.perm_sizes[1], device=dev), non_blocking=True)
 
     def __call__(self, batch):
         itf = self.itf
