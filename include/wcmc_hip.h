@@ -130,13 +130,16 @@ int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int 
                                    void* stream);
 /* Exactly one of y (fp32 NHWC view) and y_split (dense split tensor) receives the result.
  * gate_split (optional, geometry of the output, requires y_split): fused activation-derivative
- * mask evaluated from the hi plane of the post-activation tensor. */
+ * mask evaluated from the hi plane of the post-activation tensor.
+ * mask_out (optional, with y_split): uint8 [N*Ho*Wo][round_up(Cout,8)/8], bit c%8 of byte c/8 = (hi plane of
+ * output channel c > 0) -- the same predicate at 1/16 of the bytes; gate_mask (optional, instead of gate_split):
+ * such a mask of a tensor with the output's geometry. */
 int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              const void* wp, const float* bias,
                              float* y, int64_t ysn, int64_t ysh, int64_t ysw, void* y_split, int Cout,
                              int ks, int pad, int act, float slope,
                              const void* gate_split, int gate_act, float gate_slope,
-                             float* colsum_partial, void* stream);
+                             float* colsum_partial, const void* gate_mask, void* mask_out, void* stream);
 /* colsum_partial (optional, with y_split): [wcmc_conv2d_igemm_colsum_elems] floats that receive the
  * per-pixel-tile column sums of the result -- the bias gradient of the layer that consumes this
  * data gradient, finished by wcmc_colsum_finish (saves a pass over dy per layer). */

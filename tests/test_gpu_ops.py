@@ -161,6 +161,34 @@ def test_conv_wgrad_is_bitwise_reproducible():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("case", [(2, 100, 40, 37, 100, 5, 0), (3, 36, 9, 10, 64, 1, 0), (2, 64, 16, 16, 128, 3, 1)])
+def test_gate_from_bit_mask_equals_gate_from_tensor(case):
+    """The data-gradient GEMM gated by the (hi > 0) bit mask of the forward launch == gated by the activation
+    tensor itself, bit for bit (halo and streaming kernels, relu and leaky_relu)."""
+    o = ops()
+    n, cin, h, w, cout, ks, pad = case
+    ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+    xs = o.split_raw(o.to_nhwc_raw(gen(n, cin, h, w, seed=70).to(DEV)))
+    wt = gen(cout, cin, ks, ks, seed=71, scale=0.1).to(DEV)
+    b = gen(cout, seed=72, scale=0.3).to(DEV)
+    y, mask = o.conv2d_x_raw(xs, (n, cin, h, w), o._pack_x(wt, 0), b, cout, ks, pad, "relu", out_split=True, mask_out=True)
+    yd = o.unsplit_debug(y, n, cout, ho, wo)
+    bits = torch.from_numpy(np.unpackbits(mask.cpu().numpy().reshape(n * ho * wo, -1), axis=1, bitorder="little"))
+    want = (o.unsplit_debug(y, n, cout, ho, wo).permute(0, 2, 3, 1).reshape(n * ho * wo, cout) > 0).cpu()
+    # (a value whose hi plane rounds to zero is positive only through its lo plane: not produced by these inputs)
+    assert torch.equal(bits[:, :cout].bool(), want) and float((yd > 0).float().mean()) > 0.2
+    dys = o.split_raw(o.to_nhwc_raw(gen(n, 48, ho, wo, seed=73).to(DEV)))
+    w2t = o._pack_x(gen(48, cout, ks, ks, seed=74, scale=0.1).to(DEV), 1)
+    for act in ("relu", "leaky_relu"):
+        a = o.conv2d_x_raw(dys, (n, 48, ho, wo), w2t, None, cout, ks, ks - 1 - pad, "linear", out_split=True,
+                           gate=y, gate_act=act) if pad == ks // 2 or ks == 1 else None
+        if a is None:      # valid (unpadded) forward: the data gradient of the NEXT layer has y's geometry only when
+            continue       # that layer is "same"-padded or 1x1; the 5x5 valid case is covered through the chains
+        bb = o.conv2d_x_raw(dys, (n, 48, ho, wo), w2t, None, cout, ks, ks - 1 - pad, "linear", out_split=True,
+                            gate_mask=mask, gate_act=act)
+        assert torch.equal(a, bb), act
+
+
 def test_dma_fed_gemms_repeat_bitwise_at_benchmark_size():
     """Race screen for the LDS-DMA staged kernels (halo igemm weight stages, filter-row wgrad stages): their
     LDS hand-offs are ordered by counted waits + barriers, and a read that beats its DMA shows up as a

@@ -209,6 +209,18 @@ constexpr unsigned XOOB = 0x80000000u;   // byte offset beyond any buffer (num_r
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// bit e = (bf16 number e of the vector is > 0): the activation-derivative predicate of act_gate on a hi plane
+__device__ __forceinline__ unsigned char positive_mask8(const u32x4 v) {
+  unsigned m = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned lo = v[e] & 0xffffu, hi = v[e] >> 16;
+    m |= (unsigned)((lo & 0x8000u) == 0 && (lo & 0x7fffu) != 0) << (2 * e);
+    m |= (unsigned)((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0) << (2 * e + 1);
+  }
+  return (unsigned char)m;
+}
+
 struct XIgemmParams {
   const u16* x; int N, H, W, Cin, Cpi;
   const u16* wp; const float* bias;
@@ -216,6 +228,8 @@ struct XIgemmParams {
   u16* ys; int Cpo;                       // split dense output (or null)
   int Ho, Wo, Cout;
   const u16* gate; int gate_act; float gate_slope;   // split dense, geometry of y
+  const unsigned char* gate_mask;         // alternative to gate: 1 bit per element, [pixel][Cpo/8] (what mask_out wrote)
+  unsigned char* mask_out;                // optional with ys: bit = (hi plane of the result > 0), [pixel][Cpo/8]
   int ks, pad, act; float slope;
   int Kp, Kt, Np;
   int64_t M;
@@ -469,6 +483,13 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= act_gate(bf2f(g[e]), p.gate_act, p.gate_slope);
         }
+        else if (p.gate_mask && m < p.M && co < p.Cpo && p.gate_act != WCMC_ACT_LINEAR) {
+          // the same predicate (hi plane > 0) from the bit mask the producing launch left: 1/16 of the bytes
+          const unsigned bits = (unsigned)p.gate_mask[m * (p.Cpo >> 3) + (co >> 3)] >> (co & 7);
+          const float off = p.gate_act == WCMC_ACT_LEAKY_RELU ? p.gate_slope : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : off;
+        }
         u16 hi[4], lo[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split1(v[e], hi[e], lo[e]);
@@ -485,9 +506,11 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
       const int plane = q >= VPP, vec = q - plane * VPP;
       const int64_t m = m0 + pr;
       const int co = n0 + vec * 8;
-      if (m < p.M && co < p.Cpo)
-        *reinterpret_cast<u32x4*>(p.ys + (int64_t)m * 2 * p.Cpo + plane * p.Cpo + co) =
-            *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+      if (m < p.M && co < p.Cpo) {
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+        *reinterpret_cast<u32x4*>(p.ys + (int64_t)m * 2 * p.Cpo + plane * p.Cpo + co) = hv;
+        if (p.mask_out && plane == 0) p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
+      }
     }
     if (!(DBG & 64) && p.colsum && tid < BN) {
       // bias gradient of the consumer layer for free: column sums of this tile (hi + lo) while it is in LDS
@@ -776,6 +799,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= act_gate(bf2f(g[e]), p.gate_act, p.gate_slope);
         }
+        else if (p.gate_mask && ok && co < p.Cpo && p.gate_act != WCMC_ACT_LINEAR) {
+          // the same predicate (hi plane > 0) from the bit mask the producing launch left: 1/16 of the bytes
+          const unsigned bits = (unsigned)p.gate_mask[m * (p.Cpo >> 3) + (co >> 3)] >> (co & 7);
+          const float off = p.gate_act == WCMC_ACT_LEAKY_RELU ? p.gate_slope : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : off;
+        }
         u16 hi[4], lo[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split1(v[e], hi[e], lo[e]);
@@ -794,8 +824,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
       int oy, ox;
       if (pix_of(pr, oy, ox) && co < p.Cpo) {
         const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
-        *reinterpret_cast<u32x4*>(p.ys + m * 2 * p.Cpo + plane * p.Cpo + co) =
-            *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+        *reinterpret_cast<u32x4*>(p.ys + m * 2 * p.Cpo + plane * p.Cpo + co) = hv;
+        if (p.mask_out && plane == 0) p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
       }
     }
     if (!(DBG & 64) && p.colsum && tid < BN) {
@@ -1540,7 +1571,8 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
                                         const float* bias, float* y, int64_t ysn, int64_t ysh, int64_t ysw,
                                         void* y_split, int Cout, int ks, int pad, int act, float slope,
                                         const void* gate_split, int gate_act, float gate_slope,
-                                        float* colsum_partial, void* stream) {
+                                        float* colsum_partial, const void* gate_mask, void* mask_out,
+                                        void* stream) {
   WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ks > 0 && pad >= 0 && x_split && wp,
                WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: bad argument");
   WCMC_REQUIRE(!colsum_partial || y_split, WCMC_ERR_BAD_ARG,
@@ -1554,8 +1586,9 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
                WCMC_ERR_ALIGNMENT, "conv2d_igemm_bf16x3: split buffers must be 16-byte aligned");
   WCMC_REQUIRE(!y || nhwc_view_ok(y, ysn, ysh, ysw, Cout), WCMC_ERR_ALIGNMENT,
                "conv2d_igemm_bf16x3: y violates the NHWC-view contract");
-  WCMC_REQUIRE(!gate_split || y_split, WCMC_ERR_BAD_ARG,
-               "conv2d_igemm_bf16x3: a gate requires the split output geometry");
+  WCMC_REQUIRE((!gate_split && !gate_mask && !mask_out) || y_split, WCMC_ERR_BAD_ARG,
+               "conv2d_igemm_bf16x3: a gate / a mask requires the split output geometry");
+  WCMC_REQUIRE(!(gate_split && gate_mask), WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: gate_split and gate_mask are exclusive");
   XIgemmParams p;
   p.x = (const u16*)x_split; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cpi = round_up(Cin, 8);
   p.wp = (const u16*)wp; p.bias = bias;
@@ -1563,6 +1596,7 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   p.ys = (u16*)y_split; p.Cpo = y_split ? round_up(Cout, 8) : round_up(Cout, 4);
   p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.gate = (const u16*)gate_split; p.gate_act = gate_act; p.gate_slope = gate_slope;
+  p.gate_mask = (const unsigned char*)gate_mask; p.mask_out = (unsigned char*)mask_out;
   p.ks = ks; p.pad = pad; p.act = act; p.slope = slope;
   const XKPlan q = x_plan_k(Cin, ks);
   p.Kp = p.Cpi; p.Kt = q.Kt; p.Np = round_up(Cout, 16);

@@ -396,10 +396,13 @@ def _wgrad_class(n, ho, cin, cout, ks):
     return "conv_wgrad_rows" if rows else "conv_wgrad"
 
 
-def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, gate_act="linear", colsum=False):
+def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, gate_act="linear", colsum=False,
+                 gate_mask=None, mask_out=False):
     """One split-bf16 implicit-GEMM launch.  xs: split tensor of dims (n,cin,h,w).
     Returns a split tensor when out_split else an fp32 NHWC view; with colsum=True also the per-tile
-    column sums of the result (the consumer layer's bias gradient, see colsum_finish_raw)."""
+    column sums of the result (the consumer layer's bias gradient, see colsum_finish_raw); with mask_out=True
+    also the (hi plane > 0) bit mask of the result, which a later launch can take as gate_mask instead of
+    re-reading the tensor as gate."""
     n, cin, h, w = dims
     ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
     dev = xs.device
@@ -412,12 +415,16 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     part = None
     if colsum:
         part = torch.empty(lib().wcmc_conv2d_igemm_colsum_elems(n, ho, wo, cout), device=dev, dtype=torch.float32)
+    mask = None
+    if mask_out:
+        mask = torch.empty(n * ho * wo * ((cout + 7) // 8), device=dev, dtype=torch.uint8)
     with _Timed(_igemm_class(cin, cout, ks), 2.0 * n * pix * cout * cin * ks * ks, "flop"):
         check(lib().wcmc_conv2d_igemm_bf16x3(_ptr(xs), n, h, w, cin, _ptr(wp), _ptr(bias), *yv, _ptr(ysp), cout,
                                              ks, pad, ACT[act], LEAKY_SLOPE, _ptr(gate), ACT[gate_act], LEAKY_SLOPE,
-                                             _ptr(part), _stream()), "conv2d_igemm_bf16x3")
+                                             _ptr(part), _ptr(gate_mask), _ptr(mask), _stream()), "conv2d_igemm_bf16x3")
     out = ysp if out_split else yf
-    return (out, part) if colsum else out
+    ret = (out,) + ((part,) if colsum else ()) + ((mask,) if mask_out else ())
+    return ret if len(ret) > 1 else out
 
 
 def colsum_finish_raw(part, dims):
@@ -445,6 +452,11 @@ def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=Tr
     return dw, db
 
 
+# The data gradient's activation gate from the 1-bit mask the forward launch left (1/16 of the bytes of re-reading
+# the activation's hi plane; the predicate is the same, so results are bit-identical).  WCMC_GATE_MASK=0: A/B switch.
+USE_GATE_MASK = os.environ.get("WCMC_GATE_MASK", "1") != "0"
+
+
 def _chainx_forward(ctx, xs0, dims0, spec, params):
     """Shared forward of the split-bf16 chains: xs0 is the chain input as a split tensor of dims0."""
     ks, pad, acts = spec
@@ -452,21 +464,24 @@ def _chainx_forward(ctx, xs0, dims0, spec, params):
     n = dims0[0]
     dims = [dims0]
     xs = [xs0]
+    masks = []
     y = None
     for l in range(nl):
         wt, b = params[2 * l], params[2 * l + 1]
         cout = wt.shape[0]
         wp = _pack_x(wt, 0)
-        out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=(l < nl - 1))
+        hidden = l < nl - 1
+        out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=hidden, mask_out=hidden)
         hh, ww = dims[l][2] + 2 * pad - ks + 1, dims[l][3] + 2 * pad - ks + 1
         dims.append((n, cout, hh, ww))
-        if l < nl - 1:
-            xs.append(out)
+        if hidden:
+            xs.append(out[0])
+            masks.append(out[1])       # (hi > 0) bits of the hidden activation: the data gradient's ReLU gate
         else:
             y = out
     ctx.spec, ctx.dims = spec, dims
     keep_y = [y] if acts[-1] != "linear" else []
-    ctx.save_for_backward(*xs, *keep_y, *[params[2 * l] for l in range(nl)])
+    ctx.save_for_backward(*xs, *masks, *keep_y, *[params[2 * l] for l in range(nl)])
     if DEBUG_ACTS is not None:
         DEBUG_ACTS.extend(unsplit_debug(xs[l + 1], *dims[l + 1]) for l in range(nl - 1))
         if acts[-1] != "linear":
@@ -482,7 +497,8 @@ def _chainx_backward(ctx, dy, need_dx, dys=None):
     nl = len(acts)
     saved = ctx.saved_tensors
     xs = saved[:nl]
-    off = nl
+    masks = saved[nl:2 * nl - 1]
+    off = 2 * nl - 1
     if dys is None:
         dy = _as_nhwc_nograd(dy)
         if acts[-1] != "linear":
@@ -518,8 +534,9 @@ def _chainx_backward(ctx, dy, need_dx, dys=None):
         grads[2 * l], grads[2 * l + 1] = dw, db
         if l > 0:
             wpt = _pack_x(wt, 1)
+            g = dict(gate_mask=masks[l - 1]) if USE_GATE_MASK else dict(gate=xs[l])
             dys, part = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
-                                     out_split=True, gate=xs[l], gate_act=acts[l - 1], colsum=True)
+                                     out_split=True, gate_act=acts[l - 1], colsum=True, **g)
         elif need_dx:
             wpt = _pack_x(wt, 1)
             dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
