@@ -79,7 +79,8 @@ class _Level(nn.Module):
         if self.is_last:
             return left
         deeper = self.next_level(ops.maxpool2(left))
-        return self.right(ops.cat_channels(ops.upsample2(deeper), left))
+        # cat([upsampled, skip], 1) is written once, directly as the right chain's split input (S = 1 "broadcast")
+        return self.right.forward_cat_broadcast(ops.upsample2(deeper), left, 1)
 
 
 class Autoencoder(nn.Module):

@@ -633,8 +633,11 @@ class _CatBroadcastChainX(torch.autograd.Function):
         if need:
             _, _, h, w = dx.shape
             dflat = dx[:, :c1]
-            dprop = nhwc_empty(b, c2, h, w, dx.device)
-            check(lib().wcmc_spp_reduce(*_v(dx[:, c1:]), *_v(dprop), b, s, h, w, c2, 1.0, _stream()), "spp_reduce")
+            if s == 1:                               # plain concatenation: both halves are views
+                dprop = dx[:, c1:]
+            else:
+                dprop = nhwc_empty(b, c2, h, w, dx.device)
+                check(lib().wcmc_spp_reduce(*_v(dx[:, c1:]), *_v(dprop), b, s, h, w, c2, 1.0, _stream()), "spp_reduce")
         return (dflat, dprop, None, None, *grads)
 
 
