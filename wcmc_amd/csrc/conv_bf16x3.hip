@@ -512,14 +512,22 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
         if (p.mask_out && plane == 0) p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
       }
     }
-    if (!(DBG & 64) && p.colsum && tid < BN) {
-      // bias gradient of the consumer layer for free: column sums of this tile (hi + lo) while it is in LDS
+    if (!(DBG & 64) && p.colsum) {
+      // bias gradient of the consumer layer for free: column sums of this tile (hi + lo) while it is in LDS;
+      // RG row groups per column, combined through LDS in a fixed order
+      constexpr int CW = BN <= 16 ? 16 : BN <= 32 ? 32 : BN <= 64 ? 64 : 128, RG = 256 / CW;
+      float* red = reinterpret_cast<float*>(so + XBM * OLD);
+      const int c = tid % CW, rg = tid / CW;
       const int rows = (int)min((int64_t)XBM, p.M - m0);
-      float acc = 0.f;
-      for (int r = 0; r < rows; ++r) acc += bf2f(so[r * OLD + tid]) + bf2f(so[r * OLD + BN + tid]);
-      if (n0 + tid < p.Np) {
-        p.colsum[(int64_t)tile * p.Np + n0 + tid] = acc;
-        for (int r = (int)gridDim.x + tile; r < p.G; r += (int)gridDim.x) p.colsum[(int64_t)r * p.Np + n0 + tid] = 0.f;
+      float a = 0.f;
+      if (c < BN)
+        for (int r = rg; r < rows; r += RG) a += bf2f(so[r * OLD + c]) + bf2f(so[r * OLD + BN + c]);
+      if (rg > 0 && c < BN) red[(rg - 1) * BN + c] = a;
+      __syncthreads();
+      if (rg == 0 && c < BN && n0 + c < p.Np) {
+        for (int q = 0; q < RG - 1; ++q) a += red[q * BN + c];
+        p.colsum[(int64_t)tile * p.Np + n0 + c] = a;
+        for (int r = (int)gridDim.x + tile; r < p.G; r += (int)gridDim.x) p.colsum[(int64_t)r * p.Np + n0 + c] = 0.f;
       }
     }
   } else {
@@ -829,12 +837,19 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
         if (p.mask_out && plane == 0) p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
       }
     }
-    if (!(DBG & 64) && p.colsum && tid < BN) {
+    if (!(DBG & 64) && p.colsum) {
+      constexpr int CW = BN <= 16 ? 16 : BN <= 32 ? 32 : BN <= 64 ? 64 : 128, RG = NTHR / CW;
+      float* red = reinterpret_cast<float*>(so + 256 * OLD);
+      const int c = tid % CW, rg = tid / CW;
       float a = 0.f;
-      for (int r = 0; r < 256; ++r) a += bf2f(so[r * OLD + tid]) + bf2f(so[r * OLD + BN + tid]);
-      if (n0 + tid < p.Np) {
-        p.colsum[(int64_t)tile * p.Np + n0 + tid] = a;
-        for (int r = (int)gridDim.x + tile; r < p.G; r += (int)gridDim.x) p.colsum[(int64_t)r * p.Np + n0 + tid] = 0.f;
+      if (c < BN)
+        for (int r = rg; r < 256; r += RG) a += bf2f(so[r * OLD + c]) + bf2f(so[r * OLD + BN + c]);
+      if (rg > 0 && c < BN) red[(rg - 1) * BN + c] = a;
+      __syncthreads();
+      if (rg == 0 && c < BN && n0 + c < p.Np) {
+        for (int q = 0; q < RG - 1; ++q) a += red[q * BN + c];
+        p.colsum[(int64_t)tile * p.Np + n0 + c] = a;
+        for (int r = (int)gridDim.x + tile; r < p.G; r += (int)gridDim.x) p.colsum[(int64_t)r * p.Np + n0 + c] = 0.f;
       }
     }
   } else {
@@ -1486,7 +1501,7 @@ static int g_xigemm_dbuf = -1;      // WCMC_IGEMM_DBUF=0/1 (A/B switch); default
 template <int NT, bool PADDED, bool DBUF>
 static int launch_xigemm3(const XIgemmParams& p, hipStream_t stream) {
   const size_t lds_stage = (size_t)(DBUF ? 2 : 1) * (2 * XBM * XROW + 64 + 2 * NT * 16 * XROW + 64) * sizeof(u16);
-  const size_t lds_out = (size_t)XBM * (2 * NT * 16 + 8) * sizeof(u16);      // epilogue staging tile
+  const size_t lds_out = (size_t)XBM * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)16 * NT * 16 * sizeof(float);   // epilogue staging tile + column-sum partials
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1538,7 +1553,8 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   constexpr int TH = 16, TW = 16;
   const int HP = (TH + p.ks - 1) * (TW + p.ks - 1);
   const size_t lds_main = (size_t)((HP * p.PXS + 127) & ~127) + (size_t)2 * (2 * NT * 16 * XROW + 64) * sizeof(u16);
-  const size_t lds_out = p.ys ? (size_t)256 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)256 * (NT * 16 + 4) * sizeof(float);
+  const size_t lds_out = p.ys ? (size_t)256 * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)32 * NT * 16 * sizeof(float)
+                              : (size_t)256 * (NT * 16 + 4) * sizeof(float);
   const size_t lds = lds_main > lds_out ? lds_main : lds_out;
   WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
   static size_t attr = 0;
