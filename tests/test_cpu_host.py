@@ -54,6 +54,34 @@ def test_header_argument_counts_match_binding():
         assert n == len(args), (name, n, len(args))
 
 
+def test_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Every entry point validates before it launches: negative status + a message in wcmc_last_error(), no abort,
+    no exception across the ABI (include/wcmc_hip.h contract).  Argument checks precede any HIP call, so this runs
+    on the CPU-only box."""
+    import ctypes
+    from wcmc_amd import _lib
+    L = _lib.lib()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)          # a non-null, 16-byte aligned address that is never dereferenced by the checks
+    cases = {
+        "wcmc_preprocess_llpm": (null, 10, 104, 5, one, null),
+        "wcmc_preprocess_kpcn": (one, 4, 4, 2, 50, 5, one, one, 1 << 20, null),          # too few raw channels
+        "wcmc_gradients": (one, 0, 4, 3, one, null),
+        "wcmc_cat_broadcast_split": (one, 64, 16, 4, one, 64, 16, 4, one, 1, 2, 4, 4, 12, 8, null),   # C1 % 8 != 0
+        "wcmc_add_broadcast_split": (null, 0, 0, 0, null, 0, 0, 0, 1.0, one, 1, 2, 4, 4, 8, null),   # both gradients null
+        "wcmc_conv2d_igemm_bf16x3": (one, 1, 8, 8, 8, one, null, null, 0, 0, 0, null, 8, 3, 1, 0, 0.0,
+                                     null, 0, 0.0, null, null, null, null),               # neither y nor y_split
+        "wcmc_clip_adam": (null, one, one, one, 4, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, null, null),
+    }
+    for name, args in cases.items():
+        rc = getattr(L, name)(*args)
+        assert rc < 0, name
+        msg = L.wcmc_last_error().decode()
+        assert msg and name.replace("wcmc_", "").split("_bf16x3")[0].split("_fwd")[0][:8] in msg.replace("conv2d_", "conv2d_"), (name, msg)
+    assert L.wcmc_preprocess_kpcn_workspace_bytes(0, 4) == 0 and L.wcmc_preprocess_kpcn_workspace_bytes(4, 4) == (2 * 16 + 4) * 4
+    assert L.wcmc_abi_version() >= 1
+
+
 def test_ops_fail_loudly_without_gpu():
     from wcmc_amd import KPCN, ops
     with pytest.raises(RuntimeError, match="no CPU path"):
