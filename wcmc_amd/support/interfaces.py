@@ -22,67 +22,29 @@ from .. import ops as _ops
 from .utils import crop_like
 
 
+def _abstract(name):
+    def missing(self, *args, **kwargs):
+        raise NotImplementedError(name)
+    missing.__name__ = name
+    return abstractmethod(missing)
+
+
 class BaseInterface(metaclass=ABCMeta):
+    """``interfaces.py:18-77``: the state every interface carries (models / optimisers / losses by name, the
+    iteration counter, running loss sums, best validation error) and the eleven methods a training script calls
+    or a subclass must provide."""
+
+    # name -> abstract method; the reference spells them out one by one
+    for _name in ("to_train_mode", "preprocess", "train_batch", "_manifold_forward", "_regress_forward", "_backward",
+                  "_logging", "_optimization", "to_eval_mode", "validate_batch", "get_epoch_summary"):
+        locals()[_name] = _abstract(_name)
+    del _name
 
     def __init__(self, models, optims, loss_funcs, args, visual=False, use_llpm_buf=False, manif_learn=False,
                  w_manif=0.1):
-        self.models = models
-        self.optims = optims
-        self.loss_funcs = loss_funcs
-        self.args = args
-        self.visual = visual
-        self.use_llpm_buf = use_llpm_buf
-        self.manif_learn = manif_learn
-        self.w_manif = w_manif
-
-        self.iters = 0
-        self.m_losses = {}
-        self.best_err = 1e10
-        self.fixed_batch = None
-
-    @abstractmethod
-    def to_train_mode(self):
-        pass
-
-    @abstractmethod
-    def preprocess(self, batch=None):
-        pass
-
-    @abstractmethod
-    def train_batch(self, batch):
-        pass
-
-    @abstractmethod
-    def _manifold_forward(self, batch):
-        return {}
-
-    @abstractmethod
-    def _regress_forward(self, batch):
-        return {}
-
-    @abstractmethod
-    def _backward(self, batch, out, p_buffers):
-        return {}
-
-    @abstractmethod
-    def _logging(self, loss_dict):
-        pass
-
-    @abstractmethod
-    def _optimization(self):
-        pass
-
-    @abstractmethod
-    def to_eval_mode(self):
-        pass
-
-    @abstractmethod
-    def validate_batch(self, batch):
-        pass
-
-    @abstractmethod
-    def get_epoch_summary(self, mode, norm):
-        return 0.0
+        self.models, self.optims, self.loss_funcs, self.args = models, optims, loss_funcs, args
+        self.visual, self.use_llpm_buf, self.manif_learn, self.w_manif = visual, use_llpm_buf, manif_learn, w_manif
+        self.iters, self.m_losses, self.best_err, self.fixed_batch = 0, {}, 1e10, None
 
 
 _BATCH_KEYS = ('target_total', 'target_diffuse', 'target_specular', 'kpcn_diffuse_in', 'kpcn_specular_in',
@@ -322,13 +284,18 @@ class KPCNInterface(BaseInterface):
 
         out = self._regress_forward(batch)
 
-        tgt_total = crop_like(batch['target_total'], out['radiance'])
-        L_total = self.loss_funcs['l_test'](out['radiance'], tgt_total)
-        if self.m_losses['m_val'] == 0.0 and self.m_losses['m_val'].device != L_total.device:
-            self.m_losses['m_val'] = torch.tensor(0.0, device=L_total.device)
-        self.m_losses['m_val'] += L_total.detach()
+        return self._score_validation(batch, out), p_buffers
 
-        return out['radiance'], p_buffers
+    def _score_validation(self, batch, out):
+        """interfaces.py:296-300: running sum of the test loss (RelativeMSE) of the denoised radiance against the
+        cropped target; the accumulator moves to the loss's device on first use."""
+        radiance = out['radiance']
+        err = self.loss_funcs['l_test'](radiance, crop_like(batch['target_total'], radiance)).detach()
+        acc = self.m_losses['m_val']
+        if acc == 0.0 and acc.device != err.device:
+            acc = torch.tensor(0.0, device=err.device)
+        self.m_losses['m_val'] = acc + err
+        return radiance
 
     def get_epoch_summary(self, mode, norm):
         if mode == 'train':
@@ -382,12 +349,7 @@ class KPCNRefInterface(KPCNInterface):
     def validate_batch(self, batch):
         batch = self._with_targets(batch)
         out = self._regress_forward(batch)
-        tgt_total = crop_like(batch['target_total'], out['radiance'])
-        L_total = self.loss_funcs['l_test'](out['radiance'], tgt_total)
-        if self.m_losses['m_val'] == 0.0 and self.m_losses['m_val'].device != L_total.device:
-            self.m_losses['m_val'] = torch.tensor(0.0, device=L_total.device)
-        self.m_losses['m_val'] += L_total.detach()
-        return out['radiance'], None
+        return self._score_validation(batch, out), None
 
 
 class KPCNPreInterface(KPCNInterface):
@@ -450,14 +412,10 @@ class KPCNPreInterface(KPCNInterface):
             L_manif_diffuse.backward()
             L_manif_specular.backward()
         elif self.train_branches:
-            tgt_diffuse = crop_like(batch['target_diffuse'], diffuse)
-            L_diffuse = self.loss_funcs['l_diffuse'](diffuse, tgt_diffuse)
-            tgt_specular = crop_like(batch['target_specular'], specular)
-            L_specular = self.loss_funcs['l_specular'](specular, tgt_specular)
-            loss_dict['l_diffuse'] = L_diffuse.detach()
-            loss_dict['l_specular'] = L_specular.detach()
-            L_diffuse.backward()
-            L_specular.backward()
+            for br, img in (('diffuse', diffuse), ('specular', specular)):      # interfaces.py:702-712, in that order
+                L = self.loss_funcs['l_' + br](img, crop_like(batch['target_' + br], img))
+                loss_dict['l_' + br] = L.detach()
+                L.backward()
             with torch.no_grad():
                 loss_dict['l_total'] = self.loss_funcs['l_recon'](total, tgt_total).detach()
         else:
