@@ -145,16 +145,20 @@ __global__ void add_broadcast_split_kernel(const float* __restrict__ g, int64_t 
   }
 }
 
-// K order of the packed weights: k = slab*Ks + tap*CS + cl, channel = slab*CS + cl.  The streaming
+// K order of the packed weights: k = slab*Ks + tap*cs + cl, channel = slab*CS + cl (cs = CS, or CSl in the last slab).  The streaming
 // kernel uses one slab of all (padded) channels (CS = Kp, Ks = Kt); the halo kernel cuts the channels into
 // slabs of CS <= 64 that fit in LDS with their halo (x_plan_k below decides, from (kchan, ks) alone).
 __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int Cin,
-                                         int ks, int mode, int rows, int Np, int CS, int Ks, int Kt) {
+                                         int ks, int mode, int rows, int Np, int CS, int Ks, int Kt, int nslabs, int CSl) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)Np * Kt) return;
   const int n = (int)(idx / Kt), k = (int)(idx - (int64_t)n * Kt);
-  const int slab = k / Ks, kk = k - slab * Ks;
-  const int tap = kk / CS, c = slab * CS + (kk - tap * CS);
+  int slab = k / Ks;
+  if (slab > nslabs - 1) slab = nslabs - 1;                 // (the last slab's Ks may be the smaller one)
+  const int kk = k - slab * Ks;
+  const int cs = slab == nslabs - 1 ? CSl : CS;
+  const int tap = kk / cs, cl = kk - tap * cs;
+  const int c = slab * CS + cl;
   const int taps = ks * ks;
   const int kchan = mode == 0 ? Cin : Cout;
   float v = 0.f;
@@ -168,7 +172,7 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __res
   wp[((int64_t)n * 2 + 1) * Kt + k] = lo;
 }
 
-struct XKPlan { bool halo; int Kp, CS, nslabs, Ks, Kt, PXS; };
+struct XKPlan { bool halo; int Kp, CS, nslabs, Ks, Kt, PXS, CSl, Ksl; };     // CSl / Ksl: the last (narrower) slab
 static XKPlan x_plan_k(int kchan, int ks) {
   static int enable = -1;
   if (enable < 0) { const char* e = getenv("WCMC_IGEMM_HALO"); enable = (e && e[0] == '0') ? 0 : 1; }
@@ -180,11 +184,17 @@ static XKPlan x_plan_k(int kchan, int ks) {
     q.CS = round_up((q.Kp + q.nslabs - 1) / q.nslabs, 8);
     q.PXS = q.CS <= 56 ? 224 : 288;           // halo pixel stride: 16 B x (2 or 14 mod 16) -> conflict-free b128 reads
     q.Ks = round_up(ks * ks * q.CS, 32);
+    // the last slab holds what is left (104 channels = 56 + 48: 1408 + 1216 k instead of 2 x 1408); the lane's
+    // tap stepping assumes at most one wrap per 32-k stage, so a slab narrower than 32 channels is padded instead
+    q.CSl = q.Kp - (q.nslabs - 1) * q.CS;
+    if (q.CSl < 32) q.CSl = q.CS;
+    q.Ksl = round_up(ks * ks * q.CSl, 32);
   } else {
     q.nslabs = 1; q.CS = q.Kp; q.PXS = 0;
     q.Ks = round_up(ks * ks * q.Kp, 32);
+    q.CSl = q.CS; q.Ksl = q.Ks;
   }
-  q.Kt = q.nslabs * q.Ks;
+  q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
   return q;
 }
 // rows of the per-tile column-sum buffer: enough for either kernel's tiling of (N, Ho, Wo)
@@ -237,6 +247,7 @@ struct XIgemmParams {
   float* colsum;                          // optional [G][Np] per-tile column sums of the split output
   int G;                                  // rows of colsum (tiles past the kernel's own are zero-filled)
   int CS, nslabs, SPS, PXS, tilesX, tilesY;   // halo kernel: channel slab, stages per slab, halo pixel stride
+  int CSl, SPSl;                              // ... of the last slab
 };
 
 // DBUF: two LDS stage buffers and one barrier per stage (2 workgroups per CU), or one buffer and two
@@ -610,11 +621,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   // ---- halo: [pixel][hi CS][lo CS] at stride PXS; out-of-image pixels and channels >= Cpi read zeros.
   // Filled by LDS-DMA as one linear run of 16-byte vectors (PXS / 16 per pixel, the last ones pad): wave
   // instruction ii writes vectors [64 ii, 64 ii + 64), the per-lane source picks pixel / plane / channel.
-  const int V = p.CS / 4;                      // data vectors per halo pixel (2 planes x CS/8)
+  int cs_cur = p.nslabs == 1 ? p.CSl : p.CS;   // channels of the slab being multiplied (the last one may be narrower)
+  int sps_cur = p.nslabs == 1 ? p.SPSl : p.SPS;
   const int VP = p.PXS / 16;                   // vectors per halo pixel with pad
   const int hvecs = HP * VP;
   const float invVP = 1.0f / (float)VP, invHW = 1.0f / (float)HWd;
   auto dma_halo = [&](int slab) {
+    const int V = (slab == p.nslabs - 1 ? p.CSl : p.CS) / 4;      // data vectors per halo pixel (2 planes x cs/8)
     for (int ii = wave; ii * 64 < hvecs; ii += NTHR / 64) {
       const int v = ii * 64 + lane;
       if (v < hvecs) {
@@ -675,7 +688,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     abase[i] = ((pt / TPR) * HWd + (pt % TPR) * 16 + frow) * p.PXS;
   }
   int cl = kg * 8, tdx = 0, tdy = 0, aoff = cl * 2;      // this lane's (channel, tap) inside the slab
-  const int lo_off = p.CS * 2;
+  int lo_off = cs_cur * 2;
   // Software pipeline inside every wave (stamps of the first version: all eight waves read fragments,
   // then all multiply -- 53 % MFMA issue occupancy; a two-group ping-pong did no better): the fragments of
   // stage g+1 are read WHILE the MFMAs of stage g issue, cout tile by cout tile into the registers the
@@ -692,7 +705,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     // the following stage's tap / channel of this lane (CS >= 32: at most one wrap); taps past ks*ks (slab
     // padding, zero weights) read the tile's first pixels
     cl += XKC;
-    if (cl >= p.CS) { cl -= p.CS; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
+    if (cl >= cs_cur) { cl -= cs_cur; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
     aoff = tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0;
   };
   const u16* const bfrag = bsm + frow * XROW + fslot;
@@ -717,7 +730,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     __syncthreads();                             // ... everyone's; and everyone has read stage g's fragments
     stamp(0);
     dma_b(g + 2, g & 1);
-    const bool last_of_slab = (s_in + 1 == p.SPS);
+    const bool last_of_slab = (s_in + 1 == sps_cur);
     // the fragments of a slab's last stage are in registers and the barrier above retired every read of the
     // halo: the next slab's halo lands while this stage multiplies
     if (last_of_slab && slab + 1 < p.nslabs) dma_halo(slab + 1);
@@ -747,12 +760,13 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
 #pragma unroll
       for (int i = 0; i < 2; ++i) { ah[i] = ahn[i]; al[i] = aln[i]; }
       cl += XKC;
-      if (cl >= p.CS) { cl -= p.CS; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
+      if (cl >= cs_cur) { cl -= cs_cur; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
       aoff = tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0;
       ++s_in;
     } else {                                     // slab boundary: the next A fragments come from the next halo
       s_in = 0;
       ++slab;
+      if (slab == p.nslabs - 1) { cs_cur = p.CSl; sps_cur = p.SPSl; lo_off = cs_cur * 2; }
       cl = kg * 8; tdx = 0; tdy = 0; aoff = cl * 2;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the new halo (and of stage g+2)
       __syncthreads();
@@ -1493,7 +1507,7 @@ extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout
   const XKPlan q = x_plan_k(kchan, ks);
   const int64_t total = (int64_t)Np * q.Kt;
   hipLaunchKernelGGL(pack_weight_split_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, mode, rows, Np, q.CS, q.Ks, q.Kt);
+                     (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, mode, rows, Np, q.CS, q.Ks, q.Kt, q.nslabs, q.CSl);
   return check_launch("conv2d_pack_weight_bf16x3");
 }
 
@@ -1617,6 +1631,7 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   const XKPlan q = x_plan_k(Cin, ks);
   p.Kp = p.Cpi; p.Kt = q.Kt; p.Np = round_up(Cout, 16);
   p.CS = q.CS; p.nslabs = q.nslabs; p.SPS = q.Ks / 32; p.PXS = q.halo ? q.PXS : 0;
+  p.CSl = q.CSl; p.SPSl = q.Ksl / 32;
   p.tilesY = (Ho + 15) / 16; p.tilesX = (Wo + 15) / 16;
   p.G = x_colsum_rows(N, Ho, Wo);
   p.M = (int64_t)N * Ho * Wo;
