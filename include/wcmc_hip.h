@@ -280,6 +280,11 @@ int wcmc_grs_bwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t 
                  void* workspace, size_t workspace_bytes,
                  int B, int S, int C, int h, int w, void* stream);
 
+/* A pseudo-random permutation of [0, n) as int64 indices, keyed by `seed` (6-round Feistel network, cycle-walked):
+ * the `rng='device'` source of the FeatureMSE / GRS pairings instead of the sort behind torch.randperm.  The
+ * reference draws its pairings with torch.randperm on the CPU generator (support/losses.py:35,50). */
+int wcmc_random_permutation(int64_t* out, int64_t n, uint64_t seed, void* stream);
+
 /* ---------------------------------------------------------------- clip + Adam
  * support/interfaces.py:260-261 (clip_grad_value_) + :269-271 (Adam.step,
  * train_kpcn.py:274-277: default betas/eps, no weight decay, no amsgrad) fused

@@ -213,6 +213,27 @@ def test_dma_fed_gemms_repeat_bitwise_at_benchmark_size():
                 assert torch.equal(a, bb), "run-to-run difference in " + what
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 1000, 541696, 4333568])
+def test_random_permutation_is_a_bijection_and_seeded(n):
+    """The sort-free device permutation behind FeatureMSE(rng='device'): every index exactly once, reproducible
+    under torch.manual_seed, different for different seeds, and not the identity."""
+    o = ops()
+    torch.manual_seed(5)
+    a = o.random_permutation(n, DEV)
+    assert a.dtype == torch.int64 and a.numel() == n
+    assert torch.equal(torch.sort(a).values, torch.arange(n, device=DEV))
+    torch.manual_seed(5)
+    assert torch.equal(o.random_permutation(n, DEV), a)
+    if n >= 64:
+        b = o.random_permutation(n, DEV)                    # next key of the same generator
+        assert not torch.equal(a, b)
+        fixed = float((a == torch.arange(n, device=DEV)).float().mean())
+        assert fixed < 0.1                                  # E[fixed points] = 1 for a uniform permutation
+        # neighbours are scattered: mean |pi(i+1) - pi(i)| ~ n/3 for a uniform permutation
+        gap = float((a[1:] - a[:-1]).abs().double().mean())
+        assert 0.2 * n < gap < 0.45 * n
+
+
 def test_split_roundtrip_is_near_fp32():
     o = ops()
     x = o.to_nhwc_raw((gen(2, 37, 9, 11, seed=22) * 100).to(DEV))

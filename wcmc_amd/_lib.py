@@ -55,6 +55,7 @@ SIGNATURES = {
     "wcmc_feature_mse_bwd": (I, [P, L, L, L, L, L, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "wcmc_grs_fwd": (I, [P, L, L, L, L, L, P, L, L, L, L, P, P, F, P, P, Z, I, I, I, I, I, P]),
     "wcmc_grs_bwd": (I, [P, L, L, L, L, L, P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "wcmc_random_permutation": (I, [P, L, ctypes.c_uint64, P]),
     "wcmc_clip_adam": (I, [P, P, P, P, L, F, D, D, D, D, I, F, P, P]),
     "wcmc_preprocess_llpm": (I, [P, L, I, I, P, P]),
     "wcmc_preprocess_kpcn_workspace_bytes": (Z, [I, I]),

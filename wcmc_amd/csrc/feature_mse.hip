@@ -325,3 +325,46 @@ extern "C" int wcmc_grs_bwd(const float* p, int64_t psb, int64_t pss, int64_t ps
   hipLaunchKernelGGL(fm_bwd_kernel<true>, dim3(gb), dim3(256), 0, (hipStream_t)stream, q, grad_scale, dp);
   return check_launch("grs_bwd");
 }
+
+// ---------------------------------------------------------------- pseudo-random permutation of [0, n)
+// For the `rng='device'` pairings of FeatureMSE / GRS (wcmc_amd/support/losses.py): torch.randperm on the device
+// is four sort passes per call (0.12 ms for 541,696 rows; four calls per step).  A keyed bijection needs no sort:
+// a 6-round balanced Feistel network on 2h bits (2^(2h) >= n), cycle-walked back into [0, n).  Every i < n maps
+// to a distinct value < n; which permutation is drawn depends on the 64-bit seed only.
+namespace wcmc {
+__device__ __forceinline__ unsigned perm_mix(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(256) void random_permutation_kernel(int64_t* __restrict__ out, int64_t n, int h,
+                                                                unsigned k0, unsigned k1) {
+  const unsigned mask = (1u << h) - 1u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t x = (uint64_t)i;
+    do {
+      unsigned l = (unsigned)(x >> h) & mask, r = (unsigned)x & mask;
+#pragma unroll
+      for (int rd = 0; rd < 6; ++rd) {
+        const unsigned f = perm_mix(r ^ (rd & 1 ? k1 : k0) ^ (0x9e3779b9u * (unsigned)(rd + 1))) & mask;
+        const unsigned t = l ^ f;
+        l = r; r = t;
+      }
+      x = ((uint64_t)l << h) | r;
+    } while (x >= (uint64_t)n);
+    out[i] = (int64_t)x;
+  }
+}
+}  // namespace wcmc
+
+extern "C" int wcmc_random_permutation(int64_t* out, int64_t n, uint64_t seed, void* stream) {
+  WCMC_REQUIRE(out && n > 0 && n < ((int64_t)1 << 62), WCMC_ERR_BAD_ARG, "random_permutation: bad argument");
+  int bits = 1;
+  while (((int64_t)1 << bits) < n) ++bits;
+  const int h = (bits + 1) / 2 < 1 ? 1 : (bits + 1) / 2;
+  WCMC_REQUIRE(h <= 31, WCMC_ERR_BAD_ARG, "random_permutation: n too large");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(wcmc::random_permutation_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, out, n, h, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32));
+  return wcmc::check_launch("random_permutation");
+}
+

@@ -54,11 +54,15 @@ class GraphedTrainStep:
 
     def _draw(self):
         """Fresh pairings, in the reference's call order (diffuse: patch, batch; specular: patch, batch)."""
-        dev = self.perms[0][0].device if self.fm.rng == 'device' else None
         for ip, ib in self.perms:
-            ip.copy_(torch.randperm(self.perm_sizes[0], device=dev), non_blocking=True)
-            if ib is not None:
-                ib.copy_(torch.randperm(self.perm_sizes[1], device=dev), non_blocking=True)
+            if self.fm.rng == 'device':                   # written in place: no sort, no copy
+                ops.random_permutation(self.perm_sizes[0], ip.device, out=ip)
+                if ib is not None:
+                    ops.random_permutation(self.perm_sizes[1], ib.device, out=ib)
+            else:
+                ip.copy_(torch.randperm(self.perm_sizes[0]), non_blocking=True)
+                if ib is not None:
+                    ib.copy_(torch.randperm(self.perm_sizes[1]), non_blocking=True)
 
     def __call__(self, batch):
         itf = self.itf

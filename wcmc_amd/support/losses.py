@@ -23,7 +23,7 @@ class FeatureMSE(torch.nn.Module):
              'cpu'    -- torch.randperm on the global CPU generator, patch then batch: bit-identical pairs
                          to the reference under torch.manual_seed (losses.py:35,50); costs ~23 ms of host
                          time per 541,696-row permutation on the MI355X host.
-             'device' -- torch.randperm on the GPU (0.2 ms): the same distribution of pairs from another
+             'device' -- a keyed bijection generated on the GPU (ops.random_permutation, no sort): random pairs from another
                          random stream."""
         super(FeatureMSE, self).__init__()
         if color != 'rgb':
@@ -39,9 +39,11 @@ class FeatureMSE(torch.nn.Module):
         print('FeatureMSE locality: %s' % ('Non-local' if non_local else 'Local'))
 
     def draw_permutations(self, b, s, h, w, device=None):
-        dev = device if self.rng == 'device' else None
-        idx_patch = torch.randperm(s * h * w, device=dev)
-        idx_batch = torch.randperm(b * s * h * w, device=dev) if self.non_local else None
+        if self.rng == 'device':
+            return (ops.random_permutation(s * h * w, device),
+                    ops.random_permutation(b * s * h * w, device) if self.non_local else None)
+        idx_patch = torch.randperm(s * h * w)
+        idx_batch = torch.randperm(b * s * h * w) if self.non_local else None
         return idx_patch, idx_batch
 
     def forward(self, p_buffer, ref, perms=None):
@@ -85,8 +87,10 @@ class GlobalRelativeSimilarityLoss(torch.nn.Module):
         b, s, c, h, w = p_buffer.shape
         dev = p_buffer.device
         if perms is None:
-            d = dev if self.rng == 'device' else None
-            perms = (torch.randperm(s * h * w, device=d), torch.randperm(b * s * h * w, device=d))
+            if self.rng == 'device':
+                perms = (ops.random_permutation(s * h * w, dev), ops.random_permutation(b * s * h * w, dev))
+            else:
+                perms = (torch.randperm(s * h * w), torch.randperm(b * s * h * w))
         self.last_perms = perms
         loss = ops.grs_loss(p_buffer, ref, perms[0].to(dev, non_blocking=True), perms[1].to(dev, non_blocking=True),
                             float(self.alpha))
