@@ -189,6 +189,93 @@ def test_gate_from_bit_mask_equals_gate_from_tensor(case):
         assert torch.equal(a, bb), act
 
 
+PW_CASES = [
+    # N, H, W, widths of a 1x1 chain, output activation -- the PathNet chains (support/networks.py:22-27)
+    (5, 37, 41, (36, 64, 64, 64), "linear"),     # embedding: 7585 pixels = 118 tiles + 33 (ragged last tile)
+    (2, 33, 29, (128, 128, 3), "relu"),          # final: 128 -> 128 persistent, 128 -> 3 tiled; gradients 3 -> 128 -> 128
+    (1, 3, 3, (64, 64, 64), "relu"),             # 9 pixels: less than one tile, most workgroups idle
+]
+
+
+def _pw_chain(o, case, seed):
+    n, h, w, widths, out_act = case
+    acts = ["relu"] * (len(widths) - 2) + [out_act]
+    x = gen(n, widths[0], h, w, seed=seed)
+    params = []
+    for l in range(len(widths) - 1):
+        params.append(gen(widths[l + 1], widths[l], 1, 1, seed=seed + 1 + 2 * l, scale=(2.0 / widths[l]) ** 0.5 * 1.7))
+        params.append(gen(widths[l + 1], seed=seed + 2 + 2 * l, scale=0.2))
+    return x, params, acts
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_pointwise_chain_matches_fp64_and_the_tiled_kernel_bitwise(case, monkeypatch):
+    """The persistent 1x1 kernel (LDS-DMA ring, weights in registers) against an fp64 chain, and bit for bit
+    against the tiled streaming kernel it replaces (same MFMA sequence per output): outputs, data gradients,
+    weight gradients (which consume the hidden activations it wrote) and bias gradients (its column sums are
+    grouped differently: tolerance)."""
+    o = ops()
+    x, params, acts = _pw_chain(o, case, seed=80)
+    pr = [t.double().requires_grad_(True) for t in params]
+    xr = x.double().requires_grad_(True)
+    hcur, pres = xr, []
+    for l, a in enumerate(acts):
+        pre = F.conv2d(hcur, pr[2 * l], pr[2 * l + 1])
+        pres.append(pre)
+        hcur = om._activation(pre, a)
+    kink = torch.ones_like(pres[-1][:, :1])
+    for pre in pres:       # no gradient through pixels with a pre-activation within rounding of a kink
+        kink = kink * (pre.detach().abs().amin(dim=1, keepdim=True) > 1e-5).double()
+    gy = gen(*hcur.shape, seed=99).double() * kink
+    hcur.backward(gy)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WCMC_IGEMM_PW", flag)
+        xd = x.to(DEV).requires_grad_(True)
+        pd = [t.to(DEV).requires_grad_(True) for t in params]
+        y = o.conv_chain(xd, 1, 0, acts, pd)
+        y.backward(gy.float().to(DEV))
+        got[flag] = [y.detach().clone(), xd.grad.clone()] + [t.grad.clone() for t in pd]
+    names = ["fwd", "dx"] + ["dw%d" % (i // 2) if i % 2 == 0 else "db%d" % (i // 2) for i in range(len(params))]
+    want = [hcur, xr.grad] + [t.grad for t in pr]
+    for nm, a, b, r in zip(names, got["1"], got["0"], want):
+        assert_close(a, r, tol=1e-4, what="pointwise " + nm)
+        if nm.startswith("db"):
+            assert_close(a, b, tol=1e-5, what="pointwise vs tiled " + nm)
+        else:
+            assert torch.equal(a, b), "pointwise vs tiled kernel differ in " + nm
+
+
+def test_pointwise_kernel_repeats_bitwise_at_benchmark_size(monkeypatch):
+    """Race screen for the persistent 1x1 kernel at full occupancy (1 M pixels, every ring stage reused
+    thousands of times): run-to-run identical, and identical to the tiled kernel."""
+    o = ops()
+    n, h = 64, 128
+    xs = o.split_raw(o.to_nhwc_raw(gen(n, 64, h, h, seed=40).to(DEV)))
+    w = gen(64, 64, 1, 1, seed=41, scale=0.2).to(DEV)
+    b = gen(64, seed=42, scale=0.1).to(DEV)
+    wp, wpt = o._pack_x(w, 0), o._pack_x(w, 1)
+
+    def run():
+        y, mask = o.conv2d_x_raw(xs, (n, 64, h, h), wp, b, 64, 1, 0, "relu", out_split=True, mask_out=True)
+        dx, part = o.conv2d_x_raw(y, (n, 64, h, h), wpt, None, 64, 1, 0, "linear", out_split=True, gate_act="relu",
+                                  gate_mask=mask, colsum=True)
+        yf = o.conv2d_x_raw(xs, (n, 64, h, h), wp, b, 64, 1, 0, "relu", out_split=False)
+        return y.clone(), mask.clone(), dx.clone(), o.colsum_finish_raw(part, (n, 64, h, h)).clone(), yf.clone()
+
+    monkeypatch.setenv("WCMC_IGEMM_PW", "0")
+    ref = run()
+    monkeypatch.setenv("WCMC_IGEMM_PW", "1")
+    for _ in range(6):
+        cur = run()
+        for a, bb, what in zip(ref, cur, ("split out", "mask", "gated dgrad", "column sums", "fp32 out")):
+            if what == "column sums":
+                assert_close(bb, a, tol=1e-5, what=what)
+            else:
+                assert torch.equal(a, bb), "pointwise kernel differs from the tiled kernel in " + what
+    del ref, cur
+
+
 def test_dma_fed_gemms_repeat_bitwise_at_benchmark_size():
     """Race screen for the LDS-DMA staged kernels (halo igemm weight stages, filter-row wgrad stages): their
     LDS hand-offs are ordered by counted waits + barriers, and a read that beats its DMA shows up as a

@@ -248,6 +248,7 @@ struct XIgemmParams {
   int G;                                  // rows of colsum (tiles past the kernel's own are zero-filled)
   int CS, nslabs, SPS, PXS, tilesX, tilesY;   // halo kernel: channel slab, stages per slab, halo pixel stride
   int CSl, SPSl;                              // ... of the last slab
+  unsigned y_bytes, m_bytes;                  // pointwise kernel: extents of the output and of the 1-bit masks
 };
 
 // DBUF: two LDS stage buffers and one barrier per stage (2 workgroups per CU), or one buffer and two
@@ -899,6 +900,299 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
             *reinterpret_cast<const float4*>(so + pr * OLD + vec * 4);
     }
   }
+}
+
+
+// ------------------------------------------------------------------ pointwise (1x1) GEMM, persistent
+// The PathNet chains are 1x1 convolutions over B*S*H*W = 1 M pixels with 36..128 channels: 0.5-1 GB of HBM
+// traffic and a few hundred MFMAs per 64 pixels -- pure streaming.  The tiled kernel above reaches 3 TB/s on
+// them (a workgroup loads, multiplies, then writes; two per CU cannot keep ~40 KB per CU in flight) and
+// re-reads the weights (and, for 128 couts, the input) once per tile.  Here a workgroup stays on its CU
+// and walks pixel tiles (64 pixels, grid-stride): the tile's split input lands in a 3-stage LDS ring by
+// LDS-DMA two tiles ahead (a pixel tile is one contiguous run of bytes: the copy is linear, with the
+// 16-byte units of a pixel XOR-swizzled on the SOURCE side where the pixel stride would otherwise put all
+// rows of a fragment read on the same banks); every wave owns one 16-cout tile and holds its weight fragments
+// in registers for the whole launch; results go through an LDS staging tile and leave as whole 16-byte
+// vectors.  All global traffic of the loop is counted buffer instructions (out-of-range = dropped), so a
+// wave waits with an exact vmcnt for the tile it is about to read and never for the tiles behind it.
+// U = 16-byte units per input pixel (2 planes x Cpi / 8).
+// Workgroup barrier for kernels that keep LDS-DMA in flight across it: __syncthreads() carries a release fence,
+// for which hipcc waits for EVERY outstanding LDS-DMA (vmcnt(0)); the ring below orders its DMA by explicit counts.
+__device__ __forceinline__ void pw_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// LDS stores the compiler does not see as such: behind an LDS-DMA it orders every ds_write it knows of with
+// vmcnt(0) (write-after-write on LDS it cannot disambiguate).  The staging tile never overlaps the ring.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pw_lds_store_b64(unsigned addr, u32x2 v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void pw_lds_store_b128(unsigned addr, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+template <int NTW, int U, bool SPLIT>
+__global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_kernel(XIgemmParams p) {
+  constexpr int NW = NTW, NTHR = NW * 64, TP = 64, RT = TP / 16, BN = NTW * 16;
+  constexpr int KC = U > 16 ? 4 : (U > 8 ? 2 : 1);     // 32-k steps: Kt = 128 / 64 / 32
+  constexpr int HALF = U / 2;                          // units per plane
+  constexpr bool SWZ = (U & 3) == 0;                   // pixel stride = 0 mod 64 B: swizzle (else u = 2 mod 4: conflict-free as is)
+  constexpr int D = (U + NW - 1) / NW;                 // tile DMA instructions per wave (1 KB each)
+  constexpr int AREG = D * NW * 1024;                  // tile region of a stage (data, then zeros)
+  constexpr int STAGE = AREG + (SPLIT ? NW * 256 : 0); // + one gate-mask slot per wave
+  constexpr int NS = 3;
+  constexpr int DM = D + (SPLIT ? 1 : 0);              // vector-memory instructions per wave: fill of one stage,
+  constexpr int SI = SPLIT ? 8 : 4;                    // ... stores of one tile
+  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
+  char* const ring = reinterpret_cast<char*>(smem16);
+  char* const stg = ring + NS * STAGE;
+  const unsigned stg_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)stg);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = (int)gridDim.x, bx = (int)blockIdx.x;
+  const int ntiles = (int)((p.M + TP - 1) / TP);
+  const int nk = bx < ntiles ? (ntiles - bx + nb - 1) / nb : 0;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr =
+      __builtin_amdgcn_make_buffer_rsrc(SPLIT ? (void*)p.ys : (void*)p.yf, 0, (int)p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mor = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_out, 0, p.mask_out ? (int)p.m_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gmr = __builtin_amdgcn_make_buffer_rsrc((void*)p.gate_mask, 0, p.gate_mask ? (int)p.m_bytes : 0, 0x00020000);
+
+  // stage fill: LDS unit L = 64 * (d * NW + wave) + lane holds unit (L % U) ^ swizzle of pixel L / U
+  unsigned rel[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const int L = (d * NW + wave) * 64 + lane;
+    const int px = L / U, pos = L - px * U;
+    rel[d] = L < TP * U ? (unsigned)((px * U + (SWZ ? (pos ^ (px & 7)) : pos)) * 16) : XOOB;
+  }
+  int st_fill = 0;
+  auto fill = [&](int k) {
+    const bool live = k < nk;
+    const int tile = bx + k * nb;
+    const unsigned base = (unsigned)tile * (unsigned)(TP * U * 16), kill = live ? 0u : XOOB;
+    char* dst = ring + st_fill * STAGE + wave * 1024;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      // (a plain `unsigned`: with the type-dependent rel[d] in the argument list the host pass checks the 16-byte
+      // LDS-DMA builtin at instantiation time, against the host's feature set, and silently drops the kernel stub)
+      const unsigned off = (rel[d] + base) | kill;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(dst + d * NW * 1024), 16, off, 0, 0, 0);
+    }
+    if (SPLIT) {    // 4 mask bytes per pixel around this wave's two (couts 16 wave .. +15), pixel = lane
+      const unsigned moff = (unsigned)(((int64_t)tile * TP + lane) * (BN / 8) + ((2 * wave) & ~3));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gmr, (__attribute__((address_space(3))) void*)(ring + st_fill * STAGE + AREG + wave * 256), 4,
+                                               moff | kill, 0, 0, 0);
+    }
+    st_fill = st_fill + 1 == NS ? 0 : st_fill + 1;
+  };
+
+  // this wave's weight fragments and bias: registers for the whole launch
+  const int fr = lane & 15, q = lane >> 4;
+  bf16x8 wh[KC], wl[KC];
+  {
+    const int wrow = wave * 16 + fr;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const unsigned o = (unsigned)(((wrow * 2) * p.Kt + c * 32 + q * 8) * 2);
+      wh[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, o, 0, 0));
+      wl[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, o + (unsigned)(p.Kt * 2), 0, 0));
+    }
+  }
+  float bs[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int co = wave * 16 + q * 4 + e;
+    bs[e] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+  }
+  const bool is_relu = p.act == WCMC_ACT_RELU;
+  const float nslope = p.act == WCMC_ACT_LEAKY_RELU ? p.slope : 1.f;
+  auto actf = [&](float v) { const float neg = v * nslope; return v > 0.f ? v : (is_relu ? 0.f : neg); };   // act_apply without branches
+  const bool gated = SPLIT && p.gate_mask && p.gate_act != WCMC_ACT_LINEAR;
+  const float goff = p.gate_act == WCMC_ACT_LEAKY_RELU ? p.gate_slope : 0.f;
+  const int axor = SWZ ? (lane & 7) : 0;
+  constexpr int VPP = BN / 8;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of this thread's (plane, 8 couts) over its rows
+  const int64_t HoWo = (int64_t)p.Ho * p.Wo;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight loads are not part of the counted stream
+  fill(0);
+  fill(1);
+  int st_cur = 0;
+  for (int it = 0; it < nk; ++it) {
+    fill(it + 2);
+    // behind tile `it`'s fill: fill(it+1), the stores of tile it-1, fill(it+2)
+    if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DM) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DM + SI) : "memory");
+    pw_barrier();                                   // everyone's share of the tile; staging tile is free
+    const char* A = ring + st_cur * STAGE;
+    f32x4 acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const char* a = A + (16 * i + fr) * (U * 16);
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a + ((c * 4 + q) ^ axor) * 16);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + ((HALF + c * 4 + q) ^ axor) * 16);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[c], ah, acc[i], 0, 0, 0);   // small terms first
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c], al, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c], ah, acc[i], 0, 0, 0);
+      }
+    }
+    const int64_t m0 = (int64_t)(bx + it * nb) * TP;
+    // lane holds couts 16 wave + 4 q + {0..3} of pixel 16 i + fr
+    if (SPLIT) {
+      constexpr int OLD = 2 * BN + 8;
+      u16* so = reinterpret_cast<u16*>(stg);
+      const unsigned char* ms = reinterpret_cast<const unsigned char*>(A + AREG + wave * 256) + ((2 * wave) & 3) + (q >> 1);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const int pr = 16 * i + fr;
+        const bool ok = m0 + pr < p.M;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ok ? actf(acc[i][e] + bs[e]) : 0.f;
+        if (gated) {
+          const unsigned bits = (unsigned)ms[pr * 4] >> (4 * (q & 1));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : goff;
+        }
+        u16 hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split1(v[e], hi[e], lo[e]);
+        const unsigned sa = stg_lds + (unsigned)((pr * OLD + wave * 16 + q * 4) * 2);
+        pw_lds_store_b64(sa, u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)});
+        pw_lds_store_b64(sa + BN * 2, u32x2{(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)});
+      }
+      pw_barrier();
+      // the tile's output is one contiguous run: vector v of the tile = (pixel v / 2VPP, plane, 8 couts)
+      const unsigned ybase = (unsigned)(m0 * (4 * BN)), mbase = (unsigned)(m0 * VPP);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int v = tid + k * NTHR;
+        const int pr = v / (2 * VPP), qv = v - pr * (2 * VPP);
+        const int plane = qv >= VPP, vec = qv - plane * VPP;
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+        __builtin_amdgcn_raw_buffer_store_b128(hv, yr, ybase + (unsigned)(v * 16), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8(positive_mask8(hv), mor, plane ? XOOB : mbase + (unsigned)(pr * VPP + vec), 0, 0);
+        if (p.colsum) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            cs[2 * e] += bf2f((u16)(hv[e] & 0xffffu));
+            cs[2 * e + 1] += bf2f((u16)(hv[e] >> 16));
+          }
+        }
+      }
+    } else {
+      constexpr int OLD = BN + 4;
+      float* so = reinterpret_cast<float*>(stg);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const int pr = 16 * i + fr;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = actf(acc[i][e] + bs[e]);
+        pw_lds_store_b128(stg_lds + (unsigned)((pr * OLD + wave * 16 + q * 4) * 4),
+                          u32x4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                                __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])});
+      }
+      pw_barrier();
+      constexpr int VF = BN / 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int v = tid + k * NTHR;
+        const int pr = v / VF, vec = v - pr * VF;
+        const int64_t m = m0 + pr;
+        const int n = (int)(m / HoWo);
+        const int r = (int)(m - (int64_t)n * HoWo);
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        const int64_t off = ((int64_t)n * p.ysn + (int64_t)oy * p.ysh + (int64_t)ox * p.ysw + vec * 4) * 4;
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(so + pr * OLD + vec * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(hv, yr, m < p.M ? (unsigned)off : XOOB, 0, 0);
+      }
+    }
+    st_cur = st_cur + 1 == NS ? 0 : st_cur + 1;
+  }
+
+  if (SPLIT && p.colsum) {
+    // one row of partial column sums per workgroup (hi + lo planes, 16 row groups combined in a fixed order)
+    pw_barrier();
+    float* red = reinterpret_cast<float*>(stg);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = cs[e];      // tid = group * 2VPP + (plane * VPP + vec)
+    pw_barrier();
+    if (tid < BN) {
+      const int vec = tid >> 3, e = tid & 7;
+      float a = 0.f;
+      for (int g = 0; g < NTHR / (2 * VPP); ++g)
+        a += red[(g * 2 * VPP + vec) * 8 + e] + red[(g * 2 * VPP + VPP + vec) * 8 + e];
+      p.colsum[(int64_t)bx * p.Np + tid] = a;
+      for (int r = nb + bx; r < p.G; r += nb) p.colsum[(int64_t)r * p.Np + tid] = 0.f;
+    }
+  }
+}
+
+template <int NTW, int U, bool SPLIT>
+static int launch_xpw2(const XIgemmParams& p, hipStream_t stream) {
+  constexpr int NW = NTW, BN = NTW * 16, D = (U + NW - 1) / NW;
+  constexpr size_t stage = (size_t)D * NW * 1024 + (SPLIT ? NW * 256 : 0);
+  constexpr size_t stg = SPLIT ? (size_t)64 * (2 * BN + 8) * sizeof(u16) : (size_t)64 * (BN + 4) * sizeof(float);
+  constexpr size_t red = SPLIT ? (size_t)NW * 64 * 8 * sizeof(float) : 0;
+  constexpr size_t lds = 3 * stage + (stg > red ? stg : red);
+  static_assert(lds <= 160 * 1024, "LDS");
+  static int cus = 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_bf16x3_kernel<NTW, U, SPLIT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    attr_set = true;
+  }
+  const int64_t ntiles = ceil_div64(p.M, 64);
+  int64_t nb = (int64_t)cus * (U >= 32 ? 1 : 2);
+  if (nb > ntiles) nb = ntiles;
+  if (p.colsum && nb > p.G) nb = p.G;
+  hipLaunchKernelGGL((conv_pw_bf16x3_kernel<NTW, U, SPLIT>), dim3((unsigned)nb), dim3(NW * 64), lds, stream, p);
+  return check_launch("conv2d_igemm_bf16x3(pointwise)");
+}
+
+// 1x1, no padding, the channel counts of the PathNet chains; anything else stays on the tiled kernel
+static bool x_plan_pw(const XIgemmParams& p, int* ntw, int* u) {
+  if (p.ks != 1 || p.pad != 0 || p.gate || p.PXS) return false;
+  const char* e = getenv("WCMC_IGEMM_PW");      // read per call: the parity tests switch kernels inside one process
+  if (e && e[0] == '0') return false;
+  const int U = p.Cpi / 4;
+  if (p.Np == 64 && (U == 16 || U == 10)) *ntw = 4;
+  else if (p.Np == 128 && (U == 32 || U == 2)) *ntw = 8;
+  else return false;
+  *u = U;
+  if (p.Cout != p.Np || p.Kt != (U > 16 ? 128 : U > 8 ? 64 : 32)) return false;
+  if (p.M * 4 * p.Np >= 0x7ff00000LL) return false;
+  if (p.yf) {
+    const int64_t ext = ((int64_t)(p.N - 1) * p.ysn + (int64_t)(p.Ho - 1) * p.ysh + (int64_t)(p.Wo - 1) * p.ysw + p.Cpo) * 4;
+    if (p.ysn < 0 || p.ysh < 0 || p.ysw < 0 || ext >= 0x7ff00000LL) return false;
+  }
+  return true;
+}
+static int launch_xpw(XIgemmParams& p, int ntw, int u, hipStream_t st) {
+  if (p.ys) {
+    p.y_bytes = (unsigned)(p.M * 4 * p.Np);
+    p.m_bytes = (unsigned)(p.M * (p.Np / 8));
+    if (ntw == 4) return u == 16 ? launch_xpw2<4, 16, true>(p, st) : launch_xpw2<4, 10, true>(p, st);
+    return u == 32 ? launch_xpw2<8, 32, true>(p, st) : launch_xpw2<8, 2, true>(p, st);
+  }
+  p.y_bytes = (unsigned)(((int64_t)(p.N - 1) * p.ysn + (int64_t)(p.Ho - 1) * p.ysh + (int64_t)(p.Wo - 1) * p.ysw + p.Cpo) * 4);
+  p.m_bytes = 0;
+  if (ntw == 4) return u == 16 ? launch_xpw2<4, 16, false>(p, st) : launch_xpw2<4, 10, false>(p, st);
+  return u == 32 ? launch_xpw2<8, 32, false>(p, st) : launch_xpw2<8, 2, false>(p, st);
 }
 
 
@@ -1647,6 +1941,11 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
     if (dbg & 2) p.wp_bytes = 0;
   }
   hipStream_t st = (hipStream_t)stream;
+  p.y_bytes = 0; p.m_bytes = 0;
+  {
+    int ntw = 0, u = 0;
+    if (x_plan_pw(p, &ntw, &u)) return launch_xpw(p, ntw, u, st);
+  }
   switch (x_pick_nt(p.Np / 16)) {
     case 7: return launch_xigemm<7>(p, st);
     case 4: return launch_xigemm<4>(p, st);
