@@ -213,7 +213,7 @@ def _side_stream(device, of=None):
 # Running the specular half on a second stream lets its kernels fill the CUs that the tail of a
 # diffuse launch leaves idle (a conv launch is a whole number of 512-workgroup waves); autograd
 # replays each half's backward on the stream its forward ran on.
-USE_BRANCH_STREAM = os.environ.get("WCMC_BRANCH_STREAM", "0") != "0"   # measured neutral at B=8
+USE_BRANCH_STREAM = os.environ.get("WCMC_BRANCH_STREAM", "1") != "0"   # +1.8 % at B=8 (331 -> 337 patches/s, same box, 3 alternations)
 _BRANCH_STREAMS = {}
 
 
