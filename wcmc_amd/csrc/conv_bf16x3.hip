@@ -582,6 +582,14 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
 }
 
 
+// Workgroup barrier for kernels that keep LDS-DMA in flight across it: __syncthreads() carries a release fence,
+// for which hipcc waits for EVERY outstanding LDS-DMA (vmcnt(0)); the ring below orders its DMA by explicit counts.
+__device__ __forceinline__ void pw_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------ implicit GEMM, halo-resident (ks 3..5)
 // Stamps of the streaming kernel above (scripts/stamp_igemm.py): per 32-k stage a wave spends 830 cycles
 // issuing its 8 buffer loads and 540 storing them to LDS, against 770 issuing MFMAs -- the L1/TA path and
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
 // stage for 256 pixels instead of 30 KB for 128).  512 threads = 8 waves, each 32 pixels (two tile rows)
 // x all NT*16 couts; one workgroup per CU (LDS: halo 90-115 KB + two weight stages).
 // K order: slab-major (pack_weight_split_kernel); stages never straddle slabs (Ks % 32 == 0).
-template <int NT, int TH, int TW, int DBG = 0>
+template <int NT, int TH, int TW, int DBG = 0, int NB = 3>
 __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p) {
   constexpr int BN = NT * 16;
   constexpr int NTHR = 512;
@@ -693,9 +701,11 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   // Software pipeline inside every wave (stamps of the first version: all eight waves read fragments,
   // then all multiply -- 53 % MFMA issue occupancy; a two-group ping-pong did no better): the fragments of
   // stage g+1 are read WHILE the MFMAs of stage g issue, cout tile by cout tile into the registers the
-  // tile's MFMAs have just consumed, so no wave ever waits for LDS with an idle matrix pipe.  Two weight
-  // buffers: while stage g multiplies (its fragments are in registers), stage g+1 is read from one buffer
-  // and the DMA of stage g+2 lands in the other; each wave waits for its own DMA before the stage barrier.
+  // tile's MFMAs have just consumed, so no wave ever waits for LDS with an idle matrix pipe.  NB weight
+  // buffers: while stage g multiplies (its fragments are in registers), stage g+1 is read from its buffer and
+  // the DMAs of stages g+2 .. g+NB-1 are in flight or landed (one stage of latency cover was not enough: stamps
+  // showed 400 of 2340 cycles per stage waiting for the weights); each wave waits for its own share of stage
+  // g+1 with a counted vmcnt before the stage barrier (no fence: a release fence would drain every DMA).
   bf16x8 ah[2], al[2], wh[NT], wl[NT];
   auto read_a = [&]() {
 #pragma unroll
@@ -715,22 +725,24 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     wl[j] = *reinterpret_cast<const bf16x8*>(bfrag + buf * B_ELEMS + B_LO + j * 16 * XROW);
   };
 
-  dma_b(0, 0);
-  dma_b(1, 1);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) dma_b(b, b);
   dma_halo(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   read_a();
 #pragma unroll
   for (int j = 0; j < NT; ++j) read_b(0, j);
-  int s_in = 0, slab = 0;
+  int s_in = 0, slab = 0, bcur = 0;
   stamp(-1);
   for (int g = 0; g < nstages; ++g) {
-    const int b1 = (g + 1) & 1;                  // buffer of stage g+1; stage g's fragments are in registers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage g+1 has landed
-    __syncthreads();                             // ... everyone's; and everyone has read stage g's fragments
+    const int b1 = bcur + 1 == NB ? 0 : bcur + 1;      // buffer of stage g+1; stage g's fragments are in registers
+    // this wave's share of stage g+1 has landed; the NB-2 stages behind it (two DMA instructions each) stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NB - 2)) : "memory");
+    pw_barrier();                                // ... everyone's; and everyone has read stage g's fragments
     stamp(0);
-    dma_b(g + 2, g & 1);
+    dma_b(g + NB, bcur);
+    bcur = b1;
     const bool last_of_slab = (s_in + 1 == sps_cur);
     // the fragments of a slab's last stage are in registers and the barrier above retired every read of the
     // halo: the next slab's halo lands while this stage multiplies
@@ -916,14 +928,6 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
 // vectors.  All global traffic of the loop is counted buffer instructions (out-of-range = dropped), so a
 // wave waits with an exact vmcnt for the tile it is about to read and never for the tiles behind it.
 // U = 16-byte units per input pixel (2 planes x Cpi / 8).
-// Workgroup barrier for kernels that keep LDS-DMA in flight across it: __syncthreads() carries a release fence,
-// for which hipcc waits for EVERY outstanding LDS-DMA (vmcnt(0)); the ring below orders its DMA by explicit counts.
-__device__ __forceinline__ void pw_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 // LDS stores the compiler does not see as such: behind an LDS-DMA it orders every ds_write it knows of with
 // vmcnt(0) (write-after-write on LDS it cannot disambiguate).  The staging tile never overlaps the ring.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -1856,34 +1860,45 @@ static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
   }
   return g_xigemm_dbuf ? launch_xigemm3<NT, PADDED, true>(p, stream) : launch_xigemm3<NT, PADDED, false>(p, stream);
 }
-template <int NT>
-static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
+template <int NT, int NB>
+static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   constexpr int TH = 16, TW = 16;
-  const int HP = (TH + p.ks - 1) * (TW + p.ks - 1);
-  const size_t lds_main = (size_t)((HP * p.PXS + 127) & ~127) + (size_t)2 * (2 * NT * 16 * XROW + 64) * sizeof(u16);
-  const size_t lds_out = p.ys ? (size_t)256 * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)32 * NT * 16 * sizeof(float)
-                              : (size_t)256 * (NT * 16 + 4) * sizeof(float);
-  const size_t lds = lds_main > lds_out ? lds_main : lds_out;
-  WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH, TW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
+  hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB>), grid, dim3(512), lds, stream, p);
+  return check_launch("conv2d_igemm_bf16x3(halo)");
+}
+template <int NT>
+static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
+  constexpr int TH = 16, TW = 16;
+  const int HP = (TH + p.ks - 1) * (TW + p.ks - 1);
+  const size_t halo = (size_t)((HP * p.PXS + 127) & ~127), bstage = (size_t)(2 * NT * 16 * XROW + 64) * sizeof(u16);
+  const size_t lds_out = p.ys ? (size_t)256 * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)32 * NT * 16 * sizeof(float)
+                              : (size_t)256 * (NT * 16 + 4) * sizeof(float);
+  // three weight stages (two stages of DMA latency cover) where LDS allows, else two
+  static int nbmax = -1;
+  if (nbmax < 0) { const char* e = getenv("WCMC_HALO_NB"); nbmax = (e && e[0] == '2') ? 2 : 3; }
+  const int nb = (nbmax >= 3 && halo + 3 * bstage <= 160 * 1024) ? 3 : 2;
+  const size_t lds_main = halo + nb * bstage;
+  const size_t lds = lds_main > lds_out ? lds_main : lds_out;
+  WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
   if (NT == 7) {
     static int ab = -1;
     if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
     if (ab == 64) {      // stamp build (scripts/stamp_igemm.py)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<7, TH, TW, 64>),
+      const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<7, TH, TW, 64, 3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL((conv_halo_bf16x3_kernel<7, TH, TW, 64>), grid, dim3(512), lds, stream, p);
+      hipLaunchKernelGGL((conv_halo_bf16x3_kernel<7, TH, TW, 64, 3>), grid, dim3(512), halo + 3 * bstage, stream, p);
       return check_launch("conv2d_igemm_bf16x3(halo, stamps)");
     }
   }
-  hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW>), grid, dim3(512), lds, stream, p);
-  return check_launch("conv2d_igemm_bf16x3(halo)");
+  return nb == 3 ? launch_xhalo2<NT, 3>(p, lds, stream) : launch_xhalo2<NT, 2>(p, lds, stream);
 }
 template <int NT>
 static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
