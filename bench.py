@@ -234,6 +234,7 @@ def main():
 
     if args.eager:
         ops.USE_SIDE_STREAM = False        # per-launch events need one stream (warm-up included: the rocprofv3
+        ops.USE_BRANCH_STREAM = False
         step = eager_profiled_step         # averages of `bench.py --eager` are then single-stream durations too)
     else:
         from wcmc_amd.graph import GraphedTrainStep
@@ -244,6 +245,7 @@ def main():
         step()
     if args.eager:
         ops.USE_SIDE_STREAM = False        # per-launch events need one stream
+        ops.USE_BRANCH_STREAM = False
         ops.set_profiler(prof)
     if world > 1:
         torch.distributed.barrier()
@@ -266,6 +268,7 @@ def main():
         itf.loss_funcs["l_manif"].check_finite = True
         nprof = max(2, min(5, args.steps))
         ops.USE_SIDE_STREAM = False        # one stream: every event pair brackets exactly one kernel class
+        ops.USE_BRANCH_STREAM = False
         eager_step()
         ops.set_profiler(prof)
         torch.cuda.synchronize()
@@ -311,8 +314,9 @@ def main():
                 # 3 bf16 MFMAs per algorithmic multiply-add (+12 % cout and 5 % k padding): the MFMA pipe does
                 # ~3.5x the counted FLOPs; for scale, the exact-fp32 MFMA peak is 157.3 TFLOP/s
                 extra = {"mfma_flops_per_algorithmic_flop": 3.0, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 3)}
-            rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 16, 16, 0>",
-                            "conv_wgrad_rows": "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>"}.get(name, name + " (several kernels)")
+            rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 16, 16, 0, 3>",
+                            "conv_wgrad_rows": "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
+                            "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}.get(name, name + " (several kernels)")
             return {"kernel": rocprof_name, "class": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": None, "launches": d["launches"], **extra,
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
@@ -345,6 +349,7 @@ def main():
                        if ops.PRECISION == "bf16x3" else "fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate"},
             "roofline": dict(roof(dominant, "mfma"), traffic=traffic.get(dominant)) if dominant else None,
             "roofline_other_conv": [dict(roof(k, "mfma"), traffic=traffic.get(k)) for k in conv_keys if k != dominant],
+            "roofline_pointwise": roof("conv_pw", "hbm"),
             "roofline_kernel_apply": ka,
         }
         if world == 1 and not args.no_cpu_baseline:

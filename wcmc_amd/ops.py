@@ -388,6 +388,9 @@ def _igemm_class(cin, cout, ks):
     tiles = (cout + 15) // 16
     nt = min((7, 4, 2, 1), key=lambda t: (-(-tiles // t)) * (t + 2))
     halo = 3 <= ks <= 5 and (cin + 7) // 8 * 8 >= 32
+    if ks == 1 and ((cin + 7) // 8 * 8, cout) in ((64, 64), (40, 64), (128, 128), (8, 128)) \
+            and os.environ.get("WCMC_IGEMM_PW", "1") != "0":
+        return "conv_pw"                    # x_plan_pw: the persistent pointwise kernel (HBM-bound class)
     return "conv_halo7" if halo and nt == 7 else "conv_igemm"
 
 
@@ -418,7 +421,12 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     mask = None
     if mask_out:
         mask = torch.empty(n * ho * wo * ((cout + 7) // 8), device=dev, dtype=torch.uint8)
-    with _Timed(_igemm_class(cin, cout, ks), 2.0 * n * pix * cout * cin * ks * ks, "flop"):
+    cls = _igemm_class(cin, cout, ks) if pad == 0 or ks > 1 else "conv_igemm"
+    if cls == "conv_pw":    # algorithmic bytes: the split input and the split / fp32 output, 4 B per channel and pixel
+        work = (4.0 * n * pix * ((cin + 7) // 8 * 8 + cout), "byte")
+    else:
+        work = (2.0 * n * pix * cout * cin * ks * ks, "flop")
+    with _Timed(cls, *work):
         check(lib().wcmc_conv2d_igemm_bf16x3(_ptr(xs), n, h, w, cin, _ptr(wp), _ptr(bias), *yv, _ptr(ysp), cout,
                                              ks, pad, ACT[act], LEAKY_SLOPE, _ptr(gate), ACT[gate_act], LEAKY_SLOPE,
                                              _ptr(part), _ptr(gate_mask), _ptr(mask), _stream()), "conv2d_igemm_bf16x3")
