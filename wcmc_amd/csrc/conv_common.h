@@ -21,7 +21,14 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
     if (ci0 + cl < Cin) {
       const float* q = slabs + ((int64_t)tap * Np + co) * Cq + ci0 + cl;
       int s = 0;
-      for (; s + 4 <= S; s += 4) {             // 4 independent loads in flight, summed in slab order
+      for (; s + 12 <= S; s += 12) {           // 12 independent loads in flight (48 slabs = 4 round trips), summed in slab order
+        float v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v[u] = q[(s + u) * sstride];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) acc += v[u];
+      }
+      for (; s + 4 <= S; s += 4) {
         const float v0 = q[(s + 0) * sstride], v1 = q[(s + 1) * sstride];
         const float v2 = q[(s + 2) * sstride], v3 = q[(s + 3) * sstride];
         acc = (((acc + v0) + v1) + v2) + v3;
