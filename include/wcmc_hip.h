@@ -142,7 +142,8 @@ int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              float* colsum_partial, const void* gate_mask, void* mask_out, void* stream);
 /* colsum_partial (optional, with y_split): [wcmc_conv2d_igemm_colsum_elems] floats that receive the
  * per-pixel-tile column sums of the result -- the bias gradient of the layer that consumes this
- * data gradient, finished by wcmc_colsum_finish (saves a pass over dy per layer). */
+ * data gradient, finished by wcmc_colsum_finish (saves a pass over dy per layer).  The buffer ends with a trailer
+ * word: the number of rows the producing launch wrote, which is all wcmc_colsum_finish reads. */
 size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout);
 int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, int Cout, float* db, void* stream);
 size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks);

@@ -539,7 +539,8 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
       if (rg == 0 && c < BN && n0 + c < p.Np) {
         for (int q = 0; q < RG - 1; ++q) a += red[q * BN + c];
         p.colsum[(int64_t)tile * p.Np + n0 + c] = a;
-        for (int r = (int)gridDim.x + tile; r < p.G; r += (int)gridDim.x) p.colsum[(int64_t)r * p.Np + n0 + c] = 0.f;
+        // trailer: the number of rows this launch wrote (the finish kernel reads no further)
+        if (tile == 0 && n0 + c == 0) reinterpret_cast<int*>(p.colsum)[(int64_t)p.G * p.Np] = (int)gridDim.x;
       }
     }
   } else {
@@ -876,7 +877,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
       if (rg == 0 && c < BN && n0 + c < p.Np) {
         for (int q = 0; q < RG - 1; ++q) a += red[q * BN + c];
         p.colsum[(int64_t)tile * p.Np + n0 + c] = a;
-        for (int r = (int)gridDim.x + tile; r < p.G; r += (int)gridDim.x) p.colsum[(int64_t)r * p.Np + n0 + c] = 0.f;
+        // trailer: the number of rows this launch wrote (the finish kernel reads no further)
+        if (tile == 0 && n0 + c == 0) reinterpret_cast<int*>(p.colsum)[(int64_t)p.G * p.Np] = (int)gridDim.x;
       }
     }
   } else {
@@ -1137,7 +1139,7 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
       for (int g = 0; g < NTHR / (2 * VPP); ++g)
         a += red[(g * 2 * VPP + vec) * 8 + e] + red[(g * 2 * VPP + VPP + vec) * 8 + e];
       p.colsum[(int64_t)bx * p.Np + tid] = a;
-      for (int r = nb + bx; r < p.G; r += nb) p.colsum[(int64_t)r * p.Np + tid] = 0.f;
+      if (bx == 0 && tid == 0) reinterpret_cast<int*>(p.colsum)[(int64_t)p.G * p.Np] = nb;   // trailer: rows written
     }
   }
 }
@@ -1971,7 +1973,7 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
 
 extern "C" size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout) {
   if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return 0;
-  return (size_t)x_colsum_rows(N, Ho, Wo) * round_up(Cout, 16);
+  return (size_t)x_colsum_rows(N, Ho, Wo) * round_up(Cout, 16) + 4;      // + trailer: rows the producing launch wrote
 }
 
 extern "C" int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, int Cout, float* db, void* stream) {

@@ -65,12 +65,14 @@ static __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* 
   }
 }
 
-// same with a row pitch (partial[g][ld], first C columns)
-static __global__ __launch_bounds__(1024) void colsum_final_strided_kernel(const float* __restrict__ partial, int G,
+// same with a row pitch (partial[g][ld], first C columns); the producing launch left the number of rows it wrote
+// in the trailer word partial[Gmax * ld] (one row per workgroup: 512 for the persistent 1x1 kernel on 8192 tiles)
+static __global__ __launch_bounds__(1024) void colsum_final_strided_kernel(const float* __restrict__ partial, int Gmax,
                                                                            int ld, int C, float* __restrict__ out) {
   __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, gg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
+  const int G = min(Gmax, reinterpret_cast<const int*>(partial)[(int64_t)Gmax * ld]);
   float acc = 0.f;
   if (c < C) {
     // eight independent loads in flight per thread (one block reduces up to 8192 tile rows: latency-bound)
