@@ -249,6 +249,9 @@ struct XIgemmParams {
   int CS, nslabs, SPS, PXS, tilesX, tilesY;   // halo kernel: channel slab, stages per slab, halo pixel stride
   int CSl, SPSl;                              // ... of the last slab
   unsigned y_bytes, m_bytes;                  // pointwise kernel: extents of the output and of the 1-bit masks
+  // pointwise kernel, optional tail layer (a second 1x1 conv of <= 4 couts applied to the tile while it is in LDS)
+  const u16* wp2; const float* bias2; float* y2; int64_t y2sn, y2sh, y2sw;
+  int Cout2, act2, Kt2; float slope2; unsigned wp2_bytes, y2_bytes;
 };
 
 // DBUF: two LDS stage buffers and one barrier per stage (2 workgroups per CU), or one buffer and two
@@ -940,7 +943,7 @@ __device__ __forceinline__ void pw_lds_store_b128(unsigned addr, u32x4 v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-template <int NTW, int U, bool SPLIT>
+template <int NTW, int U, bool SPLIT, bool TAIL = false>
 __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_kernel(XIgemmParams p) {
   constexpr int NW = NTW, NTHR = NW * 64, TP = 64, RT = TP / 16, BN = NTW * 16;
   constexpr int KC = U > 16 ? 4 : (U > 8 ? 2 : 1);     // 32-k steps: Kt = 128 / 64 / 32
@@ -951,7 +954,8 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
   constexpr int STAGE = AREG + (SPLIT ? NW * 256 : 0); // + one gate-mask slot per wave
   constexpr int NS = 3;
   constexpr int DM = D + (SPLIT ? 1 : 0);              // vector-memory instructions per wave: fill of one stage,
-  constexpr int SI = SPLIT ? 8 : 4;                    // ... stores of one tile
+  constexpr int SI = (SPLIT ? 8 : 4) + (TAIL ? 1 : 0); // ... stores of one tile
+  static_assert(!TAIL || (SPLIT && NTW >= 4), "the tail layer reads the split staging tile, one wave per 16 pixels");
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
   char* const ring = reinterpret_cast<char*>(smem16);
   char* const stg = ring + NS * STAGE;
@@ -1015,6 +1019,25 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
   for (int e = 0; e < 4; ++e) {
     const int co = wave * 16 + q * 4 + e;
     bs[e] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+  }
+  // tail layer (TAIL): y2 = act2(W2 * tile + b2) with <= 4 couts, e.g. the 128 -> 3 output layer of the PathNet
+  // `final` chain: wave i < 4 multiplies pixel tile i of the staging tile by W2's only cout tile (fragments in
+  // registers) -- the hidden activation is written once and never re-read by a second launch.
+  constexpr int KC2 = TAIL ? BN / 32 : 1;
+  bf16x8 w2h[KC2], w2l[KC2];
+  float bs2[4] = {0.f, 0.f, 0.f, 0.f};
+  __amdgpu_buffer_rsrc_t y2r = yr;
+  if (TAIL) {
+    const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp2, 0, (int)p.wp2_bytes, 0x00020000);
+    y2r = __builtin_amdgcn_make_buffer_rsrc((void*)p.y2, 0, (int)p.y2_bytes, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < KC2; ++c) {
+      const unsigned o = (unsigned)(((fr * 2) * p.Kt2 + c * 32 + q * 8) * 2);
+      w2h[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2r, o, 0, 0));
+      w2l[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2r, o + (unsigned)(p.Kt2 * 2), 0, 0));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bs2[e] = (p.bias2 && q == 0 && e < p.Cout2) ? p.bias2[e] : 0.f;
   }
   const bool is_relu = p.act == WCMC_ACT_RELU;
   const float nslope = p.act == WCMC_ACT_LEAKY_RELU ? p.slope : 1.f;
@@ -1095,6 +1118,36 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
           }
         }
       }
+      if (TAIL) {
+        f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int pr = 16 * (wave & 3) + fr;
+        if (wave < 4) {
+#pragma unroll
+          for (int c = 0; c < KC2; ++c) {
+            const bf16x8 th = *reinterpret_cast<const bf16x8*>(so + pr * OLD + c * 32 + q * 8);
+            const bf16x8 tl = *reinterpret_cast<const bf16x8*>(so + pr * OLD + BN + c * 32 + q * 8);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2l[c], th, a2, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[c], tl, a2, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[c], th, a2, 0, 0, 0);
+          }
+        }
+        // lanes q == 0 hold couts 0..3 of pixel pr: one 16-byte store per pixel (Cout2 <= 4, the view's channel pad is 4)
+        const bool relu2 = p.act2 == WCMC_ACT_RELU;
+        const float ns2 = p.act2 == WCMC_ACT_LEAKY_RELU ? p.slope2 : 1.f;
+        u32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = a2[e] + bs2[e], neg = t * ns2;
+          const float r = e < p.Cout2 ? (t > 0.f ? t : (relu2 ? 0.f : neg)) : 0.f;
+          ov[e] = __builtin_bit_cast(unsigned, r);
+        }
+        const int64_t m = m0 + pr;
+        const int n2 = (int)(m / HoWo);
+        const int r2 = (int)(m - (int64_t)n2 * HoWo);
+        const int oy2 = r2 / p.Wo, ox2 = r2 - oy2 * p.Wo;
+        const int64_t off2 = ((int64_t)n2 * p.y2sn + (int64_t)oy2 * p.y2sh + (int64_t)ox2 * p.y2sw) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(ov, y2r, (wave < 4 && q == 0 && m < p.M) ? (unsigned)off2 : XOOB, 0, 0);
+      }
     } else {
       constexpr int OLD = BN + 4;
       float* so = reinterpret_cast<float*>(stg);
@@ -1144,7 +1197,7 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
   }
 }
 
-template <int NTW, int U, bool SPLIT>
+template <int NTW, int U, bool SPLIT, bool TAIL = false>
 static int launch_xpw2(const XIgemmParams& p, hipStream_t stream) {
   constexpr int NW = NTW, BN = NTW * 16, D = (U + NW - 1) / NW;
   constexpr size_t stage = (size_t)D * NW * 1024 + (SPLIT ? NW * 256 : 0);
@@ -1155,7 +1208,7 @@ static int launch_xpw2(const XIgemmParams& p, hipStream_t stream) {
   static int cus = 0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_bf16x3_kernel<NTW, U, SPLIT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_bf16x3_kernel<NTW, U, SPLIT, TAIL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1166,7 +1219,7 @@ static int launch_xpw2(const XIgemmParams& p, hipStream_t stream) {
   int64_t nb = (int64_t)cus * (U >= 32 ? 1 : 2);
   if (nb > ntiles) nb = ntiles;
   if (p.colsum && nb > p.G) nb = p.G;
-  hipLaunchKernelGGL((conv_pw_bf16x3_kernel<NTW, U, SPLIT>), dim3((unsigned)nb), dim3(NW * 64), lds, stream, p);
+  hipLaunchKernelGGL((conv_pw_bf16x3_kernel<NTW, U, SPLIT, TAIL>), dim3((unsigned)nb), dim3(NW * 64), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(pointwise)");
 }
 
@@ -1959,6 +2012,8 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   }
   hipStream_t st = (hipStream_t)stream;
   p.y_bytes = 0; p.m_bytes = 0;
+  p.wp2 = nullptr; p.bias2 = nullptr; p.y2 = nullptr; p.y2sn = p.y2sh = p.y2sw = 0; p.Cout2 = 0; p.act2 = 0; p.Kt2 = 0;
+  p.slope2 = 0.f; p.wp2_bytes = p.y2_bytes = 0;
   {
     int ntw = 0, u = 0;
     if (x_plan_pw(p, &ntw, &u)) return launch_xpw(p, ntw, u, st);
@@ -1969,6 +2024,52 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
     case 2: return launch_xigemm<2>(p, st);
     default: return launch_xigemm<1>(p, st);
   }
+}
+
+static bool x_pair_enabled() {
+  const char* e = getenv("WCMC_IGEMM_PW");
+  const char* t = getenv("WCMC_PW_TAIL");       // WCMC_PW_TAIL=0: A/B switch back to two launches
+  return !(e && e[0] == '0') && !(t && t[0] == '0');
+}
+
+extern "C" int wcmc_conv1x1_pair_supported(int Cin, int Cout1, int Cout2) {
+  return x_pair_enabled() && round_up(Cin, 8) == 128 && Cout1 == 128 && Cout2 >= 1 && Cout2 <= 4;
+}
+
+extern "C" int wcmc_conv1x1_pair_bf16x3(const void* x_split, int N, int H, int W, int Cin, const void* wp1,
+                                        const float* bias1, int Cout1, int act1, float slope1, void* y1_split,
+                                        void* mask1, const void* wp2, const float* bias2, int Cout2, int act2,
+                                        float slope2, float* y2, int64_t y2sn, int64_t y2sh, int64_t y2sw, void* stream) {
+  WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && x_split && wp1 && wp2 && y1_split && y2, WCMC_ERR_BAD_ARG,
+               "conv1x1_pair_bf16x3: bad argument");
+  WCMC_REQUIRE(wcmc_conv1x1_pair_supported(Cin, Cout1, Cout2), WCMC_ERR_BAD_ARG,
+               "conv1x1_pair_bf16x3: no fused instance for %d -> %d -> %d channels", Cin, Cout1, Cout2);
+  WCMC_REQUIRE(aligned16(x_split) && aligned16(wp1) && aligned16(wp2) && aligned16(y1_split), WCMC_ERR_ALIGNMENT,
+               "conv1x1_pair_bf16x3: split buffers must be 16-byte aligned");
+  WCMC_REQUIRE(nhwc_view_ok(y2, y2sn, y2sh, y2sw, Cout2), WCMC_ERR_ALIGNMENT, "conv1x1_pair_bf16x3: y2 violates the NHWC-view contract");
+  XIgemmParams p;
+  p.x = (const u16*)x_split; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cpi = round_up(Cin, 8);
+  p.wp = (const u16*)wp1; p.bias = bias1;
+  p.yf = nullptr; p.ysn = p.ysh = p.ysw = 0;
+  p.ys = (u16*)y1_split; p.Cpo = round_up(Cout1, 8);
+  p.Ho = H; p.Wo = W; p.Cout = Cout1;
+  p.gate = nullptr; p.gate_act = WCMC_ACT_LINEAR; p.gate_slope = 0.f; p.gate_mask = nullptr;
+  p.mask_out = (unsigned char*)mask1;
+  p.ks = 1; p.pad = 0; p.act = act1; p.slope = slope1;
+  p.Kp = p.Cpi; p.Kt = round_up(p.Cpi, 32); p.Np = round_up(Cout1, 16);
+  p.CS = p.Kp; p.nslabs = 1; p.SPS = p.Kt / 32; p.PXS = 0; p.CSl = p.CS; p.SPSl = p.SPS;
+  p.tilesY = p.tilesX = 0; p.G = 0; p.colsum = nullptr;
+  p.M = (int64_t)N * H * W;
+  const int64_t xb = p.M * 4 * p.Cpi, yb = p.M * 4 * p.Np;
+  const int64_t y2b = ((int64_t)(N - 1) * y2sn + (int64_t)(H - 1) * y2sh + (int64_t)(W - 1) * y2sw + 4) * 4;
+  WCMC_REQUIRE(xb < 0x7ff00000LL && yb < 0x7ff00000LL && y2b < 0x7ff00000LL && y2sn >= 0 && y2sh >= 0 && y2sw >= 4,
+               WCMC_ERR_BAD_ARG, "conv1x1_pair_bf16x3: operand larger than 2 GiB (split the batch)");
+  p.x_bytes = (unsigned)xb; p.wp_bytes = (unsigned)((size_t)p.Np * 2 * p.Kt * sizeof(u16));
+  p.y_bytes = (unsigned)yb; p.m_bytes = (unsigned)(p.M * (p.Np / 8));
+  p.wp2 = (const u16*)wp2; p.bias2 = bias2; p.y2 = y2; p.y2sn = y2sn; p.y2sh = y2sh; p.y2sw = y2sw;
+  p.Cout2 = Cout2; p.act2 = act2; p.slope2 = slope2; p.Kt2 = p.Np;
+  p.wp2_bytes = (unsigned)((size_t)16 * 2 * p.Kt2 * sizeof(u16)); p.y2_bytes = (unsigned)y2b;
+  return launch_xpw2<8, 32, true, true>(p, (hipStream_t)stream);
 }
 
 extern "C" size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout) {

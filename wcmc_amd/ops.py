@@ -435,6 +435,21 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     return ret if len(ret) > 1 else out
 
 
+def conv1x1_pair_x_raw(xs, dims, wp1, b1, cout1, act1, wp2, b2, cout2, act2):
+    """Two 1x1 layers in one launch (wcmc_conv1x1_pair_bf16x3): returns (split hidden activation, its 1-bit
+    mask, fp32 NHWC output of the second layer)."""
+    n, cin, h, w = dims
+    dev = xs.device
+    ysp = _split_empty(n, cout1, h, w, dev)
+    mask = torch.empty(n * h * w * ((cout1 + 7) // 8), device=dev, dtype=torch.uint8)
+    y2 = nhwc_empty(n, cout2, h, w, dev)
+    with _Timed("conv_pw", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + cout1 + 4), "byte"):
+        check(lib().wcmc_conv1x1_pair_bf16x3(_ptr(xs), n, h, w, cin, _ptr(wp1), _ptr(b1), cout1, ACT[act1], LEAKY_SLOPE,
+                                             _ptr(ysp), _ptr(mask), _ptr(wp2), _ptr(b2), cout2, ACT[act2], LEAKY_SLOPE,
+                                             *_v(y2), _stream()), "conv1x1_pair_bf16x3")
+    return ysp, mask, y2
+
+
 def colsum_finish_raw(part, dims):
     n, c, h, w = dims
     db = torch.empty(c, device=part.device, dtype=torch.float32)
@@ -474,11 +489,25 @@ def _chainx_forward(ctx, xs0, dims0, spec, params):
     xs = [xs0]
     masks = []
     y = None
+    # the last two layers of a 1x1 chain in one launch where the library has a fused instance (PathNet.final:
+    # 128 -> 128 -> 3): the hidden activation is written once and not re-read
+    pair = (ks == 1 and pad == 0 and nl >= 2 and
+            lib().wcmc_conv1x1_pair_supported(params[2 * nl - 4].shape[1], params[2 * nl - 4].shape[0],
+                                              params[2 * nl - 2].shape[0]))
     for l in range(nl):
         wt, b = params[2 * l], params[2 * l + 1]
         cout = wt.shape[0]
         wp = _pack_x(wt, 0)
         hidden = l < nl - 1
+        if pair and l == nl - 2:
+            xs1, mask1, y = conv1x1_pair_x_raw(xs[l], dims[l], wp, b.detach(), cout, acts[l], _pack_x(params[2 * l + 2], 0),
+                                               params[2 * l + 3].detach(), params[2 * l + 2].shape[0], acts[l + 1])
+            hh, ww = dims[l][2], dims[l][3]
+            dims.append((n, cout, hh, ww))
+            dims.append((n, params[2 * l + 2].shape[0], hh, ww))
+            xs.append(xs1)
+            masks.append(mask1)
+            break
         out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=hidden, mask_out=hidden)
         hh, ww = dims[l][2] + 2 * pad - ks + 1, dims[l][3] + 2 * pad - ks + 1
         dims.append((n, cout, hh, ww))
