@@ -144,17 +144,19 @@ int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin,
  * per-pixel-tile column sums of the result -- the bias gradient of the layer that consumes this
  * data gradient, finished by wcmc_colsum_finish (saves a pass over dy per layer).  The buffer ends with a trailer
  * word: the number of rows the producing launch wrote, which is all wcmc_colsum_finish reads. */
-/* Two 1x1 layers in one launch (sbmc.modules.ConvChain with ksize 1, the last two layers of PathNet.final,
- * support/networks.py:26-27,41): y1 = act1(W1 x + b1) is written as a split tensor with its 1-bit mask (the
- * backward needs both) and y2 = act2(W2 y1 + b2), Cout2 <= 4, is computed from the tile while it is on chip, so
- * the 128-channel hidden activation is not re-read by a second launch.  wcmc_conv1x1_pair_supported says whether
- * a fused instance exists for the channel counts (else: two wcmc_conv2d_igemm_bf16x3 launches, same results
- * bit for bit).  wp1 / wp2: wcmc_conv2d_pack_weight_bf16x3(mode 0). */
+/* Two 1x1 layers in one launch (sbmc.modules.ConvChain with ksize 1: the last two layers of PathNet.final and of
+ * PathNet.embedding, support/networks.py:22-27,33-41, and the data gradient of the former): y1 = gate * act1(W1 x + b1)
+ * is written as a split tensor -- with its 1-bit mask (mask1) on the forward, gated by gate_mask1 and with column
+ * sums (colsum1, see below) on the backward, exactly as wcmc_conv2d_igemm_bf16x3 would -- and y2 = act2(W2 y1 + b2)
+ * (fp32 NHWC view) is computed from the tile while it is on chip, so the hidden tensor is not re-read by a second
+ * launch.  wcmc_conv1x1_pair_supported says whether a fused instance exists for the channel counts (else: two
+ * wcmc_conv2d_igemm_bf16x3 launches, same results bit for bit).  wp1 / wp2: wcmc_conv2d_pack_weight_bf16x3. */
 int wcmc_conv1x1_pair_supported(int Cin, int Cout1, int Cout2);
 int wcmc_conv1x1_pair_bf16x3(const void* x_split, int N, int H, int W, int Cin, const void* wp1, const float* bias1,
-                             int Cout1, int act1, float slope1, void* y1_split, void* mask1, const void* wp2,
-                             const float* bias2, int Cout2, int act2, float slope2, float* y2, int64_t y2sn,
-                             int64_t y2sh, int64_t y2sw, void* stream);
+                             int Cout1, int act1, float slope1, void* y1_split, void* mask1, const void* gate_mask1,
+                             int gate_act1, float gate_slope1, float* colsum1, const void* wp2, const float* bias2,
+                             int Cout2, int act2, float slope2, float* y2, int64_t y2sn, int64_t y2sh, int64_t y2sw,
+                             void* stream);
 size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout);
 int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, int Cout, float* db, void* stream);
 size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks);

@@ -943,7 +943,7 @@ __device__ __forceinline__ void pw_lds_store_b128(unsigned addr, u32x4 v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-template <int NTW, int U, bool SPLIT, bool TAIL = false>
+template <int NTW, int U, bool SPLIT, int TAIL = 0>
 __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_kernel(XIgemmParams p) {
   constexpr int NW = NTW, NTHR = NW * 64, TP = 64, RT = TP / 16, BN = NTW * 16;
   constexpr int KC = U > 16 ? 4 : (U > 8 ? 2 : 1);     // 32-k steps: Kt = 128 / 64 / 32
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
   constexpr int STAGE = AREG + (SPLIT ? NW * 256 : 0); // + one gate-mask slot per wave
   constexpr int NS = 3;
   constexpr int DM = D + (SPLIT ? 1 : 0);              // vector-memory instructions per wave: fill of one stage,
-  constexpr int SI = (SPLIT ? 8 : 4) + (TAIL ? 1 : 0); // ... stores of one tile
+  constexpr int SI = (SPLIT ? 8 : 4) + (TAIL == 1 ? 1 : TAIL == 2 ? 4 : 0);   // ... stores of one tile
   static_assert(!TAIL || (SPLIT && NTW >= 4), "the tail layer reads the split staging tile, one wave per 16 pixels");
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
   char* const ring = reinterpret_cast<char*>(smem16);
@@ -1020,9 +1020,11 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
     const int co = wave * 16 + q * 4 + e;
     bs[e] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
   }
-  // tail layer (TAIL): y2 = act2(W2 * tile + b2) with <= 4 couts, e.g. the 128 -> 3 output layer of the PathNet
-  // `final` chain: wave i < 4 multiplies pixel tile i of the staging tile by W2's only cout tile (fragments in
-  // registers) -- the hidden activation is written once and never re-read by a second launch.
+  // tail layer: y2 = act2(W2 * tile + b2), a second 1x1 layer applied to the split tile while it is in LDS -- the
+  // hidden activation is written once and never re-read by a second launch.  TAIL == 1: <= 4 couts (the 128 -> 3
+  // output layer of PathNet.final): wave i < 4 multiplies pixel tile i by W2's only cout tile.  TAIL == 2: as many
+  // couts as the first layer (64 -> 64 of the embedding chain; the 128 -> 128 data gradient behind 3 -> 128):
+  // every wave multiplies the four pixel tiles by ITS cout tile, the fp32 result takes the staging tile's place.
   constexpr int KC2 = TAIL ? BN / 32 : 1;
   bf16x8 w2h[KC2], w2l[KC2];
   float bs2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1032,12 +1034,15 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
     y2r = __builtin_amdgcn_make_buffer_rsrc((void*)p.y2, 0, (int)p.y2_bytes, 0x00020000);
 #pragma unroll
     for (int c = 0; c < KC2; ++c) {
-      const unsigned o = (unsigned)(((fr * 2) * p.Kt2 + c * 32 + q * 8) * 2);
+      const unsigned o = (unsigned)((((TAIL == 2 ? wave * 16 : 0) + fr) * 2 * p.Kt2 + c * 32 + q * 8) * 2);
       w2h[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2r, o, 0, 0));
       w2l[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2r, o + (unsigned)(p.Kt2 * 2), 0, 0));
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bs2[e] = (p.bias2 && q == 0 && e < p.Cout2) ? p.bias2[e] : 0.f;
+    for (int e = 0; e < 4; ++e) {
+      const int co2 = (TAIL == 2 ? wave * 16 + q * 4 : 0) + e;
+      bs2[e] = (p.bias2 && (TAIL == 2 || q == 0) && co2 < p.Cout2) ? p.bias2[co2] : 0.f;
+    }
   }
   const bool is_relu = p.act == WCMC_ACT_RELU;
   const float nslope = p.act == WCMC_ACT_LEAKY_RELU ? p.slope : 1.f;
@@ -1118,7 +1123,7 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
           }
         }
       }
-      if (TAIL) {
+      if (TAIL == 1) {
         f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
         const int pr = 16 * (wave & 3) + fr;
         if (wave < 4) {
@@ -1147,6 +1152,51 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
         const int oy2 = r2 / p.Wo, ox2 = r2 - oy2 * p.Wo;
         const int64_t off2 = ((int64_t)n2 * p.y2sn + (int64_t)oy2 * p.y2sh + (int64_t)ox2 * p.y2sw) * 4;
         __builtin_amdgcn_raw_buffer_store_b128(ov, y2r, (wave < 4 && q == 0 && m < p.M) ? (unsigned)off2 : XOOB, 0, 0);
+      }
+      if (TAIL == 2) {
+        f32x4 a2[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          a2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const u16* t0 = so + (16 * i + fr) * OLD + q * 8;
+#pragma unroll
+          for (int c = 0; c < KC2; ++c) {
+            const bf16x8 th = *reinterpret_cast<const bf16x8*>(t0 + c * 32);
+            const bf16x8 tl = *reinterpret_cast<const bf16x8*>(t0 + BN + c * 32);
+            a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2l[c], th, a2[i], 0, 0, 0);
+            a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[c], tl, a2[i], 0, 0, 0);
+            a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[c], th, a2[i], 0, 0, 0);
+          }
+        }
+        pw_barrier();                                    // everyone is done with the split tile (stores and fragments)
+        constexpr int OLF = BN + 4;                      // floats per pixel row: same bytes as the split tile
+        const bool relu2 = p.act2 == WCMC_ACT_RELU;
+        const float ns2 = p.act2 == WCMC_ACT_LEAKY_RELU ? p.slope2 : 1.f;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          u32x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = a2[i][e] + bs2[e], neg = t * ns2;
+            ov[e] = __builtin_bit_cast(unsigned, t > 0.f ? t : (relu2 ? 0.f : neg));
+          }
+          pw_lds_store_b128(stg_lds + (unsigned)(((16 * i + fr) * OLF + wave * 16 + q * 4) * 4), ov);
+        }
+        pw_barrier();
+        const float* sf = reinterpret_cast<const float*>(stg);
+        constexpr int VF = BN / 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int v = tid + k * NTHR;
+          const int pr = v / VF, vec = v - pr * VF;
+          const int64_t m = m0 + pr;
+          const int n2 = (int)(m / HoWo);
+          const int r2 = (int)(m - (int64_t)n2 * HoWo);
+          const int oy2 = r2 / p.Wo, ox2 = r2 - oy2 * p.Wo;
+          const int64_t off2 = ((int64_t)n2 * p.y2sn + (int64_t)oy2 * p.y2sh + (int64_t)ox2 * p.y2sw + vec * 4) * 4;
+          const u32x4 hv = *reinterpret_cast<const u32x4*>(sf + pr * OLF + vec * 4);
+          __builtin_amdgcn_raw_buffer_store_b128(hv, y2r, m < p.M ? (unsigned)off2 : XOOB, 0, 0);
+        }
       }
     } else {
       constexpr int OLD = BN + 4;
@@ -1197,7 +1247,7 @@ __global__ __launch_bounds__(NTW * 64, (U >= 32 ? 1 : 2)) void conv_pw_bf16x3_ke
   }
 }
 
-template <int NTW, int U, bool SPLIT, bool TAIL = false>
+template <int NTW, int U, bool SPLIT, int TAIL = 0>
 static int launch_xpw2(const XIgemmParams& p, hipStream_t stream) {
   constexpr int NW = NTW, BN = NTW * 16, D = (U + NW - 1) / NW;
   constexpr size_t stage = (size_t)D * NW * 1024 + (SPLIT ? NW * 256 : 0);
@@ -2031,19 +2081,29 @@ static bool x_pair_enabled() {
   const char* t = getenv("WCMC_PW_TAIL");       // WCMC_PW_TAIL=0: A/B switch back to two launches
   return !(e && e[0] == '0') && !(t && t[0] == '0');
 }
+// fused instances: (input units, couts of the first layer, tail kind)
+static int x_pair_kind(int Cin, int Cout1, int Cout2) {
+  const int cpi = round_up(Cin, 8);
+  if (cpi == 128 && Cout1 == 128 && Cout2 >= 1 && Cout2 <= 4) return 1;     // PathNet.final forward: 128 -> 128 -> 3
+  if (cpi == 8 && Cout1 == 128 && Cout2 == 128) return 2;                    // its data gradient: 3 -> 128 -> 128
+  if (cpi == 64 && Cout1 == 64 && Cout2 == 64) return 3;                     // PathNet.embedding forward: 64 -> 64 -> 64
+  return 0;
+}
 
 extern "C" int wcmc_conv1x1_pair_supported(int Cin, int Cout1, int Cout2) {
-  return x_pair_enabled() && round_up(Cin, 8) == 128 && Cout1 == 128 && Cout2 >= 1 && Cout2 <= 4;
+  return x_pair_enabled() && x_pair_kind(Cin, Cout1, Cout2) != 0;
 }
 
 extern "C" int wcmc_conv1x1_pair_bf16x3(const void* x_split, int N, int H, int W, int Cin, const void* wp1,
                                         const float* bias1, int Cout1, int act1, float slope1, void* y1_split,
-                                        void* mask1, const void* wp2, const float* bias2, int Cout2, int act2,
+                                        void* mask1, const void* gate_mask1, int gate_act1, float gate_slope1,
+                                        float* colsum1, const void* wp2, const float* bias2, int Cout2, int act2,
                                         float slope2, float* y2, int64_t y2sn, int64_t y2sh, int64_t y2sw, void* stream) {
   WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && x_split && wp1 && wp2 && y1_split && y2, WCMC_ERR_BAD_ARG,
                "conv1x1_pair_bf16x3: bad argument");
-  WCMC_REQUIRE(wcmc_conv1x1_pair_supported(Cin, Cout1, Cout2), WCMC_ERR_BAD_ARG,
-               "conv1x1_pair_bf16x3: no fused instance for %d -> %d -> %d channels", Cin, Cout1, Cout2);
+  const int kind = x_pair_enabled() ? x_pair_kind(Cin, Cout1, Cout2) : 0;
+  WCMC_REQUIRE(kind != 0, WCMC_ERR_BAD_ARG, "conv1x1_pair_bf16x3: no fused instance for %d -> %d -> %d channels", Cin,
+               Cout1, Cout2);
   WCMC_REQUIRE(aligned16(x_split) && aligned16(wp1) && aligned16(wp2) && aligned16(y1_split), WCMC_ERR_ALIGNMENT,
                "conv1x1_pair_bf16x3: split buffers must be 16-byte aligned");
   WCMC_REQUIRE(nhwc_view_ok(y2, y2sn, y2sh, y2sw, Cout2), WCMC_ERR_ALIGNMENT, "conv1x1_pair_bf16x3: y2 violates the NHWC-view contract");
@@ -2053,23 +2113,27 @@ extern "C" int wcmc_conv1x1_pair_bf16x3(const void* x_split, int N, int H, int W
   p.yf = nullptr; p.ysn = p.ysh = p.ysw = 0;
   p.ys = (u16*)y1_split; p.Cpo = round_up(Cout1, 8);
   p.Ho = H; p.Wo = W; p.Cout = Cout1;
-  p.gate = nullptr; p.gate_act = WCMC_ACT_LINEAR; p.gate_slope = 0.f; p.gate_mask = nullptr;
+  p.gate = nullptr; p.gate_act = gate_act1; p.gate_slope = gate_slope1; p.gate_mask = (const unsigned char*)gate_mask1;
   p.mask_out = (unsigned char*)mask1;
   p.ks = 1; p.pad = 0; p.act = act1; p.slope = slope1;
   p.Kp = p.Cpi; p.Kt = round_up(p.Cpi, 32); p.Np = round_up(Cout1, 16);
   p.CS = p.Kp; p.nslabs = 1; p.SPS = p.Kt / 32; p.PXS = 0; p.CSl = p.CS; p.SPSl = p.SPS;
-  p.tilesY = p.tilesX = 0; p.G = 0; p.colsum = nullptr;
+  p.tilesY = p.tilesX = 0; p.G = x_colsum_rows(N, H, W); p.colsum = colsum1;
   p.M = (int64_t)N * H * W;
+  const int cp2 = round_up(Cout2, 4);
   const int64_t xb = p.M * 4 * p.Cpi, yb = p.M * 4 * p.Np;
-  const int64_t y2b = ((int64_t)(N - 1) * y2sn + (int64_t)(H - 1) * y2sh + (int64_t)(W - 1) * y2sw + 4) * 4;
-  WCMC_REQUIRE(xb < 0x7ff00000LL && yb < 0x7ff00000LL && y2b < 0x7ff00000LL && y2sn >= 0 && y2sh >= 0 && y2sw >= 4,
+  const int64_t y2b = ((int64_t)(N - 1) * y2sn + (int64_t)(H - 1) * y2sh + (int64_t)(W - 1) * y2sw + cp2) * 4;
+  WCMC_REQUIRE(xb < 0x7ff00000LL && yb < 0x7ff00000LL && y2b < 0x7ff00000LL && y2sn >= 0 && y2sh >= 0 && y2sw >= cp2,
                WCMC_ERR_BAD_ARG, "conv1x1_pair_bf16x3: operand larger than 2 GiB (split the batch)");
   p.x_bytes = (unsigned)xb; p.wp_bytes = (unsigned)((size_t)p.Np * 2 * p.Kt * sizeof(u16));
   p.y_bytes = (unsigned)yb; p.m_bytes = (unsigned)(p.M * (p.Np / 8));
   p.wp2 = (const u16*)wp2; p.bias2 = bias2; p.y2 = y2; p.y2sn = y2sn; p.y2sh = y2sh; p.y2sw = y2sw;
   p.Cout2 = Cout2; p.act2 = act2; p.slope2 = slope2; p.Kt2 = p.Np;
-  p.wp2_bytes = (unsigned)((size_t)16 * 2 * p.Kt2 * sizeof(u16)); p.y2_bytes = (unsigned)y2b;
-  return launch_xpw2<8, 32, true, true>(p, (hipStream_t)stream);
+  p.wp2_bytes = (unsigned)((size_t)round_up(Cout2, 16) * 2 * p.Kt2 * sizeof(u16)); p.y2_bytes = (unsigned)y2b;
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 1) return launch_xpw2<8, 32, true, 1>(p, st);
+  if (kind == 2) return launch_xpw2<8, 2, true, 2>(p, st);
+  return launch_xpw2<4, 16, true, 2>(p, st);
 }
 
 extern "C" size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout) {

@@ -435,19 +435,24 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     return ret if len(ret) > 1 else out
 
 
-def conv1x1_pair_x_raw(xs, dims, wp1, b1, cout1, act1, wp2, b2, cout2, act2):
-    """Two 1x1 layers in one launch (wcmc_conv1x1_pair_bf16x3): returns (split hidden activation, its 1-bit
-    mask, fp32 NHWC output of the second layer)."""
+def conv1x1_pair_x_raw(xs, dims, wp1, b1, cout1, act1, wp2, b2, cout2, act2, gate_mask=None, gate_act="linear",
+                       colsum=False, mask_out=True):
+    """Two 1x1 layers in one launch (wcmc_conv1x1_pair_bf16x3): returns (split result of the first layer, its 1-bit
+    mask or None, its column-sum partials or None, fp32 NHWC output of the second layer)."""
     n, cin, h, w = dims
     dev = xs.device
     ysp = _split_empty(n, cout1, h, w, dev)
-    mask = torch.empty(n * h * w * ((cout1 + 7) // 8), device=dev, dtype=torch.uint8)
+    mask = torch.empty(n * h * w * ((cout1 + 7) // 8), device=dev, dtype=torch.uint8) if mask_out else None
+    part = None
+    if colsum:
+        part = torch.empty(lib().wcmc_conv2d_igemm_colsum_elems(n, h, w, cout1), device=dev, dtype=torch.float32)
     y2 = nhwc_empty(n, cout2, h, w, dev)
-    with _Timed("conv_pw", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + cout1 + 4), "byte"):
+    with _Timed("conv_pw", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + cout1 + (cout2 + 3) // 4 * 4), "byte"):
         check(lib().wcmc_conv1x1_pair_bf16x3(_ptr(xs), n, h, w, cin, _ptr(wp1), _ptr(b1), cout1, ACT[act1], LEAKY_SLOPE,
-                                             _ptr(ysp), _ptr(mask), _ptr(wp2), _ptr(b2), cout2, ACT[act2], LEAKY_SLOPE,
+                                             _ptr(ysp), _ptr(mask), _ptr(gate_mask), ACT[gate_act], LEAKY_SLOPE,
+                                             _ptr(part), _ptr(wp2), _ptr(b2), cout2, ACT[act2], LEAKY_SLOPE,
                                              *_v(y2), _stream()), "conv1x1_pair_bf16x3")
-    return ysp, mask, y2
+    return ysp, mask, part, y2
 
 
 def colsum_finish_raw(part, dims):
@@ -500,8 +505,8 @@ def _chainx_forward(ctx, xs0, dims0, spec, params):
         wp = _pack_x(wt, 0)
         hidden = l < nl - 1
         if pair and l == nl - 2:
-            xs1, mask1, y = conv1x1_pair_x_raw(xs[l], dims[l], wp, b.detach(), cout, acts[l], _pack_x(params[2 * l + 2], 0),
-                                               params[2 * l + 3].detach(), params[2 * l + 2].shape[0], acts[l + 1])
+            xs1, mask1, _, y = conv1x1_pair_x_raw(xs[l], dims[l], wp, b.detach(), cout, acts[l], _pack_x(params[2 * l + 2], 0),
+                                                  params[2 * l + 3].detach(), params[2 * l + 2].shape[0], acts[l + 1])
             hh, ww = dims[l][2], dims[l][3]
             dims.append((n, cout, hh, ww))
             dims.append((n, params[2 * l + 2].shape[0], hh, ww))
@@ -569,12 +574,20 @@ def _chainx_backward(ctx, dy, need_dx, dys=None):
             if part is not None:
                 db = colsum_finish_raw(part, dims[l + 1])
         grads[2 * l], grads[2 * l + 1] = dw, db
-        if l > 0:
+        if (l == 1 and need_dx and ks == 1 and pad == 0 and USE_GATE_MASK and
+                lib().wcmc_conv1x1_pair_supported(cout, wt.shape[1], ws[0].shape[1])):
+            # the data gradients of layers 1 and 0 in one launch (PathNet.final: 3 -> 128 -> 128): the 128-channel
+            # gradient of the hidden activation is written once (the weight gradient of layer 0 reads it) and feeds
+            # the second GEMM from LDS
+            dys, _, part, dx = conv1x1_pair_x_raw(dys, dims[2], _pack_x(wt, 1), None, wt.shape[1], "linear",
+                                                  _pack_x(ws[0], 1), None, ws[0].shape[1], "linear",
+                                                  gate_mask=masks[0], gate_act=acts[0], colsum=True, mask_out=False)
+        elif l > 0:
             wpt = _pack_x(wt, 1)
             g = dict(gate_mask=masks[l - 1]) if USE_GATE_MASK else dict(gate=xs[l])
             dys, part = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
                                      out_split=True, gate_act=acts[l - 1], colsum=True, **g)
-        elif need_dx:
+        elif need_dx and dx is None:
             wpt = _pack_x(wt, 1)
             dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
                               out_split=False)
