@@ -241,6 +241,14 @@ int wcmc_spp_broadcast(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
                        int B, int S, int H, int W, int C, float scale, int accumulate,
                        void* stream);
 
+/* Per-sample feature assembly of the sample-based denoisers (SBMCInterface / LBMCInterface,
+ * support/interfaces.py:394-403, :797-806): out (B, S, C + Cp + 1, H, W, contiguous) =
+ * cat([features (B,S,C,H,W), P (B,S,Cp,H,W), repeat_S(P.var(1).mean(1, keepdims) / S)], 2); element strides for the
+ * two inputs.  The variance channel carries no gradient (.detach() in the reference): the backward is two slices. */
+int wcmc_sample_cat_fwd(const float* feat, int64_t fsb, int64_t fss, int64_t fsc, int64_t fsh, int64_t fsw,
+                        const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh, int64_t psw, float* out,
+                        int B, int S, int C, int Cp, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- P-buffer statistics
  * support/interfaces.py:165-176: builds the KPCN input
  *   out = cat([base, mean_s P, (var_s P (unbiased)).mean_c / S], channel)

@@ -32,3 +32,20 @@ class KPCN(nn.Module):
         albedo = crop_like(data["kpcn_albedo"], r_diffuse)
         radiance = albedo * r_diffuse + torch.exp(r_specular) - 1
         return dict(radiance=radiance, diffuse=r_diffuse, specular=r_specular)
+
+
+class SampleDenoiserStandIn(nn.Module):
+    """Stand-in for the external sample-based denoisers (``sbmc.Multisteps``, ``train_sbmc.py:80-93``; layerdenoise's
+    ``LayerNet``, ``train_lbmc.py:84-97``), which are absent from the reference tree: it only honours their I/O contract
+    -- batch dict with per-sample ``radiance`` (B,S,3,H,W) and ``features`` (B,S,C,H,W) in, (B,3,H',W') out -- so that
+    the reference's ``SBMCInterface`` / ``LBMCInterface`` can be driven for the golden fixtures: one valid 3x3
+    ConvChain per sample over cat([radiance, features]), averaged over the samples."""
+
+    def __init__(self, n_features, width=8, depth=2):
+        super().__init__()
+        self.net = ConvChain(3 + n_features, 3, ksize=3, width=width, depth=depth, pad=False, output_type="linear")
+
+    def forward(self, data):
+        x = torch.cat([data["radiance"], data["features"]], 2)
+        b, s = x.shape[:2]
+        return self.net(x.flatten(0, 1)).unflatten(0, (b, s)).mean(1)

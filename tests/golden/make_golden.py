@@ -17,6 +17,8 @@ Fixtures
   losses_image.npz     G4  support/losses.py:245-320 (RelativeMSE, SMAPE, Tonemapped*)
   interface_<case>.npz G5  support/interfaces.py:80-333 driven with the build's
                            oracle modules (``oracle/``) as stand-ins for ``sbmc``.
+  interface_{sbmc,lbmc}_*.npz  G7  support/interfaces.py:336-523, 753-839 (SBMCInterface, LBMCInterface) around
+                           ``oracle.models.SampleDenoiserStandIn`` for the external base denoisers.
 """
 import os
 import sys
@@ -330,6 +332,108 @@ def gen_interface_variants(ref_losses, ref_itf):
         print("G5b", case, {k: float(v) for k, v in itf.m_losses.items()})
 
 
+# ---------------------------------------------------------------------------------- G7
+SAMPLE_CASES = {
+    # name: (class, use_llpm, manif_learn, disentangle, pnet_out, recon loss, features)
+    "sbmc_vanilla": ("SBMCInterface", False, False, "m11r11", 0, "TonemappedRelativeMSE", 7),     # train_sbmc.py:125-135
+    "sbmc_manifold": ("SBMCInterface", True, True, "m11r11", 3, "TonemappedRelativeMSE", 7),
+    "sbmc_m10r01": ("SBMCInterface", True, True, "m10r01", 6, "TonemappedRelativeMSE", 7),
+    "lbmc_manifold": ("LBMCInterface", True, True, "m11r01", 4, "SMAPE", 5),                       # train_lbmc.py:129-139
+    "lbmc_m10r11": ("LBMCInterface", True, True, "m10r11", 4, "SMAPE", 5),
+    # features x 3000 under an L1 reconstruction loss: gradient norms in the thousands, so the 250 / 1000 norm clamps bite
+    "lbmc_clipped": ("LBMCInterface", True, False, "m11r11", 3, "L1Loss", 5),
+    "sbmc_clipped": ("SBMCInterface", False, False, "m11r11", 0, "L1Loss", 7),
+}
+SAMPLE_FEATURE_SCALE = {"lbmc_clipped": 3000.0, "sbmc_clipped": 20000.0}
+G7_GEOM = dict(B=2, S=3, H=16, INTERMC=4, WIDTH=8, DEPTH=2)
+
+
+def sample_batch(seed, use_llpm, nfeat):
+    g = torch.Generator().manual_seed(seed)
+    B, S, H = G7_GEOM["B"], G7_GEOM["S"], G7_GEOM["H"]
+    r = lambda *s: torch.rand(*s, generator=g)
+    batch = {"target_image": r(B, 3, H, H) * 3, "radiance": r(B, S, 3, H, H) * 3, "features": r(B, S, nfeat, H, H) - 0.3}
+    if use_llpm:
+        batch["paths"] = r(B, S, 36, H, H) - 0.4
+    return batch
+
+
+def build_sample_models(case, seed):
+    from oracle.models import SampleDenoiserStandIn
+    from oracle.networks import PathNet
+    kind, use_llpm, manif, option, pout, recon, nfeat = SAMPLE_CASES[case]
+    torch.manual_seed(seed)
+    c_r = 0
+    if use_llpm:
+        c_r = (pout // 2 if option in ("m10r01", "m11r01") else pout) + 1
+    models = {"dncnn": SampleDenoiserStandIn(nfeat + c_r, width=G7_GEOM["WIDTH"], depth=G7_GEOM["DEPTH"])}
+    if use_llpm:
+        models["backbone"] = PathNet(36, intermc=G7_GEOM["INTERMC"], outc=pout)
+    with torch.no_grad():
+        for m in models.values():
+            for n, p in m.named_parameters():
+                if n.endswith("bias"):
+                    p.uniform_(-0.1, 0.1)
+    return models
+
+
+def gen_interface_samples(ref_losses, ref_itf):
+    """The reference's SBMCInterface / LBMCInterface (interfaces.py:336-523, 753-839) around stand-ins for the external
+    base denoisers: one train step (loss sums, gradients after the norm clip, parameters after Adam) and one
+    validation step.  The large initial gradient scale (x 4000 on the target) makes the LBMC clamp (250) bite."""
+    from oracle.step import draw_perms
+    for ci, case in enumerate(SAMPLE_CASES):
+        kind, use_llpm, manif, option, pout, recon, nfeat = SAMPLE_CASES[case]
+        models = build_sample_models(case, 900 + ci)
+        init_state = {"%s/%s" % (mn, k): np_(v) for mn, m in models.items() for k, v in m.state_dict().items()}
+        optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+                  for mn, m in models.items()}
+        loss_funcs = {"l_recon": torch.nn.L1Loss() if recon == "L1Loss" else getattr(ref_losses, recon)(),
+                      "l_test": ref_losses.RelativeMSE()}
+        if manif:
+            loss_funcs["l_manif"] = ref_losses.FeatureMSE(non_local=True)
+        args = types.SimpleNamespace(model_name="golden")
+        if kind == "SBMCInterface":
+            itf = ref_itf.SBMCInterface(models, optims, loss_funcs, args, use_llpm_buf=use_llpm, manif_learn=manif,
+                                        w_manif=0.1, disentangle=option)
+        else:
+            itf = ref_itf.LBMCInterface(models, optims, loss_funcs, args, use_llpm_buf=use_llpm, manif_learn=manif,
+                                        w_manif=0.1, disentangle=option)
+        itf.iters = 1
+        batch = sample_batch(950 + ci, use_llpm, nfeat)
+        batch["features"] = batch["features"] * SAMPLE_FEATURE_SCALE.get(case, 1.0)
+        out = {"batch/" + k: np_(v) for k, v in batch.items()}
+        out.update({"init/" + k: v for k, v in init_state.items()})
+        B, S, H = G7_GEOM["B"], G7_GEOM["S"], G7_GEOM["H"]
+        hc = H - 2 * G7_GEOM["DEPTH"]                        # the stand-in's valid 3x3 convs crop the P-buffer too
+        seed = 980 + ci
+        torch.manual_seed(seed)
+        ip, ib = draw_perms(B, S, hc, hc)
+        out["perm/patch"], out["perm/batch"], out["seed"] = np_(ip), np_(ib), np.array(seed)
+        itf.to_train_mode()
+        torch.manual_seed(seed)
+        itf.preprocess(batch)
+        itf.train_batch(batch)
+        for k, v in itf.m_losses.items():
+            out["m_losses/" + k] = np_(v)
+        for mn, m in models.items():
+            for k, v in m.state_dict().items():
+                out["after/%s/%s" % (mn, k)] = np_(v)
+            for k, p in m.named_parameters():
+                out["grad/%s/%s" % (mn, k)] = np_(p.grad) if p.grad is not None else np.zeros(0, np.float32)
+            out["gradnorm/" + mn] = np.array(float(torch.sqrt(sum((p.grad ** 2).sum() for p in m.parameters()
+                                                                   if p.grad is not None))))
+        itf.to_eval_mode()
+        with torch.no_grad():
+            rad, pb = itf.validate_batch(batch)
+        out["val/out"] = np_(rad)
+        if pb is not None:
+            out["val/p_buffer"] = np_(pb)
+        out["val/summary"] = np.array(itf.get_epoch_summary(mode="eval", norm=1))
+        np.savez_compressed(os.path.join(HERE, "interface_%s.npz" % case), **out)
+        print("G7", case, {k: float(v) for k, v in itf.m_losses.items()}, {k: float(out[k]) for k in out if k.startswith("gradnorm/")})
+
+
 # ---------------------------------------------------------------------------------- G6 (SURVEY.md 8f rank 3)
 def raw_samples(h, w, s, seed, zero_depth=False):
     """Random raw renderer output (h, w, s, 104) with the value ranges the preprocessors care about:
@@ -374,6 +478,15 @@ def main():
         import support.datasets as ref_datasets
         gen_preprocess(ref_datasets)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "samples":           # only the rank-2 "next" interfaces (SBMC / LBMC glue)
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                gen_interface_samples(ref_losses, ref_itf)
+            finally:
+                os.chdir(cwd)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "variants":          # only the rank-1 "next" interfaces
         cwd = os.getcwd()
         with tempfile.TemporaryDirectory() as tmp:
@@ -393,6 +506,7 @@ def main():
             gen_image_losses(ref_losses)
             gen_interface(ref_losses, ref_itf)
             gen_interface_variants(ref_losses, ref_itf)
+            gen_interface_samples(ref_losses, ref_itf)
             import support.datasets as ref_datasets
             gen_preprocess(ref_datasets)
         finally:

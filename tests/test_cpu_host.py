@@ -122,6 +122,12 @@ class _OracleOps:
         return assemble_input(base, p)
 
     @staticmethod
+    def sample_features_cat(features, p):                     # interfaces.py:394-403 spelled out
+        s = p.shape[1]
+        p_var = p.var(1).mean(1, keepdims=True) / s
+        return torch.cat([features, p, torch.stack([p_var] * s, axis=1).detach()], 2)
+
+    @staticmethod
     def join_all_streams(device):
         pass
 
@@ -249,6 +255,66 @@ def test_ref_and_pre_interfaces_host_logic_against_reference_golden(golden_dir, 
     np.testing.assert_allclose(rad.numpy(), d["val/radiance"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(itf.get_epoch_summary("eval", 1), d["val/summary"], rtol=1e-5)
     assert (pb is None) == ("val/p_diffuse" not in d.files)
+
+
+@pytest.mark.parametrize("case", list(mg.SAMPLE_CASES))
+def test_sbmc_and_lbmc_interfaces_host_logic_against_reference_golden(golden_dir, case, monkeypatch):
+    """SBMCInterface / LBMCInterface == the real reference classes around a stand-in for the
+    external base denoiser: disentanglement slicing, per-sample feature assembly, loss keys (incl. the reference's
+    aliased l_recon == l_total), gradient-norm clamp 1000 / 250, Adam step, validation."""
+    from wcmc_amd.support import interfaces as itf_mod
+    monkeypatch.setattr(itf_mod, "_ops", _OracleOps)
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    kind, use_llpm, manif, option, pout, recon, nfeat = mg.SAMPLE_CASES[case]
+    models = mg.build_sample_models(case, 0)
+    for mn, m in models.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    lf = {"l_recon": torch.nn.L1Loss() if recon == "L1Loss" else getattr(ol, recon)(), "l_test": ol.RelativeMSE()}
+    if manif:
+        lf["l_manif"] = _OracleFeatureMSE()
+    args = types.SimpleNamespace(model_name="g")
+    cls = getattr(itf_mod, kind)
+    kw = dict(use_llpm_buf=use_llpm, manif_learn=manif, w_manif=0.1, disentangle=option)
+    itf = cls(models, optims, lf, args, **kw)
+    assert str(itf) == kind and itf.GRAD_NORM_CLIP == (1000.0 if kind == "SBMCInterface" else 250.0)
+    with pytest.raises(AssertionError):
+        cls(models, optims, lf, args, disentangle="m00r00")
+    with pytest.raises(AssertionError):
+        cls({k: v for k, v in models.items() if k != "dncnn"}, optims, lf, args)
+    itf.iters = 1
+    batch = {k[len("batch/"):]: T(d[k]) for k in d.files if k.startswith("batch/")}
+    with pytest.raises(AssertionError):
+        itf.preprocess({k: v for k, v in batch.items() if k != "radiance"})
+    itf.iters = 1
+    itf.to_train_mode()
+    torch.manual_seed(int(d["seed"]))
+    itf.preprocess(batch)
+    itf.train_batch(batch)
+    if manif:
+        assert np.array_equal(lf["l_manif"].last_perms[0].numpy(), d["perm/patch"])
+    assert set("m_losses/" + k for k in itf.m_losses) == set(k for k in d.files if k.startswith("m_losses/")) - {"m_losses/m_val"}
+    for k, v in itf.m_losses.items():
+        np.testing.assert_allclose(v.item(), d["m_losses/" + k], rtol=2e-5, err_msg=k)
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            np.testing.assert_allclose(p.grad.numpy(), d["grad/%s/%s" % (mn, k)], rtol=2e-4, atol=1e-7, err_msg="%s %s" % (mn, k))
+        norm = float(torch.sqrt(sum((p.grad ** 2).sum() for p in m.parameters())))
+        np.testing.assert_allclose(norm, d["gradnorm/" + mn], rtol=1e-4)
+        for k, v in m.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), d["after/%s/%s" % (mn, k)], rtol=1e-4, atol=2e-6, err_msg="after %s %s" % (mn, k))
+    if case.endswith("clipped"):
+        np.testing.assert_allclose(float(d["gradnorm/dncnn"]), itf.GRAD_NORM_CLIP, rtol=1e-5)     # the clamp did bite
+    itf.to_eval_mode()
+    with torch.no_grad():
+        out, pb = itf.validate_batch(batch)
+    np.testing.assert_allclose(out.numpy(), d["val/out"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(itf.get_epoch_summary("eval", 1), d["val/summary"], rtol=1e-5)
+    assert (pb is None) == ("val/p_buffer" not in d.files)
+    if pb is not None:
+        np.testing.assert_allclose(pb.numpy(), d["val/p_buffer"], rtol=1e-4, atol=1e-6)
+    assert itf.get_epoch_summary("train", 1) == -1.0
 
 
 def test_tiled_inference_stitches_every_pixel_once():

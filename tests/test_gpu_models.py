@@ -247,6 +247,63 @@ def test_ref_and_pre_interfaces_against_reference_golden(golden_dir, case, preci
     np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=5e-3)
 
 
+@pytest.mark.parametrize("case", list(mg.SAMPLE_CASES))
+def test_sbmc_and_lbmc_interfaces_against_reference_golden(golden_dir, case, precision):
+    """SBMCInterface / LBMCInterface on the HIP path -- PathNet backbone, FeatureMSE, the
+    per-sample feature assembly kernel, the stand-in denoiser on the HIP conv ops -- against the REAL reference
+    interfaces driven with the oracle's twins of the same modules (tests/golden/interface_{sbmc,lbmc}_*.npz)."""
+    from standins import SampleDenoiserStandIn
+    from wcmc_amd.support import interfaces as itf_mod
+    from wcmc_amd.support import losses as pl
+    from wcmc_amd.support.networks import PathNet
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    kind, use_llpm, manif, option, pout, recon, nfeat = mg.SAMPLE_CASES[case]
+    G = mg.G7_GEOM
+    c_r = ((pout // 2 if option in ("m10r01", "m11r01") else pout) + 1) if use_llpm else 0
+    models = {"dncnn": SampleDenoiserStandIn(nfeat + c_r, width=G["WIDTH"], depth=G["DEPTH"])}
+    if use_llpm:
+        models["backbone"] = PathNet(36, intermc=G["INTERMC"], outc=pout)
+    for mn, m in models.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+        m.to(DEV)
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    lf = {"l_recon": torch.nn.L1Loss() if recon == "L1Loss" else getattr(pl, recon)(), "l_test": pl.RelativeMSE()}
+    if manif:
+        lf["l_manif"] = pl.FeatureMSE(non_local=True)
+    itf = getattr(itf_mod, kind)(models, optims, lf, types.SimpleNamespace(model_name="golden"), use_llpm_buf=use_llpm,
+                                 manif_learn=manif, w_manif=0.1, disentangle=option)
+    itf.iters = 1
+    batch = {k[len("batch/"):]: T(d[k]).to(DEV) for k in d.files if k.startswith("batch/")}
+    itf.to_train_mode()
+    torch.manual_seed(int(d["seed"]))
+    itf.preprocess(batch)
+    itf.train_batch(batch)
+    if manif:
+        assert np.array_equal(lf["l_manif"].last_perms[0].numpy(), d["perm/patch"])
+    for k in d.files:
+        if k.startswith("m_losses/") and k != "m_losses/m_val":
+            np.testing.assert_allclose(itf.m_losses[k[len("m_losses/"):]].item(), d[k], rtol=1e-3, err_msg=k)
+    loose = 5e-2 if precision == "fp32" else 0.3      # tiny golden networks: a ReLU flip moves a whole gradient row
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            assert_close(p.grad, T(d["grad/%s/%s" % (mn, k)]), tol=loose, what="post-clip grad %s %s" % (mn, k))
+        norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
+        np.testing.assert_allclose(norm, d["gradnorm/" + mn], rtol=5e-2)
+        for k, v in m.state_dict().items():
+            want, got = d["after/%s/%s" % (mn, k)], v.cpu().numpy()
+            big = np.abs(d["grad/%s/%s" % (mn, k)]) > 1e-4 * max(1.0, float(d["gradnorm/" + mn]))
+            np.testing.assert_allclose(got[big], want[big], rtol=1e-3, atol=5e-5, err_msg="after %s %s" % (mn, k))
+            np.testing.assert_allclose(got[~big], want[~big], atol=4.1e-3)
+    itf.to_eval_mode()
+    with torch.no_grad():
+        out, pb = itf.validate_batch(batch)
+    assert_close(out, T(d["val/out"]), tol=5e-3, what="validate output")
+    np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=5e-3)
+    if pb is not None:
+        assert_close(pb, T(d["val/p_buffer"]), tol=5e-3, what="validate p_buffer")
+
+
 def test_full_size_step_against_oracle(precision):
     """One KPCN-Manifold step at the benchmark geometry (128x128, S=8, pnet_out 3) with B=1 against the
     CPU oracle: same weights, inputs and permutations."""

@@ -456,6 +456,40 @@ def test_fused_chain_glue_matches_the_separate_ops(geom):
         assert_close(bb, a, tol=2e-5, what="fused vs separate: " + nm)
 
 
+@pytest.mark.parametrize("geom", [(2, 3, 7, 3, 9, 11), (1, 8, 5, 6, 16, 70), (2, 2, 24, 2, 5, 4)])
+def test_sample_features_cat(geom):
+    """interfaces.py:394-403 / 797-806: cat([features, P, repeat_S(P.var(1).mean(1) / S).detach()], 2), P possibly a
+    channel slice (the disentanglement options hand the lower half to the denoiser)."""
+    o = ops()
+    b, s, c, cp, h, w = geom
+    feat = gen(b, s, c, h, w, seed=50)
+    pfull = gen(b, s, 2 * cp, h, w, seed=51)
+    fr, pr = feat.double().requires_grad_(True), pfull.double().requires_grad_(True)
+    psl = pr[:, :, :cp]
+    pvar = psl.var(1).mean(1, keepdims=True) / s
+    want = torch.cat([fr, psl, torch.stack([pvar] * s, axis=1).detach()], 2)
+    g = gen(*want.shape, seed=52)
+    want.backward(g.double())
+    fd, pd = feat.to(DEV).requires_grad_(True), pfull.to(DEV).requires_grad_(True)
+    got = o.sample_features_cat(fd, pd[:, :, :cp])
+    got.backward(g.to(DEV))
+    assert_close(got, want, tol=1e-6, what="sample cat")
+    assert torch.equal(fd.grad.cpu(), fr.grad.float()) and torch.equal(pd.grad.cpu(), pr.grad.float())
+
+
+def test_image_losses_against_reference_goldens(golden_dir):
+    """support/losses.py:245-320 on device tensors (RelativeMSE, SMAPE, TonemappedMSE, TonemappedRelativeMSE)."""
+    from wcmc_amd.support import losses as pl
+    d = np.load(os.path.join(golden_dir, "losses_image.npz"))
+    ref = torch.from_numpy(d["ref"]).to(DEV)
+    for name in ("RelativeMSE", "SMAPE", "TonemappedMSE", "TonemappedRelativeMSE"):
+        x = torch.from_numpy(d["im"]).to(DEV).requires_grad_(True)
+        loss = getattr(pl, name)()(x, ref)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), d[name], rtol=1e-5, err_msg=name)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), d[name + "_grad"], rtol=1e-4, atol=1e-9, err_msg=name)
+
+
 @pytest.mark.parametrize("cp", [3, 2, 6])
 def test_pbuffer_cat(cp):
     o = ops()

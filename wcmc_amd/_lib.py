@@ -48,6 +48,7 @@ SIGNATURES = {
     "wcmc_maxpool2_bwd": (I, [P, L, L, L, P, L, L, L, P, L, L, L, I, I, I, I, P]),
     "wcmc_upsample2_fwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),
     "wcmc_upsample2_bwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),
+    "wcmc_sample_cat_fwd": (I, [P, L, L, L, L, L, P, L, L, L, L, L, P, I, I, I, I, I, I, P]),
     "wcmc_spp_reduce": (I, [P, L, L, L, P, L, L, L, I, I, I, I, I, F, P]),
     "wcmc_spp_broadcast": (I, [P, L, L, L, P, L, L, L, I, I, I, I, I, F, I, P]),
     "wcmc_pbuffer_cat_fwd": (I, [P, L, L, L, L, P, L, L, L, L, L, P, L, L, L, I, I, I, I, I, I, P]),

@@ -396,6 +396,55 @@ extern "C" int wcmc_spp_broadcast(const float* x, int64_t xsn, int64_t xsh, int6
   return check_launch("spp_broadcast");
 }
 
+// ---- per-sample feature assembly of the sample-based denoisers (SBMCInterface / LBMCInterface,
+// support/interfaces.py:394-403 and :797-806): features' = cat([features, P, repeat_S(var_S(P).mean_c / S)], 2).
+// out is contiguous (B, S, C + Cp + 1, H, W); one thread per (b, y, x): consecutive lanes = consecutive x in every
+// (s, c) plane, so all loads and stores are coalesced rows.
+namespace wcmc {
+__global__ __launch_bounds__(256) void sample_cat_kernel(const float* __restrict__ f, int64_t fsb, int64_t fss, int64_t fsc,
+                                                         int64_t fsh, int64_t fsw, const float* __restrict__ p, int64_t psb,
+                                                         int64_t pss, int64_t psc, int64_t psh, int64_t psw,
+                                                         float* __restrict__ out, int B, int S, int C, int Cp, int H, int W) {
+  const int64_t total = (int64_t)B * H * W;
+  const int CT = C + Cp + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int b = (int)(i / ((int64_t)W * H));
+    const float* pb = p + b * psb + y * psh + x * psw;
+    const float* fb = f + b * fsb + y * fsh + x * fsw;
+    float* ob = out + (((int64_t)b * S * CT) * H + y) * W + x;
+    const int64_t plane = (int64_t)H * W;
+    float acc = 0.f;
+    for (int c = 0; c < Cp; ++c) {                       // unbiased variance over the samples, two passes (torch.var)
+      float m = 0.f;
+      for (int s = 0; s < S; ++s) m += pb[s * pss + c * psc];
+      m /= (float)S;
+      float v = 0.f;
+      for (int s = 0; s < S; ++s) { const float d = pb[s * pss + c * psc] - m; v += d * d; }
+      acc += v / (float)(S - 1);
+    }
+    const float pvar = acc / (float)Cp / (float)S;
+    for (int s = 0; s < S; ++s) {
+      float* o = ob + (int64_t)s * CT * plane;
+      for (int c = 0; c < C; ++c) o[c * plane] = fb[s * fss + c * fsc];
+      for (int c = 0; c < Cp; ++c) o[(C + c) * plane] = pb[s * pss + c * psc];
+      o[(C + Cp) * plane] = pvar;
+    }
+  }
+}
+}  // namespace wcmc
+
+extern "C" int wcmc_sample_cat_fwd(const float* feat, int64_t fsb, int64_t fss, int64_t fsc, int64_t fsh, int64_t fsw,
+                                   const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh, int64_t psw,
+                                   float* out, int B, int S, int C, int Cp, int H, int W, void* stream) {
+  WCMC_REQUIRE(feat && p && out && B > 0 && S > 1 && C > 0 && Cp > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG,
+               "sample_cat_fwd: bad argument (S must be >= 2 for the unbiased variance)");
+  hipLaunchKernelGGL(wcmc::sample_cat_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, feat,
+                     fsb, fss, fsc, fsh, fsw, p, psb, pss, psc, psh, psw, out, B, S, C, Cp, H, W);
+  return check_launch("sample_cat_fwd");
+}
+
 extern "C" int wcmc_pbuffer_cat_fwd(const float* base, int64_t bsn, int64_t bsc, int64_t bsh, int64_t bsw,
                                     const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t psh, int64_t psw,
                                     float* out, int64_t osn, int64_t osh, int64_t osw, int B, int S, int Cb, int Cp,

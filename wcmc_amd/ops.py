@@ -939,6 +939,32 @@ def pbuffer_cat(base, p):
     return _PBufferCat.apply(base, p)
 
 
+class _SampleCat(torch.autograd.Function):
+    """cat([features, P, repeat_S(P.var(1).mean(1, keepdims).detach() / S)], 2) on (B,S,C,H,W) per-sample tensors
+    (interfaces.py:394-403, 797-806)."""
+
+    @staticmethod
+    def forward(ctx, features, p):
+        _need_cuda(features, p)
+        b, s, c, h, w = features.shape
+        cp = p.shape[2]
+        assert p.shape[:2] == (b, s) and p.shape[3:] == (h, w)
+        out = torch.empty((b, s, c + cp + 1, h, w), device=p.device, dtype=torch.float32)
+        check(lib().wcmc_sample_cat_fwd(_ptr(features), *features.stride(), _ptr(p), *p.stride(), _ptr(out),
+                                        b, s, c, cp, h, w, _stream()), "sample_cat_fwd")
+        ctx.split = (c, cp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        c, cp = ctx.split
+        return g[:, :, :c], g[:, :, c:c + cp]
+
+
+def sample_features_cat(features, p):
+    return _SampleCat.apply(features, p)
+
+
 class _FeatureMSE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, ref, idx_patch, idx_batch):

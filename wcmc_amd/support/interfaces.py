@@ -442,3 +442,164 @@ class KPCNPreInterface(KPCNInterface):
         for model_name in self.models:
             if self._trained(model_name):
                 self.optims['optim_' + model_name].step()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the glue of the two sample-based denoisers (train_sbmc.py / train_lbmc.py).  The base
+# denoisers themselves (sbmc.Multisteps, layerdenoise's LayerNet) are external to the reference tree; what lives
+# here is everything interfaces.py:336-523 and :753-839 do around them: the single PathNet backbone, the
+# disentanglement slicing, the per-sample feature assembly (one HIP kernel, ops.sample_features_cat), the
+# reconstruction + manifold loss, gradient-NORM clipping (1000 / 250) and the running sums.
+class SBMCInterface(BaseInterface):
+    GRAD_NORM_CLIP = 1000.0                   # interfaces.py:452-456
+
+    def __init__(self, models, optims, loss_funcs, args, visual=False, use_llpm_buf=False, manif_learn=False,
+                 w_manif=0.1, use_sbmc_buf=True, disentangle="m11r11"):
+        if manif_learn:
+            assert 'backbone' in models, "argument `models` dictionary should contain `'backbone'` key."
+        assert 'dncnn' in models, "argument `models` dictionary should contain `'dncnn'` key."
+        if manif_learn:
+            assert 'l_manif' in loss_funcs
+        assert 'l_recon' in loss_funcs
+        assert 'l_test' in loss_funcs
+        assert disentangle in _OPTIONS
+        super(SBMCInterface, self).__init__(models, optims, loss_funcs, args, visual, use_llpm_buf, manif_learn, w_manif)
+        self.disentangle, self.use_sbmc_buf = disentangle, use_sbmc_buf
+
+    def __str__(self):
+        return 'SBMCInterface'
+
+    def to_train_mode(self):
+        for name, model in self.models.items():
+            model.train()
+            assert 'optim_' + name in self.optims, '`optim_%s`: an optimization algorithm is not defined.' % (name)
+
+    def preprocess(self, batch=None):
+        for key in ('target_image', 'radiance', 'features') + (('paths',) if self.use_llpm_buf else ()):
+            assert key in batch
+        self.iters += 1
+
+    def _manifold_forward(self, batch):
+        return self.models['backbone'](batch)
+
+    def _regress_forward(self, batch):
+        return self.models['dncnn'](batch)
+
+    def _split(self, p_buffer, train):
+        """interfaces.py:378-388 / :484-489: (what the manifold loss sees, what the denoiser sees)."""
+        c = p_buffer.shape[2]
+        assert c >= 2
+        lo, hi = p_buffer[:, :, :c // 2, ...], p_buffer[:, :, c // 2:, ...]
+        regress = lo if self.disentangle in ('m10r01', 'm11r01') else p_buffer
+        if not train:
+            return None, regress
+        return (p_buffer if self.disentangle in ('m11r11', 'm11r01') else hi), regress
+
+    @staticmethod
+    def _assemble(batch, p_regress):
+        """interfaces.py:390-403: features' = cat([features, P, P.var(1).mean(1) / S (detached, per sample)], 2)."""
+        return {'target_image': batch['target_image'], 'radiance': batch['radiance'],
+                'features': _ops.sample_features_cat(batch['features'], p_regress)}
+
+    def _dump_pbuffer(self, p_buffer):
+        if not os.path.isdir('../LLPM_results'):     # interfaces.py:371-374 (debug PNG every 1000 iterations)
+            return
+        import numpy as np
+        import matplotlib.pyplot as plt
+        pimg = np.mean(np.transpose(p_buffer.detach().cpu().numpy()[0, :, :3, ...], (2, 3, 0, 1)), 2)
+        plt.imsave('../LLPM_results/pbuf_%s.png' % (self.args.model_name), np.clip(pimg, 0.0, 1.0))
+
+    def train_batch(self, batch, grad_hook_mode=False):
+        out_manif = None
+        if self.use_llpm_buf:
+            self.models['backbone'].zero_grad()
+            p_buffer = self._manifold_forward(batch)
+            if self.iters % 1000 == 1:
+                self._dump_pbuffer(p_buffer)
+            out_manif, p_regress = self._split(p_buffer, train=True)
+            batch = self._assemble(batch, p_regress)
+        self.models['dncnn'].zero_grad()
+        out = self._regress_forward(batch)
+        loss_dict = self._backward(batch, out, out_manif)
+        if grad_hook_mode:  # do not update this model
+            return
+        self._logging(loss_dict)
+        self._optimization()
+
+    def _backward(self, batch, out, p_buffer):
+        loss_dict = {}
+        tgt_total = crop_like(batch['target_image'], out)
+        L_total = self.loss_funcs['l_recon'](out, tgt_total)
+        if self.manif_learn:
+            L_manif = self.loss_funcs['l_manif'](crop_like(p_buffer, out), tgt_total)
+            loss_dict['l_manif'], loss_dict['l_recon'] = L_manif.detach(), L_total.detach()
+            # in place, as interfaces.py:427: `l_recon` above aliases this tensor (detach shares storage), so the
+            # reference's logged l_recon equals l_total -- kept
+            L_total += L_manif * self.w_manif
+        loss_dict['l_total'] = L_total.detach()
+        L_total.backward()
+        with torch.no_grad():
+            loss_dict['rmse'] = self.loss_funcs['l_test'](out, tgt_total).detach()
+        return loss_dict
+
+    def _logging(self, loss_dict):
+        for key in loss_dict:
+            if not torch.isfinite(loss_dict[key]).all():
+                raise RuntimeError("%s: Non-finite loss at train time." % (key))
+        for name, model in self.models.items():
+            actual = nn.utils.clip_grad_norm_(model.parameters(), max_norm=self.GRAD_NORM_CLIP)
+            if actual > self.GRAD_NORM_CLIP:
+                print("Clipped %s gradients %f -> %f" % (name, self.GRAD_NORM_CLIP, actual))
+        for key in loss_dict:
+            if 'm_' + key not in self.m_losses:
+                self.m_losses['m_' + key] = torch.tensor(0.0, device=loss_dict[key].device)
+            self.m_losses['m_' + key] += loss_dict[key]
+
+    def _optimization(self):
+        for name in self.models:
+            self.optims['optim_' + name].step()
+
+    def to_eval_mode(self):
+        for model in self.models.values():
+            model.eval()
+        self.m_losses['m_val'] = torch.tensor(0.0)
+
+    def validate_batch(self, batch):
+        p_buffer = None
+        if self.use_llpm_buf:
+            _, p_buffer = self._split(self._manifold_forward(batch), train=False)
+            batch = self._assemble(batch, p_buffer)
+        out = self._regress_forward(batch)
+        self._score(self.loss_funcs['l_test'](out, crop_like(batch['target_image'], out)))
+        return out, p_buffer
+
+    def _score(self, L_total):
+        if self.m_losses['m_val'] == 0.0 and self.m_losses['m_val'].device != L_total.device:
+            self.m_losses['m_val'] = torch.tensor(0.0, device=L_total.device)
+        self.m_losses['m_val'] += L_total.detach()
+
+    def get_epoch_summary(self, mode, norm):
+        if mode != 'train':
+            return self.m_losses['m_val'].item() / (norm * 2)
+        print('[][][]', end=' ')
+        for key in self.m_losses:
+            if key == 'm_val':
+                continue
+            print('%s: %.3fE-3' % (key, self.m_losses[key] / (norm * 2) * 1000), end='\t')
+            self.m_losses[key] = torch.tensor(0.0, device=self.m_losses[key].device)
+        print('')
+        return -1.0
+
+
+class LBMCInterface(SBMCInterface):
+    """interfaces.py:753-839: SBMCInterface without the visual / sbmc-buffer switches and with the layer-based
+    denoiser's clamp, GRADIENT_CLAMP_N = 0.25 * 1000."""
+    GRAD_NORM_CLIP = 250.0
+
+    def __init__(self, models, optims, loss_funcs, args, use_llpm_buf=False, manif_learn=False, w_manif=0.1,
+                 disentangle='m11r11'):
+        super(LBMCInterface, self).__init__(models, optims, loss_funcs, args, False, use_llpm_buf, manif_learn,
+                                            w_manif, False, disentangle)
+
+    def __str__(self):
+        return 'LBMCInterface'

@@ -111,18 +111,42 @@ class RelativeMSE(torch.nn.Module):
         return 0.5 * torch.mean(mse / (torch.pow(ref, 2) + self.eps))
 
 
-def _unbuilt(name):
-    class _Loss(torch.nn.Module):
-        def __init__(self, eps=1e-2):
-            super().__init__()
-            self.eps = eps
-
-        def forward(self, im, ref):
-            raise NotImplementedError("%s is used only by the SBMC/LBMC scripts (SURVEY.md 8f)" % name)
-    _Loss.__name__ = name
-    return _Loss
+def _reinhard(im):
+    """``losses.py:234-242``: Reinhard tone map of the clamped image."""
+    im = torch.clamp(im, min=0)
+    return im / (1 + im)
 
 
-SMAPE = _unbuilt("SMAPE")
-TonemappedMSE = _unbuilt("TonemappedMSE")
-TonemappedRelativeMSE = _unbuilt("TonemappedRelativeMSE")
+class SMAPE(torch.nn.Module):
+    """mean(|im - ref| / (eps + |im| + |ref|)) with a gradient-free denominator (``losses.py:267-284``; LBMC's loss)."""
+
+    def __init__(self, eps=1e-2):
+        super(SMAPE, self).__init__()
+        self.eps = eps
+
+    def forward(self, im, ref):
+        scale = self.eps + im.detach().abs() + ref.detach().abs()
+        return torch.mean((im - ref).abs() / scale)
+
+
+class TonemappedMSE(torch.nn.Module):
+    """0.5 * mean((T(im) - T(ref))^2), T = Reinhard (``losses.py:287-302``)."""
+
+    def __init__(self, eps=1e-2):
+        super(TonemappedMSE, self).__init__()
+        self.eps = eps
+
+    def forward(self, im, ref):
+        return 0.5 * torch.mean(torch.pow(_reinhard(im) - _reinhard(ref), 2))
+
+
+class TonemappedRelativeMSE(torch.nn.Module):
+    """RelativeMSE of the tone-mapped images (``losses.py:305-320``; SBMC's loss)."""
+
+    def __init__(self, eps=1e-2):
+        super(TonemappedRelativeMSE, self).__init__()
+        self.eps = eps
+
+    def forward(self, im, ref):
+        im, ref = _reinhard(im), _reinhard(ref)
+        return 0.5 * torch.mean(torch.pow(im - ref, 2) / (torch.pow(ref, 2) + self.eps))
