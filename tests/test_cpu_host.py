@@ -317,6 +317,64 @@ def test_sbmc_and_lbmc_interfaces_host_logic_against_reference_golden(golden_dir
     assert itf.get_epoch_summary("train", 1) == -1.0
 
 
+def test_checkpoint_format_round_trip_and_reference_layouts(tmp_path):
+    """SURVEY.md 8f rank 4, train_kpcn.py:106-124 (save) / :240-296 (load): the dict keys, the pickled optimiser
+    objects, the DataParallel prefix fallback, the older `params` location of the optimisers, the learning-rate
+    override."""
+    from wcmc_amd.support import checkpoint as ck_mod
+    from oracle.networks import PathNet
+
+    def build(seed):
+        torch.manual_seed(seed)
+        models = {"dncnn": torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.ReLU(), torch.nn.Conv2d(4, 3, 3)),
+                  "backbone_diffuse": PathNet(36, intermc=4, outc=3)}
+        optims = {"optim_" + n: torch.optim.Adam(m.parameters(), lr=1e-3 if n == "dncnn" else 2e-3) for n, m in models.items()}
+        return models, optims
+
+    models, optims = build(1)
+    for n, m in models.items():                                  # two Adam steps so that the moments are non-trivial
+        for _ in range(2):
+            optims["optim_" + n].zero_grad()
+            sum((p ** 2).sum() for p in m.parameters()).backward()
+            optims["optim_" + n].step()
+    itf = types.SimpleNamespace(models=models, optims=optims, best_err=0.125)
+    args = types.SimpleNamespace(desc="unit", model_name="m", lr_dncnn=1e-3)
+    path = str(tmp_path / "weights" / "latest_m.pth")
+    ck_mod.save_checkpoint(path, itf, epoch=4, args=args, params={"vis": object, "batch_size": 8})
+    ck = ck_mod.load_checkpoint(path)
+    assert set(ck) == {"description", "start_epoch", "model", "params", "optims", "args", "best_err",
+                       "state_dict_dncnn", "state_dict_backbone_diffuse"}                    # train_kpcn.py:110-121
+    assert ck["start_epoch"] == 5 and ck["model"] == str(models["dncnn"]) and ck["params"]["vis"] is None
+    assert ck["description"] == "unit" and ck["args"].model_name == "m" and ck["params"]["batch_size"] == 8
+
+    def same(a, b):
+        return all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))
+
+    m2, o2 = build(2)
+    assert not same(m2["dncnn"], models["dncnn"])
+    assert ck_mod.restore_models(ck, m2) == (5, 0.125)
+    assert all(same(m2[n], models[n]) for n in models)
+    logs = []
+    ck_mod.restore_optims(ck, o2, {"optim_dncnn": 5e-4, "optim_backbone_diffuse": 7e-4}, log=logs.append)
+    assert o2["optim_dncnn"].param_groups[0]["lr"] == 5e-4 and len(logs) == 2               # command line wins
+    for n in models:
+        a, b = optims["optim_" + n].state_dict()["state"], o2["optim_" + n].state_dict()["state"]
+        assert a.keys() == b.keys() and all(torch.equal(a[k]["exp_avg_sq"], b[k]["exp_avg_sq"]) and a[k]["step"] == b[k]["step"] for k in a)
+    ck_mod.restore_optims(ck, o2, {"optim_dncnn": 5e-4, "optim_backbone_diffuse": 7e-4}, lr_ckpt=True, log=logs.append)
+    assert o2["optim_dncnn"].param_groups[0]["lr"] == 1e-3                                  # --lr_ckpt keeps the stored one
+    # a file saved from inside nn.DataParallel ('module.' prefix) and with the optimisers under `params` (older layout)
+    old = {k: v for k, v in ck.items() if k != "optims"}
+    old["state_dict_dncnn"] = {"module." + k: v for k, v in ck["state_dict_dncnn"].items()}
+    old["params"] = dict(ck["params"], optim_dncnn=optims["optim_dncnn"])
+    m3, o3 = build(3)
+    ck_mod.restore_models(old, m3)
+    assert same(m3["dncnn"], models["dncnn"])
+    logs.clear()
+    ck_mod.restore_optims(old, o3, {"optim_dncnn": 1e-3, "optim_backbone_diffuse": 2e-3}, log=logs.append)
+    assert any("No state for the optimizer for backbone_diffuse" in l for l in logs)
+    assert len(o3["optim_dncnn"].state_dict()["state"]) > 0 and len(o3["optim_backbone_diffuse"].state_dict()["state"]) == 0
+
+
 def test_tiled_inference_stitches_every_pixel_once():
     """Rank-4 host logic (test_models.py:49-101, datasets.py:1276-1299): with a network that returns the centre
     crop of its input, the stitched image equals the input wherever tiles own pixels from their valid interior,
