@@ -331,6 +331,17 @@ int wcmc_preprocess_kpcn(const float* raw, int h, int w, int s, int C, int max_d
                          void* workspace, size_t workspace_bytes, void* stream);
 int wcmc_gradients(const float* buf, int h, int w, int c, float* out, void* stream);
 
+/* Batch assembly for the KPCN base model (DenoiseDataset.__getitem__ + _sample_patches + _transpose,
+ * support/datasets.py:795-840,1026-1146): crops B windows of P x P pixels at origins[b] = (row, column) out of the
+ * per-image buffers kpcn (H, W, 44), llpm (H, W, S, 37; null without --use_llpm_buf) and gt (H, W, 9) and writes the
+ * batch dictionary's tensors channel-first and contiguous: diffuse_in / specular_in (B, 34 [+1], P, P), the two
+ * 3-channel radiance buffers, albedo + 0.00316, paths (B, S, 36, P, P), and the three targets
+ * (total, diffuse / (albedo + 0.00316), log(1 + total - diffuse)).  origins: device int32 [B][2], windows in bounds. */
+int wcmc_assemble_kpcn_patches(const float* kpcn, const float* llpm, const float* gt, const int* origins, int B, int H,
+                               int W, int S, int P, float* diffuse_in, float* specular_in, float* diffuse_buffer,
+                               float* specular_buffer, float* albedo, float* paths, float* target_diffuse,
+                               float* target_specular, float* target_total, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,3 +80,40 @@ def preprocess_kpcn(sample, max_depth=MAX_DEPTH):
              normal, normal_v, gradients(normal), depth, depth_v, gradients(depth),
              albedo, albedo_v, gradients(albedo)]
     return np.concatenate(feats, axis=2)
+
+
+def sample_patch_origins(prob, n):
+    """``_sample_patches`` (datasets.py:795-810): n flat indices drawn with np.random.choice over the probability
+    map (uniform when the map is not a distribution); returns (row, column) = (idx // w, idx % w)."""
+    h, w = prob.shape
+    try:
+        roi = np.random.choice(h * w, size=n, p=prob.reshape(h * w))
+    except ValueError:
+        roi = np.random.choice(h * w, size=n)
+    return np.stack([roi // w, roi % w], axis=1)
+
+
+def assemble_kpcn_patch(kpcn, llpm, gt, origin, patch):
+    """One item of ``DenoiseDataset.__getitem__`` for the KPCN base model (datasets.py:1076-1126), cropped at
+    ``origin`` (:811-838) and transposed channel-first (:760-791).  kpcn (H,W,44), llpm (H,W,S,37) or None, gt (H,W,9)."""
+    s = {}
+    s["kpcn_diffuse_in"] = np.concatenate([kpcn[..., :10], kpcn[..., 20:]], axis=2)
+    s["kpcn_specular_in"] = kpcn[..., 10:]
+    s["kpcn_diffuse_buffer"] = kpcn[..., :3]
+    s["kpcn_specular_buffer"] = kpcn[..., 10:13]
+    s["kpcn_albedo"] = kpcn[..., 34:37] + 0.00316
+    if llpm is not None:
+        pw = llpm[..., :1].mean(2)
+        s["kpcn_diffuse_in"] = np.concatenate((s["kpcn_diffuse_in"], pw), axis=2)
+        s["kpcn_specular_in"] = np.concatenate((s["kpcn_specular_in"], pw), axis=2)
+        s["paths"] = np.array(llpm[..., 1:])
+    total, diffuse, albedo = gt[:, :, 0:3], gt[:, :, 3:6], gt[:, :, 6:]
+    s["target_diffuse"] = diffuse / (albedo + 0.00316)
+    s["target_specular"] = np.log(1 + total - diffuse)
+    s["target_total"] = total
+    x, y = int(origin[0]), int(origin[1])
+    out = {}
+    for k, v in s.items():
+        v = v[x:x + patch, y:y + patch, ...]
+        out[k] = np.transpose(v, (2, 0, 1)) if v.ndim == 3 else np.transpose(v, (2, 3, 0, 1))
+    return out

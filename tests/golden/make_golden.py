@@ -17,6 +17,7 @@ Fixtures
   losses_image.npz     G4  support/losses.py:245-320 (RelativeMSE, SMAPE, Tonemapped*)
   interface_<case>.npz G5  support/interfaces.py:80-333 driven with the build's
                            oracle modules (``oracle/``) as stand-ins for ``sbmc``.
+  patches.npz          G8  support/datasets.py:795-840,1026-1146 (DenoiseDataset.__getitem__: patch sampling, batch keys)
   interface_{sbmc,lbmc}_*.npz  G7  support/interfaces.py:336-523, 753-839 (SBMCInterface, LBMCInterface) around
                            ``oracle.models.SampleDenoiserStandIn`` for the external base denoisers.
 """
@@ -472,11 +473,51 @@ def gen_preprocess(ref_datasets):
         print("G6", {k: v.shape for k, v in out.items()})
 
 
+def gen_patches(ref_datasets):
+    """G8: the REAL DenoiseDataset.__getitem__ (datasets.py:1026-1146, with _sample_patches :795-840 and _transpose
+    :760-791) over a one-image dataset written to a temporary directory in the layout it expects; PATCH_SIZE is
+    lowered from 128 to 12 on the instance so that the fixture stays small (the code path is the same)."""
+    H, W, S, P, NPI = 28, 30, 2, 12, 4
+    rs = np.random.RandomState(1234)
+    kpcn = rs.rand(H, W, 44).astype(np.float32) * 2 - 0.5
+    llpm = rs.rand(H, W, S, 37).astype(np.float32) - 0.3
+    gt = rs.rand(H, W, 9).astype(np.float32) * 2            # total, diffuse, albedo (total - diffuse may be negative but > -1)
+    gt[..., 0:3] = gt[..., 3:6] + rs.rand(H, W, 3).astype(np.float32)
+    prob = np.zeros((H, W), np.float64)
+    prob[:H - P + 1, :W - P + 1] = rs.rand(H - P + 1, W - P + 1)
+    prob /= prob.sum()
+    out = {"kpcn": kpcn, "llpm": llpm, "gt": gt, "prob": prob, "patch": np.array(P), "seed": np.array(4321)}
+    for use_llpm in (True, False):
+        with tempfile.TemporaryDirectory() as tmp:
+            for sub in ("KPCN/train/gt", "KPCN/train/input", "LLPM/train/input"):
+                os.makedirs(os.path.join(tmp, sub))
+            np.save(os.path.join(tmp, "KPCN/train/gt/img0.npy"), gt)
+            np.save(os.path.join(tmp, "KPCN/train/input/img0_kpcn_%d.npy" % S), kpcn)
+            np.save(os.path.join(tmp, "KPCN/train/input/img0_prob_imp.npy"), prob)
+            np.save(os.path.join(tmp, "LLPM/train/input/img0_llpm.npy"), llpm)
+            ds = ref_datasets.DenoiseDataset(os.path.join(tmp, "KPCN"), S, base_model="kpcn", mode="train", batch_size=8,
+                                             sampling="random", use_llpm_buf=use_llpm)
+            ds.PATCH_SIZE = P
+            np.random.seed(4321)
+            items = [ds[i] for i in range(NPI)]             # item 0 draws all patches_per_image origins
+            tag = "llpm" if use_llpm else "vanilla"
+            out[tag + "/patches_per_image"] = np.array(ds.patches_per_image)
+            for i, it in enumerate(items):
+                for k, v in it.items():
+                    out["%s/%d/%s" % (tag, i, k)] = np.ascontiguousarray(v)
+    np.savez_compressed(os.path.join(HERE, "patches.npz"), **out)
+    print("G8", sorted(set(k.split("/")[-1] for k in out if "/0/" in k)), {k: out[k].shape for k in out if k.startswith("llpm/0/")})
+
+
 def main():
     ref_losses, ref_utils, ref_itf = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "preprocess":          # only the data-step functions
         import support.datasets as ref_datasets
         gen_preprocess(ref_datasets)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "patches":           # only the loader item (rank 3)
+        import support.datasets as ref_datasets
+        gen_patches(ref_datasets)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "samples":           # only the rank-2 "next" interfaces (SBMC / LBMC glue)
         cwd = os.getcwd()
@@ -509,6 +550,7 @@ def main():
             gen_interface_samples(ref_losses, ref_itf)
             import support.datasets as ref_datasets
             gen_preprocess(ref_datasets)
+            gen_patches(ref_datasets)
         finally:
             os.chdir(cwd)
     print("goldens written to", HERE)

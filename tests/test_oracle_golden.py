@@ -134,3 +134,21 @@ def test_preprocess_golden(golden_dir):
         np.testing.assert_array_equal(od.preprocess_kpcn(raw), d[name + "/kpcn"])
     np.testing.assert_array_equal(od.gradients(d["grad/buf"]), d["grad/out"])
     assert d["a/llpm"].shape[-1] == 37 and d["a/kpcn"].shape[-1] == 44
+
+
+def test_patch_loader_item_golden(golden_dir):
+    """oracle.datasets.sample_patch_origins / assemble_kpcn_patch == the real DenoiseDataset.__getitem__
+    (datasets.py:795-840,1026-1146) on the fixture image: same numpy draws, bit-identical items."""
+    from oracle import datasets as od
+    d = np.load(os.path.join(golden_dir, "patches.npz"))
+    P = int(d["patch"])
+    for tag in ("llpm", "vanilla"):
+        np.random.seed(int(d["seed"]))
+        origins = od.sample_patch_origins(d["prob"], int(d[tag + "/patches_per_image"]))
+        n = len([k for k in d.files if k.startswith(tag + "/") and k.endswith("/target_total")])
+        for i in range(n):
+            item = od.assemble_kpcn_patch(d["kpcn"], d["llpm"] if tag == "llpm" else None, d["gt"], origins[i], P)
+            keys = {k.split("/")[-1] for k in d.files if k.startswith("%s/%d/" % (tag, i))}
+            assert keys == set(item)
+            for k in keys:
+                np.testing.assert_array_equal(item[k], d["%s/%d/%s" % (tag, i, k)], err_msg="%s %d %s" % (tag, i, k))

@@ -64,6 +64,7 @@ SIGNATURES = {
     "wcmc_preprocess_kpcn_workspace_bytes": (Z, [I, I]),
     "wcmc_preprocess_kpcn": (I, [P, I, I, I, I, I, P, P, Z, P]),
     "wcmc_gradients": (I, [P, I, I, I, P, P]),
+    "wcmc_assemble_kpcn_patches": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
 }
 
 _lib = None

@@ -325,3 +325,80 @@ extern "C" int wcmc_preprocess_kpcn(const float* raw, int h, int w, int s, int C
   hipLaunchKernelGGL(pp_kpcn_finish_kernel, dim3(pp_grid(npix * KP_C)), dim3(256), 0, st, out, ws, h, w, s);
   return check_launch("preprocess_kpcn(finish)");
 }
+
+// ------------------------------------------------------------------ patch batch assembly (datasets.py:1026-1146)
+// What DenoiseDataset.__getitem__ + _sample_patches + _transpose do per patch on the loader's CPU worker, for the
+// KPCN base model: crop a P x P window out of the preprocessed per-image buffers and lay the batch dictionary's
+// tensors out channel-first --
+//   kpcn_diffuse_in  = [kpcn 0:10, kpcn 20:44 (, mean_s llpm[..., 0])]       34 (+1) channels      :1080,1099-1103
+//   kpcn_specular_in = [kpcn 10:44 (, mean_s llpm[..., 0])]                  34 (+1)               :1081,1104-1107
+//   kpcn_diffuse_buffer = kpcn 0:3, kpcn_specular_buffer = kpcn 10:13, kpcn_albedo = kpcn 34:37 + 0.00316  :1082-1084
+//   paths = llpm[..., 1:37] as (S, 36, P, P)                                                       :1110
+//   target_total = gt 0:3, target_diffuse = gt 3:6 / (gt 6:9 + 0.00316), target_specular = log(1 + total - diffuse)  :1117-1126
+// One thread per (patch, y, x): every output plane is written as coalesced rows, the inputs are read once.
+namespace wcmc {
+struct PatchOut {
+  float *din, *sin, *dbuf, *sbuf, *alb, *paths, *tdif, *tspec, *ttot;
+};
+__global__ __launch_bounds__(256) void pp_assemble_kpcn_kernel(const float* __restrict__ kpcn, const float* __restrict__ llpm,
+                                                               const float* __restrict__ gt, const int* __restrict__ origins,
+                                                               PatchOut o, int B, int H, int W, int S, int P) {
+  const int64_t total = (int64_t)B * P * P;
+  const int cin = llpm ? 35 : 34;
+  const int64_t plane = (int64_t)P * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % P), y = (int)((i / P) % P), b = (int)(i / plane);
+    const int r = origins[2 * b] + y, c = origins[2 * b + 1] + x;             // (row, column) of the image
+    const int64_t pix = (int64_t)r * W + c;
+    const float* k = kpcn + pix * 44;
+    const int64_t po = (int64_t)y * P + x;
+    float* din = o.din + (int64_t)b * cin * plane + po;
+    float* sin = o.sin + (int64_t)b * cin * plane + po;
+    for (int ch = 0; ch < 10; ++ch) din[ch * plane] = k[ch];
+    for (int ch = 20; ch < 44; ++ch) din[(ch - 10) * plane] = k[ch];
+    for (int ch = 10; ch < 44; ++ch) sin[(ch - 10) * plane] = k[ch];
+    for (int ch = 0; ch < 3; ++ch) {
+      o.dbuf[((int64_t)b * 3 + ch) * plane + po] = k[ch];
+      o.sbuf[((int64_t)b * 3 + ch) * plane + po] = k[10 + ch];
+      o.alb[((int64_t)b * 3 + ch) * plane + po] = k[34 + ch] + 0.00316f;
+    }
+    if (llpm) {
+      const float* l = llpm + pix * S * 37;
+      float pw = 0.f;
+      for (int s = 0; s < S; ++s) {
+        pw += l[s * 37];
+        float* pp = o.paths + (((int64_t)b * S + s) * 36) * plane + po;
+        for (int ch = 0; ch < 36; ++ch) pp[ch * plane] = l[s * 37 + 1 + ch];
+      }
+      pw /= (float)S;
+      din[34 * plane] = pw;
+      sin[34 * plane] = pw;
+    }
+    const float* g = gt + pix * 9;
+    for (int ch = 0; ch < 3; ++ch) {
+      const float tot = g[ch], dif = g[3 + ch], alb = g[6 + ch];
+      o.ttot[((int64_t)b * 3 + ch) * plane + po] = tot;
+      o.tdif[((int64_t)b * 3 + ch) * plane + po] = dif / (alb + 0.00316f);
+      o.tspec[((int64_t)b * 3 + ch) * plane + po] = logf(1.f + tot - dif);
+    }
+  }
+}
+}  // namespace wcmc
+
+extern "C" int wcmc_assemble_kpcn_patches(const float* kpcn, const float* llpm, const float* gt, const int* origins,
+                                          int B, int H, int W, int S, int P, float* diffuse_in, float* specular_in,
+                                          float* diffuse_buffer, float* specular_buffer, float* albedo, float* paths,
+                                          float* target_diffuse, float* target_specular, float* target_total,
+                                          void* stream) {
+  WCMC_REQUIRE(kpcn && gt && origins && B > 0 && H > 0 && W > 0 && P > 0 && P <= H && P <= W && diffuse_in &&
+                   specular_in && diffuse_buffer && specular_buffer && albedo && target_diffuse && target_specular &&
+                   target_total && (!llpm || (paths && S > 0)),
+               WCMC_ERR_BAD_ARG, "assemble_kpcn_patches: bad argument");
+  wcmc::PatchOut o{diffuse_in, specular_in, diffuse_buffer, specular_buffer, albedo, paths, target_diffuse,
+                   target_specular, target_total};
+  const int64_t total = (int64_t)B * P * P;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+  hipLaunchKernelGGL(wcmc::pp_assemble_kpcn_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, kpcn, llpm, gt, origins, o,
+                     B, H, W, S, P);
+  return wcmc::check_launch("assemble_kpcn_patches");
+}

@@ -1072,6 +1072,38 @@ def preprocess_kpcn(sample, max_depth=5):
     return out
 
 
+
+def assemble_kpcn_patches(kpcn, llpm, gt, origins, patch):
+    """The batch dictionary of the KPCN base model for windows of `patch` pixels at `origins` ((B, 2) int32 device
+    tensor of (row, column)) of one image's preprocessed buffers (datasets.py:1026-1146 on the device)."""
+    _need_cuda(kpcn, gt)
+    if not origins.is_cuda:
+        raise RuntimeError("assemble_kpcn_patches: origins must be a device tensor")
+    h, w = kpcn.shape[:2]
+    assert kpcn.shape == (h, w, 44) and gt.shape == (h, w, 9) and kpcn.is_contiguous() and gt.is_contiguous()
+    assert origins.dtype == torch.int32 and origins.dim() == 2 and origins.shape[1] == 2 and origins.is_contiguous()
+    b, s = origins.shape[0], 0
+    if llpm is not None:
+        assert llpm.shape[:2] == (h, w) and llpm.shape[3] == 37 and llpm.is_contiguous()
+        s = llpm.shape[2]
+    dev = kpcn.device
+    new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    cin = 35 if llpm is not None else 34
+    out = {"kpcn_diffuse_in": new(b, cin, patch, patch), "kpcn_specular_in": new(b, cin, patch, patch),
+           "kpcn_diffuse_buffer": new(b, 3, patch, patch), "kpcn_specular_buffer": new(b, 3, patch, patch),
+           "kpcn_albedo": new(b, 3, patch, patch), "target_diffuse": new(b, 3, patch, patch),
+           "target_specular": new(b, 3, patch, patch), "target_total": new(b, 3, patch, patch)}
+    if llpm is not None:
+        out["paths"] = new(b, s, 36, patch, patch)
+    check(lib().wcmc_assemble_kpcn_patches(_ptr(kpcn), _ptr(llpm), _ptr(gt), ctypes.c_void_p(origins.data_ptr()), b, h, w,
+                                           s, patch, _ptr(out["kpcn_diffuse_in"]), _ptr(out["kpcn_specular_in"]),
+                                           _ptr(out["kpcn_diffuse_buffer"]), _ptr(out["kpcn_specular_buffer"]),
+                                           _ptr(out["kpcn_albedo"]), _ptr(out.get("paths")), _ptr(out["target_diffuse"]),
+                                           _ptr(out["target_specular"]), _ptr(out["target_total"]), _stream()),
+          "assemble_kpcn_patches")
+    return out
+
+
 def gradients(buf):
     """``DenoiseDataset._gradients`` (datasets.py:286-300): (h,w,c) -> (h,w,2c)."""
     _need_dense(buf, 3)
