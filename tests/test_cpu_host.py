@@ -72,6 +72,12 @@ def test_abi_rejects_bad_arguments_without_touching_the_gpu():
         "wcmc_conv2d_igemm_bf16x3": (one, 1, 8, 8, 8, one, null, null, 0, 0, 0, null, 8, 3, 1, 0, 0.0,
                                      null, 0, 0.0, null, null, null, null),               # neither y nor y_split
         "wcmc_clip_adam": (null, one, one, one, 4, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, null, null),
+        # no fused instance for 100 -> 128 -> 3 channels
+        "wcmc_conv1x1_pair_bf16x3": (one, 1, 8, 8, 100, one, null, 128, 1, 0.0, one, null, null, 0, 0.0, null, one, null, 3,
+                                     1, 0.0, one, 256, 32, 4, null),
+        "wcmc_sample_cat_fwd": (one, 1, 1, 1, 1, 1, one, 1, 1, 1, 1, 1, one, 2, 1, 4, 3, 8, 8, null),     # S = 1: no variance
+        "wcmc_assemble_kpcn_patches": (one, null, one, one, 2, 16, 16, 0, 32, one, one, one, one, one, null, one, one, one,
+                                       null),                                                      # patch larger than the image
     }
     for name, args in cases.items():
         rc = getattr(L, name)(*args)
@@ -80,6 +86,10 @@ def test_abi_rejects_bad_arguments_without_touching_the_gpu():
         assert msg and name.replace("wcmc_", "").split("_bf16x3")[0].split("_fwd")[0][:8] in msg.replace("conv2d_", "conv2d_"), (name, msg)
     assert L.wcmc_preprocess_kpcn_workspace_bytes(0, 4) == 0 and L.wcmc_preprocess_kpcn_workspace_bytes(4, 4) == (2 * 16 + 4) * 4
     assert L.wcmc_abi_version() >= 1
+    # which 1x1 layer pairs have a fused instance is a pure host-side question
+    assert L.wcmc_conv1x1_pair_supported(128, 128, 3) and L.wcmc_conv1x1_pair_supported(3, 128, 128)
+    assert L.wcmc_conv1x1_pair_supported(64, 64, 64) and not L.wcmc_conv1x1_pair_supported(36, 64, 64)
+    assert not L.wcmc_conv1x1_pair_supported(128, 128, 8)
 
 
 def test_ops_fail_loudly_without_gpu():
