@@ -17,14 +17,15 @@ torch.cuda.synchronize()
 ho = h - ks + 1
 halo = os.environ.get("WCMC_IGEMM_HALO", "1") != "0"
 if halo:
-    tiles, nw, nstage = n * ((ho + 15) // 16) ** 2, 8, 2 * ((ks * ks * 56 + 31) // 32)
+    tiles, nw, nstage = n * ((ho + 15) // 16) ** 2, 8, ((ks * ks * 56 + 31) // 32) + ((ks * ks * 48 + 31) // 32)
 else:
     tiles, nw, nstage = (n * ho * ho + 127) // 128, 4, (ks * ks * 104 + 31) // 32
 st = part.cpu().numpy().view(np.uint64)[: tiles * nw * 8].reshape(tiles, nw, 8).astype(np.float64)
 names = ["load issue", "frag reads+wait", "mfma issue", "vmcnt+lds store", "barrier", "slab boundary"]
 if halo:
-    names = ["barrier", "weight store + load issue", "mfma + fragment reads (drained)", "stage tail / slab boundary"]
-NB = 4 if halo else 5
+    names = ["vmcnt + barrier", "halo DMA issue (slab ends)", "mfma + fragment reads (drained)", "stage tail",
+             "slab boundary (halo wait, barrier, re-read)", "weight DMA issue"]
+NB = 6 if halo else 5
 tot = st[:, :, :NB].sum(axis=2)
 print("tiles", tiles, "stages/tile", nstage)
 print("cycles per tile (s_memtime ticks = 100 MHz?): mean %.0f min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))

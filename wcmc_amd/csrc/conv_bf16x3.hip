@@ -747,6 +747,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     stamp(0);
     dma_b(g + NB, bcur);
     bcur = b1;
+    stamp(5);                                    // weight DMA issued
     const bool last_of_slab = (s_in + 1 == sps_cur);
     // the fragments of a slab's last stage are in registers and the barrier above retired every read of the
     // halo: the next slab's halo lands while this stage multiplies
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
       __syncthreads();
       read_a();
     }
-    stamp(3);
+    stamp(last_of_slab ? 4 : 3);             // 3: tail of an ordinary stage, 4: slab boundary (halo wait + barrier + re-read)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (zero) weight stages past the end have landed:
   __syncthreads();                                     // LDS is free for the epilogue staging
