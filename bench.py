@@ -314,7 +314,7 @@ def main():
                 # 3 bf16 MFMAs per algorithmic multiply-add (+12 % cout and 5 % k padding): the MFMA pipe does
                 # ~3.5x the counted FLOPs; for scale, the exact-fp32 MFMA peak is 157.3 TFLOP/s
                 extra = {"mfma_flops_per_algorithmic_flop": 3.0, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 3)}
-            rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 16, 16, 0, 3>",
+            rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 8, 16, 0, 2>",
                             "conv_wgrad_rows": "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
                             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}.get(name, name + " (several kernels)")
             return {"kernel": rocprof_name, "class": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,

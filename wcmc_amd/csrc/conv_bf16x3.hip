@@ -179,6 +179,17 @@ static XKPlan x_plan_k(int kchan, int ks) {
   XKPlan q;
   q.Kp = round_up(kchan, 8);
   q.halo = enable && ks >= 3 && ks <= 5 && q.Kp >= 32;
+  static int th8 = -1;                // WCMC_HALO_TH8_5X5=0: A/B switch back to 16x16 tiles with 56/48-channel slabs
+  if (th8 < 0) { const char* e = getenv("WCMC_HALO_TH8_5X5"); th8 = (e && e[0] == '0') ? 0 : 1; }
+  if (q.halo && th8 && ks == 5 && (q.Kp % 32 == 0 || q.Kp % 32 == 8)) {
+    // slabs of 32 channels, the last one 32 or 40: halo pixel stride 160 B (10 units = 2 mod 4), 38 KB for a 12x20 halo
+    q.nslabs = q.Kp / 32;
+    q.CS = 32; q.CSl = q.Kp - (q.nslabs - 1) * 32;
+    q.PXS = 160;
+    q.Ks = round_up(ks * ks * q.CS, 32); q.Ksl = round_up(ks * ks * q.CSl, 32);
+    q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
+    return q;
+  }
   if (q.halo) {
     q.nslabs = (q.Kp + 63) / 64;
     q.CS = round_up((q.Kp + q.nslabs - 1) / q.nslabs, 8);
@@ -200,7 +211,7 @@ static XKPlan x_plan_k(int kchan, int ks) {
 // rows of the per-tile column-sum buffer: enough for either kernel's tiling of (N, Ho, Wo)
 static int x_colsum_rows(int N, int Ho, int Wo) {
   const int64_t gl = ceil_div64((int64_t)N * Ho * Wo, 128);
-  const int64_t gh = (int64_t)N * ((Ho + 15) / 16) * ((Wo + 15) / 16);
+  const int64_t gh = (int64_t)N * ((Ho + 7) / 8) * ((Wo + 15) / 16);      // 8x16 halo tiles (16x16: fewer)
   return (int)(gl > gh ? gl : gh);
 }
 
@@ -605,11 +616,11 @@ __device__ __forceinline__ void pw_barrier() {
 // x all NT*16 couts; one workgroup per CU (LDS: halo 90-115 KB + two weight stages).
 // K order: slab-major (pack_weight_split_kernel); stages never straddle slabs (Ks % 32 == 0).
 template <int NT, int TH, int TW, int DBG = 0, int NB = 3>
-__global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p) {
+__global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_halo_bf16x3_kernel(XIgemmParams p) {
   constexpr int BN = NT * 16;
-  constexpr int NTHR = 512;
+  constexpr int TPX = TH * TW, NTHR = TPX * 2, NWV = NTHR / 64;   // one wave per 32 pixels (two MFMA pixel tiles)
   constexpr int TPR = TW / 16;                 // MFMA pixel tiles per tile row
-  static_assert(TH * TW == 256 && TW % 16 == 0, "8 waves x 2 pixel tiles of 16");
+  static_assert(TPX % 32 == 0 && TW % 16 == 0, "a wave = 2 pixel tiles of 16");
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
   constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
   const int HWd = TW + p.ks - 1, HHt = TH + p.ks - 1, HP = HWd * HHt;
@@ -661,17 +672,28 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   // instruction fills 16 cout rows x 64 B of one plane (1 KB, lane-linear destination: row 16*wave + lane/4,
   // 16-byte slot lane%4); the XOR swizzle of the slot goes on the per-lane SOURCE column.
   const int nstages = p.Kt / XKC;
-  const int drow = 16 * wave + (lane >> 2);
-  const int dvq = (lane & 3) ^ ((drow >> 1) & 3);
-  const unsigned dbase = (16 * wave < BN && n0 + drow < p.Np) ? (unsigned)(((n0 + drow) * 2 * p.Kt + dvq * 8) * 2) : XOOB;
+  // row group = 16 cout rows; wave w fills groups w, w + NWV, ... (one each with 8 waves; up to two with 4)
+  constexpr int NGMAX = (NT + NWV - 1) / NWV;
+  const int ngroups = wave < NT ? (NT - wave + NWV - 1) / NWV : 0;       // wave-uniform
+  unsigned dbase[NGMAX];
+#pragma unroll
+  for (int q = 0; q < NGMAX; ++q) {
+    const int drow = 16 * (wave + q * NWV) + (lane >> 2);
+    const int dvq = (lane & 3) ^ ((drow >> 1) & 3);
+    dbase[q] = (q < ngroups && n0 + drow < p.Np) ? (unsigned)(((n0 + drow) * 2 * p.Kt + dvq * 8) * 2) : XOOB;
+  }
   auto dma_b = [&](int g, int buf) {
-    if (16 * wave < BN) {
-      const unsigned kill = g < nstages ? 0u : XOOB;
-      const unsigned off = (dbase + (unsigned)(g * XKC * 2)) | kill;
-      u16* d = bsm + buf * B_ELEMS + 16 * wave * XROW;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, off, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16,
-                                               dbase >= XOOB ? XOOB : (off + (unsigned)(p.Kt * 2)) | kill, 0, 0, 0);
+    const unsigned kill = g < nstages ? 0u : XOOB;
+#pragma unroll
+    for (int q = 0; q < NGMAX; ++q) {
+      if (q < ngroups) {
+        const unsigned db = dbase[q];
+        const unsigned off = (db + (unsigned)(g * XKC * 2)) | kill;
+        const unsigned off2 = db >= XOOB ? XOOB : (off + (unsigned)(p.Kt * 2)) | kill;
+        u16* d = bsm + buf * B_ELEMS + 16 * (wave + q * NWV) * XROW;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, off2, 0, 0, 0);
+      }
     }
   };
 
@@ -742,7 +764,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   for (int g = 0; g < nstages; ++g) {
     const int b1 = bcur + 1 == NB ? 0 : bcur + 1;      // buffer of stage g+1; stage g's fragments are in registers
     // this wave's share of stage g+1 has landed; the NB-2 stages behind it (two DMA instructions each) stay in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NB - 2)) : "memory");
+    if (NGMAX == 1 || ngroups < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NB - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 2)) : "memory");
     pw_barrier();                                // ... everyone's; and everyone has read stage g's fragments
     stamp(0);
     dma_b(g + NB, bcur);
@@ -796,7 +819,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
   __syncthreads();                                     // LDS is free for the epilogue staging
   if (DBG & 64) {
     if (lane == 0) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * 8 + wave) * 8;
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * NWV + wave) * 8;
       for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
       o[6] = st_prev;
     }
@@ -857,7 +880,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     }
     __syncthreads();
     constexpr int VPP = BN / 8;
-    for (int v = tid; v < 256 * 2 * VPP; v += NTHR) {
+    for (int v = tid; v < TPX * 2 * VPP; v += NTHR) {
       const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
       const int plane = q >= VPP, vec = q - plane * VPP;
       const int co = n0 + vec * 8;
@@ -871,11 +894,11 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     }
     if (!(DBG & 64) && p.colsum) {
       constexpr int CW = BN <= 16 ? 16 : BN <= 32 ? 32 : BN <= 64 ? 64 : 128, RG = NTHR / CW;
-      float* red = reinterpret_cast<float*>(so + 256 * OLD);
+      float* red = reinterpret_cast<float*>(so + TPX * OLD);
       const int c = tid % CW, rg = tid / CW;
       float a = 0.f;
       if (c < BN)
-        for (int r = rg; r < 256; r += RG) a += bf2f(so[r * OLD + c]) + bf2f(so[r * OLD + BN + c]);
+        for (int r = rg; r < TPX; r += RG) a += bf2f(so[r * OLD + c]) + bf2f(so[r * OLD + BN + c]);
       if (rg > 0 && c < BN) red[(rg - 1) * BN + c] = a;
       __syncthreads();
       if (rg == 0 && c < BN && n0 + c < p.Np) {
@@ -909,7 +932,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_bf16x3_kernel(XIgemmParams p
     }
     __syncthreads();
     constexpr int VPP = BN / 4;
-    for (int v = tid; v < 256 * VPP; v += NTHR) {
+    for (int v = tid; v < TPX * VPP; v += NTHR) {
       const int pr = v / VPP, vec = v - pr * VPP;
       const int co = n0 + vec * 4;
       int oy, ox;
@@ -2003,6 +2026,27 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
       hipLaunchKernelGGL((conv_halo_bf16x3_kernel<7, TH, TW, 64, 3>), grid, dim3(512), halo + 3 * bstage, stream, p);
       return check_launch("conv2d_igemm_bf16x3(halo, stamps)");
     }
+  }
+  if (p.PXS == 160 && p.ks == 5) {
+    // WCMC_HALO_TH8_5X5 plan (32-channel slabs): 8x16-pixel tiles, four waves, TWO workgroups per CU -- their stage
+    // barriers are independent, so the non-MFMA phases of one hide behind the MFMAs of the other
+    constexpr int TH8 = 8;
+    XIgemmParams q = p;
+    q.tilesY = (p.Ho + TH8 - 1) / TH8;
+    const size_t halo8 = (size_t)(((TH8 + p.ks - 1) * (TW + p.ks - 1) * p.PXS + 127) & ~127);
+    const size_t out8 = p.ys ? (size_t)TH8 * TW * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)32 * NT * 16 * sizeof(float)
+                             : (size_t)TH8 * TW * (NT * 16 + 4) * sizeof(float);
+    const size_t main8 = halo8 + 2 * bstage;
+    const size_t lds8 = main8 > out8 ? main8 : out8;
+    static size_t attr8 = 0;
+    if (lds8 > attr8) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+      attr8 = lds8;
+    }
+    const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)((q.Np / 16 + NT - 1) / NT));
+    hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>), grid, dim3(TH8 * TW * 2), lds8, stream, q);
+    return check_launch("conv2d_igemm_bf16x3(halo, 8x16)");
   }
   return nb == 3 ? launch_xhalo2<NT, 3>(p, lds, stream) : launch_xhalo2<NT, 2>(p, lds, stream);
 }
