@@ -391,7 +391,7 @@ def _igemm_class(cin, cout, ks):
     if ks == 1 and ((cin + 7) // 8 * 8, cout) in ((64, 64), (40, 64), (128, 128), (8, 128)) \
             and os.environ.get("WCMC_IGEMM_PW", "1") != "0":
         return "conv_pw"                    # x_plan_pw: the persistent pointwise kernel (HBM-bound class)
-    return "conv_halo7" if halo and nt == 7 else "conv_igemm"
+    return "conv_halo7" if halo and nt == 7 and ks == 5 else "conv_igemm"     # conv_halo_bf16x3_kernel<7, 8, 16, 0, 2>
 
 
 def _wgrad_class(n, ho, cin, cout, ks):
