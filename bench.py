@@ -147,11 +147,13 @@ def pmc_traffic():
     pick = {}
     for k, v in d.items():
         for tag, key in (("conv_halo_bf16x3_kernel<7", "conv_halo7"), ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
+                         ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("kernel_apply_kernel<false", "kernel_apply_fwd"), ("kernel_apply_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
-                pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"],
-                             "shape": "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else
-                                      "logits (8,441,92,92)", "source": "profiles/r01_pmc_summary.json"}
+                shape = ("64x128x128 64->64 1x1 hidden layer (PathNet embedding): 536.9 MB algorithmic" if key == "conv_pw" else
+                         "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else "logits (8,441,92,92)")
+                pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "shape": shape,
+                             "source": "profiles/r01_pmc_summary.json"}
     return pick
 
 
@@ -354,7 +356,7 @@ def main():
                        if ops.PRECISION == "bf16x3" else "fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate"},
             "roofline": dict(roof(dominant, "mfma"), traffic=traffic.get(dominant)) if dominant else None,
             "roofline_other_conv": [dict(roof(k, "mfma"), traffic=traffic.get(k)) for k in conv_keys if k != dominant],
-            "roofline_pointwise": roof("conv_pw", "hbm"),
+            "roofline_pointwise": (dict(roof("conv_pw", "hbm"), traffic=traffic.get("conv_pw")) if roof("conv_pw", "hbm") else None),
             "roofline_kernel_apply": ka,
         }
         if world == 1 and not args.no_cpu_baseline:
