@@ -114,6 +114,11 @@ int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
 size_t wcmc_split_elems(int N, int H, int W, int C);
 int wcmc_split_bf16(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, void* out_split,
                     int N, int H, int W, int C, void* stream);
+/* split(dy * act'(post)): the backward of a chain's output activation (wcmc_act_backward) folded into the split of
+ * the upstream gradient; dy and post are fp32 NHWC views of the same geometry. */
+int wcmc_split_gated_bf16(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw, const float* post, int64_t psn,
+                          int64_t psh, int64_t psw, int act, float slope, void* out_split, int N, int H, int W, int C,
+                          void* stream);
 /* cat([flat (B*S,C1,H,W), repeat_S(prop (B,C2,H,W))], 1) (support/networks.py:39-40) written directly as a
  * split tensor of B*S images with C1 + C2 channels; C1 % 8 == 0. */
 int wcmc_cat_broadcast_split(const float* flat, int64_t fsn, int64_t fsh, int64_t fsw,

@@ -32,8 +32,12 @@ __device__ __forceinline__ void split1(float x, u16& hi, u16& lo) {
 }
 
 // ------------------------------------------------------------------ fp32 NHWC view -> split
+// Optional gate (post != nullptr): out = split(x * act'(post)), the output-activation backward of a chain
+// (wcmc_act_backward) folded into the split of its upstream gradient -- one pass over dy instead of two.
 __global__ void split_kernel(const float* __restrict__ x, int64_t xsn, int64_t xsh, int64_t xsw,
-                             u16* __restrict__ out, int H, int W, int C, int Cp, int64_t total) {
+                             u16* __restrict__ out, int H, int W, int C, int Cp, int64_t total,
+                             const float* __restrict__ post = nullptr, int64_t psn = 0, int64_t psh = 0, int64_t psw = 0,
+                             int act = 0, float slope = 0.f) {
   const int V = Cp / 8;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -49,6 +53,12 @@ __global__ void split_kernel(const float* __restrict__ x, int64_t xsn, int64_t x
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = (c0 + e < C) ? src[e] : 0.f;
+    }
+    if (post) {
+      const float* ps = post + n * psn + y * psh + xx * psw + c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e < C) f[e] *= act_gate(ps[e], act, slope);
     }
     u16 hi[8], lo[8];
 #pragma unroll
@@ -1882,8 +1892,23 @@ extern "C" int wcmc_split_bf16(const float* x, int64_t xsn, int64_t xsh, int64_t
   const int64_t total = (int64_t)N * H * W * (Cp / 8);
   const int64_t blocks = ceil_div64(total, 256);
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
-                     x, xsn, xsh, xsw, (u16*)out, H, W, C, Cp, total);
+                     x, xsn, xsh, xsw, (u16*)out, H, W, C, Cp, total, (const float*)nullptr, (int64_t)0, (int64_t)0,
+                     (int64_t)0, 0, 0.f);
   return check_launch("split_bf16");
+}
+
+extern "C" int wcmc_split_gated_bf16(const float* dy, int64_t xsn, int64_t xsh, int64_t xsw, const float* post, int64_t psn,
+                                     int64_t psh, int64_t psw, int act, float slope, void* out, int N, int H, int W, int C,
+                                     void* stream) {
+  WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && out, WCMC_ERR_BAD_ARG, "split_gated_bf16: bad argument");
+  WCMC_REQUIRE(nhwc_view_ok(dy, xsn, xsh, xsw, C) && nhwc_view_ok(post, psn, psh, psw, C) && aligned16(out),
+               WCMC_ERR_ALIGNMENT, "split_gated_bf16: dy / post violate the NHWC-view contract (or out unaligned)");
+  const int Cp = round_up(C, 8);
+  const int64_t total = (int64_t)N * H * W * (Cp / 8);
+  const int64_t blocks = ceil_div64(total, 256);
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
+                     dy, xsn, xsh, xsw, (u16*)out, H, W, C, Cp, total, post, psn, psh, psw, act, slope);
+  return check_launch("split_gated_bf16");
 }
 
 extern "C" int wcmc_cat_broadcast_split(const float* flat, int64_t fsn, int64_t fsh, int64_t fsw, const float* prop,

@@ -363,6 +363,15 @@ def split_raw(x):
     return out
 
 
+def split_gated_raw(dy, post, act):
+    """split(dy * act'(post)) in one pass (wcmc_split_gated_bf16): act_backward_raw + split_raw."""
+    n, c, h, w = dy.shape
+    out = _split_empty(n, c, h, w, dy.device)
+    check(lib().wcmc_split_gated_bf16(*_v(dy), *_v(post), ACT[act], LEAKY_SLOPE, _ptr(out), n, h, w, c, _stream()),
+          "split_gated_bf16")
+    return out
+
+
 def unsplit_debug(t, n, c, h, w):
     """split tensor -> fp32 (N,C,H,W) with torch ops; test / debug only."""
     cp = (c + 7) // 8 * 8
@@ -544,9 +553,10 @@ def _chainx_backward(ctx, dy, need_dx, dys=None):
     if dys is None:
         dy = _as_nhwc_nograd(dy)
         if acts[-1] != "linear":
-            dy = act_backward_raw(dy, saved[off], acts[-1])
+            dys = split_gated_raw(dy, saved[off], acts[-1])       # output-activation backward folded into the split
             off += 1
-        dys = split_raw(dy)
+        else:
+            dys = split_raw(dy)
     else:
         assert acts[-1] == "linear"
     ws = saved[off:]
