@@ -321,6 +321,19 @@ def test_random_permutation_is_a_bijection_and_seeded(n):
         assert 0.2 * n < gap < 0.45 * n
 
 
+@pytest.mark.parametrize("act", ["relu", "leaky_relu"])
+def test_gated_split_equals_act_backward_then_split(act):
+    """wcmc_split_gated_bf16 (a chain's output-activation backward folded into the split of dy) is bit-identical to the
+    two launches it replaces, on a ragged channel count and a strided dy view."""
+    o = ops()
+    dyb = o.to_nhwc_raw(gen(2, 21, 9, 11, seed=60).to(DEV))
+    dy = dyb[:, :19]                                   # strided channel view (19 of 21 channels)
+    post = o.to_nhwc_raw((gen(2, 19, 9, 11, seed=61)).to(DEV))
+    want = o.split_raw(o.act_backward_raw(dy, post, act))
+    got = o.split_gated_raw(dy, post, act)
+    assert torch.equal(want, got)
+
+
 def test_split_roundtrip_is_near_fp32():
     o = ops()
     x = o.to_nhwc_raw((gen(2, 37, 9, 11, seed=22) * 100).to(DEV))
