@@ -124,6 +124,14 @@ int wcmc_split_gated_bf16(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw
 int wcmc_cat_broadcast_split(const float* flat, int64_t fsn, int64_t fsh, int64_t fsw,
                              const float* prop, int64_t psn, int64_t psh, int64_t psw,
                              void* out_split, int B, int S, int H, int W, int C1, int C2, void* stream);
+/* U-Net skip concatenation (sbmc.modules.Autoencoder: cat([upsample_x2(deeper), skip], 1) feeding a level's right
+ * ConvChain): the bilinear upsampling (align_corners=False, as wcmc_upsample2_fwd) is evaluated on the fly and the
+ * concatenation is written once, directly as the chain's split input.  deep: (N, C1, H/2, W/2), skip: (N, C2, H, W),
+ * C1 % 8 == 0; the result equals wcmc_upsample2_fwd + wcmc_cat_broadcast_split(S = 1) bit for bit. */
+int wcmc_cat_upsample_split(const float* deep, int64_t dsn, int64_t dsh, int64_t dsw, const float* skip, int64_t ssn,
+                            int64_t ssh, int64_t ssw, void* out_split, int N, int H, int W, int C1, int C2,
+                            void* stream);
+
 /* split(g (B*S,C,H,W) + repeat_S(gm (B,C,H,W)) * scale): the gradient of a chain output that feeds both the
  * concatenation and the spp mean (support/networks.py:35-40), as the split dy of the chain's backward.  Either
  * gradient may be null. */

@@ -503,6 +503,36 @@ def test_image_losses_against_reference_goldens(golden_dir):
         np.testing.assert_allclose(x.grad.cpu().numpy(), d[name + "_grad"], rtol=1e-4, atol=1e-9, err_msg=name)
 
 
+@pytest.mark.parametrize("geom", [(2, 16, 8, 6, 10), (1, 128, 64, 16, 12), (3, 8, 5, 4, 2)])
+def test_cat_upsample_chain_equals_upsample_then_cat(geom):
+    """A U-Net level's right chain on cat([upsample2(deep), skip], 1): the kernel that upsamples inside the
+    concatenation (wcmc_cat_upsample_split) gives the separate ops' results bit for bit, forward and backward."""
+    o = ops()
+    n, c1, c2, hd, wd = geom
+    deep, skip = gen(n, c1, hd, wd, seed=90), gen(n, c2, 2 * hd, 2 * wd, seed=91)
+    wt = [gen(12, c1 + c2, 3, 3, seed=92, scale=0.2), gen(12, seed=93, scale=0.1), gen(5, 12, 3, 3, seed=94, scale=0.2),
+          gen(5, seed=95, scale=0.1)]
+    g = gen(n, 5, 2 * hd, 2 * wd, seed=96)
+    res = []
+    for fused in (True, False):
+        d, s_ = deep.to(DEV).requires_grad_(True), skip.to(DEV).requires_grad_(True)
+        ps = [t.to(DEV).requires_grad_(True) for t in wt]
+        if fused:
+            y = o.cat_upsample_chain(d, s_, 3, 1, ["relu", "leaky_relu"], ps)
+        else:
+            y = o.cat_broadcast_chain(o.upsample2(d), s_, 1, 3, 1, ["relu", "leaky_relu"], ps)
+        y.backward(g.to(DEV))
+        res.append([y.detach().clone(), d.grad.clone(), s_.grad.clone()] + [t.grad.clone() for t in ps])
+    for a, b, nm in zip(res[0], res[1], ["y", "d_deep", "d_skip", "dw0", "db0", "dw1", "db1"]):
+        assert torch.equal(a, b), "fused upsample-concat differs in " + nm
+    # and against torch's bilinear upsampling (align_corners=False) in fp64
+    up = F.interpolate(deep.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    x = torch.cat([up, skip.double()], 1)
+    h1 = F.relu(F.conv2d(x, wt[0].double(), wt[1].double(), padding=1))
+    want = F.leaky_relu(F.conv2d(h1, wt[2].double(), wt[3].double(), padding=1), 0.01)
+    assert_close(res[0][0], want, tol=1e-4, what="cat-upsample chain vs fp64")
+
+
 @pytest.mark.parametrize("cp", [3, 2, 6])
 def test_pbuffer_cat(cp):
     o = ops()

@@ -74,10 +74,13 @@ __global__ void split_kernel(const float* __restrict__ x, int64_t xsn, int64_t x
 // embedding (B*S images) and the spp-broadcast U-Net output (B images) is written once, directly as the
 // chain's split-bf16 input (separately: copy 268 MB + broadcast 268 MB into an fp32 tensor, then read its
 // 537 MB and write 537 MB of split planes).  One thread = 8 channels of one pixel.
+// up != 0 (U-Net skip concatenation, Autoencoder of sbmc.modules): `flat` is the level below at (H/2, W/2) and is
+// upsampled on the fly -- bilinear x2, align_corners=False, the same four taps and the same fma chain as
+// upsample2_fwd_kernel (elementwise.hip), so the result equals upsample + concatenation bit for bit.
 __global__ void cat_broadcast_split_kernel(const float* __restrict__ flat, int64_t fsn, int64_t fsh, int64_t fsw,
                                            const float* __restrict__ prop, int64_t psn, int64_t psh, int64_t psw,
                                            u16* __restrict__ out, int S, int H, int W, int C1, int C2, int Cp,
-                                           int64_t total) {
+                                           int64_t total, int up = 0) {
   const int V = Cp / 8;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -86,7 +89,24 @@ __global__ void cat_broadcast_split_kernel(const float* __restrict__ flat, int64
     const int y = (int)(t % H); const int n = (int)(t / H);
     const int c0 = v * 8;
     float f[8];
-    if (c0 < C1) {                                   // C1 % 8 == 0: a vector never straddles the two sources
+    if (c0 < C1 && up) {
+      const int hh = H >> 1, wh = W >> 1, iy = y >> 1, ix = xx >> 1;
+      const int ny = (y & 1) ? min(iy + 1, hh - 1) : max(iy - 1, 0);
+      const int nx = (xx & 1) ? min(ix + 1, wh - 1) : max(ix - 1, 0);
+      const float* b0 = flat + n * fsn + c0;
+      const float* p00 = b0 + iy * fsh + ix * fsw;
+      const float* p01 = b0 + iy * fsh + nx * fsw;
+      const float* p10 = b0 + ny * fsh + ix * fsw;
+      const float* p11 = b0 + ny * fsh + nx * fsw;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float r = 0.5625f * p00[e];
+        r = fmaf(0.1875f, p01[e], r);
+        r = fmaf(0.1875f, p10[e], r);
+        r = fmaf(0.0625f, p11[e], r);
+        f[e] = r;
+      }
+    } else if (c0 < C1) {                            // C1 % 8 == 0: a vector never straddles the two sources
       const float* src = flat + n * fsn + y * fsh + xx * fsw + c0;
       const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
       f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
@@ -1924,8 +1944,25 @@ extern "C" int wcmc_cat_broadcast_split(const float* flat, int64_t fsn, int64_t 
   const int64_t blocks = ceil_div64(total, 256);
   hipLaunchKernelGGL(cat_broadcast_split_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0,
                      (hipStream_t)stream, flat, fsn, fsh, fsw, prop, psn, psh, psw, (u16*)out_split, S, H, W, C1, C2, Cp,
-                     total);
+                     total, 0);
   return check_launch("cat_broadcast_split");
+}
+
+extern "C" int wcmc_cat_upsample_split(const float* deep, int64_t dsn, int64_t dsh, int64_t dsw, const float* skip,
+                                       int64_t ssn, int64_t ssh, int64_t ssw, void* out_split, int N, int H, int W, int C1,
+                                       int C2, void* stream) {
+  WCMC_REQUIRE(deep && skip && out_split && N > 0 && H > 1 && W > 1 && (H % 2) == 0 && (W % 2) == 0 && C1 > 0 && C2 > 0,
+               WCMC_ERR_BAD_ARG, "cat_upsample_split: bad argument (H and W are the fine, even, geometry)");
+  WCMC_REQUIRE(C1 % 8 == 0, WCMC_ERR_BAD_ARG, "cat_upsample_split: the upsampled operand needs a multiple of 8 channels");
+  WCMC_REQUIRE(nhwc_view_ok(deep, dsn, dsh, dsw, C1) && nhwc_view_ok(skip, ssn, ssh, ssw, C2) && aligned16(out_split),
+               WCMC_ERR_ALIGNMENT, "cat_upsample_split: a view violates the NHWC-view contract");
+  const int Cp = round_up(C1 + C2, 8);
+  const int64_t total = (int64_t)N * H * W * (Cp / 8);
+  const int64_t blocks = ceil_div64(total, 256);
+  hipLaunchKernelGGL(cat_broadcast_split_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, deep, dsn, dsh, dsw, skip, ssn, ssh, ssw, (u16*)out_split, 1, H, W, C1, C2, Cp,
+                     total, 1);
+  return check_launch("cat_upsample_split");
 }
 
 extern "C" int wcmc_add_broadcast_split(const float* g, int64_t gsn, int64_t gsh, int64_t gsw, const float* gm,

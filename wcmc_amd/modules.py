@@ -60,6 +60,12 @@ class ConvChain(nn.Module):
         return ops.cat_broadcast_chain(flat, prop, s, self.ksize, self.padding, acts, params)
 
 
+    def forward_cat_upsample(self, deep, skip):
+        """``self(cat([upsample2(deep), skip], 1))`` (a U-Net level's right chain) without the upsampled tensor."""
+        acts, params = self._acts_params()
+        return ops.cat_upsample_chain(deep, skip, self.ksize, self.padding, acts, params)
+
+
 class _Level(nn.Module):
     def __init__(self, n_in, n_out, width, num_convs, ksize, output_type, next_level=None, n_up=None):
         super().__init__()
@@ -79,8 +85,9 @@ class _Level(nn.Module):
         if self.is_last:
             return left
         deeper = self.next_level(ops.maxpool2(left))
-        # cat([upsampled, skip], 1) is written once, directly as the right chain's split input (S = 1 "broadcast")
-        return self.right.forward_cat_broadcast(ops.upsample2(deeper), left, 1)
+        # cat([upsample2(deeper), skip], 1) is written once, directly as the right chain's split input, the bilinear
+        # upsampling evaluated inside that kernel
+        return self.right.forward_cat_upsample(deeper, left)
 
 
 class Autoencoder(nn.Module):

@@ -701,6 +701,43 @@ class _CatBroadcastChainX(torch.autograd.Function):
         return (dflat, dprop, None, None, *grads)
 
 
+class _CatUpsampleChainX(torch.autograd.Function):
+    """``chain(cat([upsample2(deep), skip], 1))`` (a U-Net level's right chain) with the bilinear upsampling evaluated
+    inside the concatenation kernel (``wcmc_cat_upsample_split``): the upsampled tensor is never written; the
+    backward is the chain's, then ``upsample2``'s on the first channels of its input gradient."""
+
+    @staticmethod
+    def forward(ctx, deep, skip, spec, *params):
+        _need_cuda(deep, skip, *params)
+        n, c1, hd, wd = deep.shape
+        c2, h, w = skip.shape[1:]
+        assert skip.shape[0] == n and h == 2 * hd and w == 2 * wd and c1 % 8 == 0
+        xs0 = _split_empty(n, c1 + c2, h, w, deep.device)
+        check(lib().wcmc_cat_upsample_split(*_v(deep), *_v(skip), _ptr(xs0), n, h, w, c1, c2, _stream()), "cat_upsample_split")
+        ctx.cat = (n, c1, c2, h, w)
+        return _chainx_forward(ctx, xs0, (n, c1 + c2, h, w), spec, params)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c1, c2, h, w = ctx.cat
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dx, grads = _chainx_backward(ctx, dy, need)
+        ddeep = dskip = None
+        if need:
+            g = dx[:, :c1]
+            ddeep = nhwc_empty(n, c1, h // 2, w // 2, dx.device)
+            check(lib().wcmc_upsample2_bwd(*_v(g), *_v(ddeep), n, h // 2, w // 2, c1, _stream()), "upsample2_bwd")
+            dskip = dx[:, c1:]
+        return (ddeep, dskip, None, *grads)
+
+
+def cat_upsample_chain(deep, skip, ksize, pad, acts, params):
+    """``conv_chain(cat([upsample2(deep), skip], 1), ...)``; one autograd node on the split-bf16 path."""
+    if FUSE_CHAIN_GLUE and PRECISION == "bf16x3" and deep.shape[1] % 8 == 0:
+        return _CatUpsampleChainX.apply(as_nhwc(deep), as_nhwc(skip), (ksize, pad, tuple(acts)), *params)
+    return cat_broadcast_chain(upsample2(deep), skip, 1, ksize, pad, acts, params)
+
+
 def conv_chain(x, ksize, pad, acts, params):
     fn = _ConvChainX if PRECISION == "bf16x3" else _ConvChain
     return fn.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
