@@ -103,6 +103,11 @@ int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
                       int ks, int pad, float* dw_oihw, float* db,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Strided channel-first (N,C,H,W) fp32 -> dense split tensor in one pass (element strides; C <= 64): the per-sample
+ * path descriptors `paths` (support/networks.py:31-33) are only read as the embedding chain's split input. */
+int wcmc_split_from_nchw(const float* src, int64_t ssn, int64_t ssc, int64_t ssh, int64_t ssw, void* out_split, int N,
+                         int C, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- split-bf16 ("bf16x3") convolution
  * Same reference expressions as above (torch.nn.Conv2d fwd/bwd in sbmc.modules.ConvChain), computed
  * with every fp32 operand carried as two bf16 planes hi = bf16(x), lo = bf16(x - hi) and each product

@@ -60,6 +60,17 @@ def test_layout_roundtrip(shape):
     assert torch.equal(o.to_nhwc_raw(xs).cpu(), xs.cpu())
 
 
+@pytest.mark.parametrize("shape", [(3, 36, 5, 70), (2, 64, 4, 64), (1, 7, 3, 9)])
+def test_split_from_channel_first_equals_convert_then_split(shape):
+    """wcmc_split_from_nchw (transpose + split in one pass, what PathNet does with `paths`) == to_nhwc + split, bit for
+    bit, also from a strided source; and the attached split is what conv_chain_spp_mean consumes."""
+    o = ops()
+    x = gen(*shape, seed=65).to(DEV)
+    assert torch.equal(o.split_from_nchw_raw(x), o.split_raw(o.to_nhwc_raw(x)))
+    xs = gen(shape[0], shape[1] + 3, shape[2] + 2, shape[3] + 5, seed=66).to(DEV)[:, 2:-1, 1:-1, 3:-2]
+    assert torch.equal(o.split_from_nchw_raw(xs), o.split_raw(o.to_nhwc_raw(xs)))
+
+
 CONV_CASES = [
     # N, Cin, H, W, Cout, ks, pad, act
     (2, 39, 20, 20, 100, 5, 0, "relu"),

@@ -27,6 +27,7 @@ SIGNATURES = {
     "wcmc_conv2d_wgrad": (I, [P, L, L, L, I, I, I, I, P, L, L, L, I, I, I, P, P, P, Z, P]),
     "wcmc_split_elems": (Z, [I, I, I, I]),
     "wcmc_split_bf16": (I, [P, L, L, L, P, I, I, I, I, P]),
+    "wcmc_split_from_nchw": (I, [P, L, L, L, L, P, I, I, I, I, P]),
     "wcmc_split_gated_bf16": (I, [P, L, L, L, P, L, L, L, I, F, P, I, I, I, I, P]),
     "wcmc_cat_broadcast_split": (I, [P, L, L, L, P, L, L, L, P, I, I, I, I, I, I, P]),
     "wcmc_cat_upsample_split": (I, [P, L, L, L, P, L, L, L, P, I, I, I, I, I, P]),

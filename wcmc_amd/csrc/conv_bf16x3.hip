@@ -69,6 +69,33 @@ __global__ void split_kernel(const float* __restrict__ x, int64_t xsn, int64_t x
   }
 }
 
+// ------------------------------------------------------------------ strided (N,C,H,W) -> split
+// The per-sample path descriptors arrive channel-first (`paths` (B,S,36,H,W), support/networks.py:31-33) and are only
+// ever read as the embedding chain's split input: transpose and split in one pass (64 pixels of one image row x all
+// channels through LDS) instead of a channel-last fp32 copy that is then split (0.3 GB less traffic per step).
+__global__ __launch_bounds__(256) void nchw_split_kernel(const float* __restrict__ src, int64_t ssn, int64_t ssc, int64_t ssh,
+                                                         int64_t ssw, u16* __restrict__ out, int C, int Cp, int H, int W) {
+  __shared__ float tile[64][65];                    // [channel][pixel]
+  const int xt = blockIdx.x * 64, y = blockIdx.y % H, n = blockIdx.y / H;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int c = grp; c < Cp; c += 4) {
+    const int x = xt + lane;
+    tile[c][lane] = (c < C && x < W) ? src[(int64_t)n * ssn + (int64_t)c * ssc + (int64_t)y * ssh + (int64_t)x * ssw] : 0.f;
+  }
+  __syncthreads();
+  const int V = Cp / 8;
+  for (int i = threadIdx.x; i < 64 * V; i += 256) {
+    const int px = i / V, v = i - px * V, x = xt + px;
+    if (x >= W) continue;
+    u16 hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split1(tile[v * 8 + e][px], hi[e], lo[e]);
+    u16* o = out + (((int64_t)n * H + y) * W + x) * 2 * Cp + v * 8;
+    *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(hi);
+    *reinterpret_cast<uint4*>(o + Cp) = *reinterpret_cast<const uint4*>(lo);
+  }
+}
+
 // ------------------------------------------------------------------ cat([flat, repeat_S(prop)], 1) -> split
 // support/networks.py:39-40 feeding the `final` ConvChain: the 128-channel concatenation of the per-sample
 // embedding (B*S images) and the spp-broadcast U-Net output (B images) is written once, directly as the
@@ -1929,6 +1956,17 @@ extern "C" int wcmc_split_gated_bf16(const float* dy, int64_t xsn, int64_t xsh, 
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
                      dy, xsn, xsh, xsw, (u16*)out, H, W, C, Cp, total, post, psn, psh, psw, act, slope);
   return check_launch("split_gated_bf16");
+}
+
+extern "C" int wcmc_split_from_nchw(const float* src, int64_t ssn, int64_t ssc, int64_t ssh, int64_t ssw, void* out_split,
+                                    int N, int C, int H, int W, void* stream) {
+  WCMC_REQUIRE(src && out_split && N > 0 && C > 0 && C <= 64 && H > 0 && W > 0, WCMC_ERR_BAD_ARG,
+               "split_from_nchw: bad argument (at most 64 channels)");
+  WCMC_REQUIRE(aligned16(out_split), WCMC_ERR_ALIGNMENT, "split_from_nchw: out must be 16-byte aligned");
+  WCMC_REQUIRE((int64_t)N * H <= 65535, WCMC_ERR_BAD_ARG, "split_from_nchw: N*H > 65535");
+  hipLaunchKernelGGL(nchw_split_kernel, dim3((unsigned)((W + 63) / 64), (unsigned)(N * H)), dim3(256), 0,
+                     (hipStream_t)stream, src, ssn, ssc, ssh, ssw, (u16*)out_split, C, round_up(C, 8), H, W);
+  return check_launch("split_from_nchw");
 }
 
 extern "C" int wcmc_cat_broadcast_split(const float* flat, int64_t fsn, int64_t fsh, int64_t fsw, const float* prop,

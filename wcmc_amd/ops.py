@@ -363,6 +363,23 @@ def split_raw(x):
     return out
 
 
+def split_from_nchw_raw(x):
+    """Strided channel-first (N,C,H,W) fp32 -> split tensor in one pass (wcmc_split_from_nchw; C <= 64)."""
+    n, c, h, w = x.shape
+    out = _split_empty(n, c, h, w, x.device)
+    check(lib().wcmc_split_from_nchw(_ptr(x), *x.stride(), _ptr(out), n, c, h, w, _stream()), "split_from_nchw")
+    return out
+
+
+def presplit_shared(x):
+    """Attach the split form of the channel-first tensor `x` to it so that ``conv_chain_spp_mean(x, ...)`` consumes it
+    directly -- on ANY stream that was forked after this call (the two PathNets embed the same `paths`, the second one on
+    the forked specular stream: the split is made once, before the fork).  Returns x."""
+    _need_cuda(x)
+    x._wcmc_split = ((x._version, None), split_from_nchw_raw(x))
+    return x
+
+
 def split_gated_raw(dy, post, act):
     """split(dy * act'(post)) in one pass (wcmc_split_gated_bf16): act_backward_raw + split_raw."""
     n, c, h, w = dy.shape
@@ -630,6 +647,9 @@ def _split_shared(x):
     cached = getattr(x, "_wcmc_split", None)
     if cached is not None and cached[0] == tag:
         return cached[1]
+    if cached is not None and cached[0] == (x._version, None):      # presplit_shared: made before the streams forked
+        cached[1].record_stream(torch.cuda.current_stream())
+        return cached[1]
     xs = split_raw(x)
     if not x.requires_grad:
         x._wcmc_split = (tag, xs)
@@ -750,6 +770,9 @@ FUSE_CHAIN_GLUE = os.environ.get("WCMC_FUSE_CHAIN_GLUE", "1") != "0"
 def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
     """``y = conv_chain(x, ...); return y, spp_mean(y, s)``; one autograd node on the split-bf16 path."""
     if FUSE_CHAIN_GLUE and PRECISION == "bf16x3" and acts[-1] == "linear":
+        pre = getattr(x, "_wcmc_split", None)
+        if pre is not None and pre[0] == (x._version, None) and not x.requires_grad:
+            return _ChainSppMeanX.apply(x, s, (ksize, pad, tuple(acts)), *params)      # channel-first x, split attached
         return _ChainSppMeanX.apply(as_nhwc(x), s, (ksize, pad, tuple(acts)), *params)
     y = conv_chain(x, ksize, pad, acts, params)
     return y, spp_mean(y, s)

@@ -37,7 +37,13 @@ class PathNet(nn.Module):
         if cached is not None and cached[0] == key:
             return cached[1]
         bs, spp, nf, h, w = paths.shape
-        flat = ops.as_nhwc(paths.reshape(bs * spp, nf, h, w))
+        flat = paths.reshape(bs * spp, nf, h, w)
+        if (ops.FUSE_CHAIN_GLUE and ops.PRECISION == "bf16x3" and not paths.requires_grad and nf <= 64 and paths.is_cuda
+                and bs * spp * h <= 65535):
+            # the embedding chain is the only reader: transpose + split in one pass, once for both backbones
+            flat = ops.presplit_shared(flat.detach())
+        else:
+            flat = ops.as_nhwc(flat)
         if not paths.requires_grad:
             samples["_wcmc_paths_nhwc"] = (key, flat)
         return flat
