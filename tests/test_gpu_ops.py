@@ -383,6 +383,30 @@ def test_kernel_apply_fwd_bwd(shape):
     assert_close(dd.grad, dr.grad, what="kernel_apply d_data")
 
 
+def test_chain_kernel_apply_node_equals_the_separate_ops():
+    """One half of sbmc.KPCN.forward as one autograd node (the apply's backward writes d_logits straight into the
+    chain's split gradient, wcmc_kernel_apply_bwd_split) == conv_chain followed by kernel_apply, bit for bit."""
+    o = ops()
+    n, cin, h = 2, 12, 30
+    x, data = gen(n, cin, h, h, seed=110), gen(n, 3, h - 8, h - 8, seed=111).abs()
+    wt = [gen(16, cin, 5, 5, seed=112, scale=0.1), gen(16, seed=113, scale=0.1),
+          gen(441, 16, 5, 5, seed=114, scale=0.1), gen(441, seed=115, scale=0.1)]
+    g = gen(n, 3, h - 8, h - 8, seed=116)
+    res = []
+    for fused in (True, False):
+        xd = x.to(DEV).requires_grad_(True)
+        ps = [t.to(DEV).requires_grad_(True) for t in wt]
+        d = data.to(DEV)
+        if fused:
+            y = o._ChainKernelApplyX.apply(o.as_nhwc(xd), d, (5, 0, ("relu", "linear")), *ps)
+        else:
+            y = o.kernel_apply(d, o.conv_chain(xd, 5, 0, ["relu", "linear"], ps))
+        y.backward(g.to(DEV))
+        res.append([y.detach().clone(), xd.grad.clone()] + [t.grad.clone() for t in ps])
+    for a, b, nm in zip(res[0], res[1], ["out", "dx", "dw0", "db0", "dw1", "db1"]):
+        assert torch.equal(a, b), "fused chain + kernel-apply differs in " + nm
+
+
 def test_kernel_apply_known_answers():
     o = ops()
     n, h, w, k = 1, 26, 29, 21

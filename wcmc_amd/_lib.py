@@ -45,6 +45,7 @@ SIGNATURES = {
     "wcmc_kernel_apply_fwd": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, I, I, I, I, I, P]),
     "wcmc_kernel_apply_bwd": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P,
                                   P, L, L, L, P, I, I, I, I, I, P]),
+    "wcmc_kernel_apply_bwd_split": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P, P, I, I, I, I, I, P]),
     "wcmc_recombine_fwd": (I, [P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P, I, I, I, I, P]),
     "wcmc_recombine_bwd": (I, [P, P, L, L, L, L, P, L, L, L, L, P, P, I, I, I, I, P]),
     "wcmc_maxpool2_fwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),

@@ -1,5 +1,7 @@
 """MI355X-native ``sbmc.KPCN`` (constructed at ``train_kpcn.py:213,229``; result keys consumed
 at ``support/interfaces.py:207-211``).  Same specification as ``oracle/models.py``."""
+import types
+
 import torch.nn as nn
 
 from . import ops
@@ -17,14 +19,18 @@ class KPCN(nn.Module):
                                   output_type="linear")
         self.kernel_apply = KernelApply(softmax=True, splat=False)
 
+    @staticmethod
+    def _branch(chain, x, buffer):
+        """kernel_apply(crop_like(buffer, k), k) with k = chain(x): chain and apply are one autograd node on the
+        split-bf16 path (the kernel gradient goes from the apply to the chain without an fp32 round trip)."""
+        shrink = chain.depth * (chain.ksize - 1 - 2 * chain.padding)
+        k_like = types.SimpleNamespace(shape=tuple(x.shape[:2]) + (x.shape[2] - shrink, x.shape[3] - shrink))
+        return chain.forward_kernel_apply(x, crop_like(buffer, k_like))
+
     def forward(self, data):
         with ops.on_branch(data["kpcn_specular_in"].device) as br:      # specular half on the branch stream
-            k_specular = self.specular(data["kpcn_specular_in"])
-            b_specular = crop_like(data["kpcn_specular_buffer"], k_specular)
-            r_specular = self.kernel_apply(b_specular, k_specular)
-        k_diffuse = self.diffuse(data["kpcn_diffuse_in"])
-        b_diffuse = crop_like(data["kpcn_diffuse_buffer"], k_diffuse)
-        r_diffuse = self.kernel_apply(b_diffuse, k_diffuse)
+            r_specular = self._branch(self.specular, data["kpcn_specular_in"], data["kpcn_specular_buffer"])
+        r_diffuse = self._branch(self.diffuse, data["kpcn_diffuse_in"], data["kpcn_diffuse_buffer"])
         br.join(r_specular)
         albedo = crop_like(data["kpcn_albedo"], r_diffuse)
         radiance = ops.recombine(albedo, r_diffuse, r_specular)

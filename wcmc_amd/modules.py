@@ -60,6 +60,11 @@ class ConvChain(nn.Module):
         return ops.cat_broadcast_chain(flat, prop, s, self.ksize, self.padding, acts, params)
 
 
+    def forward_kernel_apply(self, x, data):
+        """``kernel_apply(data, self(x))`` (one half of sbmc.KPCN.forward); data cropped to the chain's output size."""
+        acts, params = self._acts_params()
+        return ops.chain_kernel_apply(x, data, self.ksize, self.padding, acts, params)
+
     def forward_cat_upsample(self, deep, skip):
         """``self(cat([upsample2(deep), skip], 1))`` (a U-Net level's right chain) without the upsampled tensor."""
         acts, params = self._acts_params()

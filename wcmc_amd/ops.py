@@ -511,8 +511,9 @@ def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=Tr
 USE_GATE_MASK = os.environ.get("WCMC_GATE_MASK", "1") != "0"
 
 
-def _chainx_forward(ctx, xs0, dims0, spec, params):
-    """Shared forward of the split-bf16 chains: xs0 is the chain input as a split tensor of dims0."""
+def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
+    """Shared forward of the split-bf16 chains: xs0 is the chain input as a split tensor of dims0.  extra_saved: a
+    callable y -> tensors saved behind the chain's own (a fused consumer of the chain's output)."""
     ks, pad, acts = spec
     nl = len(acts)
     n = dims0[0]
@@ -549,7 +550,9 @@ def _chainx_forward(ctx, xs0, dims0, spec, params):
             y = out
     ctx.spec, ctx.dims = spec, dims
     keep_y = [y] if acts[-1] != "linear" else []
-    ctx.save_for_backward(*xs, *masks, *keep_y, *[params[2 * l] for l in range(nl)])
+    extra = tuple(extra_saved(y)) if extra_saved is not None else ()
+    ctx.n_extra = len(extra)
+    ctx.save_for_backward(*xs, *masks, *keep_y, *[params[2 * l] for l in range(nl)], *extra)
     if DEBUG_ACTS is not None:
         DEBUG_ACTS.extend(unsplit_debug(xs[l + 1], *dims[l + 1]) for l in range(nl - 1))
         if acts[-1] != "linear":
@@ -576,7 +579,7 @@ def _chainx_backward(ctx, dy, need_dx, dys=None):
             dys = split_raw(dy)
     else:
         assert acts[-1] == "linear"
-    ws = saved[off:]
+    ws = saved[off:len(saved) - getattr(ctx, "n_extra", 0)]
     part = None                     # per-tile column sums of dys when the dgrad GEMM produced them
     grads = [None] * (2 * nl)
     dx = None
@@ -823,6 +826,62 @@ class _KernelApply(torch.autograd.Function):
 def kernel_apply(data, logits):
     """softmax(k*k logits) applied as a zero-extended gather kernel over ``data``."""
     return _KernelApply.apply(data, as_nhwc(logits))
+
+
+class _ChainKernelApplyX(torch.autograd.Function):
+    """``kernel_apply(crop(data), chain(x))`` -- one half of ``sbmc.KPCN.forward`` -- as one node: the backward's
+    kernel-apply writes d_logits directly as the split gradient of the chain's backward
+    (``wcmc_kernel_apply_bwd_split``) instead of an fp32 tensor that a split pass would re-read."""
+
+    @staticmethod
+    def forward(ctx, x, data, spec, *params):
+        _need_cuda(x, data, *params)
+        assert spec[2][-1] == "linear" and not data.requires_grad
+        out_box = []
+
+        def apply(logits):
+            n, k2, h, w = logits.shape
+            k = int(round(k2 ** 0.5))
+            c = data.shape[1]
+            assert k * k == k2 and data.shape[0] == n and data.shape[2:] == logits.shape[2:]
+            out = torch.empty((n, c, h, w), device=logits.device, dtype=torch.float32)
+            lse = torch.empty(n * h * w, device=logits.device, dtype=torch.float32)
+            with _Timed("kernel_apply_fwd", 4.0 * n * h * w * (k2 + 2 * c), "byte"):
+                check(lib().wcmc_kernel_apply_fwd(*_v(logits), _ptr(data), *data.stride(), _ptr(out), *out.stride(),
+                                                  _ptr(lse), n, c, h, w, k, _stream()), "kernel_apply_fwd")
+            ctx.k = k
+            out_box.append(out)
+            return data, logits, out, lse
+
+        _chainx_forward(ctx, split_raw(x), tuple(x.shape), spec, params, extra_saved=apply)
+        return out_box[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        data, logits, out, lse = ctx.saved_tensors[-4:]
+        n, k2, h, w = logits.shape
+        c = data.shape[1]
+        g = g.contiguous()
+        dys = _split_empty(n, k2, h, w, logits.device)
+        with _Timed("kernel_apply_bwd", 4.0 * n * h * w * (2 * k2 + 3 * c), "byte"):
+            check(lib().wcmc_kernel_apply_bwd_split(*_v(logits), _ptr(data), *data.stride(), _ptr(out), *out.stride(),
+                                                    _ptr(g), *g.stride(), _ptr(lse), _ptr(dys), n, c, h, w, ctx.k,
+                                                    _stream()), "kernel_apply_bwd_split")
+        dx, grads = _chainx_backward(ctx, None, ctx.needs_input_grad[0], dys=dys)
+        return (dx, None, None, *grads)
+
+
+# Measured neutral at the benchmark shapes (369-371 patches/s either way, three alternations on one box: the 8-byte
+# split stores of the apply's backward cost what the saved fp32 round trip gains) -- off unless WCMC_FUSE_KA=1.
+FUSE_KERNEL_APPLY = os.environ.get("WCMC_FUSE_KA", "0") != "0"
+
+
+def chain_kernel_apply(x, data, ksize, pad, acts, params):
+    """``kernel_apply(data, conv_chain(x, ...))`` with ``data`` already cropped to the chain's output size."""
+    if (FUSE_CHAIN_GLUE and PRECISION == "bf16x3" and acts[-1] == "linear" and not data.requires_grad
+            and FUSE_KERNEL_APPLY):
+        return _ChainKernelApplyX.apply(as_nhwc(x), data, (ksize, pad, tuple(acts)), *params)
+    return kernel_apply(data, conv_chain(x, ksize, pad, acts, params))
 
 
 class _Recombine(torch.autograd.Function):
