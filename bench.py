@@ -196,9 +196,42 @@ def cpu_baseline():
     while len(times) < 12 and sum(times) < 12.0:
         times.append(one(1, PATCH))
     t = sum(times) / len(times)
+    # BASELINE configs[0] (the reference's own CPU-runnable case): KPCN-Vanilla, 64x64, batch 2, 3 steps after a warm-up
+    vmodels = {"dncnn": OKPCN(34)}
+    voptims = {"optim_dncnn": torch.optim.Adam(vmodels["dncnn"].parameters(), lr=1e-4)}
+    vbatch = make_batch(2, SPP, 64, seed=0, device="cpu", use_llpm=False)
+    vcfg = dict(use_llpm_buf=False, manif_learn=False, train_branches=True)
+    c1 = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        ostep.train_step(vmodels, voptims, vbatch, vcfg, None)
+        c1.append(time.perf_counter() - t0)
+    c1_t = sum(c1[1:]) / 3
     return {"value": 1.0 / t, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_logical_cpus": os.cpu_count(), "host_cpus_in_affinity_mask": avail,
             "sample": "%d train steps of the PyTorch-CPU oracle after one warm-up, KPCN-Manifold C3 shape at batch 1 "
-                      "(128x128, S=8), %.1f s in total, %.2f s per step" % (len(times), sum(times), t)}
+                      "(128x128, S=8), %.1f s in total, %.2f s per step; `cores` = torch intra-op threads, chosen by a "
+                      "scaling probe (more threads are slower on this host)" % (len(times), sum(times), t),
+            "c1": {"value": 2.0 / c1_t, "unit": "64x64 patches/s", "sample": "BASELINE configs[0]: KPCN-Vanilla (n_in=34, both "
+                   "branches), 64x64, batch 2, 3 train steps after one warm-up, %.2f s per step" % c1_t}}
+
+
+def self_launch(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N fresh worker processes (one per GPU) through
+    ``torch.distributed.run`` BEFORE this process makes any GPU call, pass rank 0's JSON line through, and exit with
+    the workers' status.  (Never an exec of a process that touched the GPU; this parent never does.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL fails with the legacy mode on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
 
 
 def main():
@@ -210,13 +243,21 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of one hipGraph")
     ap.add_argument("--cpu-rng", action="store_true",
                     help="draw the FeatureMSE pairings on the global CPU generator like the reference (+46 ms/step)")
+    ap.add_argument("--precision", choices=("bf16x3", "fp32"), default=None,
+                    help="conv GEMM arithmetic: split-bf16 (default) or exact fp32 MFMA (roofline vs the 157.3 TF/s peak)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, sys.argv[1:])
 
     from wcmc_amd import distributed as wd
     from wcmc_amd import ops
     from wcmc_amd.synthetic import make_batch
+    if args.precision:
+        ops.set_precision(args.precision)
     rank, world, local = wd.init("nccl")
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or "
+                 "without a launcher: bench.py starts its own workers)" % (args.gpus, world, args.gpus))
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -264,6 +305,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     elapsed = wd.max_over_ranks(time.perf_counter() - t0, device)
+    last_losses = {k: float(v) for k, v in itf.last_loss_dict.items()}       # of step warmup + steps, this rank
     ops.set_profiler(None)
     prof_elapsed = elapsed
     if not args.eager:
@@ -324,6 +366,9 @@ def main():
             rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 8, 16, 0, 2>",
                             "conv_wgrad_rows": "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
                             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}.get(name, name + " (several kernels)")
+            if ops.PRECISION == "fp32":
+                rocprof_name = ("wcmc::conv_wgrad_kernel" if "wgrad" in name else "wcmc::conv_igemm_kernel") + \
+                    " (exact fp32 MFMA; launches of class %s)" % name
             return {"kernel": rocprof_name, "class": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": None, "launches": d["launches"], **extra,
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
@@ -343,7 +388,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3" if ops.PRECISION == "bf16x3" else "f32",
-            "data": "synthetic",
+            "data": "synthetic", "rccl_ranks": world,
+            # loss_dict of the last timed step on rank 0 (seeded weights, inputs and pairings: reproducible run to run
+            # with the same binary; a stream-ordering race in the captured step would show here)
+            "losses_last_step": {k: round(v, 6) for k, v in last_losses.items()},
             "config": {"workload": "BASELINE configs[2]: KPCN-Manifold (KPCN n_in=39 + 2xPathNet 36->3 + "
                                    "FeatureMSE w=0.1 m11r11, train_branches), 128x128, S=8 spp, "
                                    "%d patches/GPU, global batch %d" % (B_PER_GPU, global_batch),

@@ -38,6 +38,28 @@ def ptol(precision, fp32_tol, x3_tol):
     return fp32_tol if precision == "fp32" else x3_tol
 
 
+def rel_l2(a, b):
+    """||a - b||_2 / ||b||_2 in fp64: the flip-robust gradient metric.  A ReLU unit whose pre-activation is within
+    rounding of zero may land on either side in two correct implementations; it moves a handful of entries of an
+    upstream weight gradient by a visible amount (so max|a-b|/max|b| jumps) but changes the tensor's L2 distance by
+    ~1/sqrt(units) only."""
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+
+
+def cosine(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return (torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300)).item()
+
+
+def assert_grad_close(got, want, what="", l2=1e-3, cos=1e-6):
+    """Gradient parity without a fallback: relative L2 <= l2 AND 1 - cosine <= cos, per tensor."""
+    assert tuple(got.shape) == tuple(want.shape), (what, got.shape, want.shape)
+    e, c = rel_l2(got, want), cosine(got, want)
+    assert e <= l2 and 1.0 - c <= cos, "%s: rel L2 %.3e (<= %.1e), 1-cos %.3e (<= %.1e)" % (what, e, l2, 1.0 - c, cos)
+    return e
+
+
 class FlipCounter:
     """Counts ReLU / LeakyReLU sign disagreements between the HIP path and the oracle.
 

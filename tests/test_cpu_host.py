@@ -502,3 +502,118 @@ def test_two_rank_gloo_gradient_average_and_broadcast():
     assert set(g0) == {1.5, 2.5}                        # mean of (1,2) and of (2,3)
     assert t0 == t1 == 1.0                              # MAX over ranks
     assert (s0, s1) == (7, 8)                           # disjoint data shards
+
+
+def _emulated_clip_adam(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0,
+                        guard=None):
+    """torch emulation of the wcmc_clip_adam kernel's contract (csrc/optim.hip) for the host-logic test: scale, clip
+    (NaN-propagating), Adam; no-op when the device guard is 0."""
+    import math
+    if guard is not None and float(guard) == 0.0:
+        return
+    grad.mul_(grad_scale).clamp_(-clip, clip)
+    m.mul_(beta1).add_(grad, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    param.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+
+def _fused_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from wcmc_amd import distributed as wd
+    from wcmc_amd import ops, optim as wo
+    wd.init("gloo")
+    ops.clip_adam_ = _emulated_clip_adam
+
+    def build():
+        torch.manual_seed(5)                                  # same weights on both ranks
+        # parameter sizes that are not multiples of 4 floats (441-style biases): exercises the aligned flat layout
+        models = {"dncnn": torch.nn.Linear(7, 3), "backbone_diffuse": torch.nn.Linear(5, 2),
+                  "backbone_specular": torch.nn.Linear(3, 3)}
+        optims = {"optim_" + n: torch.optim.Adam(m.parameters(), lr=1e-2) for n, m in models.items()}
+        return models, optims
+
+    def grads_for(models, r, step):
+        g = torch.Generator().manual_seed(1000 * step + r)
+        return {n: [torch.randn(p.shape, generator=g) * 1.5 for p in m.parameters()] for n, m in models.items()}
+
+    models, optims = build()
+    fused = wo.FusedClipAdam(models, optims, process_group=dist.group.WORLD)
+    assert list(fused.flats) == ["backbone_diffuse", "dncnn", "backbone_specular"]      # backward order
+    ref_models, ref_optims = build()
+    log = {}
+    for step in (1, 2):
+        mine = grads_for(models, rank, step)
+        for n, m in models.items():
+            for p, g in zip(m.parameters(), mine[n]):
+                p.grad = g.clone()
+        gg = fused.step(models, optims, guard=torch.tensor(1.0))
+        assert float(gg) == 1.0
+        # reference: nn.DataParallel sums the replicas' gradients (train_kpcn.py:266-269) -> mean -> clip_grad_value_
+        # (interfaces.py:260-261) -> Adam
+        both = [grads_for(models, r, step) for r in range(world)]
+        for n, m in ref_models.items():
+            for i, p in enumerate(m.parameters()):
+                p.grad = sum(b[n][i] for b in both) / world
+            torch.nn.utils.clip_grad_value_(m.parameters(), 1.0)
+            ref_optims["optim_" + n].step()
+    log["params"] = max(float((p - q).abs().max()) for n in models
+                        for p, q in zip(models[n].parameters(), ref_models[n].parameters()))
+    log["grads_left"] = max(float((p.grad - q.grad).abs().max()) for n in models
+                            for p, q in zip(models[n].parameters(), ref_models[n].parameters()))
+    # clip-then-average would differ: make sure this test could tell
+    both = [grads_for(models, r, 2) for r in range(world)]
+    wrong = sum(b["dncnn"][0].clamp(-1, 1) for b in both) / world
+    log["order_matters"] = float((wrong - ref_models["dncnn"].weight.grad).abs().max())
+    log["state_step"] = float(optims["optim_dncnn"].state[models["dncnn"].weight]["step"])
+    # one rank sees a non-finite loss: EVERY rank skips the update, rolls the counters back (ADVICE r1)
+    before = torch.cat([p.detach().reshape(-1).clone() for m in models.values() for p in m.parameters()])
+    for n, m in models.items():
+        for p in m.parameters():
+            p.grad = torch.ones_like(p)
+    gg = fused.step(models, optims, guard=torch.tensor(0.0 if rank == 1 else 1.0))
+    log["global_guard"] = float(gg)
+    if float(gg) == 0.0:
+        fused.rollback()
+    after = torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()])
+    log["skipped"] = bool(torch.equal(before, after))
+    log["steps_after_rollback"] = [fl.steps for fl in fused.flats.values()]
+    # a parameter without a gradient is skipped like torch.optim.Adam skips it (no moment decay, no update)
+    for n, m in models.items():
+        for p in m.parameters():
+            p.grad = torch.full_like(p, 0.25 * (rank + 1))
+    models["dncnn"].bias.grad = None
+    ref_b = models["dncnn"].bias.detach().clone()
+    ref_m = optims["optim_dncnn"].state[models["dncnn"].bias]["exp_avg"].clone()
+    fused.step(models, optims, guard=torch.tensor(1.0))
+    log["none_grad_skipped"] = bool(torch.equal(models["dncnn"].bias.detach(), ref_b) and
+                                    torch.equal(optims["optim_dncnn"].state[models["dncnn"].bias]["exp_avg"], ref_m))
+    log["weight_moved"] = float((models["dncnn"].weight.detach() - ref_models["dncnn"].weight.detach()).abs().max())
+    q.put((rank, log))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_fused_clip_adam_reduce_then_scale_then_clip():
+    """The multi-rank path bench.py runs (FusedClipAdam(process_group=...)): per-bucket async all-reduce (sum),
+    grad_scale = 1/world inside the kernel, clip AFTER the mean, Adam; the non-finite guard reduced over the ranks;
+    parameters without a gradient skipped.  The kernel is replaced by a torch emulation of its contract (no GPU here)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_fused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        log = res[rank]
+        assert log["params"] <= 1e-6 and log["grads_left"] <= 1e-6, log
+        assert log["order_matters"] > 1e-2, log
+        assert log["state_step"] == 2.0
+        assert log["global_guard"] == 0.0 and log["skipped"] and log["steps_after_rollback"] == [2, 2, 2], log
+        assert log["none_grad_skipped"] and log["weight_moved"] > 1e-4, log

@@ -1,0 +1,129 @@
+"""Parity of the configuration ``bench.py`` measures -- not a smaller or simpler relative of it.
+
+``bench.build_interface`` + ``GraphedTrainStep`` with the library's default switches (split-bf16 GEMMs, forked
+weight-gradient stream, forked specular stream, fused chain glue, fused 1x1 pairs, fused clip + Adam), BASELINE
+configs[2] at its per-GPU shape (8 patches of 128x128, S=8), for two consecutive steps, against
+``oracle.step.train_step`` on the same weights, inputs and FeatureMSE pairings (``rng='cpu'``: the reference's
+``torch.randperm`` stream, ``losses.py:35,50``).  What is compared, per step (``interfaces.py:122-251``):
+
+  * every ``loss_dict`` scalar, 1e-3 relative (north star);
+  * the denoised patches ``radiance / diffuse / specular`` (8,3,92,92), 1e-3 of the tensor's max (north star);
+  * every parameter gradient with the flip-robust metric of ``conftest.assert_grad_close``: relative L2 and
+    cosine, no fallback (the max-norm is printed for information only);
+  * after step 2, the parameter DELTAS of both Adam steps against the oracle's.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from conftest import assert_grad_close, cosine, rel_l2      # noqa: E402
+from oracle import step as ostep                             # noqa: E402
+from oracle.models import KPCN as OKPCN                      # noqa: E402
+from oracle.networks import PathNet as OPathNet              # noqa: E402
+
+DEV = "cuda"
+GRAD_L2, GRAD_COS = 1e-3, 1e-6       # per-tensor gradient bar: relative L2 and 1 - cosine, no fallback
+
+
+def _max_rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("rng_mode", ["cpu"])
+def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
+    import bench
+    from wcmc_amd import ops
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.synthetic import make_batch
+    assert ops.PRECISION == "bf16x3" and ops.USE_SIDE_STREAM and ops.USE_BRANCH_STREAM and ops.FUSE_CHAIN_GLUE, \
+        "this test pins the DEFAULT switches (the ones bench.py runs with)"
+    B, S, H = bench.B_PER_GPU, bench.SPP, bench.PATCH
+    device = torch.device("cuda", 0)
+    itf = bench.build_interface(device, None, rng=rng_mode)              # the bench's own constructor, seed 0
+    hmods = itf.models
+    omods = {"dncnn": OKPCN(39), "backbone_diffuse": OPathNet(36), "backbone_specular": OPathNet(36)}
+    # biases are zero at init (a degenerate case for bias-path bugs): give both sides the same random ones
+    g = torch.Generator().manual_seed(77)
+    for k, m in hmods.items():
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith("bias"):
+                    p.copy_((torch.rand(p.shape, generator=g) * 0.2 - 0.1).to(device))
+        omods[k].load_state_dict({n: v.detach().cpu().clone() for n, v in m.state_dict().items()})
+    oopt = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in omods.items()}
+    cfg = dict(use_llpm_buf=True, manif_learn=True, train_branches=True, disentanglement_option="m11r11", w_manif=0.1)
+    batches = [make_batch(B, S, H, seed=40 + i, device="cpu") for i in range(2)]
+    dbatches = [{k: v.to(device) for k, v in b.items()} for b in batches]
+
+    graphed = GraphedTrainStep(itf, dbatches[0])                          # capture (its warm-up draws pairings)
+    p_start = {mn: {k: v.detach().cpu().clone() for k, v in m.named_parameters()} for mn, m in hmods.items()}
+    for mn in omods:                                                      # warm-up runs no optimiser: still equal
+        for k, q in omods[mn].named_parameters():
+            assert torch.equal(p_start[mn][k], q.detach()), (mn, k)
+
+    ho = H - 36
+    torch.manual_seed(1234)
+    perms = [[ostep.draw_perms(B, S, ho, ho), ostep.draw_perms(B, S, ho, ho)] for _ in range(2)]
+    torch.manual_seed(1234)                                               # the graph draws the same stream, same order
+    report, fails = [], []
+    ograds = [{}, {}]
+    for step in range(2):
+        loss_o, out_o = ostep.train_step(omods, oopt, batches[step], cfg, perms[step])
+        graphed(dbatches[step])
+        torch.cuda.synchronize()
+        assert torch.equal(itf.loss_funcs["l_manif"].static_perms[1][0].cpu(), perms[step][1][0])
+        for k, v in loss_o.items():
+            np.testing.assert_allclose(graphed.losses[k].item(), v.item(), rtol=1e-3, err_msg="step %d %s" % (step, k))
+        for k in ("radiance", "diffuse", "specular"):
+            e = _max_rel(itf.last_out[k], out_o[k])
+            if e > 1e-3:
+                fails.append("step %d denoised %s: %.3e" % (step, k, e))
+            report.append(("step%d out %s" % (step, k), e, None, None))
+        for mn in omods:
+            for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
+                got = p.grad.clamp(-1.0, 1.0)          # the oracle's .grad is post clip_grad_value_ (interfaces.py:260-261)
+                ograds[step][(mn, k)] = q.grad.detach().clone()
+                try:
+                    e = assert_grad_close(got, q.grad, what="step %d grad %s %s" % (step, mn, k), l2=GRAD_L2, cos=GRAD_COS)
+                except AssertionError as err:
+                    fails.append(str(err))
+                    e = rel_l2(got, q.grad)
+                report.append(("step%d grad %s %s" % (step, mn, k), e, 1.0 - cosine(got, q.grad), _max_rel(got, q.grad)))
+    # Both Adam steps: parameter DELTAS against the oracle's.  Step 1 of Adam is -lr * g / (|g| + eps) = -lr * sign(g):
+    # an entry whose gradient is smaller than the gradient error may go the other way (2 * lr apart) in two correct
+    # implementations, so entries are held tightly where both steps' oracle gradients are well conditioned
+    # (> 5 % of the tensor's rms) and the whole tensor to a relative L2 that allows ~0.5 % of such sign ties.
+    lr = 1e-4
+    for mn in omods:
+        for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
+            d_h = p.detach().cpu() - p_start[mn][k]
+            d_o = q.detach() - p_start[mn][k]
+            g1, g2 = ograds[0][(mn, k)], ograds[1][(mn, k)]
+            well = (g1.abs() > 0.05 * g1.pow(2).mean().sqrt()) & (g2.abs() > 0.05 * g2.pow(2).mean().sqrt())
+            assert float(well.float().mean()) > 0.5, (mn, k)
+            worst = float((d_h - d_o)[well].abs().max())
+            e = rel_l2(d_h, d_o)
+            report.append(("delta %s %s" % (mn, k), e, None, worst / lr))
+            if worst > 0.1 * lr:
+                fails.append("parameter delta %s %s: %.3e lr apart on a well-conditioned entry" % (mn, k, worst / lr))
+            if e > 0.15:
+                fails.append("parameter delta %s %s: rel L2 %.3e" % (mn, k, e))
+            if float(d_h.abs().max()) <= 0.5 * lr:
+                fails.append("parameters of %s %s did not move" % (mn, k))
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "bench_config_parity.txt"), "w") as f:
+        for name, e, c, mx in sorted(report, key=lambda r: -r[1]):
+            f.write("%-60s relL2/err %.3e%s%s\n" % (name, e, "" if c is None else "  1-cos %.2e" % c,
+                                                    "" if mx is None else "  max-norm %.2e" % mx))
+    assert not fails, "\n".join(fails)

@@ -398,6 +398,63 @@ def test_graphed_step_equals_eager_step():
         ops.set_precision(old)
 
 
+def test_graphed_unfused_step_with_grad_sync_equals_eager():
+    """GraphedTrainStep on the UN-fused path INTEGRATION.md documents (itf.grad_sync = wd.average_gradients, torch's
+    clip_grad_value_ + Adam.step): ``p.grad`` must keep pointing at the buffers the captured backward writes, so the
+    gradient average is written back in place.  Three steps on three different batches against the eager step, bit for
+    bit, default (split-bf16) arithmetic, over a one-rank RCCL group."""
+    import torch.distributed as dist
+    from wcmc_amd import KPCN
+    from wcmc_amd import distributed as wd
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
+    from wcmc_amd.support.networks import PathNet
+    from wcmc_amd.synthetic import make_batch
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1)
+    try:
+        results = []
+        for graphed in (False, True):
+            torch.manual_seed(21)
+            kw = dict(ksize=21, depth=3, width=24)
+            models = {"dncnn": KPCN(39, **kw), "backbone_diffuse": PathNet(36, intermc=16),
+                      "backbone_specular": PathNet(36, intermc=16)}
+            for m in models.values():
+                m.to(DEV)
+            optims = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-3) for k, m in models.items()}
+            lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+                  "l_test": RelativeMSE(), "l_manif": FeatureMSE(non_local=True, rng="cpu")}
+            itf = KPCNInterface(models, optims, lf, types.SimpleNamespace(model_name="g"), use_llpm_buf=True,
+                                manif_learn=True, w_manif=0.1, train_branches=True)
+            itf.grad_sync = wd.average_gradients
+            itf.iters = 1
+            itf.to_train_mode()
+            batches = [make_batch(2, 4, 48, seed=30 + i, device=DEV) for i in range(3)]
+            if graphed:
+                step = GraphedTrainStep(itf, batches[0])
+            else:
+                def step(b):
+                    itf.preprocess(b)
+                    itf.train_batch(b)
+            torch.manual_seed(22)
+            trace = []
+            for b in batches:
+                step(b)
+                trace.append(torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()]).cpu())
+            results.append(({k: v.item() for k, v in itf.m_losses.items()}, trace))
+        (l0, t0), (l1, t1) = results
+        for k in l0:
+            np.testing.assert_allclose(l1[k], l0[k], rtol=1e-6, err_msg=k)
+        for i, (a, b) in enumerate(zip(t0, t1)):
+            assert torch.equal(a, b), "parameters differ after step %d" % (i + 1)
+        assert not torch.equal(t0[0], t0[1]) and not torch.equal(t0[1], t0[2])
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 def test_nonfinite_loss_raises_and_skips_the_update():
     """interfaces.py:254-257: a non-finite loss raises RuntimeError; with the fused optimiser the raise comes
     after the (guarded, hence skipped) update has been enqueued -- parameters must be untouched."""
@@ -426,3 +483,9 @@ def test_nonfinite_loss_raises_and_skips_the_update():
         itf.train_batch(bad)
     after = torch.cat([p.detach().reshape(-1) for p in models["dncnn"].parameters()])
     assert torch.equal(before, after)
+    # the reference never reaches optim.step() on a non-finite loss: Adam's step counter stays where it was
+    p0 = next(models["dncnn"].parameters())
+    assert float(optims["optim_dncnn"].state[p0]["step"]) == 1.0 and itf.fused_optim.flats["dncnn"].steps == 1
+    itf.preprocess(batch)
+    itf.train_batch(batch)                                   # and training can go on
+    assert float(optims["optim_dncnn"].state[p0]["step"]) == 2.0

@@ -688,3 +688,14 @@ def test_clip_adam_matches_torch():
     assert torch.equal(p, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
     o.clip_adam_(p, (g0 * 7).to(DEV), m, v, 4, 1e-3, guard=torch.ones((), device=DEV))
     assert not torch.equal(p, before[0])
+    # a NaN gradient reaches the parameter like through clip_grad_value_ (torch.clamp propagates NaN) + Adam; a
+    # min/max clamp would turn it into -clip and train on silently.  Entries 5 (vector body) and n-1 (scalar tail).
+    gn = g0.clone()
+    gn[5] = gn[n - 1] = float("nan")
+    pr.grad = gn.clone()
+    torch.nn.utils.clip_grad_value_([pr], 1.0)
+    opt.step()
+    o.clip_adam_(p, gn.to(DEV), m, v, 5, 1e-3)
+    for i in (5, n - 1):
+        assert torch.isnan(pr[i]) and torch.isnan(p[i]) and torch.isnan(m[i])
+    assert int(torch.isnan(p).sum()) == 2

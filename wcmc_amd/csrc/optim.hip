@@ -8,6 +8,13 @@
 
 namespace wcmc {
 
+// torch.clamp (what clip_grad_value_ calls) propagates NaN; fminf / fmaxf return the non-NaN operand and would turn a
+// NaN gradient into exactly -clip.  The reference lets the NaN reach the parameters, so that the next loss is
+// non-finite and training stops (interfaces.py:254-257); so does this.
+__device__ __forceinline__ float clamp_nan(float g, float clip) {
+  return g != g ? g : fminf(fmaxf(g, -clip), clip);
+}
+
 __global__ void clip_adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float clip, float step_size, float beta1,
                                  float beta2, float omb1, float omb2, float eps, float inv_bc2_sqrt,
@@ -23,7 +30,7 @@ __global__ void clip_adam_kernel(float* __restrict__ param, float* __restrict__ 
     float* mp = reinterpret_cast<float*>(&mm); float* vp = reinterpret_cast<float*>(&vv);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float gc = fminf(fmaxf(gp[e] * grad_scale, -clip), clip);
+      const float gc = clamp_nan(gp[e] * grad_scale, clip);
       gp[e] = gc;
       mp[e] = beta1 * mp[e] + omb1 * gc;
       vp[e] = beta2 * vp[e] + omb2 * gc * gc;
@@ -37,7 +44,7 @@ __global__ void clip_adam_kernel(float* __restrict__ param, float* __restrict__ 
   // tail (n not a multiple of 4)
   const int64_t t = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) {
-    const float gc = fminf(fmaxf(grad[t] * grad_scale, -clip), clip);
+    const float gc = clamp_nan(grad[t] * grad_scale, clip);
     grad[t] = gc;
     const float m1 = beta1 * m[t] + omb1 * gc;
     const float v1 = beta2 * v[t] + omb2 * gc * gc;

@@ -38,7 +38,11 @@ def shard_seed(base_seed, rank):
 
 
 def average_gradients(models, group=None):
-    """Flat per-model all-reduce + mean, written back into ``p.grad`` (the un-fused path)."""
+    """Flat per-model all-reduce + mean, written back INTO the existing ``p.grad`` tensors (the un-fused path).
+
+    In place on purpose: under ``wcmc_amd.graph.GraphedTrainStep`` ``p.grad`` are the buffers the captured
+    backward writes on every replay; rebinding ``p.grad`` to views of a fresh flat buffer would leave every later
+    step clipping and stepping on step 1's gradients."""
     world = dist.get_world_size(group)
     for name in sorted(models):
         params = [p for p in models[name].parameters() if p.grad is not None]
@@ -47,11 +51,12 @@ def average_gradients(models, group=None):
         flat = torch.cat([p.grad.reshape(-1) for p in params])
         dist.all_reduce(flat, group=group)
         flat.div_(world)
-        off = 0
+        off, views = 0, []
         for p in params:
             n = p.numel()
-            p.grad = flat[off:off + n].view(p.shape)
+            views.append(flat[off:off + n].view(p.shape))
             off += n
+        torch._foreach_copy_([p.grad for p in params], views)
 
 
 def max_over_ranks(value, device):

@@ -1,8 +1,19 @@
 """Fused ``clip_grad_value_(1.0)`` + ``Adam.step()`` (+ the cross-rank gradient average).
 
 Replaces ``support/interfaces.py:260-261`` and ``:269-271`` (optimisers built at
-``train_kpcn.py:274-277``): per model one flat parameter buffer, one flat gradient gather, one
-RCCL all-reduce when a process group is given, one ``wcmc_clip_adam`` launch.
+``train_kpcn.py:274-277``): per model one flat parameter buffer, one flat gradient bucket, one
+RCCL all-reduce per bucket when a process group is given, one ``wcmc_clip_adam`` launch.
+
+Multi-rank order of operations (``train_kpcn.py:266-269``: ``nn.DataParallel`` sums the replica
+gradients, ``interfaces.py:260-261`` clips the sum's mean afterwards): buckets are issued in the
+order the backward passes complete them (``interfaces.py:237-238``: diffuse PathNet, KPCN, specular
+PathNet) as asynchronous all-reduces (SUM) on the communicator's stream; the launch stream waits for
+bucket *i* only, so the clip + Adam of bucket *i* runs while buckets *i+1..* are still on the wire.
+The 1/world mean is folded into the kernel (``grad_scale``) -- reduce, then scale, then clip.
+
+The non-finite guard is global: every rank appends ``1 - guard`` to its first bucket, so after the
+sum every rank holds the number of ranks whose loss was not finite and either all ranks skip the
+update and raise (``interfaces.py:254-257``), or none does.
 
 The ``torch.optim.Adam`` objects the caller built stay the source of truth for hyper-parameters
 (``param_groups[0]['lr'|'betas'|'eps']`` are read every step) and keep a regular ``state``
@@ -13,6 +24,13 @@ The ``torch.optim.Adam`` objects the caller built stay the source of truth for h
 import torch
 
 from . import ops
+
+_ALIGN = 4                      # floats: every parameter starts on a 16-byte boundary of the flat buffers
+BUCKET_ORDER = ("backbone_diffuse", "dncnn", "backbone_specular")
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
 
 
 class _Flat:
@@ -27,25 +45,27 @@ class _Flat:
             raise NotImplementedError("FusedClipAdam: only plain Adam (train_kpcn.py:277)")
         self.params = params
         self.sizes = [p.numel() for p in params]
-        total = sum(self.sizes)
+        self.offsets, off = [], 0
+        for n in self.sizes:
+            self.offsets.append(off)
+            off += _round_up(n, _ALIGN)
+        self.total = off                                   # multiple of _ALIGN; the gaps hold zeros forever
         dev = params[0].device
-        self.flat = torch.empty(total, device=dev, dtype=torch.float32)
-        self.m = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.v = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        # gradient bucket: [total gradients | flag slot (number of ranks with a non-finite loss) | 3 x pad]
+        self.g = torch.zeros(self.total + _ALIGN, device=dev, dtype=torch.float32)
         self.steps = 0
-        off = 0
-        for p, n in zip(params, self.sizes):
-            self.flat[off:off + n].copy_(p.data.reshape(-1))
-            p.data = self.flat[off:off + n].view(p.shape)
-            off += n
+        self.step_t = torch.tensor(0.0)                    # shared by every optim.state[p]['step'] of this model
+        self.stepped = False                               # did the last FusedClipAdam.step() touch this model
+        for p, n, o in zip(params, self.sizes, self.offsets):
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
         self._adopt_state(optim)
 
     def _views(self, buf):
-        out, off = [], 0
-        for p, n in zip(self.params, self.sizes):
-            out.append(buf[off:off + n].view(p.shape))
-            off += n
-        return out
+        return [buf[o:o + n].view(p.shape) for p, n, o in zip(self.params, self.sizes, self.offsets)]
 
     def _adopt_state(self, optim):
         """(Re)bind optim.state to views of the flat moments, importing loaded checkpoints."""
@@ -57,11 +77,26 @@ class _Flat:
                 v.copy_(st["exp_avg_sq"])
                 self.steps = int(st["step"]) if "step" in st else self.steps
             st["exp_avg"], st["exp_avg_sq"] = m, v
-            st["step"] = torch.tensor(float(self.steps))
+            st["step"] = self.step_t
+        self.step_t.fill_(float(self.steps))
 
     def bound(self, optim):
         st = optim.state.get(self.params[0], {})
         return "exp_avg" in st and st["exp_avg"].data_ptr() == self.m.data_ptr()
+
+    def segments(self, have):
+        """Runs of consecutive parameters that have a gradient, as (first offset, end offset) of the flat buffers.
+        ``torch.optim.Adam`` skips a parameter whose ``.grad`` is None (no moment decay, no update): so do we."""
+        out, start = [], None
+        for i, h in enumerate(have):
+            if h and start is None:
+                start = self.offsets[i]
+            if not h and start is not None:
+                out.append((start, self.offsets[i]))
+                start = None
+        if start is not None:
+            out.append((start, self.total))
+        return out
 
 
 class FusedClipAdam:
@@ -70,26 +105,68 @@ class FusedClipAdam:
         self.leave_grads = True      # re-point p.grad at the clipped flat gradient like clip_grad_value_ leaves it
         self.group = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
-        self.flats = {name: _Flat(models[name], optims["optim_" + name]) for name in models}
+        order = [n for n in BUCKET_ORDER if n in models] + [n for n in models if n not in BUCKET_ORDER]
+        self.flats = {name: _Flat(models[name], optims["optim_" + name]) for name in order}
+        self.last_guard = None       # device float: 1 when every rank's losses were finite at the last step
 
     def step(self, models, optims, guard=None):
-        """guard: optional device float; 0 turns every update of this step into a no-op."""
+        """guard: optional device float of THIS rank; 0 turns the update of this step into a no-op -- on every
+        rank.  Returns the global guard (device float) or None when no guard was given."""
+        work = []
+        first = True
         for name, fl in self.flats.items():
             optim = optims["optim_" + name]
             if not fl.bound(optim):
                 fl._adopt_state(optim)
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in fl.params]
-            flat_g = torch.cat([g.reshape(-1) for g in grads])          # one gather (device copy)
-            if self.world > 1:
-                torch.distributed.all_reduce(flat_g, group=self.group)  # RCCL sum; the mean is folded below
+            have = [p.grad is not None for p in fl.params]
+            fl.stepped = any(have)
+            if not fl.stepped:                              # e.g. a frozen model: Adam.step() does nothing
+                work.append(None)
+                continue
+            gv = fl._views(fl.g)
+            idx = [i for i, h in enumerate(have) if h]
+            torch._foreach_copy_([gv[i] for i in idx], [fl.params[i].grad for i in idx])   # the gather (device copies)
+            n_msg = fl.total
+            if first and guard is not None:
+                fl.g[fl.total:fl.total + 1].copy_((1.0 - guard).reshape(1))
+                n_msg = fl.total + _ALIGN
+            if self.world > 1:                               # RCCL sum on the communicator's stream
+                work.append(torch.distributed.all_reduce(fl.g[:n_msg], group=self.group, async_op=True))
+            else:
+                work.append(None)
+            if first:
+                first_fl = fl
+            first = False
+        gguard = None
+        for (name, fl), w in zip(self.flats.items(), work):
+            if not fl.stepped:
+                continue
+            if w is not None:
+                w.wait()                                     # launch stream waits for THIS bucket only
+            if guard is not None and gguard is None:
+                gguard = (first_fl.g[first_fl.total] == 0).to(torch.float32)
+            optim = optims["optim_" + name]
             g0 = optim.param_groups[0]
             fl.steps += 1
-            ops.clip_adam_(fl.flat, flat_g, fl.m, fl.v, fl.steps, float(g0["lr"]), float(g0["betas"][0]),
-                           float(g0["betas"][1]), float(g0["eps"]), clip=self.clip, grad_scale=1.0 / self.world,
-                           guard=guard)
+            have = [p.grad is not None for p in fl.params]
+            for a, b in fl.segments(have):
+                ops.clip_adam_(fl.flat[a:b], fl.g[a:b], fl.m[a:b], fl.v[a:b], fl.steps, float(g0["lr"]),
+                               float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), clip=self.clip,
+                               grad_scale=1.0 / self.world, guard=gguard)
             # leave the (averaged, clipped) gradients behind as the reference does
             if self.leave_grads:
-                for p, gv in zip(fl.params, fl._views(flat_g)):
-                    p.grad = gv
-            for p in fl.params:
-                optim.state[p]["step"] = torch.tensor(float(fl.steps))
+                for p, gview, h in zip(fl.params, fl._views(fl.g), have):
+                    if h:
+                        p.grad = gview
+            fl.step_t.fill_(float(fl.steps))
+        self.last_guard = gguard
+        return gguard
+
+    def rollback(self):
+        """The guard turned the last step into a no-op (non-finite loss): take the step counters back, as the
+        reference never reaches ``optim.step()`` in that case (``interfaces.py:254-271``)."""
+        for fl in self.flats.values():
+            if fl.stepped:
+                fl.steps -= 1
+                fl.step_t.fill_(float(fl.steps))
+                fl.stepped = False

@@ -74,8 +74,9 @@ class KPCNInterface(BaseInterface):
         self.train_branches = train_branches
         self.disentanglement_option = disentanglement_option
         # build-specific hooks (None = the reference's behaviour)
-        self.grad_sync = None       # callable(models) -> None, averages .grad across ranks
+        self.grad_sync = None       # callable(models) -> None, averages .grad across ranks IN PLACE
         self.fused_optim = None     # wcmc_amd.optim.FusedClipAdam
+        self.last_out = None        # {'radiance','diffuse','specular'} of the last training forward (detached)
 
     def __str__(self):
         return 'KPCNInterface'
@@ -150,6 +151,7 @@ class KPCNInterface(BaseInterface):
 
         self.models['dncnn'].zero_grad()
         out = self._regress_forward(batch)
+        self.last_out = {k: v.detach() for k, v in out.items()}      # denoised patches of the step (parity tests)
 
         loss_dict = self._backward(batch, out, out_manif)
         _ops.join_all_streams(dev)
@@ -230,6 +232,7 @@ class KPCNInterface(BaseInterface):
 
     def _logging(self, loss_dict):
         """ error handling """
+        self.last_loss_dict = loss_dict
         keys = list(loss_dict)
         finite = torch.isfinite(torch.stack([loss_dict[k].reshape(()) for k in keys]))
         if self.fused_optim is not None:
@@ -262,8 +265,16 @@ class KPCNInterface(BaseInterface):
         if self.fused_optim is not None:
             keys, finite = self._pending_finite
             guard = finite.all().to(torch.float32)
-            self.fused_optim.step(self.models, self.optims, guard=guard)   # clip_grad_value_(1.0) + Adam, fused
-            self._raise_if_nonfinite(keys, finite)
+            # clip_grad_value_(1.0) + Adam, fused; the guard comes back reduced over the ranks (all skip or none)
+            gguard = self.fused_optim.step(self.models, self.optims, guard=guard)
+            flags = torch.cat([finite.to(torch.float32), gguard.reshape(1)]).tolist()          # the step's one sync
+            if flags[-1] == 0:
+                self.fused_optim.rollback()          # the reference never reaches optim.step() (interfaces.py:254-271)
+            for key, ok in zip(keys, flags[:-1]):
+                if not ok:
+                    raise RuntimeError("%s: Non-finite loss at train time." % (key))
+            if flags[-1] == 0:
+                raise RuntimeError("Non-finite loss at train time on another rank.")
             return
         for model_name in self.models:
             self.optims['optim_' + model_name].step()
