@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 import make_golden as mg                      # noqa: E402  (geometry/builders only)
-from conftest import FlipCounter              # noqa: E402
+from conftest import FlipCounter, cosine, rel_l2   # noqa: E402
 from oracle import step as ostep              # noqa: E402
 from oracle.models import KPCN as OKPCN       # noqa: E402
 from oracle.networks import PathNet as OPathNet   # noqa: E402
@@ -37,6 +37,24 @@ def assert_close(a, b, tol=1e-3, what=""):
 
 def T(a):
     return torch.from_numpy(np.asarray(a))
+
+
+_GRAD_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "grad_l2.txt")
+
+
+def grad_close(got, want, l2, what, cos=None):
+    """Flip-robust gradient parity (conftest.rel_l2): relative L2 per tensor, no fallback; the value is logged."""
+    assert tuple(got.shape) == tuple(want.shape), (what, got.shape, want.shape)
+    e = rel_l2(got, want)
+    try:
+        os.makedirs(os.path.dirname(_GRAD_LOG), exist_ok=True)
+        with open(_GRAD_LOG, "a") as f:
+            f.write("%-90s relL2 %.3e 1-cos %.2e\n" % (what, e, 1.0 - cosine(got, want)))
+    except OSError:
+        pass
+    assert e <= l2, "%s: relative L2 %.3e > %.1e" % (what, e, l2)
+    if cos is not None:
+        assert 1.0 - cosine(got, want) <= cos, "%s: 1 - cosine %.3e" % (what, 1.0 - cosine(got, want))
 
 
 def randomize_bias(m, seed):
@@ -68,7 +86,7 @@ def test_pathnet_matches_oracle(precision):
     out.backward(gout.to(DEV))
     assert_close(out, out_r, what="PathNet fwd")
     for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
-        assert_close(p.grad, q.grad, tol=fc.tol(1e-3), what="PathNet grad " + k)
+        fc.check(p.grad, q.grad, 1e-3, what="PathNet grad " + k, l2=2e-2)    # 16-channel test network: 37k units / layer
 
 
 def test_kpcn_c1_config_matches_oracle(precision):
@@ -95,7 +113,20 @@ def test_kpcn_c1_config_matches_oracle(precision):
     for k in ("radiance", "diffuse", "specular"):
         assert_close(out[k], out_r[k], tol=1e-4 if precision == "fp32" else 1e-3, what="KPCN " + k)
     for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
-        assert_close(p.grad, q.grad, tol=fc.tol(1e-4 if precision == "fp32" else 1e-3), what="KPCN grad " + k)
+        fc.check(p.grad, q.grad, 1e-4 if precision == "fp32" else 1e-3, what="KPCN grad " + k, l2=1e-2)   # 2 x 60 x 60 px
+
+
+# Golden networks are 4..8 channels wide on 20x20 images (~1,600 units per layer): ONE ReLU unit or max-pool winner
+# landing on the other side moves a gradient tensor by ~1/sqrt(units) = 2.5e-2 in relative L2 (measured values are
+# logged to gpurun_out/grad_l2.txt).  The bars below are per tensor, relative L2, no fallback.
+# Measured (MI355X, all golden cases, gpurun_out/grad_l2.txt): exact-fp32 MFMA <= 5.3e-6 whatever happens; split-bf16
+# <= 4.9e-5 when no unit flipped against the oracle forward, <= 3.4e-2 with one flipped unit, 1.07e-1 with two.
+def golden_l2(precision, flips=None):
+    if precision == "fp32":
+        return 1e-4
+    if flips is None:          # (tests that do not run the oracle forward beside the step: <= 1.7e-2 measured)
+        return 1e-1
+    return 2e-4 if flips == 0 else 8e-2 * flips
 
 
 def build_hip_models(case, d):
@@ -154,6 +185,7 @@ def test_interface_step_against_reference_golden(golden_dir, case, fused, precis
         torch.manual_seed(int(d["seed"]))          # the reference's draws: same generator, same order
         itf.preprocess(batch)
         itf.train_batch(batch)
+    nflips = fc.flips()
     if manif and tb:
         assert np.array_equal(loss_funcs["l_manif"].last_perms[0].numpy(), d["perm/specular_patch"])
     for k in d.files:
@@ -162,10 +194,7 @@ def test_interface_step_against_reference_golden(golden_dir, case, fused, precis
     for mn, m in models.items():
         for k, p in m.named_parameters():
             want = T(d["grad/%s/%s" % (mn, k)])
-            # golden networks are 4..8 channels wide: in split-bf16 mode a flipped ReLU / max-pool winner
-            # moves a PathNet gradient by >10 % (the fp32-MFMA run of this test pins it to 1e-3)
-            loose = 1e-1 if precision == "fp32" else 0.5
-            assert_close(p.grad, want, tol=fc.tol(1e-3, loose), what="post-clip grad %s %s" % (mn, k))
+            grad_close(p.grad, want, golden_l2(precision, nflips), "golden %s %s fused=%d (%d flips) post-clip grad %s %s" % (case, precision, fused, nflips, mn, k))
         for k, v in m.state_dict().items():
             g = np.abs(d["grad/%s/%s" % (mn, k)])
             want, got = d["after/%s/%s" % (mn, k)], v.cpu().numpy()
@@ -223,14 +252,13 @@ def test_ref_and_pre_interfaces_against_reference_golden(golden_dir, case, preci
     for k in d.files:
         if k.startswith("m_losses/") and k != "m_losses/m_val":
             np.testing.assert_allclose(itf.m_losses[k[len("m_losses/"):]].item(), d[k], rtol=1e-3, err_msg=k)
-    loose = 1e-1 if precision == "fp32" else 0.5      # tiny golden networks: see the main interface test
     for mn, m in models.items():
         for k, p in m.named_parameters():
             want = d["grad/%s/%s" % (mn, k)]
             if want.size == 0:
                 assert p.grad is None
                 continue
-            assert_close(p.grad, T(want), tol=loose, what="post-clip grad %s %s" % (mn, k))
+            grad_close(p.grad, T(want), golden_l2(precision), "golden %s %s post-clip grad %s %s" % (case, precision, mn, k))
         for k, v in m.state_dict().items():
             want, got = d["after/%s/%s" % (mn, k)], v.cpu().numpy()
             g = np.abs(d["grad/%s/%s" % (mn, k)])
@@ -284,10 +312,9 @@ def test_sbmc_and_lbmc_interfaces_against_reference_golden(golden_dir, case, pre
     for k in d.files:
         if k.startswith("m_losses/") and k != "m_losses/m_val":
             np.testing.assert_allclose(itf.m_losses[k[len("m_losses/"):]].item(), d[k], rtol=1e-3, err_msg=k)
-    loose = 5e-2 if precision == "fp32" else 0.3      # tiny golden networks: a ReLU flip moves a whole gradient row
     for mn, m in models.items():
         for k, p in m.named_parameters():
-            assert_close(p.grad, T(d["grad/%s/%s" % (mn, k)]), tol=loose, what="post-clip grad %s %s" % (mn, k))
+            grad_close(p.grad, T(d["grad/%s/%s" % (mn, k)]), golden_l2(precision), "golden %s %s post-clip grad %s %s" % (case, precision, mn, k))
         norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
         np.testing.assert_allclose(norm, d["gradnorm/" + mn], rtol=5e-2)
         for k, v in m.state_dict().items():
@@ -339,11 +366,16 @@ def test_full_size_step_against_oracle(precision):
     itf.preprocess(dbatch)
     itf.train_batch(dbatch)
     fc.__exit__()
+    nfl = fc.flips()
     for k, v in loss_o.items():
         np.testing.assert_allclose(itf.m_losses["m_" + k].item(), v.item(), rtol=1e-3, err_msg=k)
+    for k in ("radiance", "diffuse", "specular"):        # the denoised patches (north star: 1e-3)
+        assert_close(itf.last_out[k], out_o[k], tol=1e-3 if precision == "bf16x3" else 1e-4, what="denoised " + k)
     for mn in omods:
         for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
-            assert_close(p.grad, q.grad, tol=fc.tol(1e-3), what="grad %s %s" % (mn, k))
+            # one patch: 1/8 of the benchmark's units, so sqrt(8) x its relative L2 (tests/test_gpu_bench_config.py holds
+            # B=8 to 2e-3); measured here 3.9e-3 (exact-fp32 MFMA: fp32 against fp32 in another summation order) and 3.5e-3
+            grad_close(p.grad, q.grad, 8e-3, "full-size B=1 %s (%d flips) grad %s %s" % (precision, nfl, mn, k), cos=2e-5)
 
 
 def test_graphed_step_equals_eager_step():

@@ -148,9 +148,9 @@ def test_conv_chain_deep_matches_oracle_chain(precision):
     yr.backward(g.double())
     y.backward(g.to(DEV))
     assert_close(y, yr, tol=tol, what="chain fwd")
-    assert_close(xd.grad, xr.grad, tol=fc.tol(tol), what="chain dx")
+    fc.check(xd.grad, xr.grad, tol, what="chain dx", l2=2e-2)                # 20-channel test chain: ~10k units / layer
     for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
-        assert_close(p.grad, q.grad, tol=fc.tol(tol), what="chain grad " + k)
+        fc.check(p.grad, q.grad, tol, what="chain grad " + k, l2=2e-2)
 
 
 def test_conv_wgrad_is_bitwise_reproducible():

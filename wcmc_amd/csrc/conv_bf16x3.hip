@@ -1796,6 +1796,7 @@ template <int KS, int TM, int NW>
 static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
   constexpr size_t lds = xwr_lds_bytes<KS, TM, NW>();
   const dim3 grid((unsigned)(((q.S * q.coBlocks * q.ciBlocks + 7) / 8) * 8 * KS));
+#ifdef WCMC_DEBUG_BUILD        // `make debug` only: timing-only instances that compute WRONG results are not in the release library
   if (KS == 5 && TM == 7 && NW == 7) {
     static int ab = -1;                 // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills, 4 = clock probe)
     if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
@@ -1808,6 +1809,7 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
       return check_launch("conv2d_wgrad_bf16x3(rows ablation)");
     }
   }
+#endif
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<KS, TM, NW>),
@@ -2054,6 +2056,7 @@ static int launch_xigemm3(const XIgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3");
 }
+#ifdef WCMC_DEBUG_BUILD
 template <int DBG>
 static int launch_xigemm_dbg(const XIgemmParams& p, hipStream_t stream) {
   const size_t lds = (size_t)2 * (2 * XBM * XROW + 64 + 2 * 7 * 16 * XROW + 64) * sizeof(u16);
@@ -2063,8 +2066,10 @@ static int launch_xigemm_dbg(const XIgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<7, false, true, DBG>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(ablation)");
 }
+#endif
 template <int NT, bool PADDED>
 static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
+#ifdef WCMC_DEBUG_BUILD
   if (NT == 7 && !PADDED) {       // WCMC_DEBUG_ABLATE=<mask>: timing-only ablation builds of the 5x5 forward GEMM
     static int ab = -1;
     if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
@@ -2083,6 +2088,7 @@ static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
       default: break;
     }
   }
+#endif
   if (g_xigemm_dbuf < 0) {
     const char* e = getenv("WCMC_IGEMM_DBUF");
     g_xigemm_dbuf = (e && e[0] == '0') ? 0 : 1;
@@ -2116,6 +2122,7 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   const size_t lds_main = halo + nb * bstage;
   const size_t lds = lds_main > lds_out ? lds_main : lds_out;
   WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
+#ifdef WCMC_DEBUG_BUILD
   if (NT == 7) {
     static int ab = -1;
     if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
@@ -2127,6 +2134,7 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
       return check_launch("conv2d_igemm_bf16x3(halo, stamps)");
     }
   }
+#endif
   // ... and for any launch whose 16x16 tiling has fewer workgroups than the chip has CUs (the deepest U-Net level: 32 tiles
   // x 4 cout blocks), where half-size tiles simply fill the machine (<= 4 cout tiles: one wave per weight row group pair)
   const int64_t blocks16 = (int64_t)p.N * p.tilesX * p.tilesY * ((p.Np / 16 + NT - 1) / NT);
@@ -2203,12 +2211,14 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
                "conv2d_igemm_bf16x3: operand larger than 2 GiB (split the batch)");
   p.x_bytes = (unsigned)xb; p.wp_bytes = (unsigned)wb;
   p.colsum = colsum_partial;
+#ifdef WCMC_DEBUG_BUILD
   {  // timing-only experiments (guide section 7: zero-record descriptors drop one operand's traffic)
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("WCMC_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
     if (dbg & 1) p.x_bytes = 0;
     if (dbg & 2) p.wp_bytes = 0;
   }
+#endif
   hipStream_t st = (hipStream_t)stream;
   p.y_bytes = 0; p.m_bytes = 0;
   p.wp2 = nullptr; p.bias2 = nullptr; p.y2 = nullptr; p.y2sn = p.y2sh = p.y2sw = 0; p.Cout2 = 0; p.act2 = 0; p.Kt2 = 0;
