@@ -383,6 +383,35 @@ def test_kernel_apply_fwd_bwd(shape):
     assert_close(dd.grad, dr.grad, what="kernel_apply d_data")
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 37, 45), (1, 3, 5, 7), (3, 2, 16, 16), (1, 1, 92, 92), (2, 3, 21, 130),
+                                   (70, 3, 92, 20)])       # (the last one: blocks that own rows of two strips / two images)
+def test_kernel_apply_strip_equals_tile_kernel(shape, monkeypatch):
+    """The persistent strip kernel (LDS-DMA ring per wave; the one the KPCN path runs: k = 21, C <= 3, no d_data) against
+    the tile kernel it replaced (WCMC_KA_TILE=1), forward (result + log-sum-exp) and backward (d_logits), bit for bit:
+    same lane / tap assignment, same arithmetic, same reduction order.  Shapes: ragged strips (w % 16 != 0), an image
+    smaller than a strip, more strips than rows, several images per block."""
+    o = ops()
+    n, c, h, w = shape
+    data = (gen(n, c, h, w, seed=35) + 0.5).to(DEV)
+    logits = o.as_nhwc((gen(n, 441, h, w, seed=36, scale=3.0)).to(DEV))
+    g = gen(n, c, h, w, seed=37).to(DEV)
+    res = []
+    for tile in ("1", "0"):
+        monkeypatch.setenv("WCMC_KA_TILE", tile)
+        ld = o.nhwc_empty(n, 441, h, w, DEV)
+        ld.copy_(logits)
+        ld.requires_grad_(True)
+        assert o.is_nhwc_view(ld)
+        out = o._KernelApply.apply(data, ld)
+        out.backward(g)
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), ld.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]), "forward differs"
+    assert torch.equal(res[0][1], res[1][1]), "d_logits differs"
+    ref = om.kernel_apply(data.double().cpu(), logits.double().cpu())
+    assert_close(res[1][0], ref, what="strip kernel fwd vs oracle")
+
+
 def test_chain_kernel_apply_node_equals_the_separate_ops():
     """One half of sbmc.KPCN.forward as one autograd node (the apply's backward writes d_logits straight into the
     chain's split gradient, wcmc_kernel_apply_bwd_split) == conv_chain followed by kernel_apply, bit for bit."""
