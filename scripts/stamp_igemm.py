@@ -1,5 +1,5 @@
 """Phase shares of the split-bf16 implicit-GEMM main loop from in-kernel stamps (WCMC_DEBUG_ABLATE=64).
-   WCMC_DEBUG_ABLATE=64 python3 scripts/stamp_igemm.py"""
+   make -C wcmc_amd/csrc debug; WCMC_DEBUG_LIB=1 WCMC_DEBUG_ABLATE=64 python3 scripts/stamp_igemm.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,15 +16,15 @@ for _ in range(3):
 torch.cuda.synchronize()
 ho = h - ks + 1
 halo = os.environ.get("WCMC_IGEMM_HALO", "1") != "0"
-if halo:
-    tiles, nw, nstage = n * ((ho + 15) // 16) ** 2, 8, ((ks * ks * 56 + 31) // 32) + ((ks * ks * 48 + 31) // 32)
+if halo:      # the shipped 8x16 tiling: 4 waves, 32-channel slabs (32 + 32 + 40 of the 104 padded channels)
+    tiles, nw, nstage = n * ((ho + 7) // 8) * ((ho + 15) // 16), 4, 2 * ((ks * ks * 32 + 31) // 32) + ((ks * ks * 40 + 31) // 32)
 else:
     tiles, nw, nstage = (n * ho * ho + 127) // 128, 4, (ks * ks * 104 + 31) // 32
 st = part.cpu().numpy().view(np.uint64)[: tiles * nw * 8].reshape(tiles, nw, 8).astype(np.float64)
 names = ["load issue", "frag reads+wait", "mfma issue", "vmcnt+lds store", "barrier", "slab boundary"]
 if halo:
-    names = ["vmcnt + barrier", "halo DMA issue (slab ends)", "mfma + fragment reads (drained)", "stage tail",
-             "slab boundary (halo wait, barrier, re-read)", "weight DMA issue"]
+    names = ["stage barrier", "halo DMA issue (slab ends)", "mfma + fragment reads (drained)", "stage tail (+ slab boundaries)",
+             "wait for own weight DMA (vmcnt)", "weight DMA issue outside the MFMA stream"]
 NB = 6 if halo else 5
 tot = st[:, :, :NB].sum(axis=2)
 print("tiles", tiles, "stages/tile", nstage)

@@ -739,19 +739,21 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     const int dvq = (lane & 3) ^ ((drow >> 1) & 3);
     dbase[q] = (q < ngroups && n0 + drow < p.Np) ? (unsigned)(((n0 + drow) * 2 * p.Kt + dvq * 8) * 2) : XOOB;
   }
-  auto dma_b = [&](int g, int buf) {
-    const unsigned kill = g < nstages ? 0u : XOOB;
-#pragma unroll
-    for (int q = 0; q < NGMAX; ++q) {
-      if (q < ngroups) {
-        const unsigned db = dbase[q];
-        const unsigned off = (db + (unsigned)(g * XKC * 2)) | kill;
-        const unsigned off2 = db >= XOOB ? XOOB : (off + (unsigned)(p.Kt * 2)) | kill;
-        u16* d = bsm + buf * B_ELEMS + 16 * (wave + q * NWV) * XROW;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, off2, 0, 0, 0);
-      }
+  // one row group (hi + lo plane: two wave instructions) of stage g's weights
+  auto dma_b_group = [&](int g, int buf, int q) {
+    if (q < ngroups) {
+      const unsigned kill = g < nstages ? 0u : XOOB;
+      const unsigned db = dbase[q];
+      const unsigned off = (db + (unsigned)(g * XKC * 2)) | kill;
+      const unsigned off2 = db >= XOOB ? XOOB : (off + (unsigned)(p.Kt * 2)) | kill;
+      u16* d = bsm + buf * B_ELEMS + 16 * (wave + q * NWV) * XROW;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, off2, 0, 0, 0);
     }
+  };
+  auto dma_b = [&](int g, int buf) {
+#pragma unroll
+    for (int q = 0; q < NGMAX; ++q) dma_b_group(g, buf, q);
   };
 
   f32x4 acc[NT][2];
@@ -823,6 +825,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     // this wave's share of stage g+1 has landed; the NB-2 stages behind it (two DMA instructions each) stay in flight
     if (NGMAX == 1 || ngroups < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NB - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 2)) : "memory");
+    stamp(4);                                    // (stamp builds: slot 4 = the wait for this wave's own weight DMA)
     pw_barrier();                                // ... everyone's; and everyone has read stage g's fragments
     stamp(0);
     dma_b(g + NB, bcur);
@@ -870,7 +873,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
       __syncthreads();
       read_a();
     }
-    stamp(last_of_slab ? 4 : 3);             // 3: tail of an ordinary stage, 4: slab boundary (halo wait + barrier + re-read)
+    stamp(3);                                // tail of the stage (slab boundaries included: halo wait + barrier + re-read)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (zero) weight stages past the end have landed:
   __syncthreads();                                     // LDS is free for the epilogue staging
@@ -2123,15 +2126,19 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   const size_t lds = lds_main > lds_out ? lds_main : lds_out;
   WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
 #ifdef WCMC_DEBUG_BUILD
-  if (NT == 7) {
+  if (NT == 7 && p.PXS == 160 && p.ks == 5) {
     static int ab = -1;
     if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
-    if (ab == 64) {      // stamp build (scripts/stamp_igemm.py)
-      const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<7, TH, TW, 64, 3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL((conv_halo_bf16x3_kernel<7, TH, TW, 64, 3>), grid, dim3(512), halo + 3 * bstage, stream, p);
-      return check_launch("conv2d_igemm_bf16x3(halo, stamps)");
+    if (ab == 64) {      // stamp build of the shipped 8x16 tiling (scripts/stamp_igemm.py)
+      constexpr int TH8 = 8;
+      XIgemmParams q = p;
+      q.tilesY = (p.Ho + TH8 - 1) / TH8;
+      const size_t halo8 = (size_t)(((TH8 + p.ks - 1) * (TW + p.ks - 1) * p.PXS + 127) & ~127);
+      const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)((q.Np / 16 + NT - 1) / NT));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<7, TH8, TW, 64, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      hipLaunchKernelGGL((conv_halo_bf16x3_kernel<7, TH8, TW, 64, 2>), grid, dim3(TH8 * TW * 2), halo8 + 2 * bstage, stream, q);
+      return check_launch("conv2d_igemm_bf16x3(halo 8x16, stamps)");
     }
   }
 #endif
