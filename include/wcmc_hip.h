@@ -179,11 +179,15 @@ size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout);
 int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, int Cout, float* db, void* stream);
 size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks);
 /* phase: 0 = everything; 1 = the split-K GEMM into the workspace only; 2 = the slab reduction and
- * bias gradient only (1 then 2 == 0; lets a profiler bracket the GEMM launch alone). */
+ * bias gradient only (1 then 2 == 0; lets a profiler bracket the GEMM launch alone).
+ * dy_colsum_partial (optional): the per-tile column sums of dy that the launch which PRODUCED dy left
+ * (wcmc_conv2d_igemm_bf16x3 / wcmc_conv1x1_pair_bf16x3 colsum output, wcmc_conv2d_igemm_colsum_elems floats): the bias
+ * gradient db is then finished from them by extra blocks of the slab-reduction launch -- same sums, same order as
+ * wcmc_colsum_finish, bit for bit -- instead of a column-sum pass over dy plus a finish launch. */
 int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W, int Cin,
-                             const void* dy_split, int Cout, int ks, int pad,
-                             float* dw_oihw, float* db, void* workspace, size_t workspace_bytes,
-                             int phase, void* stream);
+                             const void* dy_split, int Cout, int ks, int pad, float* dw, float* db,
+                             void* workspace, size_t workspace_bytes, int phase, const float* dy_colsum_partial,
+                             void* stream);
 
 /* dx = dy * act'(y) from the post-activation value y (NHWC views of equal geometry). */
 int wcmc_act_backward(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw,

@@ -521,3 +521,81 @@ def test_nonfinite_loss_raises_and_skips_the_update():
     itf.preprocess(batch)
     itf.train_batch(batch)                                   # and training can go on
     assert float(optims["optim_dncnn"].state[p0]["step"]) == 2.0
+
+
+# ---------------------------------------------------------------------------------------------- A/B switch matrix
+# Every behaviour switch of the library against the default configuration on one full KPCN-Manifold step (default-width
+# PathNets so that the persistent 1x1 kernel and its fused pairs engage; 100-wide KPCN so that the 8x16 halo tiling and the
+# filter-row weight gradient engage).  "exact": the alternative path must reproduce the default bit for bit (same MFMA
+# sequence / same order of additions per output); "close": another K order, split-K order or grouping of the bias sums,
+# held to 5e-4 relative L2 (measured: <= 1.3e-4, on gradients at the far end of the backward pass).
+_SWITCHES = [
+    ("attr", "FUSE_BIAS_GRAD", False, "exact"),          # bias gradient finished by wcmc_colsum_finish launches
+    ("attr", "USE_GATE_MASK", False, "close"),           # gate from the activation, not the 1-bit mask (and no fused 1x1
+                                                         # dgrad pair: the bias sums group per tile, not per workgroup)
+    ("attr", "FUSE_CHAIN_GLUE", False, "exact"),         # separate spp-mean / concat / upsample nodes
+    ("attr", "FUSE_KERNEL_APPLY", True, "exact"),        # chain + kernel-apply as one node (split d_logits; tile kernel)
+    ("attr", "USE_BRANCH_STREAM", False, "exact"),       # specular half on the main stream
+    ("attr", "USE_SIDE_STREAM", False, "exact"),         # weight gradients on the main stream
+    ("env", "WCMC_IGEMM_PW", "0", "close"),              # tiled kernel for the 1x1 layers (bias sums group per tile)
+    ("env", "WCMC_PW_TAIL", "0", "exact"),               # no fused 1x1 layer pairs
+    ("env", "WCMC_KA_TILE", "1", "exact"),               # tile kernel-apply instead of the strip kernel
+    ("env", "WCMC_HALO_TH8_5X5", "0", "close"),          # 16x16 tiles, 56/48-channel slabs (another K order)
+    ("env", "WCMC_HALO_NB", "2", "exact"),               # two weight stages in the 16x16 halo igemm
+    ("env", "WCMC_IGEMM_DBUF", "0", "exact"),            # single-buffered streaming igemm
+    ("env", "WCMC_IGEMM_HALO", "0", "close"),            # streaming igemm for the 3x3 / 5x5 layers (another K order)
+    ("env", "WCMC_WGRAD_ROWS", "0", "close"),            # one-tap weight-gradient kernel (another split-K order)
+]
+
+
+def _switch_step():
+    from wcmc_amd import KPCN
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
+    from wcmc_amd.support.networks import PathNet
+    from wcmc_amd.synthetic import make_batch
+    torch.manual_seed(5)
+    models = {"dncnn": KPCN(39, ksize=21, depth=3, width=100), "backbone_diffuse": PathNet(36), "backbone_specular": PathNet(36)}
+    for m in models.values():
+        randomize_bias(m, 6)
+        m.to(DEV)
+    optims = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-3) for k, m in models.items()}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+          "l_test": RelativeMSE(), "l_manif": FeatureMSE(non_local=True, rng="cpu")}
+    itf = KPCNInterface(models, optims, lf, types.SimpleNamespace(model_name="s"), use_llpm_buf=True, manif_learn=True,
+                        w_manif=0.1, train_branches=True)
+    itf.iters = 1
+    itf.to_train_mode()
+    batch = make_batch(2, 4, 64, seed=50, device=DEV)
+    torch.manual_seed(51)
+    loss = itf._forward_backward(batch)
+    torch.cuda.synchronize()
+    out = {"loss/" + k: v.detach().clone().reshape(1) for k, v in loss.items()}
+    out.update({"out/" + k: v.clone() for k, v in itf.last_out.items()})
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            out["grad/%s/%s" % (mn, k)] = p.grad.detach().clone()
+    return out
+
+
+@pytest.fixture(scope="module")
+def switch_baseline():
+    return _switch_step()
+
+
+@pytest.mark.parametrize("kind,name,value,how", _SWITCHES, ids=[s[1] for s in _SWITCHES])
+def test_switch_matrix_against_default_step(switch_baseline, kind, name, value, how, monkeypatch):
+    from wcmc_amd import ops
+    if kind == "attr":
+        monkeypatch.setattr(ops, name, value)
+    else:
+        monkeypatch.setenv(name, value)
+    got = _switch_step()
+    assert got.keys() == switch_baseline.keys()
+    for k, want in switch_baseline.items():
+        if how == "exact":
+            assert torch.equal(got[k], want), "%s=%s changes %s (max |diff| %.3e)" % (
+                name, value, k, (got[k] - want).abs().max().item())
+        else:
+            e = rel_l2(got[k], want)
+            assert e <= 5e-4, "%s=%s: %s relative L2 %.3e" % (name, value, k, e)

@@ -229,15 +229,18 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __res
   wp[((int64_t)n * 2 + 1) * Kt + k] = lo;
 }
 
+static int x_env_on(const char* name) {           // switch is ON unless the variable starts with '0'
+  const char* e = getenv(name);
+  return (e && e[0] == '0') ? 0 : 1;
+}
 struct XKPlan { bool halo; int Kp, CS, nslabs, Ks, Kt, PXS, CSl, Ksl; };     // CSl / Ksl: the last (narrower) slab
 static XKPlan x_plan_k(int kchan, int ks) {
-  static int enable = -1;
-  if (enable < 0) { const char* e = getenv("WCMC_IGEMM_HALO"); enable = (e && e[0] == '0') ? 0 : 1; }
+  // (A/B switches are read per call -- a getenv per launch -- so that tests/test_gpu_models.py can flip them in one process)
+  const int enable = x_env_on("WCMC_IGEMM_HALO");
   XKPlan q;
   q.Kp = round_up(kchan, 8);
   q.halo = enable && ks >= 3 && ks <= 5 && q.Kp >= 32;
-  static int th8 = -1;                // WCMC_HALO_TH8_5X5=0: A/B switch back to 16x16 tiles with 56/48-channel slabs
-  if (th8 < 0) { const char* e = getenv("WCMC_HALO_TH8_5X5"); th8 = (e && e[0] == '0') ? 0 : 1; }
+  const int th8 = x_env_on("WCMC_HALO_TH8_5X5");   // =0: A/B switch back to 16x16 tiles with 56/48-channel slabs
   if (q.halo && th8 && ks == 5 && (q.Kp % 32 == 0 || q.Kp % 32 == 8)) {
     // slabs of 32 channels, the last one 32 or 40: halo pixel stride 160 B (10 units = 2 mod 4), 38 KB for a 12x20 halo
     q.nslabs = q.Kp / 32;
@@ -1879,8 +1882,7 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
   pl.ciBlocks = (ciT + 3) / 4;
   const int64_t M = (int64_t)N * Ho * Wo;
   const int taps = ks * ks;
-  static int rows_on = -1;            // WCMC_WGRAD_ROWS=0: A/B switch back to the one-tap-per-block kernel
-  if (rows_on < 0) { const char* e = getenv("WCMC_WGRAD_ROWS"); rows_on = (e && e[0] == '0') ? 0 : 1; }
+  const int rows_on = x_env_on("WCMC_WGRAD_ROWS");   // =0: A/B switch back to the one-tap-per-block kernel
   // filter-row kernel: (KS, TM, NW) instances below; TM / NW must divide the tile counts
   pl.R = N * Ho; pl.rps = 0; pl.rows = 0; pl.rTM = pl.rNW = 0;
   if (rows_on && (ks == 5 || ks == 3) && (int64_t)N * Ho >= 64) {
@@ -2092,10 +2094,7 @@ static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
     }
   }
 #endif
-  if (g_xigemm_dbuf < 0) {
-    const char* e = getenv("WCMC_IGEMM_DBUF");
-    g_xigemm_dbuf = (e && e[0] == '0') ? 0 : 1;
-  }
+  g_xigemm_dbuf = x_env_on("WCMC_IGEMM_DBUF");
   return g_xigemm_dbuf ? launch_xigemm3<NT, PADDED, true>(p, stream) : launch_xigemm3<NT, PADDED, false>(p, stream);
 }
 template <int NT, int NB>
@@ -2119,8 +2118,8 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   const size_t lds_out = p.ys ? (size_t)256 * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)32 * NT * 16 * sizeof(float)
                               : (size_t)256 * (NT * 16 + 4) * sizeof(float);
   // three weight stages (two stages of DMA latency cover) where LDS allows, else two
-  static int nbmax = -1;
-  if (nbmax < 0) { const char* e = getenv("WCMC_HALO_NB"); nbmax = (e && e[0] == '2') ? 2 : 3; }
+  const char* nbe = getenv("WCMC_HALO_NB");
+  const int nbmax = (nbe && nbe[0] == '2') ? 2 : 3;
   const int nb = (nbmax >= 3 && halo + 3 * bstage <= 160 * 1024) ? 3 : 2;
   const size_t lds_main = halo + nb * bstage;
   const size_t lds = lds_main > lds_out ? lds_main : lds_out;
@@ -2334,7 +2333,7 @@ static int launch_xwgrad(const XWgradParams& p, hipStream_t stream) {
 
 extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W, int Cin, const void* dy_split,
                                         int Cout, int ks, int pad, float* dw, float* db, void* workspace,
-                                        size_t workspace_bytes, int phase, void* stream) {
+                                        size_t workspace_bytes, int phase, const float* dy_colsum_partial, void* stream) {
   WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ks > 0 && pad >= 0 && dw && workspace &&
                    x_split && dy_split,
                WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: bad argument");
@@ -2374,10 +2373,16 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
     rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
   }
   if (rc || phase == 1) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + WR_CI - 1) / WR_CI), (unsigned)Cout), dim3(256),
-                     (size_t)WR_CI * (ks * ks + 1) * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq);
+  // the slab reduction; with the column sums of dy at hand its launch also finishes the bias gradient (extra grid rows)
+  const bool fuse_db = db && dy_colsum_partial;
+  const int cs_rows = fuse_db ? (Cout + 63) / 64 : 0;
+  size_t red_lds = (size_t)WR_CI * (ks * ks + 1) * sizeof(float);
+  if (fuse_db && red_lds < (size_t)16 * 64 * sizeof(float)) red_lds = (size_t)16 * 64 * sizeof(float);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + WR_CI - 1) / WR_CI), (unsigned)(Cout + cs_rows)), dim3(256),
+                     red_lds, st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq, fuse_db ? dy_colsum_partial : nullptr,
+                     x_colsum_rows(N, Ho, Wo), round_up(Cout, 16), db);
   rc = check_launch("conv2d_wgrad_bf16x3_reduce");
-  if (rc || !db) return rc;
+  if (rc || !db || fuse_db) return rc;
   float* partial = (float*)workspace + pl.slab_elems;
   WCMC_REQUIRE(p.Cpo / 8 <= 256, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: Cout > 2048 unsupported");
   hipLaunchKernelGGL(colsum_split_kernel, dim3((unsigned)pl.G), dim3(256), (size_t)256 * 8 * sizeof(float), st, p.dy,

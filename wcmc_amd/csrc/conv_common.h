@@ -9,9 +9,45 @@ namespace wcmc {
 // slab reads are coalesced along ci (128 B per half wave), the OIHW write is contiguous ((ci, tap)
 // row-major) after an LDS transpose.  The s-loop runs in a fixed order -> bitwise reproducible.
 constexpr int WR_CI = 32;
+//
+// Rows blockIdx.y >= Cout of the grid (present when cs_partial is given; blockIdx.x == 0 only) finish the BIAS gradient
+// from the per-tile column sums of dy that the launch producing dy left: 64 channels per block, the 16 row groups of
+// colsum_final_strided_kernel (four per quarter of the block), same order of additions -- the bias gradient costs no
+// launch of its own.
 static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                                  int S, int taps, int Cout, int Cin, int Np, int Cq) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [WR_CI][taps + 1]
+                                                                  int S, int taps, int Cout, int Cin, int Np, int Cq,
+                                                                  const float* __restrict__ cs_partial, int cs_gmax,
+                                                                  int cs_ld, float* __restrict__ db) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [WR_CI][taps + 1] (>= 16 x 64 floats with cs_partial)
+  if ((int)blockIdx.y >= Cout) {
+    if (blockIdx.x != 0) return;
+    float (*red)[64] = reinterpret_cast<float (*)[64]>(smem);
+    const int cl = threadIdx.x & 63, q4 = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.y - Cout) * 64 + cl;
+    const int G = min(cs_gmax, reinterpret_cast<const int*>(cs_partial)[(int64_t)cs_gmax * cs_ld]);
+    for (int gg = q4; gg < 16; gg += 4) {
+      float acc = 0.f;
+      if (c < Cout) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int g = gg;
+        for (; g + 7 * 16 < G; g += 8 * 16) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] += cs_partial[(int64_t)(g + u * 16) * cs_ld + c];
+        }
+        for (; g < G; g += 16) a[0] += cs_partial[(int64_t)g * cs_ld + c];
+        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      }
+      red[gg][cl] = acc;
+    }
+    __syncthreads();
+    if (q4 == 0 && c < Cout) {
+      float t = red[0][cl];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) t += red[q][cl];
+      db[c] = t;
+    }
+    return;
+  }
   const int co = blockIdx.y, ci0 = blockIdx.x * WR_CI;
   const int LD = taps + 1;
   const int64_t sstride = (int64_t)taps * Np * Cq;
