@@ -240,6 +240,19 @@ int wcmc_recombine_bwd(const float* grad_out,
                        const float* r_specular, int64_t ssn, int64_t ssc, int64_t ssh, int64_t ssw,
                        float* d_diffuse, float* d_specular, int N, int C, int H, int W, void* stream);
 
+/* Image losses on the (N,C,H,W) outputs: torch.nn.L1Loss (train_kpcn.py:299-304; applied at
+ * support/interfaces.py:213-249) and RelativeMSE (support/losses.py:245-264: 0.5 * mean((x - ref)^2 / (ref^2 + eps))) of
+ * one pair in one pass; either output may be null.  Both tensors with arbitrary element strides.  Deterministic
+ * (fixed-order two-level sum).  wcmc_l1_mean_bwd: dx = grad_loss[0] * sign(x - ref) / (N*C*H*W), contiguous (N,C,H,W). */
+size_t wcmc_image_loss_workspace_bytes(void);
+int wcmc_image_loss_fwd(const float* x, int64_t xsn, int64_t xsc, int64_t xsh, int64_t xsw,
+                        const float* ref, int64_t rsn, int64_t rsc, int64_t rsh, int64_t rsw, float eps,
+                        float* l1_mean, float* relative_mse, void* workspace, size_t workspace_bytes,
+                        int N, int C, int H, int W, void* stream);
+int wcmc_l1_mean_bwd(const float* x, int64_t xsn, int64_t xsc, int64_t xsh, int64_t xsw,
+                     const float* ref, int64_t rsn, int64_t rsc, int64_t rsh, int64_t rsw,
+                     const float* grad_loss, float* dx, int N, int C, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- U-Net glue
  * F.max_pool2d(x,2,2) / F.interpolate(x, scale_factor=2, 'bilinear',
  * align_corners=False) inside sbmc.modules.Autoencoder (support/networks.py:20-22). */

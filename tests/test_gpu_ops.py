@@ -554,6 +554,43 @@ def test_sample_features_cat(geom):
     assert torch.equal(fd.grad.cpu(), fr.grad.float()) and torch.equal(pd.grad.cpu(), pr.grad.float())
 
 
+@pytest.mark.parametrize("shape", [(8, 3, 92, 92), (2, 3, 20, 20), (1, 1, 5, 7), (3, 4, 33, 17)])
+def test_fused_image_losses_match_torch(shape):
+    """L1Loss / RelativeMSE of the (N,C,H,W) outputs as HIP ops (wcmc_image_loss_fwd, wcmc_l1_mean_bwd)
+    against torch on strided views (crops of larger tensors, like the interface hands them over), forward and backward;
+    repeated launches agree bit for bit (fixed-order reduction)."""
+    o = ops()
+    n, c, h, w = shape
+    xb = (gen(n, c, h + 4, w + 6, seed=70) * 2).to(DEV)
+    rb = (gen(n, c, h + 8, w + 8, seed=71) * 2).abs().to(DEV)
+    rb[0, 0, 4, 4] = 0.0
+    x = xb[:, :, 2:2 + h, 3:3 + w].detach().requires_grad_(True)
+    ref = rb[:, :, 4:4 + h, 4:4 + w]
+    with torch.no_grad():
+        x.data[0, 0, 0, 0] = ref[0, 0, 0, 0]                     # an exact tie: sign(0) = 0 in the backward
+    xr = x.detach().double().cpu().requires_grad_(True)
+    rr = ref.double().cpu()
+    lr = torch.nn.L1Loss()(xr, rr)
+    (lr * 1.7).backward()
+    l = o.l1_mean(x, ref)
+    (l * 1.7).backward()
+    assert_close(l, lr, tol=1e-6, what="l1 mean")
+    assert_close(x.grad, xr.grad, tol=1e-6, what="l1 backward")
+    assert x.grad[0, 0, 0, 0] == 0
+    l1, rel = o.image_metrics(x, ref, 1e-2)
+    want_rel = 0.5 * torch.mean((xr.detach() - rr) ** 2 / (rr ** 2 + 1e-2))
+    assert_close(l1, lr, tol=1e-6, what="metrics l1")
+    assert_close(rel, want_rel, tol=1e-6, what="relative mse")
+    l1b, relb = o.image_metrics(x, ref, 1e-2)
+    assert torch.equal(l1, l1b) and torch.equal(rel, relb) and torch.equal(l1, l.detach())
+    from wcmc_amd.support.losses import RelativeMSE
+    with torch.no_grad():
+        assert torch.equal(RelativeMSE()(x, ref), rel)           # the module takes the same kernel when no gradient is needed
+    x2 = x.detach().clone().requires_grad_(True)
+    RelativeMSE()(x2, ref).backward()                            # ... and torch's expression when one is
+    assert x2.grad is not None and torch.isfinite(x2.grad).all()
+
+
 def test_image_losses_against_reference_goldens(golden_dir):
     """support/losses.py:245-320 on device tensors (RelativeMSE, SMAPE, TonemappedMSE, TonemappedRelativeMSE)."""
     from wcmc_amd.support import losses as pl

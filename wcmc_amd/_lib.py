@@ -49,6 +49,9 @@ SIGNATURES = {
                                   P, L, L, L, P, I, I, I, I, I, P]),
     "wcmc_kernel_apply_bwd_split": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P, P, I, I, I, I, I, P]),
     "wcmc_recombine_fwd": (I, [P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P, I, I, I, I, P]),
+    "wcmc_image_loss_workspace_bytes": (Z, []),
+    "wcmc_image_loss_fwd": (I, [P, L, L, L, L, P, L, L, L, L, F, P, P, P, Z, I, I, I, I, P]),
+    "wcmc_l1_mean_bwd": (I, [P, L, L, L, L, P, L, L, L, L, P, P, I, I, I, I, P]),
     "wcmc_recombine_bwd": (I, [P, P, L, L, L, L, P, L, L, L, L, P, P, I, I, I, I, P]),
     "wcmc_maxpool2_fwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),
     "wcmc_maxpool2_bwd": (I, [P, L, L, L, P, L, L, L, P, L, L, L, I, I, I, I, P]),

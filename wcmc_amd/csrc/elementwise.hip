@@ -291,6 +291,59 @@ __global__ void recombine_bwd_kernel(const float* __restrict__ g, const float* _
   }
 }
 
+
+// ------------------------------------------------------------------ image losses
+// L1Loss (mean |x - ref|; train_kpcn.py:299-304, applied at interfaces.py:213-249) and RelativeMSE
+// (0.5 * mean((x - ref)^2 / (ref^2 + eps)), losses.py:245-264) of one (N,C,H,W) pair in ONE pass: both sums are reduced
+// together -- a block sums its grid-strided share in a fixed order (wave xor-shuffles, then the waves in order), the
+// one-block finish launch adds the per-block partials in order -> bitwise reproducible, no atomics.
+constexpr int IL_BLOCKS = 64;
+__global__ __launch_bounds__(256) void image_loss_partial_kernel(const float* __restrict__ x, S4 sx, const float* __restrict__ r,
+                                                                 S4 sr, float eps, float* __restrict__ partial, int C, int H,
+                                                                 int W, int64_t total) {
+  float a = 0.f, b = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W); int64_t t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C); const int n = (int)(t / C);
+    const float v = x[n * sx.n + c * sx.c + y * sx.h + xx * sx.w];
+    const float q = r[n * sr.n + c * sr.c + y * sr.h + xx * sr.w];
+    const float d = v - q;
+    a += fabsf(d);
+    b += (d * d) / (q * q + eps);
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x + 0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    partial[2 * blockIdx.x + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+  }
+}
+__global__ __launch_bounds__(64) void image_loss_finish_kernel(const float* __restrict__ partial, int nblocks, float inv_total,
+                                                               float* __restrict__ l1, float* __restrict__ relmse) {
+  if (threadIdx.x != 0) return;
+  float a = 0.f, b = 0.f;
+  for (int g = 0; g < nblocks; ++g) { a += partial[2 * g]; b += partial[2 * g + 1]; }
+  if (l1) l1[0] = a * inv_total;
+  if (relmse) relmse[0] = 0.5f * (b * inv_total);
+}
+// d L1 / dx = g * sign(x - ref) / total  (sign(0) = 0, as torch's L1Loss backward)
+__global__ void l1_mean_bwd_kernel(const float* __restrict__ x, S4 sx, const float* __restrict__ r, S4 sr,
+                                   const float* __restrict__ g, float inv_total, float* __restrict__ dx, int C, int H, int W,
+                                   int64_t total) {
+  const float gs = g[0] * inv_total;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W); int64_t t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C); const int n = (int)(t / C);
+    const float d = x[n * sx.n + c * sx.c + y * sx.h + xx * sx.w] - r[n * sr.n + c * sr.c + y * sr.h + xx * sr.w];
+    dx[i] = d > 0.f ? gs : (d < 0.f ? -gs : (d == 0.f ? 0.f : d * gs));      // (NaN stays NaN)
+  }
+}
+
 static unsigned grid_for(int64_t total) {
   const int64_t g = ceil_div64(total, 256);
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -482,6 +535,35 @@ extern "C" int wcmc_recombine_fwd(const float* albedo, int64_t asn, int64_t asc,
                      S4{asn, asc, ash, asw}, r_diffuse, S4{dsn, dsc, dsh, dsw}, r_specular, S4{ssn, ssc, ssh, ssw}, out,
                      C, H, W, total);
   return check_launch("recombine_fwd");
+}
+
+extern "C" size_t wcmc_image_loss_workspace_bytes(void) { return (size_t)2 * IL_BLOCKS * sizeof(float); }
+
+extern "C" int wcmc_image_loss_fwd(const float* x, int64_t xsn, int64_t xsc, int64_t xsh, int64_t xsw, const float* ref,
+                                   int64_t rsn, int64_t rsc, int64_t rsh, int64_t rsw, float eps, float* l1_mean,
+                                   float* relative_mse, void* workspace, size_t workspace_bytes, int N, int C, int H, int W,
+                                   void* stream) {
+  WCMC_REQUIRE(x && ref && (l1_mean || relative_mse) && workspace && N > 0 && C > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG,
+               "image_loss_fwd: bad argument");
+  WCMC_REQUIRE(workspace_bytes >= wcmc_image_loss_workspace_bytes(), WCMC_ERR_WORKSPACE, "image_loss_fwd: workspace too small");
+  const int64_t total = (int64_t)N * C * H * W;
+  const int64_t want = ceil_div64(total, 256);
+  const int blocks = (int)(want < IL_BLOCKS ? want : IL_BLOCKS);
+  hipLaunchKernelGGL(image_loss_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                     S4{xsn, xsc, xsh, xsw}, ref, S4{rsn, rsc, rsh, rsw}, eps, (float*)workspace, C, H, W, total);
+  hipLaunchKernelGGL(image_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, blocks,
+                     (float)(1.0 / (double)total), l1_mean, relative_mse);
+  return check_launch("image_loss_fwd");
+}
+
+extern "C" int wcmc_l1_mean_bwd(const float* x, int64_t xsn, int64_t xsc, int64_t xsh, int64_t xsw, const float* ref,
+                                int64_t rsn, int64_t rsc, int64_t rsh, int64_t rsw, const float* grad_loss, float* dx, int N,
+                                int C, int H, int W, void* stream) {
+  WCMC_REQUIRE(x && ref && grad_loss && dx && N > 0 && C > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG, "l1_mean_bwd: bad argument");
+  const int64_t total = (int64_t)N * C * H * W;
+  hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, S4{xsn, xsc, xsh, xsw},
+                     ref, S4{rsn, rsc, rsh, rsw}, grad_loss, (float)(1.0 / (double)total), dx, C, H, W, total);
+  return check_launch("l1_mean_bwd");
 }
 
 extern "C" int wcmc_recombine_bwd(const float* grad_out, const float* albedo, int64_t asn, int64_t asc, int64_t ash,

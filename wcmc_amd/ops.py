@@ -924,6 +924,56 @@ def recombine(albedo, r_diffuse, r_specular):
     return _Recombine.apply(albedo, r_diffuse, r_specular)
 
 
+# ------------------------------------------------------------------------ image losses
+def _image_loss_raw(x, ref, eps, want_l1, want_rel):
+    _need_cuda(x, ref)
+    assert x.shape == ref.shape and x.dim() == 4, (x.shape, ref.shape)
+    n, c, h, w = x.shape
+    ws = torch.empty(lib().wcmc_image_loss_workspace_bytes() // 4, device=x.device, dtype=torch.float32)
+    l1 = torch.empty((), device=x.device, dtype=torch.float32) if want_l1 else None
+    rel = torch.empty((), device=x.device, dtype=torch.float32) if want_rel else None
+    check(lib().wcmc_image_loss_fwd(_ptr(x), *x.stride(), _ptr(ref), *ref.stride(), float(eps), _ptr(l1), _ptr(rel), _ptr(ws),
+                                    ws.numel() * 4, n, c, h, w, _stream()), "image_loss_fwd")
+    return l1, rel
+
+
+class _L1Mean(torch.autograd.Function):
+    """``torch.nn.L1Loss()(x, ref)`` (mean reduction; ref carries no gradient) as one pass + a one-block finish; the
+    backward is one launch: ``g * sign(x - ref) / numel``."""
+
+    @staticmethod
+    def forward(ctx, x, ref):
+        l1, _ = _image_loss_raw(x, ref, 0.0, True, False)
+        ctx.save_for_backward(x, ref)
+        return l1
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ref = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+        g = g.contiguous()
+        check(lib().wcmc_l1_mean_bwd(_ptr(x), *x.stride(), _ptr(ref), *ref.stride(), _ptr(g), _ptr(dx), n, c, h, w, _stream()),
+              "l1_mean_bwd")
+        return dx, None
+
+
+def l1_mean(x, ref):
+    """mean |x - ref| of two (N,C,H,W) tensors (any strides); differentiable in x."""
+    return _L1Mean.apply(x, ref.detach())
+
+
+def image_metrics(x, ref, eps=1e-2):
+    """(L1 mean, RelativeMSE) of x against ref in one pass, no gradient (the logged ``l_total`` and ``rmse`` of a step,
+    ``interfaces.py:240-249``)."""
+    return _image_loss_raw(x.detach(), ref.detach(), eps, True, True)
+
+
+def relative_mse(x, ref, eps=1e-2):
+    """``support.losses.RelativeMSE`` without a gradient (validation, ``interfaces.py:296-300``)."""
+    return _image_loss_raw(x.detach(), ref.detach(), eps, False, True)[1]
+
+
 # ------------------------------------------------------------------------ U-Net glue
 class _MaxPool2(torch.autograd.Function):
     @staticmethod

@@ -22,6 +22,18 @@ from .. import ops as _ops
 from .utils import crop_like
 
 
+def _is_plain_l1(fn):
+    """torch.nn.L1Loss with the default mean reduction: what train_kpcn.py:299-304 passes for every image loss."""
+    return type(fn) is nn.L1Loss and fn.reduction == 'mean'
+
+
+def _l1(fn, x, ref):
+    """``fn(x, ref)``; the reference's plain L1Loss on a CUDA image runs as the HIP loss op (one pass, K8)."""
+    if _is_plain_l1(fn) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape == ref.shape:
+        return _ops.l1_mean(x, ref)
+    return fn(x, ref)
+
+
 def _abstract(name):
     def missing(self, *args, **kwargs):
         raise NotImplementedError(name)
@@ -191,10 +203,10 @@ class KPCNInterface(BaseInterface):
 
         if self.train_branches:  # training diffuse and specular branches
             tgt_diffuse = crop_like(batch['target_diffuse'], diffuse)
-            L_diffuse = self.loss_funcs['l_diffuse'](diffuse, tgt_diffuse)
+            L_diffuse = _l1(self.loss_funcs['l_diffuse'], diffuse, tgt_diffuse)
 
             tgt_specular = crop_like(batch['target_specular'], specular)
-            L_specular = self.loss_funcs['l_specular'](specular, tgt_specular)
+            L_specular = _l1(self.loss_funcs['l_specular'], specular, tgt_specular)
 
             if self.manif_learn:
                 p_buffer_diffuse = crop_like(p_buffers['diffuse'], diffuse)
@@ -218,10 +230,13 @@ class KPCNInterface(BaseInterface):
             L_specular.backward()
 
             with torch.no_grad():
+                if self._fused_metrics(total, tgt_total):      # l_total and rmse of the step in one pass
+                    loss_dict['l_total'], loss_dict['rmse'] = _ops.image_metrics(total, tgt_total, self.loss_funcs['l_test'].eps)
+                    return loss_dict
                 L_total = self.loss_funcs['l_recon'](total, tgt_total)
                 loss_dict['l_total'] = L_total.detach()
         else:  # post-training the entire system (no manifold term: interfaces.py:243-246)
-            L_total = self.loss_funcs['l_recon'](total, tgt_total)
+            L_total = _l1(self.loss_funcs['l_recon'], total, tgt_total)
             loss_dict['l_total'] = L_total.detach()
             L_total.backward()
 
@@ -229,6 +244,11 @@ class KPCNInterface(BaseInterface):
             loss_dict['rmse'] = self.loss_funcs['l_test'](total, tgt_total).detach()
 
         return loss_dict
+
+    def _fused_metrics(self, total, tgt_total):
+        from .losses import RelativeMSE
+        return (_is_plain_l1(self.loss_funcs['l_recon']) and type(self.loss_funcs['l_test']) is RelativeMSE and
+                total.is_cuda and total.dim() == 4 and total.dtype == torch.float32 and total.shape == tgt_total.shape)
 
     def _logging(self, loss_dict):
         """ error handling """
@@ -424,13 +444,13 @@ class KPCNPreInterface(KPCNInterface):
             L_manif_specular.backward()
         elif self.train_branches:
             for br, img in (('diffuse', diffuse), ('specular', specular)):      # interfaces.py:702-712, in that order
-                L = self.loss_funcs['l_' + br](img, crop_like(batch['target_' + br], img))
+                L = _l1(self.loss_funcs['l_' + br], img, crop_like(batch['target_' + br], img))
                 loss_dict['l_' + br] = L.detach()
                 L.backward()
             with torch.no_grad():
                 loss_dict['l_total'] = self.loss_funcs['l_recon'](total, tgt_total).detach()
         else:
-            L_total = self.loss_funcs['l_recon'](total, tgt_total)
+            L_total = _l1(self.loss_funcs['l_recon'], total, tgt_total)
             loss_dict['l_total'] = L_total.detach()
             L_total.backward()
         return loss_dict
