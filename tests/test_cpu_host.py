@@ -617,3 +617,89 @@ def test_two_rank_gloo_fused_clip_adam_reduce_then_scale_then_clip():
         assert log["state_step"] == 2.0
         assert log["global_guard"] == 0.0 and log["skipped"] and log["steps_after_rollback"] == [2, 2, 2], log
         assert log["none_grad_skipped"] and log["weight_moved"] > 1e-4, log
+
+
+def test_launcher_flag_surface_and_argument_errors():
+    """wcmc_amd.train_kpcn: the reference's flags (train_kpcn.py:376-425 + BasicArgumentParser, support/utils.py:69-100)
+    with their defaults, and its argument errors (train_kpcn.py:427-441)."""
+    from wcmc_amd import train_kpcn as tk
+    p = tk.build_parser()
+    a = p.parse_args(["--desc", "d"])
+    want = dict(model_name="tSUNet", data_dir="./data", visual=False, batch_size=64, num_epoch=100, val_epoch=1, start_epoch=0,
+                save="./weights", lr_dncnn=1e-4, lr_pnet=[0.0001], lr_ckpt=False, best_err=None, pnet_out_size=[3],
+                manif_loss=None, train_branches=False, use_llpm_buf=False, manif_learn=False, w_manif=[0.1],
+                disentangle="m11r11", single_gpu=False, device_id=0, kpcn_ref=False, kpcn_pre=False, not_save=False, local=False)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    with pytest.raises(SystemExit):
+        p.parse_args([])                                                     # --desc is required
+    full = "--single_gpu --batch_size 8 --val_epoch 1 --data_dir /d --model_name M --desc x --num_epoch 8 --manif_loss FMSE " \
+           "--lr_dncnn 1e-4 --lr_pnet 1e-4 --use_llpm_buf --manif_learn --w_manif 0.1 --train_branches"
+    b = tk.check_args(p.parse_args(full.split()))                            # the README's KPCN-Manifold command line
+    assert b.batch_size == 8 and b.manif_loss == "FMSE" and b.train_branches and b.w_manif == [0.1]
+    for bad, msg in ((["--manif_learn"], "requires a llpm-specific buffer"),
+                     (["--manif_learn", "--use_llpm_buf"], "requires a manifold loss"),
+                     (["--manif_loss", "FMSE"], "not necessary"),
+                     (["--manif_learn", "--use_llpm_buf", "--manif_loss", "XYZ"], "either `FMSE` or `GRS`"),
+                     (["--disentangle", "m00r00"], "Argument `disentangle`"),
+                     (["--disentangle", "m10r01", "--pnet_out_size", "3"], "even numbers")):
+        with pytest.raises(RuntimeError, match=msg):
+            tk.check_args(p.parse_args(["--desc", "d"] + bad))
+
+
+class _CountingSched:                    # (module level: the loop pickles `params`, schedulers included, into its checkpoints)
+    n = 0
+
+    def step(self):
+        _CountingSched.n += 1
+
+
+def test_training_loop_checkpoints_latest_every_epoch_and_best_on_improvement(tmp_path):
+    """``train`` (train_kpcn.py:87-161) around a stand-in interface: interface calls per batch, ``latest_<name>.pth`` after
+    every epoch, validation every ``val_epoch`` epochs, ``<name>.pth`` only when the validation error improves, ``best_err``
+    carried in the file, the scheduler stepped once per epoch."""
+    from wcmc_amd import train_kpcn as tk
+    from wcmc_amd.support import checkpoint as ck_mod
+    errs = iter([0.5, 0.7, 0.2])                                            # validation errors of epochs 1, 3, 5
+    calls = []
+
+    class Itf:
+        def __init__(self):
+            self.models = {"dncnn": torch.nn.Linear(2, 2)}
+            self.optims = {"optim_dncnn": torch.optim.Adam(self.models["dncnn"].parameters(), lr=1e-3)}
+            self.best_err = 1e10
+
+        def to_train_mode(self): calls.append("train_mode")
+        def to_eval_mode(self): calls.append("eval_mode")
+        def preprocess(self, b): calls.append("pre")
+        def train_batch(self, b): calls.append("step")
+        def validate_batch(self, b): calls.append("val")
+
+        def get_epoch_summary(self, mode, norm):
+            calls.append((mode, norm))
+            return -1.0 if mode == "train" else next(errs)
+
+    Sched = _CountingSched
+    Sched.n = 0
+    itf = Itf()
+    args = types.SimpleNamespace(desc="t", model_name="m", start_epoch=0, num_epoch=6, val_epoch=2, visual=False,
+                                 not_save=False, save=str(tmp_path), graph=False)
+    loaders = {"train": [{"x": torch.zeros(1)}] * 3, "val": [{"x": torch.zeros(1)}] * 2}
+    params = {"data_device": "cpu", "sched_a": Sched()}
+    saved = []
+    orig = ck_mod.save_checkpoint
+    ck_mod.save_checkpoint = lambda path, *a, **k: (saved.append((os.path.basename(path), a[1], a[0].best_err)), orig(path, *a, **k))
+    try:
+        tk.train([itf], loaders, params, args)
+    finally:
+        ck_mod.save_checkpoint = orig
+    assert calls.count("step") == 18 and calls.count("pre") == 18 and calls.count("val") == 6
+    assert calls.count(("train", 3)) == 6 and calls.count(("eval", 2)) == 3
+    assert [s for s in saved if s[0] == "latest_m.pth"] == [("latest_m.pth", e, b) for e, b in
+                                                            zip(range(6), [1e10, 1e10, 0.5, 0.5, 0.5, 0.5])]
+    assert [s for s in saved if s[0] == "m.pth"] == [("m.pth", 1, 0.5), ("m.pth", 5, 0.2)]      # 0.7 did not improve
+    assert itf.best_err == 0.2 and Sched.n == 6
+    ck = ck_mod.load_checkpoint(str(tmp_path / "m.pth"))
+    assert ck["start_epoch"] == 6 and ck["best_err"] == 0.2 and ck["description"] == "t"
+    with pytest.raises(NotImplementedError):
+        tk.train([itf, itf], loaders, params, args)

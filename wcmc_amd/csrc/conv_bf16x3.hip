@@ -829,9 +829,9 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     if (NGMAX == 1 || ngroups < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NB - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 2)) : "memory");
     stamp(4);                                    // (stamp builds: slot 4 = the wait for this wave's own weight DMA)
-    pw_barrier();                                // ... everyone's; and everyone has read stage g's fragments
+    if (!(DBG & 16)) pw_barrier();               // ... everyone's; and everyone has read stage g's fragments
     stamp(0);
-    dma_b(g + NB, bcur);
+    if (!(DBG & 2)) dma_b(g + NB, bcur);           // (DBG & 2, timing only: no weight stream inside the loop)
     bcur = b1;
     stamp(5);                                    // weight DMA issued
     const bool last_of_slab = (s_in + 1 == sps_cur);
@@ -845,12 +845,14 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
+        if (!(DBG & 1)) {
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
+        }
       }
-      read_b(b1, j);                             // stage g+1, same cout tile, into the registers just consumed
-      if (j == 0 && !last_of_slab) {
+      if (!(DBG & 8)) read_b(b1, j);             // stage g+1, same cout tile, into the registers just consumed
+      if (j == 0 && !last_of_slab && !(DBG & 8)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           ahn[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
@@ -2128,6 +2130,21 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   if (NT == 7 && p.PXS == 160 && p.ks == 5) {
     static int ab = -1;
     if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    if (ab == 1 || ab == 2 || ab == 8 || ab == 16 || ab == 10 || ab == 26 || ab == 18) {
+      // timing only (WRONG results): 1 = no MFMA, 2 = no weight DMA in the stage loop, 8 = no fragment reads, 16 = no stage barrier
+      constexpr int TH8 = 8;
+      XIgemmParams q = p;
+      q.tilesY = (p.Ho + TH8 - 1) / TH8;
+      const size_t halo8 = (size_t)(((TH8 + p.ks - 1) * (TW + p.ks - 1) * p.PXS + 127) & ~127);
+      const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)((q.Np / 16 + NT - 1) / NT));
+      auto kfn = ab == 1 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 1, 2> : ab == 2 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 2, 2>
+                 : ab == 8 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 8, 2> : ab == 16 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 16, 2>
+                 : ab == 10 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 10, 2> : ab == 18 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 18, 2>
+                 : &conv_halo_bf16x3_kernel<7, TH8, TW, 26, 2>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      hipLaunchKernelGGL(kfn, grid, dim3(TH8 * TW * 2), halo8 + 2 * bstage, stream, q);
+      return check_launch("conv2d_igemm_bf16x3(halo 8x16, ablation)");
+    }
     if (ab == 64) {      // stamp build of the shipped 8x16 tiling (scripts/stamp_igemm.py)
       constexpr int TH8 = 8;
       XIgemmParams q = p;

@@ -21,6 +21,8 @@ class GraphedTrainStep:
         self.static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
         self.keys = list(self.static)                     # (PathNet stashes a converted copy of `paths` in the dict)
         self.fm = itf.loss_funcs.get('l_manif') if itf.manif_learn and itf.train_branches else None
+        if self.fm is not None:
+            self.fm.static_perms = None                   # (a re-capture on the same interface starts like a first one)
         dev = next(iter(self.static.values())).device
         cur = torch.cuda.current_stream()
         s = torch.cuda.Stream(device=dev)

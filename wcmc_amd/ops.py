@@ -303,6 +303,9 @@ class _ConvChain(torch.autograd.Function):
         xs = [x]
         for l in range(nl):
             w, b = params[2 * l], params[2 * l + 1]
+            if w.shape[1] != xs[-1].shape[1]:
+                raise RuntimeError("conv chain layer %d: weight expects %d input channels, got a tensor with %d"
+                                   % (l, w.shape[1], xs[-1].shape[1]))
             wp = _pack(w, 0)
             xs.append(conv2d_raw(xs[-1], wp, b.detach(), w.shape[0], ks, pad, acts[l]))
         ctx.spec = spec
@@ -538,6 +541,9 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
     for l in range(nl):
         wt, b = params[2 * l], params[2 * l + 1]
         cout = wt.shape[0]
+        if wt.shape[1] != dims[l][1]:
+            raise RuntimeError("conv chain layer %d: weight expects %d input channels, got a tensor with %d"
+                               % (l, wt.shape[1], dims[l][1]))
         wp = _pack_x(wt, 0)
         hidden = l < nl - 1
         if pair and l == nl - 2:
