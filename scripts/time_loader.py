@@ -1,0 +1,33 @@
+"""Staged patch loader (wcmc_amd/support/loader.py): images/s, patches/s and PCIe GB/s with raw renderer output in host
+memory, alone and feeding the graphed train step.   python3 scripts/time_loader.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+import numpy as np, torch
+import make_golden as mg
+import bench
+from wcmc_amd.support.loader import PatchLoader
+dev = torch.device("cuda", 0)
+H = W = 512; S = 8
+images = [{"raw": mg.raw_samples(H, W, S, 10 + i), "gt": np.random.rand(H, W, 9).astype(np.float32), "prob": None} for i in range(2)]
+reader = lambda i: images[i % 2]
+n_img = 6
+loader = PatchLoader(reader, range(n_img), dev, batch_size=8, patch_size=128)
+for _ in loader: pass                                   # warm-up (pinned allocations)
+torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
+for b in loader: nb += 1
+torch.cuda.synchronize(); t = time.perf_counter() - t0
+gb = n_img * (images[0]["raw"].nbytes + images[0]["gt"].nbytes) / 1e9
+print("loader alone: %d images of %dx%dx%d spp (%.2f GB raw) -> %d batches of 8 in %.3f s = %.0f patches/s, %.1f GB/s over PCIe"
+      % (n_img, H, W, S, gb, nb, t, nb * 8 / t, gb / t))
+itf = bench.build_interface(dev, None, rng="device")
+from wcmc_amd.graph import GraphedTrainStep
+first = next(iter(loader))
+step = GraphedTrainStep(itf, first)
+for b in loader: step(b)                                # warm-up
+torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
+for b in loader:
+    step(b); nb += 1
+torch.cuda.synchronize(); t = time.perf_counter() - t0
+print("loader feeding the graphed KPCN-Manifold step: %d steps in %.3f s = %.1f patches/s (bench.py on resident inputs: see its line)"
+      % (nb, t, nb * 8 / t))

@@ -102,3 +102,59 @@ def test_patch_batcher_against_the_reference_dataset_items(golden_dir):
     big = PatchBatcher().batch(kp, ll, gg, np.array([[0, 0], [128, 128], [17, 100]] + [[64, 3]] * 5))
     assert big["paths"].shape == (8, 8, 36, 128, 128) and big["kpcn_diffuse_in"].shape == (8, 35, 128, 128)
     assert torch.equal(big["paths"][2, 5, 7], ll[17:145, 100:228, 5, 8]) and torch.equal(big["target_total"][1, 2], gg[128:, 128:, 2])
+
+
+def test_patch_loader_stages_images_and_equals_the_direct_path():
+    """SURVEY.md 8f rank 3, loader half: ``PatchLoader`` (background reader thread -> pinned ring -> copy stream -> device
+    preprocessing -> importance-sampled patch batches) yields exactly what the direct, unstaged calls produce for the same
+    images and the same numpy seed; a reader error surfaces in the consumer."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    from wcmc_amd.support.datasets import DenoisePreprocessor, PatchBatcher
+    from wcmc_amd.support.loader import PatchLoader
+    H, W, S, P, B = 72, 88, 4, 32, 4
+    rng = np.random.RandomState(5)
+    images = []
+    for i in range(3):
+        prob = rng.rand(H, W)
+        prob[H - P + 1:, :] = 0
+        prob[:, W - P + 1:] = 0
+        images.append({"raw": mg.raw_samples(H, W, S, 300 + i), "gt": rng.rand(H, W, 9).astype(np.float32),
+                       "prob": prob / prob.sum()})
+    calls = []
+
+    def reader(i):
+        calls.append(i)
+        return images[i]
+
+    loader = PatchLoader(reader, range(3), DEV, batch_size=B, patch_size=P, patches_per_image=8)
+    assert len(loader) == 6
+    np.random.seed(11)
+    got = [{k: v.clone() for k, v in b.items()} for b in loader]
+    assert len(got) == 6 and calls == [0, 1, 2]
+    assert got[0]["paths"].shape == (B, S, 36, P, P) and got[0]["kpcn_diffuse_in"].shape == (B, 35, P, P)
+    assert loader.stager.bytes_moved == sum(im["raw"].nbytes + im["gt"].nbytes for im in images)
+    pre, bat = DenoisePreprocessor(), PatchBatcher(P, B)
+    bat.patches_per_image = 8
+    np.random.seed(11)
+    k = 0
+    for im in images:
+        raw = torch.from_numpy(im["raw"]).to(DEV)
+        kp, ll, gt = pre._preprocess_kpcn(raw), pre._preprocess_llpm(raw), torch.from_numpy(im["gt"]).to(DEV)
+        origins = bat.sample_origins(im["prob"])
+        for o in range(0, 8, B):
+            want = bat.batch(kp, ll, gt, origins[o:o + B])
+            assert want.keys() == got[k].keys()
+            for name in want:
+                assert torch.equal(want[name], got[k][name]), (k, name)
+            k += 1
+
+    def bad_reader(i):
+        if i == 1:
+            raise OSError("image 1 is unreadable")
+        return images[i]
+
+    with pytest.raises(OSError, match="unreadable"):
+        for _ in PatchLoader(bad_reader, range(3), DEV, batch_size=B, patch_size=P, patches_per_image=8):
+            pass

@@ -1,0 +1,136 @@
+"""Pinned, double-buffered host -> device stager and patch loader (the loader half).
+
+The reference's loader (``train_kpcn.py:177-188``: ``DataLoader(num_workers=1, pin_memory=False)`` around
+``MSDenoiseDataset.__getitem__``, ``datasets.py:1026-1146``) preprocesses every patch in numpy on ONE CPU worker and hands
+pageable tensors to ``batch[k].cuda()``.  Here the per-image arithmetic runs on the GPU (``support/datasets.py``:
+``DenoisePreprocessor``, ``PatchBatcher``), so what is left for the host is to get an image's raw renderer output across
+PCIe without stalling the training stream:
+
+  * ``ImageStager``: a background thread calls the user's ``reader(index)`` (file format and I/O are the caller's: SURVEY.md
+    8 keeps the dataset files out of scope), copies the arrays into a ring of PINNED staging buffers, enqueues the
+    host -> device copies and the two preprocessing kernels on a COPY STREAM, and hands over device-resident
+    ``(kpcn, llpm, gt, prob)`` behind an event -- image i + 1 crosses PCIe and is preprocessed while the training stream
+    is still drawing patches from image i;
+  * ``PatchLoader``: the iterable the epoch loop consumes (``dataloaders['train']`` of ``wcmc_amd.train_kpcn``):
+    ``patches_per_image`` patches per image in batches of ``batch_size``, origins importance-sampled with the reference's
+    ``np.random.choice`` call (``datasets.py:795-810``), one ``wcmc_assemble_kpcn_patches`` launch per batch.
+
+``scripts/time_loader.py`` measures it (patches/s and PCIe GB/s) next to the train step's consumption rate.
+"""
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from .datasets import DenoisePreprocessor, PatchBatcher
+
+
+class ImageStager:
+    """Iterate ``(kpcn (H,W,44), llpm (H,W,S,37) | None, gt (H,W,9), prob (H,W) numpy | None)`` device buffers of the images
+    ``indices``; ``reader(i)`` returns ``{'raw': (H,W,S,C>=104) float32, 'gt': (H,W,9) float32, 'prob': (H,W) | None}`` numpy
+    arrays (any object with the buffer protocol that ``torch.from_numpy`` / ``np.asarray`` accepts, e.g. a memmap)."""
+
+    def __init__(self, reader, indices, device, depth=2, use_llpm=True, max_depth=DenoisePreprocessor.MAX_DEPTH):
+        assert depth >= 2, "double buffering needs two staging slots"
+        self.reader, self.indices, self.device = reader, list(indices), torch.device(device)
+        if self.device.index is None:                                 # 'cuda' -> the current device, by index (threads need it)
+            self.device = torch.device(self.device.type, torch.cuda.current_device())
+        self.depth, self.use_llpm = depth, use_llpm
+        self.pre = DenoisePreprocessor(max_depth)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.bytes_moved = 0
+
+    def _pinned_like(self, slot, key, arr):
+        buf = slot.get(key)
+        if buf is None or buf.shape != arr.shape:
+            buf = torch.empty(arr.shape, dtype=torch.float32, pin_memory=True)
+            slot[key] = buf
+        return buf
+
+    def _produce(self, out_q, free_q, stop):
+        try:
+            torch.cuda.set_device(self.device)
+            for i in self.indices:
+                if stop.is_set():
+                    return
+                slot = free_q.get()                                   # a staging slot whose last copy has completed
+                if slot.get('event') is not None:
+                    slot['event'].synchronize()
+                item = self.reader(i)
+                raw = np.asarray(item['raw'], dtype=np.float32)
+                gt = np.asarray(item['gt'], dtype=np.float32)
+                p_raw, p_gt = self._pinned_like(slot, 'raw', raw), self._pinned_like(slot, 'gt', gt)
+                p_raw.copy_(torch.from_numpy(raw))                    # pageable -> pinned (host memcpy on this thread)
+                p_gt.copy_(torch.from_numpy(gt))
+                with torch.cuda.stream(self.copy_stream):
+                    d_raw = p_raw.to(self.device, non_blocking=True)
+                    d_gt = p_gt.to(self.device, non_blocking=True)
+                    kpcn = self.pre._preprocess_kpcn(d_raw)
+                    llpm = self.pre._preprocess_llpm(d_raw) if self.use_llpm else None
+                    ev = torch.cuda.Event()
+                    ev.record(self.copy_stream)
+                slot['event'] = ev
+                self.bytes_moved += raw.nbytes + gt.nbytes
+                out_q.put((kpcn, llpm, d_gt, item.get('prob'), ev, slot))
+            out_q.put(None)
+        except BaseException as exc:                                  # surface reader / CUDA errors in the consumer
+            out_q.put(exc)
+
+    def __iter__(self):
+        out_q, free_q, stop = queue.Queue(maxsize=self.depth), queue.Queue(), threading.Event()
+        for _ in range(self.depth):
+            free_q.put({})
+        worker = threading.Thread(target=self._produce, args=(out_q, free_q, stop), daemon=True)
+        worker.start()
+        try:
+            while True:
+                got = out_q.get()
+                if got is None:
+                    return
+                if isinstance(got, BaseException):
+                    raise got
+                kpcn, llpm, gt, prob, ev, slot = got
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)                                    # the consumer's stream, not the host, waits
+                for t in (kpcn, llpm, gt):
+                    if t is not None:
+                        t.record_stream(cur)
+                free_q.put(slot)                                      # (its event guards the pinned buffers' reuse)
+                yield kpcn, llpm, gt, prob
+        finally:
+            stop.set()
+
+
+class PatchLoader:
+    """Batches of the KPCN base model over the staged images; ``len()`` = batches per epoch."""
+
+    def __init__(self, reader, indices, device, batch_size=8, patch_size=PatchBatcher.PATCH_SIZE, use_llpm=True, depth=2,
+                 patches_per_image=None):
+        self.stager = ImageStager(reader, indices, device, depth=depth, use_llpm=use_llpm)
+        self.batcher = PatchBatcher(patch_size, batch_size)
+        if patches_per_image is not None:
+            self.batcher.patches_per_image = (patches_per_image // batch_size) * batch_size
+        self.batch_size = batch_size
+
+    def __len__(self):
+        return len(self.stager.indices) * (self.batcher.patches_per_image // self.batch_size)
+
+    def __iter__(self):
+        p = self.batcher.patch_size
+        for kpcn, llpm, gt, prob in self.stager:
+            h, w = kpcn.shape[:2]
+            if prob is None:
+                prob = np.zeros((h, w), dtype=np.float64)             # (not a distribution: uniform, as the reference falls back)
+            # origins must keep the window inside the image: the reference crops what it gets, which silently shrinks a
+            # patch at the border; its probability maps are zero there (datasets.py:795-810)
+            valid = np.zeros((h, w), dtype=np.float64)
+            valid[:h - p + 1, :w - p + 1] = np.asarray(prob, dtype=np.float64)[:h - p + 1, :w - p + 1]
+            s = valid.sum()
+            if s > 0:
+                valid /= s
+            else:
+                valid[:h - p + 1, :w - p + 1] = 1.0 / ((h - p + 1) * (w - p + 1))
+            origins = self.batcher.sample_origins(valid)
+            for k in range(0, len(origins), self.batch_size):
+                yield self.batcher.batch(kpcn, llpm, gt, origins[k:k + self.batch_size])
