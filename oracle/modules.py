@@ -19,7 +19,9 @@ Frozen choices (identical in the HIP path, ``wcmc_amd/modules.py``):
     index t = (dy+r)*k + (dx+r) (row-major dy, dx), zero-extended gather
     ``out[b,c,y,x] = sum_t w[b,t,y,x] * data0[b,c,y+dy,x+dx]`` with no
     renormalisation at the border.
-  * Parameter names: ``layers.<i>.weight`` / ``layers.<i>.bias`` inside a chain.
+  * Parameter names: ``layers.<i>.weight`` / ``layers.<i>.bias`` inside a chain (``layers.<i>.weight_g`` /
+    ``.weight_v`` / ``.bias`` with the explicit ``weight_norm=True`` option; default False, see ConvChain).
+  * U-Net concatenation order: ``cat([upsampled deeper level, left skip], 1)``.
   * Init: xavier-uniform with ReLU gain, zero bias.
 """
 import math
@@ -47,13 +49,19 @@ class ConvChain(nn.Module):
     """``sbmc.modules.ConvChain`` (call sites ``support/networks.py:18-19,23-24``)."""
 
     def __init__(self, ninputs, noutputs, ksize=3, width=64, depth=3, pad=True,
-                 activation="relu", output_type="linear"):
+                 activation="relu", output_type="linear", weight_norm=False):
+        """weight_norm: explicit option of this specification, default False (module docstring: "no norm").  Upstream
+        adobe/sbmc is believed -- unverifiable here, the package is absent -- to default ``weight_norm=True`` in ConvChain,
+        which ``sbmc.KPCN`` overrides to False and PathNet's calls (``support/networks.py:18-24``) do not.  With True each
+        layer is ``torch.nn.utils.weight_norm(nn.Conv2d(...))``: parameters ``weight_g`` / ``weight_v``,
+        ``weight = g * v / ||v||`` (norm per output channel)."""
         super().__init__()
         assert depth >= 1 and activation == "relu"
         self.ninputs, self.noutputs = ninputs, noutputs
         self.ksize, self.width, self.depth = ksize, width, depth
         self.padding = ksize // 2 if pad else 0
         self.output_type = output_type
+        self.weight_norm = weight_norm
         layers = []
         cin = ninputs
         for i in range(depth):
@@ -62,6 +70,12 @@ class ConvChain(nn.Module):
             cin = cout
         self.layers = nn.ModuleList(layers)
         self.reset_parameters()
+        if weight_norm:
+            import warnings
+            with warnings.catch_warnings():               # (the legacy API is what sbmc-era checkpoints were written with)
+                warnings.simplefilter("ignore", FutureWarning)
+                for conv in self.layers:
+                    nn.utils.weight_norm(conv)
 
     def reset_parameters(self):
         gain = nn.init.calculate_gain("relu")
@@ -81,18 +95,16 @@ class ConvChain(nn.Module):
 
 class _Level(nn.Module):
     def __init__(self, n_in, n_out, width, num_convs, ksize, output_type,
-                 next_level=None, n_up=None):
+                 next_level=None, n_up=None, weight_norm=False):
         super().__init__()
         self.is_last = next_level is None
+        kw = dict(ksize=ksize, width=width, depth=num_convs, pad=True, weight_norm=weight_norm)
         if self.is_last:
-            self.left = ConvChain(n_in, n_out, ksize=ksize, width=width, depth=num_convs,
-                                  pad=True, output_type=output_type)
+            self.left = ConvChain(n_in, n_out, output_type=output_type, **kw)
         else:
-            self.left = ConvChain(n_in, width, ksize=ksize, width=width, depth=num_convs,
-                                  pad=True, output_type="relu")
+            self.left = ConvChain(n_in, width, output_type="relu", **kw)
             self.next_level = next_level
-            self.right = ConvChain(n_up + width, n_out, ksize=ksize, width=width,
-                                   depth=num_convs, pad=True, output_type=output_type)
+            self.right = ConvChain(n_up + width, n_out, output_type=output_type, **kw)
 
     def forward(self, x):
         left = self.left(x)
@@ -108,7 +120,7 @@ class Autoencoder(nn.Module):
     """``sbmc.modules.Autoencoder`` (call site ``support/networks.py:20-22``)."""
 
     def __init__(self, ninputs, noutputs, ksize=3, width=64, num_levels=3, num_convs=2,
-                 max_width=512, increase_factor=1.0, output_type="linear", pooling="max"):
+                 max_width=512, increase_factor=1.0, output_type="linear", pooling="max", weight_norm=False):
         super().__init__()
         assert pooling == "max"
         self.num_levels = num_levels
@@ -123,7 +135,7 @@ class Autoencoder(nn.Module):
             if lvl == num_levels - 1:
                 n_up = None
             next_level = _Level(n_in, n_out, w, num_convs, ksize, o_type,
-                                next_level=next_level, n_up=n_up)
+                                next_level=next_level, n_up=n_up, weight_norm=weight_norm)
         self.net = next_level
 
     def forward(self, x):

@@ -12,19 +12,19 @@ from .modules import Autoencoder, ConvChain
 
 
 class PathNet(nn.Module):
-    def __init__(self, ic, intermc=64, outc=3):
+    def __init__(self, ic, intermc=64, outc=3, weight_norm=False):
         super().__init__()
         self.ic, self.intermc, self.outc = ic, intermc, outc
         self.final_ic = intermc + intermc
         # networks.py:18-19
-        self.embedding = ConvChain(ic, intermc, width=intermc, depth=3, ksize=1, pad=False)
+        self.embedding = ConvChain(ic, intermc, width=intermc, depth=3, ksize=1, pad=False, weight_norm=weight_norm)
         # networks.py:20-22
         self.propagation = Autoencoder(intermc, intermc, num_levels=3, increase_factor=2.0,
                                        num_convs=3, width=intermc, ksize=3,
-                                       output_type="leaky_relu", pooling="max")
+                                       output_type="leaky_relu", pooling="max", weight_norm=weight_norm)
         # networks.py:23-24
         self.final = ConvChain(self.final_ic, outc, width=self.final_ic, depth=2, ksize=1,
-                               pad=False, output_type="relu")
+                               pad=False, output_type="relu", weight_norm=weight_norm)
 
     def __str__(self):
         return "PathNet i{}in{}o{}".format(self.ic, self.intermc, self.outc)

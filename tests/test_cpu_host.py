@@ -703,3 +703,37 @@ def test_training_loop_checkpoints_latest_every_epoch_and_best_on_improvement(tm
     assert ck["start_epoch"] == 6 and ck["best_err"] == 0.2 and ck["description"] == "t"
     with pytest.raises(NotImplementedError):
         tk.train([itf, itf], loaders, params, args)
+
+
+def test_frozen_parameter_names_and_state_dict_round_trip():
+    """Specification choices that checkpoints depend on (oracle/modules.py docstring): parameter names of the chains
+    (``layers.<i>.weight|bias``; ``weight_g`` / ``weight_v`` with the explicit ``weight_norm=True`` option), module paths of
+    PathNet / KPCN, and that oracle and product state dicts are interchangeable in both parametrisations."""
+    from oracle.models import KPCN as OKPCN
+    from oracle.networks import PathNet as OPathNet
+    from wcmc_amd import KPCN
+    from wcmc_amd.support.networks import PathNet
+    ok, hk = OKPCN(34, depth=3, width=8), KPCN(34, depth=3, width=8)
+    assert list(ok.state_dict()) == list(hk.state_dict()) == [
+        "%s.layers.%d.%s" % (br, i, w) for br in ("diffuse", "specular") for i in range(3) for w in ("weight", "bias")]
+    hk.load_state_dict(ok.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(ok.state_dict().values(), hk.state_dict().values()))
+    op, hp = OPathNet(36, intermc=8), PathNet(36, intermc=8)
+    names = list(op.state_dict())
+    assert names == list(hp.state_dict())
+    assert names[:6] == ["embedding.layers.%d.%s" % (i, w) for i in range(3) for w in ("weight", "bias")]
+    assert "propagation.net.next_level.next_level.left.layers.2.bias" in names and names[-1] == "final.layers.1.bias"
+    assert op.propagation.net.right.layers[0].weight.shape == (8, 16 + 8, 3, 3)       # cat([upsampled deeper (16), skip (8)])
+    hp.load_state_dict(op.state_dict())
+    on, hn = OPathNet(36, intermc=8, weight_norm=True), PathNet(36, intermc=8, weight_norm=True)
+    wn = list(hn.state_dict())
+    assert set(wn) == set(on.state_dict()) and "embedding.layers.0.weight_g" in wn and "final.layers.1.weight_v" in wn
+    assert not any(k.endswith(".weight") for k in wn)
+    hn.load_state_dict(on.state_dict())
+    back = OPathNet(36, intermc=8, weight_norm=True)
+    back.load_state_dict(hn.state_dict())
+    x = {"paths": torch.rand(1, 2, 36, 8, 8)}
+    assert torch.equal(back(x), on(x))
+    # at initialisation g = ||v||: the effective weight is v, i.e. the un-normalised network
+    lay = hn.embedding.layers[0]
+    assert torch.allclose(lay.weight, lay.weight_v, rtol=1e-6, atol=1e-7)

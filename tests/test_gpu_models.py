@@ -89,6 +89,36 @@ def test_pathnet_matches_oracle(precision):
         fc.check(p.grad, q.grad, 1e-3, what="PathNet grad " + k, l2=2e-2)    # 16-channel test network: 37k units / layer
 
 
+def test_pathnet_weight_norm_option_matches_oracle():
+    """The explicit ``weight_norm=True`` option of the chains (oracle/modules.py ConvChain docstring): forward, and the
+    gradients of ``weight_g`` / ``weight_v`` through the HIP chains, against ``torch.nn.utils.weight_norm`` convolutions."""
+    from wcmc_amd.support.networks import PathNet
+    torch.manual_seed(0)
+    ref = OPathNet(36, intermc=16, outc=3, weight_norm=True)
+    randomize_bias(ref, 1)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if n.endswith("weight_g"):
+                p.mul_(torch.rand(p.shape) + 0.5)            # g != ||v||: the normalisation must actually act
+    mod = PathNet(36, intermc=16, outc=3, weight_norm=True)
+    mod.load_state_dict(ref.state_dict())
+    mod.to(DEV)
+    ref = ref.double()
+    g = torch.Generator().manual_seed(2)
+    paths = torch.rand(2, 3, 36, 16, 24, generator=g) - 0.4
+    out_r = ref({"paths": paths.double()})
+    gout = torch.rand(out_r.shape, generator=g) - 0.5
+    out_r.backward(gout.double())
+    out = mod({"paths": paths.to(DEV)})
+    out.backward(gout.to(DEV))
+    assert_close(out, out_r, what="PathNet(weight_norm) fwd")
+    named_r = dict(ref.named_parameters())
+    for k, p in mod.named_parameters():
+        assert p.grad is not None, k
+        e = rel_l2(p.grad, named_r[k].grad)
+        assert e <= 2e-2, "PathNet(weight_norm) grad %s: relative L2 %.3e" % (k, e)
+
+
 def test_kpcn_c1_config_matches_oracle(precision):
     """BASELINE config C1: KPCN-Vanilla, 64x64, batch 2, n_in=34 (the reference's CPU-runnable case)."""
     from wcmc_amd import KPCN

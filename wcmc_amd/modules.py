@@ -9,14 +9,38 @@ ordinary ``nn.Conv2d`` containers (``layers.<i>.weight|bias``, OIHW) so ``state_
 ``optim.Adam`` and ``clip_grad_value_`` in an unmodified caller keep working; the
 arithmetic runs in ``libwcmc_hip.so`` only.
 """
+import torch
 import torch.nn as nn
 
 from . import ops
 
 
+class _WeightNormConv(nn.Module):
+    """Parameter container of one weight-normalised layer: ``weight = weight_g * weight_v / ||weight_v||`` with the norm
+    over (in, kh, kw) per output channel -- ``torch.nn.utils.weight_norm(nn.Conv2d(...))``'s parametrisation and parameter
+    names.  The effective weight is formed by a handful of torch ops on the (at most 1.2 MB) weight tensor and handed to
+    the HIP chain like any other weight; autograd carries the chain's weight gradient back to ``weight_g`` / ``weight_v``."""
+
+    def __init__(self, cin, cout, ksize):
+        super().__init__()
+        self.weight_g = nn.Parameter(torch.ones(cout, 1, 1, 1))
+        self.weight_v = nn.Parameter(torch.empty(cout, cin, ksize, ksize))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+    @property
+    def weight(self):
+        v = self.weight_v
+        return v * (self.weight_g / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+
+
 class ConvChain(nn.Module):
+    """``weight_norm``: SPECIFICATION CHOICE, default False.  ``sbmc`` is absent from the reference tree; upstream
+    adobe/sbmc's ``ConvChain`` is believed (unverifiable here) to default ``weight_norm=True``, which ``sbmc.KPCN`` switches
+    off explicitly and ``support/networks.py:18-24`` (PathNet) does not.  Pass ``weight_norm=True`` (``PathNet(...,
+    weight_norm=True)``) to train that parametrisation; checkpoints then carry ``weight_g`` / ``weight_v`` per layer."""
+
     def __init__(self, ninputs, noutputs, ksize=3, width=64, depth=3, pad=True,
-                 activation="relu", output_type="linear"):
+                 activation="relu", output_type="linear", weight_norm=False):
         super().__init__()
         assert depth >= 1 and activation == "relu"
         assert output_type in ("linear", "relu", "leaky_relu")
@@ -24,10 +48,12 @@ class ConvChain(nn.Module):
         self.ksize, self.width, self.depth = ksize, width, depth
         self.padding = ksize // 2 if pad else 0
         self.output_type = output_type
+        self.weight_norm = weight_norm
         layers, cin = [], ninputs
         for i in range(depth):
             cout = width if i < depth - 1 else noutputs
-            layers.append(nn.Conv2d(cin, cout, ksize, padding=self.padding, bias=True))
+            layers.append(_WeightNormConv(cin, cout, ksize) if weight_norm
+                          else nn.Conv2d(cin, cout, ksize, padding=self.padding, bias=True))
             cin = cout
         self.layers = nn.ModuleList(layers)
         self.reset_parameters()
@@ -35,7 +61,12 @@ class ConvChain(nn.Module):
     def reset_parameters(self):
         gain = nn.init.calculate_gain("relu")
         for conv in self.layers:
-            nn.init.xavier_uniform_(conv.weight, gain=gain)
+            if self.weight_norm:                        # as weight_norm() initialises: v = the initial weight, g = ||v||
+                nn.init.xavier_uniform_(conv.weight_v, gain=gain)
+                with torch.no_grad():
+                    conv.weight_g.copy_(conv.weight_v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+            else:
+                nn.init.xavier_uniform_(conv.weight, gain=gain)
             nn.init.zeros_(conv.bias)
 
     def _acts_params(self):
@@ -72,18 +103,16 @@ class ConvChain(nn.Module):
 
 
 class _Level(nn.Module):
-    def __init__(self, n_in, n_out, width, num_convs, ksize, output_type, next_level=None, n_up=None):
+    def __init__(self, n_in, n_out, width, num_convs, ksize, output_type, next_level=None, n_up=None, weight_norm=False):
         super().__init__()
         self.is_last = next_level is None
+        kw = dict(ksize=ksize, width=width, depth=num_convs, pad=True, weight_norm=weight_norm)
         if self.is_last:
-            self.left = ConvChain(n_in, n_out, ksize=ksize, width=width, depth=num_convs, pad=True,
-                                  output_type=output_type)
+            self.left = ConvChain(n_in, n_out, output_type=output_type, **kw)
         else:
-            self.left = ConvChain(n_in, width, ksize=ksize, width=width, depth=num_convs, pad=True,
-                                  output_type="relu")
+            self.left = ConvChain(n_in, width, output_type="relu", **kw)
             self.next_level = next_level
-            self.right = ConvChain(n_up + width, n_out, ksize=ksize, width=width, depth=num_convs,
-                                   pad=True, output_type=output_type)
+            self.right = ConvChain(n_up + width, n_out, output_type=output_type, **kw)
 
     def forward(self, x):
         left = self.left(x)
@@ -97,7 +126,7 @@ class _Level(nn.Module):
 
 class Autoencoder(nn.Module):
     def __init__(self, ninputs, noutputs, ksize=3, width=64, num_levels=3, num_convs=2, max_width=512,
-                 increase_factor=1.0, output_type="linear", pooling="max"):
+                 increase_factor=1.0, output_type="linear", pooling="max", weight_norm=False):
         super().__init__()
         assert pooling == "max"
         self.num_levels = num_levels
@@ -111,7 +140,8 @@ class Autoencoder(nn.Module):
                 n_in, n_out, o_type = ninputs, noutputs, output_type
             if lvl == num_levels - 1:
                 n_up = None
-            next_level = _Level(n_in, n_out, w, num_convs, ksize, o_type, next_level=next_level, n_up=n_up)
+            next_level = _Level(n_in, n_out, w, num_convs, ksize, o_type, next_level=next_level, n_up=n_up,
+                                weight_norm=weight_norm)
         self.net = next_level
 
     def forward(self, x):

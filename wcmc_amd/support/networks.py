@@ -13,17 +13,19 @@ from ..modules import Autoencoder, ConvChain
 class PathNet(nn.Module):
     """Path embedding network"""
 
-    def __init__(self, ic, intermc=64, outc=3):
+    def __init__(self, ic, intermc=64, outc=3, weight_norm=False):
+        """weight_norm (not a reference argument; default = this build's specification): see ``modules.ConvChain``."""
         super(PathNet, self).__init__()
         self.ic = ic
         self.intermc = intermc
         self.outc = outc
         self.final_ic = intermc + intermc
-        self.embedding = ConvChain(ic, intermc, width=intermc, depth=3, ksize=1, pad=False)
+        self.embedding = ConvChain(ic, intermc, width=intermc, depth=3, ksize=1, pad=False, weight_norm=weight_norm)
         self.propagation = Autoencoder(intermc, intermc, num_levels=3, increase_factor=2.0, num_convs=3,
-                                       width=intermc, ksize=3, output_type="leaky_relu", pooling="max")
+                                       width=intermc, ksize=3, output_type="leaky_relu", pooling="max",
+                                       weight_norm=weight_norm)
         self.final = ConvChain(self.final_ic, outc, width=self.final_ic, depth=2, ksize=1, pad=False,
-                               output_type="relu")
+                               output_type="relu", weight_norm=weight_norm)
 
     def __str__(self):
         return "PathNet i{}in{}o{}".format(self.ic, self.intermc, self.outc)
