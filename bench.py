@@ -245,6 +245,12 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of one hipGraph")
     ap.add_argument("--cpu-rng", action="store_true",
                     help="draw the FeatureMSE pairings on the global CPU generator like the reference (+46 ms/step)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend of the gradient all-reduce: nccl = RCCL over xGMI (the measured "
+                         "configuration); gloo only to smoke-test the multi-rank path where RCCL cannot run")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="smoke test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL refuses two ranks "
+                         "on one device); the printed throughput is then meaningless")
     ap.add_argument("--precision", choices=("bf16x3", "fp32"), default=None,
                     help="conv GEMM arithmetic: split-bf16 (default) or exact fp32 MFMA (roofline vs the 157.3 TF/s peak)")
     args = ap.parse_args()
@@ -256,7 +262,10 @@ def main():
     from wcmc_amd.synthetic import make_batch
     if args.precision:
         ops.set_precision(args.precision)
-    rank, world, local = wd.init("nccl")
+    if args.share_gpu:
+        assert args.backend == "gloo", "--share-gpu needs --backend gloo"
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = wd.init(args.backend)
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or "
                  "without a launcher: bench.py starts its own workers)" % (args.gpus, world, args.gpus))
@@ -397,7 +406,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3" if ops.PRECISION == "bf16x3" else "f32",
-            "data": "synthetic", "rccl_ranks": world,
+            "data": "synthetic", "rccl_ranks": world if args.backend == "nccl" else 0,
+            "collective_backend": "rccl" if args.backend == "nccl" else args.backend + (" (smoke test, shared GPU)" if args.share_gpu else ""),
             # loss_dict of the last timed step on rank 0 (seeded weights, inputs and pairings: reproducible run to run
             # with the same binary; a stream-ordering race in the captured step would show here)
             "losses_last_step": {k: round(v, 6) for k, v in last_losses.items()},
