@@ -139,9 +139,9 @@ def kernel_apply_probe(device, iters=24, nsets=4):
 
 
 def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_summary.json):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_summary.json):
     (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md section HBM."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     if not os.path.isfile(path):
         return {}
     with open(path) as f:
@@ -150,12 +150,12 @@ def pmc_traffic():
     for k, v in d.items():
         for tag, key in (("conv_halo_bf16x3_kernel<7", "conv_halo7"), ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
-                         ("kernel_apply_kernel<false", "kernel_apply_fwd"), ("kernel_apply_kernel<true", "kernel_apply_bwd")):
+                         ("kernel_apply_strip_kernel<false", "kernel_apply_fwd"), ("kernel_apply_strip_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
                 shape = ("64x128x128 64->64 1x1 hidden layer (PathNet embedding): 536.9 MB algorithmic" if key == "conv_pw" else
                          "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else "logits (8,441,92,92)")
                 pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "shape": shape,
-                             "source": "profiles/r01_pmc_summary.json"}
+                             "source": "profiles/r02_pmc_summary.json"}
     return pick
 
 

@@ -1,12 +1,28 @@
+# Round-2 evidence behind profiles/: the bench line, the two rocprofv3 kernel-stats runs (graphed, eager) and the PMC passes.
+#   gpurun -- 'bash scripts/refresh_profiles.sh r02'      (then copy the summaries from gpurun_out/ into profiles/)
 set -x
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/pmc_i
-python3 bench.py --steps 30 --warmup 5 > $R/gpurun_out/bench_r1_final8.log 2>&1
-tail -1 $R/gpurun_out/bench_r1_final8.log | cut -c1-200
+O=$R/gpurun_out/$TAG
+mkdir -p $O/pmc
+python3 $R/bench.py --steps 30 --warmup 5 > $O/bench_line.log 2>&1
+tail -1 $O/bench_line.log | cut -c1-200
+python3 $R/bench.py --steps 10 --warmup 3 --precision fp32 --no-cpu-baseline > $O/bench_line_fp32.log 2>&1
+tail -1 $O/bench_line_fp32.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r1r -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench_prof_r1r.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r1s -- python3 $R/bench.py --eager --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench_prof_r1s.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_graph -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_eager -- python3 $R/bench.py --eager --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_eager_under_rocprof.log 2>&1
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc/p$i -- python3 $R/scripts/bench_kernels.py 3 > $O/pmc/log$i.txt 2>&1 || echo "pass $i failed"
+done
 cd $R
-bash scripts/pmc.sh i > $R/gpurun_out/pmc_i/run.log 2>&1
-tail -3 $R/gpurun_out/pmc_i/run.log
-find $R/gpurun_out/prof_r1r $R/gpurun_out/prof_r1s -name "*kernel_stats.csv" | head
+python3 scripts/pmc_summary.py $O/pmc > $O/pmc_summary.json
+find $O/prof_graph $O/prof_eager -name "*kernel_stats.csv" | head
+# keep the merge under the 64 MiB limit: only the stats / counter CSVs go home
+find $O -name "*kernel_trace.csv" -delete
+find $O/pmc -name "*counter_collection.csv" -size +8M -delete
+du -sh $O
