@@ -565,6 +565,7 @@ _SWITCHES = [
                                                          # dgrad pair: the bias sums group per tile, not per workgroup)
     ("attr", "FUSE_CHAIN_GLUE", False, "exact"),         # separate spp-mean / concat / upsample nodes
     ("attr", "FUSE_KERNEL_APPLY", True, "exact"),        # chain + kernel-apply as one node (split d_logits; tile kernel)
+    ("attr", "PIPELINE_BRANCHES", True, "exact"),        # the two halves as independent pipelines, specular one phase late
     ("attr", "USE_BRANCH_STREAM", False, "exact"),       # specular half on the main stream
     ("attr", "USE_SIDE_STREAM", False, "exact"),         # weight gradients on the main stream
     ("env", "WCMC_IGEMM_PW", "0", "close"),              # tiled kernel for the 1x1 layers (bias sums group per tile)

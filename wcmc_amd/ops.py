@@ -217,6 +217,15 @@ USE_BRANCH_STREAM = os.environ.get("WCMC_BRANCH_STREAM", "1") != "0"   # +1.8 % 
 _BRANCH_STREAMS = {}
 
 
+# The two halves of a KPCN-Manifold step (PathNet -> input assembly -> KPCN chain -> kernel-apply -> losses -> backward) as
+# two INDEPENDENT pipelines, the specular one started one phase late so that its HBM-bound PathNet work would run beside the
+# MFMA-bound KPCN GEMMs of the diffuse half (interfaces.KPCNInterface._forward_backward_pipelined).  Bit-identical, and
+# measured 2.5 % SLOWER than the joined structure (360 against 369 patches/s, three alternations on one box, with or
+# without the lag): the MFMA kernels of both halves time-share the chip either way, and the pipelines lose the shared
+# round-2 filling of the joined launches.  Off; WCMC_PIPELINE_BRANCHES=1 for the A/B.
+PIPELINE_BRANCHES = os.environ.get("WCMC_PIPELINE_BRANCHES", "0") != "0"
+
+
 def branch_stream(device):
     key = (device.type, device.index)
     if key not in _BRANCH_STREAMS:
