@@ -143,6 +143,16 @@ int wcmc_cat_upsample_split(const float* deep, int64_t dsn, int64_t dsh, int64_t
 int wcmc_add_broadcast_split(const float* g, int64_t gsn, int64_t gsh, int64_t gsw,
                              const float* gm, int64_t msn, int64_t msh, int64_t msw, float scale,
                              void* out_split, int B, int S, int H, int W, int C, void* stream);
+/* The gradient that ENTERS a chain's backward, split, with the column sums of the result (= the last layer's bias
+ * gradient, `interfaces.py:237-238` -> `nn.Conv2d` backward) in the same pass:
+ *   out = split((dy [+ repeat_S(gm) * scale]) [* act'(post)])      -- dy or gm may be null, post may be null --
+ * i.e. wcmc_split_bf16 / wcmc_split_gated_bf16 / wcmc_add_broadcast_split, plus colsum_partial in the layout of
+ * wcmc_conv2d_igemm_bf16x3's column sums (wcmc_conv2d_igemm_colsum_elems floats), to be handed to
+ * wcmc_conv2d_wgrad_bf16x3 as dy_colsum_partial.  N = B * S images when gm (B images) is given. */
+int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw,
+                              const float* post, int64_t psn, int64_t psh, int64_t psw, int act, float slope,
+                              const float* gm, int64_t msn, int64_t msh, int64_t msw, int S, float scale,
+                              void* out_split, float* colsum_partial, int N, int H, int W, int C, void* stream);
 size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks);
 int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
                                    void* stream);

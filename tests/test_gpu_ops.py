@@ -433,7 +433,10 @@ def test_chain_kernel_apply_node_equals_the_separate_ops():
         y.backward(g.to(DEV))
         res.append([y.detach().clone(), xd.grad.clone()] + [t.grad.clone() for t in ps])
     for a, b, nm in zip(res[0], res[1], ["out", "dx", "dw0", "db0", "dw1", "db1"]):
-        assert torch.equal(a, b), "fused chain + kernel-apply differs in " + nm
+        if nm == "db1":     # the head's bias gradient: column sums grouped by colsum_split's blocks vs by the split pass's
+            assert_close(a, b, tol=1e-5, what="fused chain + kernel-apply, db1")
+        else:
+            assert torch.equal(a, b), "fused chain + kernel-apply differs in " + nm
 
 
 def test_kernel_apply_known_answers():

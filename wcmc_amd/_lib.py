@@ -34,6 +34,7 @@ SIGNATURES = {
     "wcmc_cat_broadcast_split": (I, [P, L, L, L, P, L, L, L, P, I, I, I, I, I, I, P]),
     "wcmc_cat_upsample_split": (I, [P, L, L, L, P, L, L, L, P, I, I, I, I, I, P]),
     "wcmc_add_broadcast_split": (I, [P, L, L, L, P, L, L, L, F, P, I, I, I, I, I, P]),
+    "wcmc_split_dy_colsum_bf16": (I, [P, L, L, L, P, L, L, L, I, F, P, L, L, L, I, F, P, P, I, I, I, I, P]),
     "wcmc_conv2d_packed_elems_bf16x3": (Z, [I, I, I]),
     "wcmc_conv2d_pack_weight_bf16x3": (I, [P, P, I, I, I, I, P]),
     "wcmc_conv2d_igemm_bf16x3": (I, [P, I, I, I, I, P, P, P, L, L, L, P, I, I, I, I, F, P, I, F, P, P, P, P]),

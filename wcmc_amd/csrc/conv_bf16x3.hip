@@ -202,6 +202,87 @@ __global__ void add_broadcast_split_kernel(const float* __restrict__ g, int64_t 
   }
 }
 
+// ------------------------------------------------------------------ the gradient entering a chain's backward -> split + column sums
+// out = split((dy [+ repeat_S(gm) * scale]) [* act'(post)]) -- what split_kernel / add_broadcast_split_kernel produce for the
+// LAST layer of a chain -- and, in the same pass, the per-block column sums of the result in the layout the GEMM epilogues
+// leave ([row][Np] + trailer word = rows written): the layer's bias gradient is then finished by its weight gradient's
+// slab-reduction launch (wcmc_conv2d_wgrad_bf16x3, dy_colsum_partial) instead of a column-sum pass that re-reads the split
+// tensor (268 MB for a PathNet embedding) plus a finish launch.  One thread = one 8-channel vector of every PL-th pixel of
+// the block's range; fixed-order LDS tree over the pixel lanes: bitwise reproducible.
+__global__ __launch_bounds__(256) void split_dy_colsum_kernel(const float* __restrict__ dy, int64_t dsn, int64_t dsh, int64_t dsw,
+                                                              const float* __restrict__ post, int64_t psn, int64_t psh, int64_t psw,
+                                                              int act, float slope, const float* __restrict__ gm, int64_t msn,
+                                                              int64_t msh, int64_t msw, int S, float scale, u16* __restrict__ out,
+                                                              int H, int W, int C, int Cp, int64_t M, int64_t per_block,
+                                                              float* __restrict__ partial, int Np, int Gmax) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [PL][V][8]
+  const int V = Cp / 8, PL = 256 / V;
+  const int v = threadIdx.x % V, pl = threadIdx.x / V;
+  const int64_t p0 = (int64_t)blockIdx.x * per_block, p1 = min(M, p0 + per_block);
+  const int c0 = v * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (pl < PL) {
+    for (int64_t q = p0 + pl; q < p1; q += PL) {
+      const int xx = (int)(q % W); int64_t t = q / W;
+      const int y = (int)(t % H); const int n = (int)(t / H);
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = 0.f;
+      const bool whole = c0 + 8 <= C;
+      if (dy) {
+        const float* src = dy + n * dsn + y * dsh + xx * dsw + c0;
+        if (whole) {
+          const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+          f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (c0 + e < C) f[e] = src[e];
+        }
+      }
+      if (gm) {
+        const float* src = gm + (n / S) * msn + y * msh + xx * msw + c0;
+        if (whole) {
+          const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+          f[0] += a.x * scale; f[1] += a.y * scale; f[2] += a.z * scale; f[3] += a.w * scale;
+          f[4] += b.x * scale; f[5] += b.y * scale; f[6] += b.z * scale; f[7] += b.w * scale;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (c0 + e < C) f[e] += src[e] * scale;
+        }
+      }
+      if (post) {
+        const float* ps = post + n * psn + y * psh + xx * psw + c0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c0 + e < C) f[e] *= act_gate(ps[e], act, slope);
+      }
+      u16 hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        split1(f[e], hi[e], lo[e]);
+        acc[e] += bf2f(hi[e]) + bf2f(lo[e]);          // (the sum of what the GEMMs will see, as colsum_split_kernel)
+      }
+      u16* o = out + q * 2 * Cp + c0;
+      *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(hi);
+      *reinterpret_cast<uint4*>(o + Cp) = *reinterpret_cast<const uint4*>(lo);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) smem[(pl * V + v) * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  if (pl == 0) {
+    for (int q = 1; q < PL; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += smem[(q * V + v) * 8 + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (c0 + e < Np) partial[(int64_t)blockIdx.x * Np + c0 + e] = (c0 + e < C) ? acc[e] : 0.f;
+  }
+  // (Np - Cp can be 8: the columns past the last vector)
+  if (threadIdx.x < Np - Cp) partial[(int64_t)blockIdx.x * Np + Cp + threadIdx.x] = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(partial)[(int64_t)Gmax * Np] = (int)gridDim.x;
+}
+
 // K order of the packed weights: k = slab*Ks + tap*cs + cl, channel = slab*CS + cl (cs = CS, or CSl in the last slab).  The streaming
 // kernel uses one slab of all (padded) channels (CS = Kp, Ks = Kt); the halo kernel cuts the channels into
 // slabs of CS <= 64 that fit in LDS with their halo (x_plan_k below decides, from (kchan, ks) alone).
@@ -2035,6 +2116,28 @@ extern "C" int wcmc_add_broadcast_split(const float* g, int64_t gsn, int64_t gsh
                      (hipStream_t)stream, g, gsn, gsh, gsw, gm, msn, msh, msw, scale, (u16*)out_split, S, H, W, C, Cp,
                      total);
   return check_launch("add_broadcast_split");
+}
+
+extern "C" int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw, const float* post, int64_t psn,
+                                         int64_t psh, int64_t psw, int act, float slope, const float* gm, int64_t msn,
+                                         int64_t msh, int64_t msw, int S, float scale, void* out_split, float* colsum_partial,
+                                         int N, int H, int W, int C, void* stream) {
+  WCMC_REQUIRE((dy || gm) && out_split && colsum_partial && N > 0 && S > 0 && H > 0 && W > 0 && C > 0 && C <= 2048,
+               WCMC_ERR_BAD_ARG, "split_dy_colsum_bf16: bad argument");
+  WCMC_REQUIRE(!gm || N % S == 0, WCMC_ERR_BAD_ARG, "split_dy_colsum_bf16: N must be a multiple of S");
+  WCMC_REQUIRE((!dy || nhwc_view_ok(dy, dsn, dsh, dsw, C)) && (!post || nhwc_view_ok(post, psn, psh, psw, C)) &&
+                   (!gm || nhwc_view_ok(gm, msn, msh, msw, C)) && aligned16(out_split),
+               WCMC_ERR_ALIGNMENT, "split_dy_colsum_bf16: a view violates the NHWC-view contract (or out unaligned)");
+  const int Cp = round_up(C, 8), Np = round_up(C, 16);
+  const int64_t M = (int64_t)N * H * W;
+  const int Gmax = x_colsum_rows(N, H, W);
+  int blocks = Gmax < 1024 ? Gmax : 1024;
+  const int64_t per_block = ceil_div64(M, blocks);
+  blocks = (int)ceil_div64(M, per_block);
+  hipLaunchKernelGGL(split_dy_colsum_kernel, dim3((unsigned)blocks), dim3(256), (size_t)256 * 8 * sizeof(float),
+                     (hipStream_t)stream, dy, dsn, dsh, dsw, post, psn, psh, psw, act, slope, gm, msn, msh, msw, S, scale,
+                     (u16*)out_split, H, W, C, Cp, M, per_block, colsum_partial, Np, Gmax);
+  return check_launch("split_dy_colsum_bf16");
 }
 
 extern "C" size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks) {

@@ -401,6 +401,21 @@ def split_gated_raw(dy, post, act):
     return out
 
 
+def split_dy_colsum_raw(dims, dy=None, post=None, act="linear", gm=None, s=1, scale=1.0):
+    """``split((dy [+ repeat_S(gm) * scale]) [* act'(post)])`` and the per-block column sums of the result in one pass
+    (wcmc_split_dy_colsum_bf16): the split gradient entering a chain's backward plus its last layer's bias-gradient
+    partials.  dims = (N, C, H, W) of the result."""
+    n, c, h, w = dims
+    dev = (dy if dy is not None else gm).device
+    out = _split_empty(n, c, h, w, dev)
+    part = torch.empty(lib().wcmc_conv2d_igemm_colsum_elems(n, h, w, c), device=dev, dtype=torch.float32)
+    z = (_ptr(None), 0, 0, 0)
+    check(lib().wcmc_split_dy_colsum_bf16(*(_v(dy) if dy is not None else z), *(_v(post) if post is not None else z), ACT[act],
+                                          LEAKY_SLOPE, *(_v(gm) if gm is not None else z), s, float(scale), _ptr(out), _ptr(part),
+                                          n, h, w, c, _stream()), "split_dy_colsum_bf16")
+    return out, part
+
+
 def unsplit_debug(t, n, c, h, w):
     """split tensor -> fp32 (N,C,H,W) with torch ops; test / debug only."""
     cp = (c + 7) // 8 * 8
@@ -584,9 +599,9 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
     return y
 
 
-def _chainx_backward(ctx, dy, need_dx, dys=None):
+def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
     """Shared backward: returns (dx as an fp32 NHWC view or None, [dw0, db0, dw1, db1, ...]).
-    dys: the output gradient already as a split tensor (linear output layers only)."""
+    dys: the output gradient already as a split tensor (linear output layers only); part: its column-sum partials."""
     ks, pad, acts = ctx.spec
     dims = ctx.dims
     nl = len(acts)
@@ -596,15 +611,18 @@ def _chainx_backward(ctx, dy, need_dx, dys=None):
     off = 2 * nl - 1
     if dys is None:
         dy = _as_nhwc_nograd(dy)
-        if acts[-1] != "linear":
+        gated = acts[-1] != "linear"
+        if FUSE_BIAS_GRAD:          # split + the last layer's bias-gradient partials in one pass over dy
+            dys, part = split_dy_colsum_raw(dims[nl], dy=dy, post=saved[off] if gated else None, act=acts[-1])
+        elif gated:
             dys = split_gated_raw(dy, saved[off], acts[-1])       # output-activation backward folded into the split
-            off += 1
         else:
             dys = split_raw(dy)
+        off += 1 if gated else 0
     else:
         assert acts[-1] == "linear"
     ws = saved[off:len(saved) - getattr(ctx, "n_extra", 0)]
-    part = None                     # per-tile column sums of dys when the dgrad GEMM produced them
+    # part: per-tile column sums of dys when the launch that produced dys left them
     grads = [None] * (2 * nl)
     dx = None
     main = torch.cuda.current_stream()
@@ -708,11 +726,14 @@ class _ChainSppMeanX(torch.autograd.Function):
         gy = _as_nhwc_nograd(gy) if gy is not None else None
         gm = _as_nhwc_nograd(gm) if gm is not None else None
         dev = (gy if gy is not None else gm).device
-        dys = _split_empty(bs, c, h, w, dev)
-        z = (_ptr(None), 0, 0, 0)
-        check(lib().wcmc_add_broadcast_split(*(_v(gy) if gy is not None else z), *(_v(gm) if gm is not None else z),
-                                             1.0 / s, _ptr(dys), bs // s, s, h, w, c, _stream()), "add_broadcast_split")
-        dx, grads = _chainx_backward(ctx, None, ctx.needs_input_grad[0], dys=dys)
+        if FUSE_BIAS_GRAD:
+            dys, part = split_dy_colsum_raw((bs, c, h, w), dy=gy, gm=gm, s=s, scale=1.0 / s)
+        else:
+            dys, part = _split_empty(bs, c, h, w, dev), None
+            z = (_ptr(None), 0, 0, 0)
+            check(lib().wcmc_add_broadcast_split(*(_v(gy) if gy is not None else z), *(_v(gm) if gm is not None else z),
+                                                 1.0 / s, _ptr(dys), bs // s, s, h, w, c, _stream()), "add_broadcast_split")
+        dx, grads = _chainx_backward(ctx, None, ctx.needs_input_grad[0], dys=dys, part=part)
         return (dx, None, None, *grads)
 
 
