@@ -144,3 +144,45 @@ def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
             f.write("%-60s relL2/err %.3e%s%s\n" % (name, e, "" if c is None else "  1-cos %.2e" % c,
                                                     "" if mx is None else "  max-norm %.2e" % mx))
     assert not fails, "\n".join(fails)
+
+
+def test_c2_vanilla_full_size_graphed_step_against_oracle():
+    """BASELINE configs[1]: KPCN-Vanilla (diffuse + specular, n_in = 34, no PathNet, no manifold loss), 128x128, batch 8 on one
+    MI355X, default switches, one hipGraph replay: loss scalars and denoised patches at 1e-3, gradients by relative L2."""
+    import types
+    from wcmc_amd import KPCN, ops
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.optim import FusedClipAdam
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import RelativeMSE
+    from wcmc_amd.synthetic import make_batch
+    assert ops.PRECISION == "bf16x3"
+    torch.manual_seed(11)
+    omod = {"dncnn": OKPCN(34)}
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for n, p in omod["dncnn"].named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.rand(p.shape, generator=g) * 0.2 - 0.1)
+    hmod = {"dncnn": KPCN(34)}
+    hmod["dncnn"].load_state_dict(omod["dncnn"].state_dict())
+    hmod["dncnn"].to(DEV)
+    oopt = {"optim_dncnn": torch.optim.Adam(omod["dncnn"].parameters(), lr=1e-4)}
+    hopt = {"optim_dncnn": torch.optim.Adam(hmod["dncnn"].parameters(), lr=1e-4)}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(), "l_test": RelativeMSE()}
+    itf = KPCNInterface(hmod, hopt, lf, types.SimpleNamespace(model_name="c2"), train_branches=True)
+    itf.fused_optim = FusedClipAdam(hmod, hopt)
+    itf.iters = 1
+    itf.to_train_mode()
+    batch = make_batch(8, 8, 128, seed=60, device="cpu", use_llpm=False)
+    dbatch = {k: v.to(DEV) for k, v in batch.items()}
+    step = GraphedTrainStep(itf, dbatch)
+    loss_o, out_o = ostep.train_step(omod, oopt, batch, dict(use_llpm_buf=False, manif_learn=False, train_branches=True), None)
+    step(dbatch)
+    torch.cuda.synchronize()
+    for k, v in loss_o.items():
+        np.testing.assert_allclose(step.losses[k].item(), v.item(), rtol=1e-3, err_msg=k)
+    for k in ("radiance", "diffuse", "specular"):
+        assert _max_rel(itf.last_out[k], out_o[k]) <= 1e-3, k
+    for (k, p), (_, q) in zip(hmod["dncnn"].named_parameters(), omod["dncnn"].named_parameters()):
+        assert_grad_close(p.grad.clamp(-1.0, 1.0), q.grad, what="C2 grad " + k, l2=GRAD_L2, cos=GRAD_COS)

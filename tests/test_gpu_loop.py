@@ -166,3 +166,20 @@ def test_tiled_inference_through_hip_validate_batch_matches_oracle_tiles():
         assert e <= 1e-3, "stitched %s P-buffer: %.3e" % (br, e)
     val = itf.get_epoch_summary(mode="eval", norm=len(coords))
     assert np.isfinite(val) and val > 0
+
+
+def test_launcher_main_runs_an_epoch_end_to_end(tmp_path, capsys):
+    """``python -m wcmc_amd.train_kpcn`` with the README's KPCN-Manifold command line (full-width KPCN and PathNets, 64x64
+    synthetic patches): init_data -> init_model -> train (one epoch, validation, both checkpoint files) in one call."""
+    from wcmc_amd import train_kpcn as tk
+    tk.main(["--single_gpu", "--batch_size", "2", "--val_epoch", "1", "--model_name", "KPCN_manifold_FMSE", "--desc",
+             "KPCN manifold FMSE", "--num_epoch", "1", "--manif_loss", "FMSE", "--lr_dncnn", "1e-4", "--lr_pnet", "1e-4",
+             "--use_llpm_buf", "--manif_learn", "--w_manif", "0.1", "--train_branches", "--save", str(tmp_path),
+             "--synthetic", "2", "--patch_size", "64", "--graph", "--pairing_rng", "device"])
+    out = capsys.readouterr().out
+    assert "[] Training complete!" in out and "Model KPCN_manifold_FMSE.pth saved at epoch 0." in out
+    assert "m_l_manif_diffuse" in out and "m_rmse" in out
+    ck = torch.load(str(tmp_path / "KPCN_manifold_FMSE.pth"), weights_only=False)
+    assert ck["start_epoch"] == 1 and 0 < ck["best_err"] < 1e9 and ck["args"].w_manif == [0.1]
+    assert os.path.isfile(str(tmp_path / "latest_KPCN_manifold_FMSE.pth"))
+    assert ck["model"].startswith("KPCN(")
