@@ -156,6 +156,10 @@ int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t dsh, int64_t
 size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks);
 int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
                                    void* stream);
+/* The same for up to 20 (layer, mode) pairs of one chain in ONE launch: w[i] OIHW (Cout[i], Cin[i], ks, ks) ->
+ * wp[i] (wcmc_conv2d_packed_elems_bf16x3(rows, kchan, ks) u16 each), mode[i] as above; host arrays of n_entries items. */
+int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* w, void* const* wp, const int* Cout,
+                                  const int* Cin, const int* mode, int ks, void* stream);
 /* Exactly one of y (fp32 NHWC view) and y_split (dense split tensor) receives the result.
  * gate_split (optional, geometry of the output, requires y_split): fused activation-derivative
  * mask evaluated from the hi plane of the post-activation tensor.

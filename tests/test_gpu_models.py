@@ -562,6 +562,7 @@ def test_nonfinite_loss_raises_and_skips_the_update():
 _SWITCHES = [
     ("attr", "FUSE_BIAS_GRAD", False, "close"),          # bias gradients by column-sum / finish launches (the chain heads' sums
                                                          # then group by colsum_split's blocks, not by the split pass's)
+    ("attr", "PACK_CHAIN", False, "exact"),              # two weight-packing launches per layer instead of one per chain
     ("attr", "USE_GATE_MASK", False, "close"),           # gate from the activation, not the 1-bit mask (and no fused 1x1
                                                          # dgrad pair: the bias sums group per tile, not per workgroup)
     ("attr", "FUSE_CHAIN_GLUE", False, "exact"),         # separate spp-mean / concat / upsample nodes

@@ -37,6 +37,7 @@ SIGNATURES = {
     "wcmc_split_dy_colsum_bf16": (I, [P, L, L, L, P, L, L, L, I, F, P, L, L, L, I, F, P, P, I, I, I, I, P]),
     "wcmc_conv2d_packed_elems_bf16x3": (Z, [I, I, I]),
     "wcmc_conv2d_pack_weight_bf16x3": (I, [P, P, I, I, I, I, P]),
+    "wcmc_conv2d_pack_chain_bf16x3": (I, [I, P, P, P, P, P, I, P]),
     "wcmc_conv2d_igemm_bf16x3": (I, [P, I, I, I, I, P, P, P, L, L, L, P, I, I, I, I, F, P, I, F, P, P, P, P]),
     "wcmc_conv1x1_pair_supported": (I, [I, I, I]),
     "wcmc_conv1x1_pair_bf16x3": (I, [P, I, I, I, I, P, P, I, I, F, P, P, P, I, F, P, P, P, I, I, F, P, L, L, L, P]),

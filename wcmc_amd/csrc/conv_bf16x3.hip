@@ -349,6 +349,40 @@ static XKPlan x_plan_k(int kchan, int ks) {
   q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
   return q;
 }
+// All weights of a chain, both orientations, in ONE launch: a table of up to 20 (layer, mode) entries by value; a block
+// finds its entry by its block range and runs pack_weight_split_kernel's body on it.  (114 packing launches of ~4 us per
+// step become 16.)
+constexpr int XPACK_MAX = 20;
+struct XPackEntry { const float* w; u16* wp; int Cout, Cin, mode, rows, Np, CS, Ks, Kt, nslabs, CSl; unsigned block0; };
+struct XPackTable { XPackEntry e[XPACK_MAX]; int n, ks; };
+__global__ __launch_bounds__(256) void pack_weight_split_multi_kernel(XPackTable t) {
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < t.n; ++i)
+    if (blockIdx.x >= t.e[i].block0) k = i;
+  const XPackEntry& q = t.e[k];
+  const int64_t idx = (int64_t)(blockIdx.x - q.block0) * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)q.Np * q.Kt) return;
+  const int n = (int)(idx / q.Kt), kk0 = (int)(idx - (int64_t)n * q.Kt);
+  int slab = kk0 / q.Ks;
+  if (slab > q.nslabs - 1) slab = q.nslabs - 1;
+  const int kk = kk0 - slab * q.Ks;
+  const int cs = slab == q.nslabs - 1 ? q.CSl : q.CS;
+  const int tap = kk / cs, cl = kk - tap * cs;
+  const int c = slab * q.CS + cl;
+  const int taps = t.ks * t.ks;
+  const int kchan = q.mode == 0 ? q.Cin : q.Cout;
+  float v = 0.f;
+  if (n < q.rows && tap < taps && c < kchan) {
+    if (q.mode == 0) v = q.w[((int64_t)n * q.Cin + c) * taps + tap];
+    else             v = q.w[((int64_t)c * q.Cin + n) * taps + (taps - 1 - tap)];
+  }
+  u16 hi, lo;
+  split1(v, hi, lo);
+  q.wp[((int64_t)n * 2) * q.Kt + kk0] = hi;
+  q.wp[((int64_t)n * 2 + 1) * q.Kt + kk0] = lo;
+}
+
 // rows of the per-tile column-sum buffer: enough for either kernel's tiling of (N, Ho, Wo)
 static int x_colsum_rows(int N, int Ho, int Wo) {
   const int64_t gl = ceil_div64((int64_t)N * Ho * Wo, 128);
@@ -2156,6 +2190,30 @@ extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout
   hipLaunchKernelGGL(pack_weight_split_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, mode, rows, Np, q.CS, q.Ks, q.Kt, q.nslabs, q.CSl);
   return check_launch("conv2d_pack_weight_bf16x3");
+}
+
+extern "C" int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* w, void* const* wp, const int* Cout,
+                                             const int* Cin, const int* mode, int ks, void* stream) {
+  WCMC_REQUIRE(n_entries > 0 && n_entries <= XPACK_MAX && w && wp && Cout && Cin && mode && ks > 0, WCMC_ERR_BAD_ARG,
+               "conv2d_pack_chain_bf16x3: bad argument (at most %d entries)", XPACK_MAX);
+  XPackTable t;
+  t.n = n_entries; t.ks = ks;
+  unsigned blocks = 0;
+  for (int i = 0; i < n_entries; ++i) {
+    WCMC_REQUIRE(w[i] && wp[i] && Cout[i] > 0 && Cin[i] > 0 && (mode[i] == 0 || mode[i] == 1), WCMC_ERR_BAD_ARG,
+                 "conv2d_pack_chain_bf16x3: bad entry %d", i);
+    XPackEntry& e = t.e[i];
+    e.w = w[i]; e.wp = (u16*)wp[i]; e.Cout = Cout[i]; e.Cin = Cin[i]; e.mode = mode[i];
+    e.rows = mode[i] == 0 ? Cout[i] : Cin[i];
+    const int kchan = mode[i] == 0 ? Cin[i] : Cout[i];
+    e.Np = round_up(e.rows, 16);
+    const XKPlan q = x_plan_k(kchan, ks);
+    e.CS = q.CS; e.Ks = q.Ks; e.Kt = q.Kt; e.nslabs = q.nslabs; e.CSl = q.CSl;
+    e.block0 = blocks;
+    blocks += (unsigned)ceil_div64((int64_t)e.Np * q.Kt, 256);
+  }
+  hipLaunchKernelGGL(pack_weight_split_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+  return check_launch("conv2d_pack_chain_bf16x3");
 }
 
 static int g_xigemm_dbuf = -1;      // WCMC_IGEMM_DBUF=0/1 (A/B switch); default: double buffer

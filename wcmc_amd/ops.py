@@ -435,6 +435,37 @@ def _pack_x(weight, mode):
     return wp
 
 
+# One packing launch per chain (all layers, both orientations: wcmc_conv2d_pack_chain_bf16x3) instead of two per layer:
+# 114 launches per step become 16.  WCMC_PACK_CHAIN=0: A/B switch back to per-layer packing (bit-identical either way).
+PACK_CHAIN = os.environ.get("WCMC_PACK_CHAIN", "1") != "0"
+
+
+def _pack_chain_x(weights, ks):
+    """[(wp_mode0, wp_mode1)] of the OIHW weights of one chain, packed by ONE launch."""
+    n = len(weights)
+    assert 2 * n <= 20
+    dev = weights[0].device
+    ws, outs, couts, cins, modes, keep = [], [], [], [], [], []
+    for wt in weights:
+        w = wt.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        keep.append(w)
+        cout, cin = w.shape[0], w.shape[1]
+        pair = []
+        for mode in (0, 1):
+            rows, kch = (cout, cin) if mode == 0 else (cin, cout)
+            wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks), device=dev, dtype=torch.int16)
+            ws.append(w.data_ptr()); outs.append(wp.data_ptr()); couts.append(cout); cins.append(cin); modes.append(mode)
+            pair.append(wp)
+        keep.append(pair)
+    m = len(ws)
+    arr_p, arr_i = ctypes.c_void_p * m, ctypes.c_int * m
+    check(lib().wcmc_conv2d_pack_chain_bf16x3(m, arr_p(*ws), arr_p(*outs), arr_i(*couts), arr_i(*cins), arr_i(*modes), ks,
+                                              _stream()), "conv2d_pack_chain_bf16x3")
+    return [keep[2 * i + 1] for i in range(n)]
+
+
 def _igemm_class(cin, cout, ks):
     """Profiler class of a split-bf16 GEMM launch = the kernel the library's plan picks for it
     (csrc/conv_bf16x3.hip: x_plan_k, x_pick_nt), so that a class average is one kernel's average."""
@@ -562,16 +593,19 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
     pair = (ks == 1 and pad == 0 and nl >= 2 and
             lib().wcmc_conv1x1_pair_supported(params[2 * nl - 4].shape[1], params[2 * nl - 4].shape[0],
                                               params[2 * nl - 2].shape[0]))
+    packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks) if PACK_CHAIN and 2 * nl <= 20 else None
+    ctx.wp1 = [pk[1] for pk in packs] if packs is not None else None      # the data-gradient orientation, for the backward
+    pack0 = (lambda l: packs[l][0]) if packs is not None else (lambda l: _pack_x(params[2 * l], 0))
     for l in range(nl):
         wt, b = params[2 * l], params[2 * l + 1]
         cout = wt.shape[0]
         if wt.shape[1] != dims[l][1]:
             raise RuntimeError("conv chain layer %d: weight expects %d input channels, got a tensor with %d"
                                % (l, wt.shape[1], dims[l][1]))
-        wp = _pack_x(wt, 0)
+        wp = pack0(l)
         hidden = l < nl - 1
         if pair and l == nl - 2:
-            xs1, mask1, _, y = conv1x1_pair_x_raw(xs[l], dims[l], wp, b.detach(), cout, acts[l], _pack_x(params[2 * l + 2], 0),
+            xs1, mask1, _, y = conv1x1_pair_x_raw(xs[l], dims[l], wp, b.detach(), cout, acts[l], pack0(l + 1),
                                                   params[2 * l + 3].detach(), params[2 * l + 2].shape[0], acts[l + 1])
             hh, ww = dims[l][2], dims[l][3]
             dims.append((n, cout, hh, ww))
@@ -628,6 +662,8 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
     main = torch.cuda.current_stream()
     side = _side_stream(dys.device)
     keep = []
+    wp1 = getattr(ctx, "wp1", None)
+    pack1 = (lambda l: wp1[l]) if wp1 is not None else (lambda l: _pack_x(ws[l], 1))
     for l in range(nl - 1, -1, -1):
         wt = ws[l]
         cout = wt.shape[0]
@@ -653,16 +689,16 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
             # the data gradients of layers 1 and 0 in one launch (PathNet.final: 3 -> 128 -> 128): the 128-channel
             # gradient of the hidden activation is written once (the weight gradient of layer 0 reads it) and feeds
             # the second GEMM from LDS
-            dys, _, part, dx = conv1x1_pair_x_raw(dys, dims[2], _pack_x(wt, 1), None, wt.shape[1], "linear",
-                                                  _pack_x(ws[0], 1), None, ws[0].shape[1], "linear",
+            dys, _, part, dx = conv1x1_pair_x_raw(dys, dims[2], pack1(1), None, wt.shape[1], "linear",
+                                                  pack1(0), None, ws[0].shape[1], "linear",
                                                   gate_mask=masks[0], gate_act=acts[0], colsum=True, mask_out=False)
         elif l > 0:
-            wpt = _pack_x(wt, 1)
+            wpt = pack1(l)
             g = dict(gate_mask=masks[l - 1]) if USE_GATE_MASK else dict(gate=xs[l])
             dys, part = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
                                      out_split=True, gate_act=acts[l - 1], colsum=True, **g)
         elif need_dx and dx is None:
-            wpt = _pack_x(wt, 1)
+            wpt = pack1(l)
             dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
                               out_split=False)
     if side is not None:
