@@ -1,0 +1,45 @@
+"""Wall-clock timeline of the halo-resident 5x5 kernel's workgroups (s_memrealtime stamps of the debug build):
+   make -C wcmc_amd/csrc debug; WCMC_DEBUG_LIB=1 WCMC_DEBUG_ABLATE=64 python3 scripts/timeline_halo.py [h ...]
+Per workgroup: entry -> stage loop -> end of loop -> exit, and the CU it ran on; prints the round structure of a launch."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from wcmc_amd import ops as o
+assert os.environ.get("WCMC_DEBUG_ABLATE") == "64"
+dev = "cuda"
+n, cin, cout, ks = 8, 100, 100, 5
+for h in [int(a) for a in sys.argv[1:]] or [124, 116, 100]:
+    x = o.to_nhwc_raw(torch.randn(n, cin, h, h, device=dev))
+    w = torch.randn(cout, cin, ks, ks, device=dev) * 0.02
+    b = torch.zeros(cout, device=dev)
+    xs = o.split_raw(x); wp = o._pack_x(w, 0)
+    for _ in range(3):
+        y, part = o.conv2d_x_raw(xs, (n, cin, h, h), wp, b, cout, ks, 0, "relu", out_split=True, colsum=True)
+    torch.cuda.synchronize()
+    ho = h - ks + 1
+    tiles, nw = n * ((ho + 7) // 8) * ((ho + 15) // 16), 4
+    st = part.cpu().numpy().view(np.uint64)[: tiles * nw * 14].reshape(tiles, nw, 14)
+    rt = st[:, :, 6:13].astype(np.float64) * 0.01          # us: entry, loop start, loop end, E0, E1, E2, exit
+    t0 = rt[:, :, 0].min()
+    rt -= t0
+    hw = st[:, 0, 13]
+    cu = ((hw >> 32) & 0xf) * 1024 + ((hw >> 13) & 7) * 64 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xf)
+    ent, lp0, lp1, ex = rt[:, :, 0].min(1), rt[:, :, 1].max(1), rt[:, :, 2].max(1), rt[:, :, 6].max(1)
+    e0, e1, e2 = rt[:, :, 3].max(1), rt[:, :, 4].max(1), rt[:, :, 5].max(1)
+    print("h=%d: %d tiles on %d CUs, launch span %.1f us (entry of the first workgroup -> exit of the last)" %
+          (h, tiles, len(np.unique(cu)), ex.max()))
+    first = ent < 5.0
+    for nm, m in (("round 1 (entry < 5 us)", first), ("later", ~first)):
+        if m.sum() == 0:
+            continue
+        print("  %-22s %4d tiles: entry %6.1f..%6.1f  prologue %5.1f  loop %5.1f  epilogue %5.1f  exit %6.1f..%6.1f (mean %.1f)" %
+              (nm, m.sum(), ent[m].min(), ent[m].max(), (lp0 - ent)[m].mean(), (lp1 - lp0)[m].mean(), (ex - lp1)[m].mean(),
+               ex[m].min(), ex[m].max(), ex[m].mean()))
+        print("      epilogue: drain+barrier %.1f  act/split -> LDS %.1f  store issue %.1f  store drain %.1f" %
+              ((e0 - lp1)[m].mean(), (e1 - e0)[m].mean(), (e2 - e1)[m].mean(), (ex - e2)[m].mean()))
+    # occupancy over time: how many workgroups are inside their stage loop
+    grid = np.arange(0, ex.max(), 5.0)
+    inloop = [(int(((lp0 <= t) & (lp1 > t)).sum()), int(((ent <= t) & (ex > t)).sum())) for t in grid]
+    print("  t (us): in-loop/resident  " + "  ".join("%d:%d/%d" % (t, a, r) for t, (a, r) in zip(grid, inloop)))
+    per = np.bincount(np.unique(cu, return_inverse=True)[1])
+    print("  tiles per CU: min %d max %d" % (per.min(), per.max()))

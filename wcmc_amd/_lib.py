@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwcmc_hip.so")
 if os.environ.get("WCMC_DEBUG_LIB") == "1":      # `make -C wcmc_amd/csrc debug`: + timing-only ablation / stamp instances
     LIB_PATH = os.path.join(_HERE, "libwcmc_hip_debug.so")
+if os.environ.get("WCMC_LIB_AB"):                # A/B timing of two builds (scripts/): a file name next to the product library
+    LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ["WCMC_LIB_AB"]))
 
 _c = ctypes
 P, I, L, F, D, Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_double, _c.c_size_t

@@ -404,6 +404,7 @@ constexpr int XROW = 32;   // bf16 per LDS row
 constexpr unsigned XOOB = 0x80000000u;   // byte offset beyond any buffer (num_records < 2 GiB)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // bit e = (bf16 number e of the vector is > 0): the activation-derivative predicate of act_gate on a hi plane
 __device__ __forceinline__ unsigned char positive_mask8(const u32x4 v) {
@@ -416,6 +417,13 @@ __device__ __forceinline__ unsigned char positive_mask8(const u32x4 v) {
   }
   return (unsigned char)m;
 }
+
+// activation as selects (bit-identical to act_apply, no branches inside an unrolled epilogue)
+struct XAct { float ns; bool zero; };
+__device__ __forceinline__ XAct x_act(int act, float slope) {
+  return XAct{act == WCMC_ACT_LEAKY_RELU ? slope : 1.f, act == WCMC_ACT_RELU};
+}
+__device__ __forceinline__ float x_act_apply(float v, XAct a) { return v > 0.f ? v : (a.zero ? 0.f : v * a.ns); }
 
 struct XIgemmParams {
   const u16* x; int N, H, W, Cin, Cpi;
@@ -545,7 +553,17 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
 
   // DBG & 64: in-kernel stamps (s_memtime) accumulate per-phase cycles of every wave into p.colsum
   // reinterpreted as u64 [tile][wave][8] (diagnostic build: read the shares, not the run time).
-  unsigned long long st_prev = 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = 0, st_acc[6] = {0, 0, 0, 0, 0, 0}, st_rt[7] = {0, 0, 0, 0, 0, 0, 0};
+  auto rstamp = [&](int i) {                   // (stamp builds) wall clock, 100 MHz: kernel entry / loop start / loop end / exit
+    if (DBG & 64) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      st_rt[i] = t;
+    }
+  };
+  rstamp(0);
   auto stamp = [&](int i) {
     if (DBG & 64) {
       unsigned long long t;
@@ -878,7 +896,17 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 #pragma unroll
   for (int j = 0; j < NT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  unsigned long long st_prev = 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = 0, st_acc[6] = {0, 0, 0, 0, 0, 0}, st_rt[7] = {0, 0, 0, 0, 0, 0, 0};
+  auto rstamp = [&](int i) {                   // (stamp builds) wall clock, 100 MHz: kernel entry / loop start / loop end / exit
+    if (DBG & 64) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      st_rt[i] = t;
+    }
+  };
+  rstamp(0);
   auto stamp = [&](int i) {
     if (DBG & 64) {
       unsigned long long t;
@@ -937,6 +965,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 #pragma unroll
   for (int j = 0; j < NT; ++j) read_b(0, j);
   int s_in = 0, slab = 0, bcur = 0;
+  rstamp(1);
   stamp(-1);
   for (int g = 0; g < nstages; ++g) {
     const int b1 = bcur + 1 == NB ? 0 : bcur + 1;      // buffer of stage g+1; stage g's fragments are in registers
@@ -995,8 +1024,61 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     }
     stamp(3);                                // tail of the stage (slab boundaries included: halo wait + barrier + re-read)
   }
+  // ---- epilogue operands: the bias of this lane's couts and the gate of its (pixel, cout) quads, as ONE batch of
+  // unconditional buffer loads (out of range -> 0) issued before the drain.  (The first version loaded them one by one
+  // inside the per-element branches: 56 global loads, each with its own full wait -- 11-12 us of a ~105 us tile.)
+  const int fq = kg * 4;
+  auto pix_of = [&](int pr, int& oy, int& ox) {
+    const int pt = pr >> 4;
+    oy = oy0 + pt / TPR; ox = ox0 + (pt % TPR) * 16 + (pr & 15);
+    return oy < p.Ho && ox < p.Wo;
+  };
+  float bv[NT][4];
+  {
+    const __amdgpu_buffer_rsrc_t brs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.wp), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        bv[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (n0 + j * 16 + fq + e) * 4, 0, 0));
+  }
+  const bool use_gate = p.ys && p.gate, use_mask = p.ys && !p.gate && p.gate_mask && p.gate_act != WCMC_ACT_LINEAR;
+  u32x2 gv[2][NT];                             // split gate: 4 hi-plane bf16 per quad; bit mask: one byte in .x
+  bool okp[2]; int64_t mp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int oy, ox;
+    okp[i] = pix_of(wave * 32 + i * 16 + frow, oy, ox);
+    mp[i] = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+  }
+  if (use_gate) {
+    const int64_t gbytes = (int64_t)p.N * p.Ho * p.Wo * 4 * p.Cpo;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gate, 0, (int)(gbytes < 0x7fffffff ? gbytes : 0x7fffffff), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + fq;
+        gv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(grs, (okp[i] && co < p.Cpo) ? (unsigned)((mp[i] * 2 * p.Cpo + co) * 2) : XOOB, 0, 0);
+      }
+  } else if (use_mask) {
+    const int64_t mbytes = (int64_t)p.N * p.Ho * p.Wo * (p.Cpo >> 3);
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gate_mask, 0, (int)mbytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + fq;
+        gv[i][j].x = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(mrs, (okp[i] && co < p.Cpo) ? (unsigned)(mp[i] * (p.Cpo >> 3) + (co >> 3)) : XOOB, 0, 0);
+      }
+  }
+  const XAct ak = x_act(p.act, p.slope);
+  const float gate_off = p.gate_act == WCMC_ACT_RELU ? 0.f : p.gate_act == WCMC_ACT_LEAKY_RELU ? p.gate_slope : 1.f;
+  rstamp(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (zero) weight stages past the end have landed:
   __syncthreads();                                     // LDS is free for the epilogue staging
+  rstamp(3);
   if ((DBG & 32) && !(DBG & 64)) {                     // timing only: no epilogue (one store keeps the accumulators alive)
     float keep = 0.f;
 #pragma unroll
@@ -1007,55 +1089,44 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
   }
   if (DBG & 64) {
     if (lane == 0) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * NWV + wave) * 8;
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * NWV + wave) * 14;
       for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
-      o[6] = st_prev;
+      for (int i = 0; i < 3; ++i) o[6 + i] = st_rt[i];
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      o[13] = hw | ((unsigned long long)xcc << 32);
     }
   }
 
   // ---- epilogue (as the streaming kernel; pixels of the tile outside the image are written as zeros to LDS
   // and skipped on the way out).  Tile-local pixel pr = 16 * pixel-tile + column.
-  const int fq = kg * 4;
-  auto pix_of = [&](int pr, int& oy, int& ox) {
-    const int pt = pr >> 4;
-    oy = oy0 + pt / TPR; ox = ox0 + (pt % TPR) * 16 + (pr & 15);
-    return oy < p.Ho && ox < p.Wo;
-  };
   if (p.ys) {
     constexpr int OLD = 2 * BN + 8;
     u16* so = smem16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pr = wave * 32 + i * 16 + frow;
-      int oy, ox;
-      const bool ok = pix_of(pr, oy, ox);
-      const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
-      const u16* gp = (p.gate && ok) ? p.gate + m * 2 * p.Cpo : nullptr;
+      const bool ok = okp[i];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = n0 + j * 16 + fq;
         float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (ok && co + e < p.Cout) {
-            if (p.bias) v[e] += p.bias[co + e];
-            v[e] = act_apply(v[e], p.act, p.slope);
-          } else {
-            v[e] = 0.f;
-          }
+          const float t = x_act_apply(p.bias ? v[e] + bv[j][e] : v[e], ak);
+          v[e] = (ok && co + e < p.Cout) ? t : 0.f;
         }
-        if (gp && co < p.Cpo) {
-          const uint2 g2 = *reinterpret_cast<const uint2*>(gp + co);
-          const u16 g[4] = {(u16)(g2.x & 0xffff), (u16)(g2.x >> 16), (u16)(g2.y & 0xffff), (u16)(g2.y >> 16)};
+        if (use_gate) {                              // (a quad outside the tensor read zeros: its values are zeros too)
+          const unsigned g[4] = {gv[i][j].x & 0xffffu, gv[i][j].x >> 16, gv[i][j].y & 0xffffu, gv[i][j].y >> 16};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= act_gate(bf2f(g[e]), p.gate_act, p.gate_slope);
-        }
-        else if (p.gate_mask && ok && co < p.Cpo && p.gate_act != WCMC_ACT_LINEAR) {
+          for (int e = 0; e < 4; ++e) v[e] *= bf2f((u16)g[e]) > 0.f ? 1.f : gate_off;
+        } else if (use_mask) {
           // the same predicate (hi plane > 0) from the bit mask the producing launch left: 1/16 of the bytes
-          const unsigned bits = (unsigned)p.gate_mask[m * (p.Cpo >> 3) + (co >> 3)] >> (co & 7);
-          const float off = p.gate_act == WCMC_ACT_LEAKY_RELU ? p.gate_slope : 0.f;
+          const unsigned bits = gv[i][j].x >> (co & 7);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : off;
+          for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : gate_off;
         }
         u16 hi[4], lo[4];
 #pragma unroll
@@ -1067,6 +1138,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
       }
     }
     __syncthreads();
+    rstamp(4);
     constexpr int VPP = BN / 8;
     for (int v = tid; v < TPX * 2 * VPP; v += NTHR) {
       const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
@@ -1080,6 +1152,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
         if (p.mask_out && plane == 0) p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
       }
     }
+    rstamp(5);
     if (!(DBG & 64) && p.colsum) {
       constexpr int CW = BN <= 16 ? 16 : BN <= 32 ? 32 : BN <= 64 ? 64 : 128, RG = NTHR / CW;
       float* red = reinterpret_cast<float*>(so + TPX * OLD);
@@ -1108,12 +1181,8 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
         float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (co + e < p.Cout) {
-            if (p.bias) v[e] += p.bias[co + e];
-            v[e] = act_apply(v[e], p.act, p.slope);
-          } else {
-            v[e] = 0.f;
-          }
+          const float t = x_act_apply(p.bias ? v[e] + bv[j][e] : v[e], ak);
+          v[e] = co + e < p.Cout ? t : 0.f;
         }
         *reinterpret_cast<float4*>(so + pr * OLD + j * 16 + fq) = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -1127,6 +1196,14 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
       if (pix_of(pr, oy, ox) && co < p.Cpo)
         *reinterpret_cast<float4*>(p.yf + (int64_t)img * p.ysn + (int64_t)oy * p.ysh + (int64_t)ox * p.ysw + co) =
             *reinterpret_cast<const float4*>(so + pr * OLD + vec * 4);
+    }
+  }
+  if (DBG & 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the stores have left)
+    rstamp(6);
+    if (lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * NWV + wave) * 14;
+      for (int i = 3; i < 7; ++i) o[6 + i] = st_rt[i];
     }
   }
 }
@@ -1147,7 +1224,6 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 // U = 16-byte units per input pixel (2 planes x Cpi / 8).
 // LDS stores the compiler does not see as such: behind an LDS-DMA it orders every ds_write it knows of with
 // vmcnt(0) (write-after-write on LDS it cannot disambiguate).  The staging tile never overlaps the ring.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void pw_lds_store_b64(unsigned addr, u32x2 v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -2297,9 +2373,9 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   WCMC_REQUIRE(lds <= 160 * 1024, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: halo tile does not fit in LDS");
 #ifdef WCMC_DEBUG_BUILD
   if (NT == 7 && p.PXS == 160 && p.ks == 5) {
-    static int ab = -1;
-    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
-    if (ab == 1 || ab == 2 || ab == 8 || ab == 16 || ab == 10 || ab == 26 || ab == 18 || ab == 27 || ab == 31 || ab == 59 || ab == 63 || ab == 32) {
+    int ab;                             // (read per call: scripts interleave the modes inside one process)
+    { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    if (ab == 1 || ab == 2 || ab == 4 || ab == 8 || ab == 16 || ab == 10 || ab == 26 || ab == 18 || ab == 27 || ab == 31 || ab == 59 || ab == 63 || ab == 32) {
       // timing only (WRONG results): 1 = no MFMA, 2 = no weight DMA in the stage loop, 8 = no fragment reads, 16 = no stage
       // barrier, 4 = one halo per tile (no slab reloads), 32 = no epilogue; sums combine (27 = empty stage loop)
       constexpr int TH8 = 8;
@@ -2307,7 +2383,7 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
       q.tilesY = (p.Ho + TH8 - 1) / TH8;
       const size_t halo8 = (size_t)(((TH8 + p.ks - 1) * (TW + p.ks - 1) * p.PXS + 127) & ~127);
       const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)((q.Np / 16 + NT - 1) / NT));
-      auto kfn = ab == 1 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 1, 2> : ab == 2 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 2, 2>
+      auto kfn = ab == 4 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 4, 2> : ab == 1 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 1, 2> : ab == 2 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 2, 2>
                  : ab == 8 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 8, 2> : ab == 16 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 16, 2>
                  : ab == 10 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 10, 2> : ab == 18 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 18, 2>
                  : ab == 27 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 27, 2> : ab == 31 ? &conv_halo_bf16x3_kernel<7, TH8, TW, 31, 2>
