@@ -17,7 +17,8 @@ for h in [int(a) for a in sys.argv[1:]] or [124, 116, 100]:
         y, part = o.conv2d_x_raw(xs, (n, cin, h, h), wp, b, cout, ks, 0, "relu", out_split=True, colsum=True)
     torch.cuda.synchronize()
     ho = h - ks + 1
-    tiles, nw = n * ((ho + 7) // 8) * ((ho + 15) // 16), 4
+    th = 16 if os.environ.get("WCMC_HALO64", "1") != "0" else 8      # conv_halo64: 16x16 tiles; conv_halo<7,8,16>: 8x16
+    tiles, nw = n * ((ho + th - 1) // th) * ((ho + 15) // 16), 4
     st = part.cpu().numpy().view(np.uint64)[: tiles * nw * 14].reshape(tiles, nw, 14)
     rt = st[:, :, 6:13].astype(np.float64) * 0.01          # us: entry, loop start, loop end, E0, E1, E2, exit
     t0 = rt[:, :, 0].min()
@@ -35,8 +36,12 @@ for h in [int(a) for a in sys.argv[1:]] or [124, 116, 100]:
         print("  %-22s %4d tiles: entry %6.1f..%6.1f  prologue %5.1f  loop %5.1f  epilogue %5.1f  exit %6.1f..%6.1f (mean %.1f)" %
               (nm, m.sum(), ent[m].min(), ent[m].max(), (lp0 - ent)[m].mean(), (lp1 - lp0)[m].mean(), (ex - lp1)[m].mean(),
                ex[m].min(), ex[m].max(), ex[m].mean()))
-        print("      epilogue: drain+barrier %.1f  act/split -> LDS %.1f  store issue %.1f  store drain %.1f" %
-              ((e0 - lp1)[m].mean(), (e1 - e0)[m].mean(), (e2 - e1)[m].mean(), (ex - e2)[m].mean()))
+        if th == 8:
+            print("      epilogue: drain+barrier %.1f  act/split -> LDS %.1f  store issue %.1f  store drain %.1f" %
+                  ((e0 - lp1)[m].mean(), (e1 - e0)[m].mean(), (e2 - e1)[m].mean(), (ex - e2)[m].mean()))
+        else:
+            print("      epilogue: operand loads + drain + barrier %.1f  two halves (act/split -> LDS -> stores) %.1f  store drain %.1f" %
+                  ((e0 - lp1)[m].mean(), (e2 - e0)[m].mean(), (ex - e2)[m].mean()))
     # occupancy over time: how many workgroups are inside their stage loop
     grid = np.arange(0, ex.max(), 5.0)
     inloop = [(int(((lp0 <= t) & (lp1 > t)).sum()), int(((ent <= t) & (ex > t)).sum())) for t in grid]

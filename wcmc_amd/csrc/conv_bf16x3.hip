@@ -321,6 +321,15 @@ static XKPlan x_plan_k(int kchan, int ks) {
   XKPlan q;
   q.Kp = round_up(kchan, 8);
   q.halo = enable && ks >= 3 && ks <= 5 && q.Kp >= 32;
+  if (q.halo && ks == 5 && x_env_on("WCMC_HALO64")) {
+    // conv_halo64_bf16x3_kernel: slabs of 16 channels (the last one 8 or 16), halo pixel stride 80 B, two taps per stage
+    q.nslabs = (q.Kp + 15) / 16;
+    q.CS = 16; q.CSl = q.Kp - (q.nslabs - 1) * 16;
+    q.PXS = 80;
+    q.Ks = round_up(ks * ks * q.CS, 32); q.Ksl = round_up(ks * ks * q.CSl, 32);
+    q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
+    return q;
+  }
   const int th8 = x_env_on("WCMC_HALO_TH8_5X5");   // =0: A/B switch back to 16x16 tiles with 56/48-channel slabs
   if (q.halo && th8 && ks == 5 && (q.Kp % 32 == 0 || q.Kp % 32 == 8)) {
     // slabs of 32 channels, the last one 32 or 40: halo pixel stride 160 B (10 units = 2 mod 4), 38 KB for a 12x20 halo
@@ -1208,6 +1217,378 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
   }
 }
 
+
+// ------------------------------------------------------------------ implicit GEMM, halo-resident, 64 pixels per wave
+// Interleaved timing ablations of the kernel above (scripts/time_halo_abl.py, 175 us): without the weight stream of the
+// stage loop 156, without fragment reads 160, without both 135 -- per 32-k stage a workgroup of 128 pixels moves 86 KB
+// through LDS (14 KB of weights in, the same 14 KB out again to EACH of its four waves, 16 KB of pixels) for 168 MFMAs
+// and waits for a weight stage that was requested only one stage earlier.  This variant halves the LDS traffic and the
+// weight stream per MFMA: a wave owns FOUR pixel tiles (64 pixels x all NT*16 couts: 22 KB of fragments for 12*NT MFMAs),
+// a workgroup is four waves on a 16x16 tile, and two workgroups still share a CU (independent stage barriers) because
+// the channel slab is thinner: 16 channels (the last one 8 or 16), pixel stride 80 B, 32 KB for the 20x20 halo.  A 32-k
+// stage is then TWO filter taps x 16 channels (four taps x 8 in an 8-channel slab): k-group kg of the lanes reads tap
+// 2s + (kg >> 1); taps past ks*ks are slab padding (zero weights) and read the tile's first pixel.
+// Wave w owns tile rows w, w+4, w+8, w+12 (a tile that hangs over the image edge idles every wave equally).
+template <int NT, int NB, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams p) {
+  constexpr int BN = NT * 16, TH = 16, TW = 16, NTHR = 256, NWV = 4, PT = 4;
+  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
+  constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
+  const int HWd = TW + p.ks - 1, HHt = TH + p.ks - 1, HP = HWd * HHt;
+  char* const halo = reinterpret_cast<char*>(smem16);
+  u16* const bsm = smem16 + ((HP * p.PXS + 127) & ~127) / 2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // DBG (debug library, timing only, WRONG results): 1 no MFMA, 2 no weight DMA in the stage loop, 4 one halo per tile,
+  // 8 no fragment reads, 32 no epilogue; 64 = wall-clock stamps (scripts/timeline_halo.py)
+  unsigned long long st_rt[7] = {0, 0, 0, 0, 0, 0, 0};
+  auto rstamp = [&](int i) {
+    if (DBG & 64) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      st_rt[i] = t;
+    }
+  };
+  rstamp(0);
+  int tile;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tpi = p.tilesX * p.tilesY;
+  const int img = tile / tpi, trem = tile - img * tpi;
+  const int oy0 = (trem / p.tilesX) * TH, ox0 = (trem % p.tilesX) * TW;
+  const int n0 = blockIdx.y * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  const int pixb = 4 * p.Cpi;
+
+  // ---- halo: [pixel][hi cs][lo cs] at stride PXS, one linear run of 16-byte vectors filled by LDS-DMA
+  const int VP = p.PXS / 16;
+  const int hvecs = HP * VP;
+  const float invVP = 1.0f / (float)VP, invHW = 1.0f / (float)HWd;
+  auto dma_halo = [&](int slab) {
+    const int V = (slab == p.nslabs - 1 ? p.CSl : p.CS) / 4;      // data vectors per halo pixel (2 planes x cs/8)
+    for (int ii = wave; ii * 64 < hvecs; ii += NWV) {
+      const int v = ii * 64 + lane;
+      if (v < hvecs) {
+        const int px = (int)(((float)v + 0.5f) * invVP), part = v - px * VP;     // exact: v < 2^13
+        const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
+        const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+        const int plane = part >= (V >> 1), vec = part - plane * (V >> 1);
+        const int ch = slab * p.CS + vec * 8;
+        unsigned off = XOOB;
+        if (part < V && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Cpi)
+          off = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb + plane * 2 * p.Cpi + ch * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(halo + ii * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- weights: LDS-DMA ring of NB stages, as in the kernel above (row group = 16 cout rows x 64 B per plane)
+  const int nstages = p.Kt / XKC;
+  constexpr int NGMAX = (NT + NWV - 1) / NWV;
+  const int ngroups = wave < NT ? (NT - wave + NWV - 1) / NWV : 0;       // wave-uniform
+  unsigned dbase[NGMAX];
+#pragma unroll
+  for (int q = 0; q < NGMAX; ++q) {
+    const int drow = 16 * (wave + q * NWV) + (lane >> 2);
+    const int dvq = (lane & 3) ^ ((drow >> 1) & 3);
+    dbase[q] = (q < ngroups && n0 + drow < p.Np) ? (unsigned)(((n0 + drow) * 2 * p.Kt + dvq * 8) * 2) : XOOB;
+  }
+  auto dma_b = [&](int g, int buf) {
+#pragma unroll
+    for (int q = 0; q < NGMAX; ++q) {
+      if (q < ngroups) {
+        const unsigned kill = g < nstages ? 0u : XOOB;
+        const unsigned db = dbase[q];
+        const unsigned off = (db + (unsigned)(g * XKC * 2)) | kill;
+        const unsigned off2 = db >= XOOB ? XOOB : (off + (unsigned)(p.Kt * 2)) | kill;
+        u16* d = bsm + buf * B_ELEMS + 16 * (wave + q * NWV) * XROW;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, off2, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[NT][PT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < PT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragments: lane = pixel column (lane & 15) of its four tile rows, k group kg = lane >> 4 (8 k each)
+  const int frow = lane & 15, kg = lane >> 4;
+  const int fslot = (kg ^ ((frow >> 1) & 3)) * 8;
+  int abase[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) abase[i] = ((wave + NWV * i) * HWd + frow) * p.PXS;
+  // this lane's (tap, channel) of the stage whose A fragments are read next
+  int cs_cur, sps_cur, lo_off, tps, coff, tdx, tdy;
+  auto slab_begin = [&](int slab) {
+    cs_cur = slab == p.nslabs - 1 ? p.CSl : p.CS;
+    sps_cur = slab == p.nslabs - 1 ? p.SPSl : p.SPS;
+    lo_off = cs_cur * 2;
+    tps = 32 / cs_cur;                                   // taps per stage: 2 (16 channels) or 4 (8)
+    coff = ((kg * 8) & (cs_cur - 1)) * 2;
+    tdy = 0; tdx = cs_cur == 16 ? (kg >> 1) : kg;        // (< ks)
+  };
+  bf16x8 ah[PT], al[PT], wh[NT], wl[NT];
+  auto a_off = [&]() { return tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + coff : coff; };
+  auto a_advance = [&]() { tdx += tps; if (tdx >= p.ks) { tdx -= p.ks; ++tdy; } };
+  auto read_a1 = [&](int i, int aoff) {
+    ah[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
+    al[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
+  };
+  const u16* const bfrag = bsm + frow * XROW + fslot;
+  auto read_b = [&](int buf, int j) {
+    wh[j] = *reinterpret_cast<const bf16x8*>(bfrag + buf * B_ELEMS + j * 16 * XROW);
+    wl[j] = *reinterpret_cast<const bf16x8*>(bfrag + buf * B_ELEMS + B_LO + j * 16 * XROW);
+  };
+
+#pragma unroll
+  for (int b = 0; b < NB; ++b) dma_b(b, b);
+  dma_halo(0);
+  slab_begin(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const int aoff = a_off();
+#pragma unroll
+    for (int i = 0; i < PT; ++i) read_a1(i, aoff);
+    a_advance();
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) read_b(0, j);
+  int s_in = 0, slab = 0, bcur = 0;
+  rstamp(1);
+  for (int g = 0; g < nstages; ++g) {
+    const int b1 = bcur + 1 == NB ? 0 : bcur + 1;      // buffer of stage g+1; stage g's fragments are in registers
+    if (NGMAX == 1 || ngroups < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NB - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 2)) : "memory");
+    pw_barrier();                                // stage g+1 has landed for everyone; everyone has read stage g's fragments
+    if (!(DBG & 2)) dma_b(g + NB, bcur);
+    bcur = b1;
+    const bool last_of_slab = (s_in + 1 == sps_cur);
+    if (last_of_slab && slab + 1 < p.nslabs && !(DBG & 4)) dma_halo(slab + 1);      // (no wave reads the halo during a slab's last stage)
+    const int aoff = a_off();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        if (!(DBG & 1)) {
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
+        }
+        // the pixel tile's fragments of stage g+1 replace it as soon as its last MFMAs of this stage have issued
+        if (j == NT - 1 && !last_of_slab && !(DBG & 8)) read_a1(i, aoff);
+      }
+      if (!(DBG & 8)) read_b(b1, j);             // stage g+1, same cout tile, into the registers just consumed
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!last_of_slab) {
+      a_advance();
+      ++s_in;
+    } else {                                     // slab boundary: the next A fragments come from the next halo
+      s_in = 0;
+      ++slab;
+      slab_begin(slab < p.nslabs ? slab : p.nslabs - 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the new halo (and of the weight ring)
+      __syncthreads();
+      const int a2 = a_off();
+#pragma unroll
+      for (int i = 0; i < PT; ++i) read_a1(i, a2);
+      a_advance();
+    }
+  }
+  rstamp(2);
+  if ((DBG & 32) && !(DBG & 64)) {                     // timing only: no epilogue (one store keeps the accumulators alive)
+    float keep = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < PT; ++i) keep += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+    if (keep == 12345.678f && p.ys) p.ys[0] = 1;
+    return;
+  }
+  // ---- epilogue operands (one batch of unconditional buffer loads, issued before the drain)
+  const int fq = kg * 4;
+  float bv[NT][4];
+  {
+    const __amdgpu_buffer_rsrc_t brs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.wp), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        bv[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (n0 + j * 16 + fq + e) * 4, 0, 0));
+  }
+  const bool use_gate = p.ys && p.gate, use_mask = p.ys && !p.gate && p.gate_mask && p.gate_act != WCMC_ACT_LINEAR;
+  u32x2 gv[PT][NT];                            // split gate: 4 hi-plane bf16 per quad; bit mask: one byte in .x
+  bool okp[PT]; int64_t mp[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int oy = oy0 + wave + NWV * i, ox = ox0 + frow;
+    okp[i] = oy < p.Ho && ox < p.Wo;
+    mp[i] = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+  }
+  if (use_gate) {
+    const int64_t gbytes = (int64_t)p.N * p.Ho * p.Wo * 4 * p.Cpo;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gate, 0, (int)(gbytes < 0x7fffffff ? gbytes : 0x7fffffff), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + fq;
+        gv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(grs, (okp[i] && co < p.Cpo) ? (unsigned)((mp[i] * 2 * p.Cpo + co) * 2) : XOOB, 0, 0);
+      }
+  } else if (use_mask) {
+    const int64_t mbytes = (int64_t)p.N * p.Ho * p.Wo * (p.Cpo >> 3);
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gate_mask, 0, (int)mbytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + fq;
+        gv[i][j].x = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(mrs, (okp[i] && co < p.Cpo) ? (unsigned)(mp[i] * (p.Cpo >> 3) + (co >> 3)) : XOOB, 0, 0);
+      }
+  }
+  const XAct ak = x_act(p.act, p.slope);
+  const float gate_off = p.gate_act == WCMC_ACT_RELU ? 0.f : p.gate_act == WCMC_ACT_LEAKY_RELU ? p.gate_slope : 1.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (zero) weight stages past the end have landed:
+  __syncthreads();                                     // LDS is free for the epilogue staging
+  rstamp(3);
+
+  // ---- epilogue in two halves of 128 pixels (the staging tile of 256 split pixels would not fit beside a second
+  // workgroup): half h = pixel tiles 2h, 2h+1 of every wave; staging row pr = 32 * wave + 16 * (i & 1) + column
+  auto pix_of = [&](int h, int pr, int& oy, int& ox) {
+    oy = oy0 + (pr >> 5) + NWV * (2 * h + ((pr >> 4) & 1)); ox = ox0 + (pr & 15);
+    return oy < p.Ho && ox < p.Wo;
+  };
+  if (p.ys) {
+    constexpr int OLD = 2 * BN + 8;
+    u16* so = smem16;
+    constexpr int CW = BN <= 16 ? 16 : BN <= 32 ? 32 : BN <= 64 ? 64 : 128, RG = NTHR / CW;
+    const int cc = tid % CW, rg = tid / CW;
+    float csum = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h) __syncthreads();                            // the first half has left the staging tile
+#pragma unroll
+      for (int il = 0; il < 2; ++il) {
+        const int pr = wave * 32 + il * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int co = n0 + j * 16 + fq;
+          const f32x4 a4 = acc[j][2 * h + il];
+          const u32x2 g2 = gv[2 * h + il][j];
+          const bool ok = okp[2 * h + il];
+          float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = x_act_apply(p.bias ? v[e] + bv[j][e] : v[e], ak);
+            v[e] = (ok && co + e < p.Cout) ? t : 0.f;
+          }
+          if (use_gate) {
+            const unsigned g[4] = {g2.x & 0xffffu, g2.x >> 16, g2.y & 0xffffu, g2.y >> 16};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= bf2f((u16)g[e]) > 0.f ? 1.f : gate_off;
+          } else if (use_mask) {
+            const unsigned bits = g2.x >> (co & 7);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : gate_off;
+          }
+          u16 hi[4], lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split1(v[e], hi[e], lo[e]);
+          *reinterpret_cast<uint2*>(so + pr * OLD + j * 16 + fq) =
+              make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+          *reinterpret_cast<uint2*>(so + pr * OLD + BN + j * 16 + fq) =
+              make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+        }
+      }
+      __syncthreads();
+      constexpr int VPP = BN / 8;
+      for (int v = tid; v < 128 * 2 * VPP; v += NTHR) {
+        const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
+        const int plane = q >= VPP, vec = q - plane * VPP;
+        const int co = n0 + vec * 8;
+        int oy, ox;
+        if (pix_of(h, pr, oy, ox) && co < p.Cpo) {
+          const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+          const u32x4 hv = *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+          *reinterpret_cast<u32x4*>(p.ys + m * 2 * p.Cpo + plane * p.Cpo + co) = hv;
+          if (p.mask_out && plane == 0) p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
+        }
+      }
+      if (p.colsum && cc < BN)
+        for (int r = rg; r < 128; r += RG) csum += bf2f(so[r * OLD + cc]) + bf2f(so[r * OLD + BN + cc]);
+    }
+    rstamp(5);
+    if (p.colsum && !(DBG & 64)) {
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(so);
+      if (rg > 0 && cc < BN) red[(rg - 1) * BN + cc] = csum;
+      __syncthreads();
+      if (rg == 0 && cc < BN && n0 + cc < p.Np) {
+        for (int q = 0; q < RG - 1; ++q) csum += red[q * BN + cc];
+        p.colsum[(int64_t)tile * p.Np + n0 + cc] = csum;
+        // trailer: the number of rows this launch wrote (the finish kernel reads no further)
+        if (tile == 0 && n0 + cc == 0) reinterpret_cast<int*>(p.colsum)[(int64_t)p.G * p.Np] = (int)gridDim.x;
+      }
+    }
+  } else {
+    constexpr int OLD = BN + 4;
+    float* so = reinterpret_cast<float*>(smem16);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h) __syncthreads();
+#pragma unroll
+      for (int il = 0; il < 2; ++il) {
+        const int pr = wave * 32 + il * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int co = n0 + j * 16 + fq;
+          const f32x4 a4 = acc[j][2 * h + il];
+          float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = x_act_apply(p.bias ? v[e] + bv[j][e] : v[e], ak);
+            v[e] = co + e < p.Cout ? t : 0.f;
+          }
+          *reinterpret_cast<float4*>(so + pr * OLD + j * 16 + fq) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      __syncthreads();
+      constexpr int VPP = BN / 4;
+      for (int v = tid; v < 128 * VPP; v += NTHR) {
+        const int pr = v / VPP, vec = v - pr * VPP;
+        const int co = n0 + vec * 4;
+        int oy, ox;
+        if (pix_of(h, pr, oy, ox) && co < p.Cpo)
+          *reinterpret_cast<float4*>(p.yf + (int64_t)img * p.ysn + (int64_t)oy * p.ysh + (int64_t)ox * p.ysw + co) =
+              *reinterpret_cast<const float4*>(so + pr * OLD + vec * 4);
+      }
+    }
+  }
+  if (DBG & 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the stores have left)
+    rstamp(6);
+    if (lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * NWV + wave) * 14;
+      for (int i = 0; i < 7; ++i) o[6 + i] = st_rt[i];
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      o[13] = hw | ((unsigned long long)xcc << 32);
+    }
+  }
+}
 
 // ------------------------------------------------------------------ pointwise (1x1) GEMM, persistent
 // The PathNet chains are 1x1 convolutions over B*S*H*W = 1 M pixels with 36..128 channels: 0.5-1 GB of HBM
@@ -2357,8 +2738,50 @@ static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) 
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
+template <int NT, int NB>
+static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream) {
+  static size_t attr = 0;
+  if (lds > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = lds;
+  }
+  const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
+  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB>), grid, dim3(256), lds, stream, p);
+  return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
+}
+template <int NT>
+static int launch_xhalo64(const XIgemmParams& p, hipStream_t stream) {
+  const int HP = (16 + p.ks - 1) * (16 + p.ks - 1);
+  const size_t halo = (size_t)((HP * p.PXS + 127) & ~127), bstage = (size_t)(2 * NT * 16 * XROW + 64) * sizeof(u16);
+  const size_t out = p.ys ? (size_t)128 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)128 * (NT * 16 + 4) * sizeof(float);
+#ifdef WCMC_DEBUG_BUILD
+  if (NT == 7) {
+    const char* e = getenv("WCMC_DEBUG_ABLATE");
+    const int ab = e ? atoi(e) : 0;
+    if (ab) {
+      auto kfn = ab == 1 ? &conv_halo64_bf16x3_kernel<7, 3, 1> : ab == 2 ? &conv_halo64_bf16x3_kernel<7, 3, 2>
+                 : ab == 4 ? &conv_halo64_bf16x3_kernel<7, 3, 4> : ab == 8 ? &conv_halo64_bf16x3_kernel<7, 3, 8>
+                 : ab == 10 ? &conv_halo64_bf16x3_kernel<7, 3, 10> : ab == 14 ? &conv_halo64_bf16x3_kernel<7, 3, 14>
+                 : ab == 32 ? &conv_halo64_bf16x3_kernel<7, 3, 32> : ab == 46 ? &conv_halo64_bf16x3_kernel<7, 3, 46>
+                 : &conv_halo64_bf16x3_kernel<7, 3, 64>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
+      hipLaunchKernelGGL(kfn, grid, dim3(256), halo + 3 * bstage, stream, p);
+      return check_launch("conv2d_igemm_bf16x3(halo64, debug)");
+    }
+  }
+#endif
+  // three weight stages where two workgroups still fit a CU (80 KB each), else two
+  const char* nbe = getenv("WCMC_HALO_NB");
+  const int nb = (!(nbe && nbe[0] == '2') && halo + 3 * bstage <= 80 * 1024) ? 3 : 2;
+  const size_t main_ = halo + nb * bstage;
+  const size_t lds = main_ > out ? main_ : out;
+  return nb == 3 ? launch_xhalo64b<NT, 3>(p, lds, stream) : launch_xhalo64b<NT, 2>(p, lds, stream);
+}
 template <int NT>
 static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
+  if (p.PXS == 80 && p.ks == 5) return launch_xhalo64<NT>(p, stream);
   constexpr int TH = 16, TW = 16;
   const int HP = (TH + p.ks - 1) * (TW + p.ks - 1);
   const size_t halo = (size_t)((HP * p.PXS + 127) & ~127), bstage = (size_t)(2 * NT * 16 * XROW + 64) * sizeof(u16);
