@@ -40,11 +40,34 @@ for h in [int(a) for a in sys.argv[1:]] or [124, 116, 100]:
             print("      epilogue: drain+barrier %.1f  act/split -> LDS %.1f  store issue %.1f  store drain %.1f" %
                   ((e0 - lp1)[m].mean(), (e1 - e0)[m].mean(), (e2 - e1)[m].mean(), (ex - e2)[m].mean()))
         else:
-            print("      epilogue: operand loads + drain + barrier %.1f  two halves (act/split -> LDS -> stores) %.1f  store drain %.1f" %
-                  ((e0 - lp1)[m].mean(), (e2 - e0)[m].mean(), (ex - e2)[m].mean()))
+            print("      epilogue: operand loads + drain + barrier %.1f  first half: act/split -> LDS %.1f, store issue %.1f  second half + store drain %.1f" %
+                  ((e0 - lp1)[m].mean(), (e1 - e0)[m].mean(), (e2 - e1)[m].mean(), (ex - e2)[m].mean()))
     # occupancy over time: how many workgroups are inside their stage loop
     grid = np.arange(0, ex.max(), 5.0)
     inloop = [(int(((lp0 <= t) & (lp1 > t)).sum()), int(((ent <= t) & (ex > t)).sum())) for t in grid]
     print("  t (us): in-loop/resident  " + "  ".join("%d:%d/%d" % (t, a, r) for t, (a, r) in zip(grid, inloop)))
+    xcc, se = (hw >> 32) & 0xf, (hw >> 13) & 7
+    print("  stage-loop time by XCD: " + "  ".join("%d: %.1f (%.1f..%.1f)" % (x, (lp1 - lp0)[xcc == x].mean(), (lp1 - lp0)[xcc == x].min(),
+                                                                            (lp1 - lp0)[xcc == x].max()) for x in np.unique(xcc)))
+    x0 = xcc == np.unique(xcc)[0]
+    print("  ... inside the first XCD by shader engine: " + "  ".join("%d: %.1f" % (e, (lp1 - lp0)[x0 & (se == e)].mean()) for e in np.unique(se[x0])))
+    ucu, inv = np.unique(cu, return_inverse=True)
+    percu = np.array([(lp1 - lp0)[inv == i].mean() for i in range(len(ucu))])
+    print("  per-CU mean stage-loop time: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f" %
+          (percu.min(), np.percentile(percu, 10), np.median(percu), np.percentile(percu, 90), percu.max()))
+    # does the tile's position matter?  (tile index -> image row / column of the tile)
+    tcol = np.arange(tiles) % ((ho + 15) // 16)
+    print("  stage-loop time by tile column: " + "  ".join("%.1f" % (lp1 - lp0)[tcol == c].mean() for c in np.unique(tcol)))
+    # which workgroups share a CU?  (block index b <-> tile: the kernel's XCD-aware remap)
+    nbk = tiles; qq, rr = nbk >> 3, nbk & 7
+    blk_of_tile = np.zeros(tiles, dtype=np.int64)
+    for bidx in range(nbk):
+        x, kk = bidx & 7, bidx >> 3
+        blk_of_tile[(x * (qq + 1) if x < rr else rr * (qq + 1) + (x - rr) * qq) + kk] = bidx
+    pairs = []
+    for i in range(min(len(ucu), 6)):
+        t = np.nonzero(inv == i)[0]
+        pairs.append(" ".join("b%d(l%d):%.0f" % (blk_of_tile[j], blk_of_tile[j] >> 3, (lp1 - lp0)[j]) for j in t))
+    print("  workgroups per CU (block, local index in its XCD, stage-loop us): " + " | ".join(pairs))
     per = np.bincount(np.unique(cu, return_inverse=True)[1])
     print("  tiles per CU: min %d max %d" % (per.min(), per.max()))

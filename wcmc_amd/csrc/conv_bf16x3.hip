@@ -427,12 +427,44 @@ __device__ __forceinline__ unsigned char positive_mask8(const u32x4 v) {
   return (unsigned char)m;
 }
 
+// Epilogue of one accumulator quad (4 consecutive couts of one pixel): bias, activation, pixel validity, gate, split --
+// as packed conversions and selects.  Couts past Cout need no test: their packed weights and their bias (out-of-range
+// buffer load) are zeros, and every activation maps 0 to +0.
+typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void x_split2(float a, float b, unsigned& hi2, unsigned& lo2) {
+  const xf32x2 v = {a, b};
+  hi2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, xbf16x2));
+  const xf32x2 back = {__builtin_bit_cast(float, hi2 << 16), __builtin_bit_cast(float, hi2 & 0xffff0000u)};
+  lo2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v - back, xbf16x2));
+}
 // activation as selects (bit-identical to act_apply, no branches inside an unrolled epilogue)
 struct XAct { float ns; bool zero; };
 __device__ __forceinline__ XAct x_act(int act, float slope) {
   return XAct{act == WCMC_ACT_LEAKY_RELU ? slope : 1.f, act == WCMC_ACT_RELU};
 }
 __device__ __forceinline__ float x_act_apply(float v, XAct a) { return v > 0.f ? v : (a.zero ? 0.f : v * a.ns); }
+
+// gate kinds of x_epi_quad: 0 none, 1 split gate tensor (hi plane of 4 values in g2), 2 bit mask (byte in g2.x)
+__device__ __forceinline__ void x_epi_quad(const f32x4 a4, const float (&b)[4], bool ok, XAct ak, int gkind, u32x2 g2, int co,
+                                           float gate_off, float (&v)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float t = a4[e] + b[e];
+    const float neg = ak.zero ? 0.f : t * ak.ns;
+    const float r = t > 0.f ? t : neg;
+    v[e] = ok ? r : 0.f;
+  }
+  if (gkind == 1) {
+    const unsigned g[4] = {g2.x << 16, g2.x & 0xffff0000u, g2.y << 16, g2.y & 0xffff0000u};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, g[e]) > 0.f ? v[e] : v[e] * gate_off;
+  } else if (gkind == 2) {
+    const unsigned bits = g2.x >> (co & 7);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ((bits >> e) & 1u) ? v[e] : v[e] * gate_off;
+  }
+}
 
 struct XIgemmParams {
   const u16* x; int N, H, W, Cin, Cpi;
@@ -1084,6 +1116,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
   }
   const XAct ak = x_act(p.act, p.slope);
   const float gate_off = p.gate_act == WCMC_ACT_RELU ? 0.f : p.gate_act == WCMC_ACT_LEAKY_RELU ? p.gate_slope : 1.f;
+  const int gkind = use_gate ? 1 : use_mask ? 2 : 0;
   rstamp(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (zero) weight stages past the end have landed:
   __syncthreads();                                     // LDS is free for the epilogue staging
@@ -1121,29 +1154,14 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = n0 + j * 16 + fq;
-        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = x_act_apply(p.bias ? v[e] + bv[j][e] : v[e], ak);
-          v[e] = (ok && co + e < p.Cout) ? t : 0.f;
-        }
-        if (use_gate) {                              // (a quad outside the tensor read zeros: its values are zeros too)
-          const unsigned g[4] = {gv[i][j].x & 0xffffu, gv[i][j].x >> 16, gv[i][j].y & 0xffffu, gv[i][j].y >> 16};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= bf2f((u16)g[e]) > 0.f ? 1.f : gate_off;
-        } else if (use_mask) {
-          // the same predicate (hi plane > 0) from the bit mask the producing launch left: 1/16 of the bytes
-          const unsigned bits = gv[i][j].x >> (co & 7);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : gate_off;
-        }
-        u16 hi[4], lo[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split1(v[e], hi[e], lo[e]);
-        *reinterpret_cast<uint2*>(so + pr * OLD + j * 16 + fq) =
-            make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
-        *reinterpret_cast<uint2*>(so + pr * OLD + BN + j * 16 + fq) =
-            make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+        float v[4];
+        // (gate: the hi-plane predicate from the split tensor, or from the bit mask the producing launch left)
+        x_epi_quad(acc[j][i], bv[j], ok, ak, gkind, gv[i][j], co, gate_off, v);
+        unsigned h01, l01, h23, l23;
+        x_split2(v[0], v[1], h01, l01);
+        x_split2(v[2], v[3], h23, l23);
+        *reinterpret_cast<uint2*>(so + pr * OLD + j * 16 + fq) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(so + pr * OLD + BN + j * 16 + fq) = make_uint2(l01, l23);
       }
     }
     __syncthreads();
@@ -1187,12 +1205,8 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = n0 + j * 16 + fq;
-        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = x_act_apply(p.bias ? v[e] + bv[j][e] : v[e], ak);
-          v[e] = co + e < p.Cout ? t : 0.f;
-        }
+        float v[4];
+        x_epi_quad(acc[j][i], bv[j], true, ak, 0, u32x2{0u, 0u}, co, 1.f, v);
         *reinterpret_cast<float4*>(so + pr * OLD + j * 16 + fq) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
@@ -1330,7 +1344,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   int cs_cur, sps_cur, lo_off, tps, coff, tdx, tdy;
   auto slab_begin = [&](int slab) {
     cs_cur = slab == p.nslabs - 1 ? p.CSl : p.CS;
-    sps_cur = slab == p.nslabs - 1 ? p.SPSl : p.SPS;
+    sps_cur = slab == p.nslabs - 1 ? p.SPSl : (p.SPS & 0xff);
     lo_off = cs_cur * 2;
     tps = 32 / cs_cur;                                   // taps per stage: 2 (16 channels) or 4 (8)
     coff = ((kg * 8) & (cs_cur - 1)) * 2;
@@ -1364,12 +1378,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
 #pragma unroll
   for (int j = 0; j < NT; ++j) read_b(0, j);
   int s_in = 0, slab = 0, bcur = 0;
+  const int wgpar = (blockIdx.x >> 8) & 1;
+  const bool prio_on = p.SPS & 0x100;          // (A/B switch, set by the launcher: WCMC_HALO64_PRIO)
   rstamp(1);
   for (int g = 0; g < nstages; ++g) {
     const int b1 = bcur + 1 == NB ? 0 : bcur + 1;      // buffer of stage g+1; stage g's fragments are in registers
     if (NGMAX == 1 || ngroups < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NB - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 2)) : "memory");
     pw_barrier();                                // stage g+1 has landed for everyone; everyone has read stage g's fragments
+    // The two workgroups of a CU are dispatched one after the other (local block indices l and l + 32 of an XCD) and the
+    // instruction arbiter prefers the older wave: stamps showed the first one through its stage loop in 114 us and the
+    // second in 158, the last 40 us alone on the CU.  Alternating the priority stage by stage shares the matrix pipe.
+    if (prio_on) { if ((g ^ wgpar) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     if (!(DBG & 2)) dma_b(g + NB, bcur);
     bcur = b1;
     const bool last_of_slab = (s_in + 1 == sps_cur);
@@ -1406,6 +1426,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
       a_advance();
     }
   }
+  __builtin_amdgcn_s_setprio(0);
   rstamp(2);
   if ((DBG & 32) && !(DBG & 64)) {                     // timing only: no epilogue (one store keeps the accumulators alive)
     float keep = 0.f;
@@ -1460,6 +1481,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   }
   const XAct ak = x_act(p.act, p.slope);
   const float gate_off = p.gate_act == WCMC_ACT_RELU ? 0.f : p.gate_act == WCMC_ACT_LEAKY_RELU ? p.gate_slope : 1.f;
+  const int gkind = use_gate ? 1 : use_mask ? 2 : 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (zero) weight stages past the end have landed:
   __syncthreads();                                     // LDS is free for the epilogue staging
   rstamp(3);
@@ -1485,34 +1507,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int co = n0 + j * 16 + fq;
-          const f32x4 a4 = acc[j][2 * h + il];
-          const u32x2 g2 = gv[2 * h + il][j];
-          const bool ok = okp[2 * h + il];
-          float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = x_act_apply(p.bias ? v[e] + bv[j][e] : v[e], ak);
-            v[e] = (ok && co + e < p.Cout) ? t : 0.f;
-          }
-          if (use_gate) {
-            const unsigned g[4] = {g2.x & 0xffffu, g2.x >> 16, g2.y & 0xffffu, g2.y >> 16};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= bf2f((u16)g[e]) > 0.f ? 1.f : gate_off;
-          } else if (use_mask) {
-            const unsigned bits = g2.x >> (co & 7);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : gate_off;
-          }
-          u16 hi[4], lo[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) split1(v[e], hi[e], lo[e]);
-          *reinterpret_cast<uint2*>(so + pr * OLD + j * 16 + fq) =
-              make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
-          *reinterpret_cast<uint2*>(so + pr * OLD + BN + j * 16 + fq) =
-              make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+          float v[4];
+          x_epi_quad(acc[j][2 * h + il], bv[j], okp[2 * h + il], ak, gkind, gv[2 * h + il][j], co, gate_off, v);
+          unsigned h01, l01, h23, l23;
+          x_split2(v[0], v[1], h01, l01);
+          x_split2(v[2], v[3], h23, l23);
+          *reinterpret_cast<uint2*>(so + pr * OLD + j * 16 + fq) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(so + pr * OLD + BN + j * 16 + fq) = make_uint2(l01, l23);
         }
       }
       __syncthreads();
+      if (h == 0) rstamp(4);
       constexpr int VPP = BN / 8;
       for (int v = tid; v < 128 * 2 * VPP; v += NTHR) {
         const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
@@ -1526,10 +1531,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
           if (p.mask_out && plane == 0) p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
         }
       }
+      if (h == 0) rstamp(5);
       if (p.colsum && cc < BN)
         for (int r = rg; r < 128; r += RG) csum += bf2f(so[r * OLD + cc]) + bf2f(so[r * OLD + BN + cc]);
     }
-    rstamp(5);
     if (p.colsum && !(DBG & 64)) {
       __syncthreads();
       float* red = reinterpret_cast<float*>(so);
@@ -1555,12 +1560,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
         for (int j = 0; j < NT; ++j) {
           const int co = n0 + j * 16 + fq;
           const f32x4 a4 = acc[j][2 * h + il];
-          float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = x_act_apply(p.bias ? v[e] + bv[j][e] : v[e], ak);
-            v[e] = co + e < p.Cout ? t : 0.f;
-          }
+          float v[4];
+          x_epi_quad(a4, bv[j], true, ak, 0, u32x2{0u, 0u}, co, 1.f, v);
           *reinterpret_cast<float4*>(so + pr * OLD + j * 16 + fq) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
@@ -2191,6 +2192,21 @@ struct XWRowsParams {
 constexpr int xwr_stride(int ch) { return ((ch / 16) | 1) * 16; }
 
 // KS = filter size, TM = cout tiles (16) per block, NW = waves = cin tiles per block.
+// Transposing LDS reads the compiler does not see as LDS reads.  Behind an LDS-DMA hipcc orders every LDS read it knows of
+// with s_waitcnt vmcnt(0) (it cannot tell the stage being filled from the stage being read inside one dynamic array): the
+// first version of the kernel below therefore waited for stage st+1 to LAND before it multiplied stage st -- no overlap of
+// the fill with the MFMAs at all.  The pair (rows prow, prow + 16 of one 16-channel tile) is issued without a wait;
+// xwr_frag() orders it (lgkmcnt) and assembles the MFMA operand -- any register copy the compiler adds sits behind the wait.
+struct XwrRaw { u32x2 a, b; };
+template <int OFF2>
+__device__ __forceinline__ void xwr_tr_issue(unsigned addr, XwrRaw& r) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(r.a), "=&v"(r.b) : "v"(addr), "n"(OFF2));
+}
+__device__ __forceinline__ bf16x8 xwr_cat(const XwrRaw& r) {
+  const u32x4 c = {r.a[0], r.a[1], r.b[0], r.b[1]};
+  return __builtin_bit_cast(bf16x8, c);
+}
+
 template <int KS, int TM, int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf16x3_kernel(XWRowsParams p) {
   constexpr int CHY = TM * 16, CHX = NW * 16, PK = 64, XR = PK + KS - 1;
@@ -2228,55 +2244,69 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
   // What a lane fetches for instruction i is the same in every stage up to the stage's base address and
   // edge tests: one packed word per instruction -- bits 0..19 byte offset / 2 relative to the stage's first
   // pixel, 20..26 pixel row of the tile, 27 operand (1 = x), 28 never valid (row pad, tail of the buffer).
-  unsigned vdesc[NI];
+  // What a lane fetches for instruction i is the same in every stage up to the stage's base address and its edge tests:
+  // relv = byte offset relative to the stage's first pixel, rowv = pixel row of the tile (127: never valid -- row pad,
+  // tail of the buffer, channel past the tensor).
+  unsigned relv[NI]; int rowv[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int v = (i * NW + wave) * 64 + lane;
-    unsigned d = 1u << 28;
+    unsigned rel = 0; int rw = 127;
     if (v < 2 * YV) {
       const int plane = v >= YV, vv = v - plane * YV;
       const int row = vv / VY, vec = vv - row * VY;
       const int co = co0 + vec * 8;
-      if (vec * 8 < CHY && co < p.Cpo) d = (unsigned)((row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2) >> 1) | ((unsigned)row << 20);
+      if (vec * 8 < CHY && co < p.Cpo) { rel = (unsigned)(row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2); rw = row; }
     } else if (v < NVEC) {
       const int u = v - 2 * YV;
       const int plane = u >= XV, uu = u - plane * XV;
       const int row = uu / VX, vec = uu - row * VX;
       const int ci = ci0 + vec * 8;
-      if (vec * 8 < CHX && ci < p.Cpi)
-        d = (unsigned)((row * 4 * p.Cpi + plane * 2 * p.Cpi + ci * 2) >> 1) | ((unsigned)row << 20) | (1u << 27);
+      if (vec * 8 < CHX && ci < p.Cpi) { rel = (unsigned)(row * 4 * p.Cpi + plane * 2 * p.Cpi + ci * 2); rw = row; }
     }
-    vdesc[i] = d;
+    relv[i] = rel; rowv[i] = rw;
   }
-  auto issue = [&](int st, int buf) {
-    // Row order skewed by the filter row: at step j the KS blocks of a unit read the SAME x row r0 + j and
-    // dy rows one step apart.
-    const int rr = st / nch, c = st - rr * nch;
-    int rs = rr - trow;
-    rs = rs < 0 ? rs + ((trow + nrows - 1) / nrows) * nrows : rs;
-    const int r = r0 + rs % nrows;
-    const int n = r / p.Ho, oy = r - n * p.Ho;
-    const int ox0 = c * PK;
-    const int iy = oy + trow - p.pad;
+  // per-stage scalars of the fill (issue_prep) and one DMA instruction of it (issue_one, four vector instructions and no
+  // branch): the instructions of stage st+1 are spread over the MFMA stream of stage st (stamps of the first version,
+  // which issued them in one burst after the barrier: 1500-1950 of 10500 cycles per stage, the matrix pipe idle)
+  unsigned f_ybase = 0, f_xbase = 0, f_yn = 0, f_xn = 0; int f_xlo = 0, f_buf = 0;
+  // Row order skewed by the filter row: at step j the KS blocks of a unit read the SAME x row r0 + j and dy rows one
+  // step apart -- stage st is chunk st % nch of row r0 + (st / nch - trow) mod nrows.  The stages are prepared in order,
+  // so the cursor advances by increments (the divisions of the first version cost 500-850 cycles per stage).
+  int f_c = 0, f_rs = nrows > 0 ? (nrows - trow % nrows) % nrows : 0, f_n, f_oy;
+  const int f_n0 = r0 / p.Ho, f_oy0 = r0 - f_n0 * p.Ho;
+  { const int r = r0 + f_rs; f_n = r / p.Ho; f_oy = r - f_n * p.Ho; }
+  auto issue_prep = [&](int buf) {
+    const int ox0 = f_c * PK;
+    const int iy = f_oy + trow - p.pad;
     const bool rowok = (unsigned)iy < (unsigned)p.H;
-    const unsigned ybase = (unsigned)(((n * p.Ho + oy) * p.Wo + ox0) * 4 * p.Cpo);
-    const unsigned xbase = (unsigned)(((n * p.H + iy) * p.W + ox0 - p.pad) * 4 * p.Cpi);   // may wrap: only used when valid
-    const int yrows = p.Wo - ox0;                              // dy rows [0, yrows) exist
-    const int xlo = p.pad - ox0, xhi = p.W + p.pad - ox0;      // x rows [xlo, xhi) are inside the image
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const unsigned d = vdesc[i];
-      const int row = (int)((d >> 20) & 127u);
-      const unsigned rel = (d & 0xfffffu) << 1;
-      const bool isx = (d >> 27) & 1u;
-      const bool ok = !(d >> 28) && (isx ? (rowok && row >= xlo && row < xhi) : (row < yrows));
-      const unsigned off = ok ? (isx ? xbase : ybase) + rel : XOOB;
-      __attribute__((address_space(3))) void* dst =
-          (__attribute__((address_space(3))) void*)(smem16 + buf * BUF + (i * NW + wave) * 512);
-      // 2*YV is a multiple of 64: a wave-instruction is all dy or all x (wave-uniform choice of descriptor)
-      if ((i * NW + wave) * 64 < 2 * YV) __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, dst, 16, off, 0, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, off, 0, 0, 0);
+    f_ybase = (unsigned)(((f_n * p.Ho + f_oy) * p.Wo + ox0) * 4 * p.Cpo);
+    f_xbase = (unsigned)(((f_n * p.H + iy) * p.W + ox0 - p.pad) * 4 * p.Cpi);   // may wrap: only used when valid
+    f_yn = (unsigned)max(0, p.Wo - ox0);               // dy rows [0, yn) exist
+    f_xlo = p.pad - ox0;                               // x rows [xlo, xlo + xn) are inside the image
+    f_xn = rowok ? (unsigned)p.W : 0u;
+    f_buf = buf;
+    if (++f_c == nch) {                                // the cursor of the following stage
+      f_c = 0;
+      if (++f_rs == nrows) { f_rs = 0; f_n = f_n0; f_oy = f_oy0; }
+      else if (++f_oy == p.Ho) { f_oy = 0; ++f_n; }
     }
+  };
+  auto issue_one = [&](int i) {
+    // 2*YV is a multiple of 64: a wave-instruction is all dy or all x (wave-uniform choice of descriptor and base)
+    const bool isx = (2 * VY) % NW == 0 ? i >= (2 * VY) / NW : (i * NW + wave) * 64 >= 2 * YV;
+    const unsigned base = isx ? f_xbase : f_ybase, cnt = isx ? f_xn : f_yn;
+    const int lo = isx ? f_xlo : 0;
+    const unsigned off = (unsigned)(rowv[i] - lo) < cnt ? base + relv[i] : XOOB;
+    __attribute__((address_space(3))) void* dst =
+        (__attribute__((address_space(3))) void*)(smem16 + f_buf * BUF + (i * NW + wave) * 512);
+    if (!isx) __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, dst, 16, off, 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, off, 0, 0, 0);
+  };
+  auto issue = [&](int buf) {
+    issue_prep(buf);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) issue_one(i);
   };
 
   f32x4 acc[KS][TM];
@@ -2288,51 +2318,122 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
   // transposing read (see conv_wgrad_bf16x3_kernel): lane addresses pixel row 4g + q (+16) and channels
   // 4pp..4pp+3 of a 16-channel tile and receives channel (lane & 15) of pixels {4g..4g+3, 16+4g..16+4g+3}
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  auto tr_read = [&](const u16* base, int stride, int prow, int col0, bf16x8& out) {
-    const u16* a0 = base + prow * stride + col0 + 4 * tp;
-    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
-    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 16 * stride));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 cat = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-    out = __builtin_bit_cast(bf16x8, cat);
-  };
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) u16*)smem16);
 
   unsigned long long tc0 = 0, tr0 = 0;
   if (DBG & 4) { tc0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
-  if (nst > 0) issue(0, 0);
+  // DBG & 16 (scripts/timeline_wgrad.py): wall-clock stamps (100 MHz) of entry / loop start / loop end / exit and the
+  // shader-clock cycles of the stage loop spent waiting (DMA + barrier), issuing the next stage and multiplying
+  unsigned long long rt[4] = {0, 0, 0, 0}, cyc[3] = {0, 0, 0}, tprev = 0;
+  auto rts = [&](int i) {
+    if (DBG & 16) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      rt[i] = t;
+    }
+  };
+  auto cst = [&](int i) {
+    if (DBG & 16) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (i >= 0) cyc[i] += t - tprev;
+      tprev = t;
+    }
+  };
+  rts(0);
+  if (nst > 0) issue(0);
+  rts(1);
+  cst(-1);
   for (int st = 0; st < nst; ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of stage st has landed
     __syncthreads();                                      // ... everyone's; and everyone is done with stage st-1
-    if (st + 1 < nst && !((DBG & 2) && st > 0)) issue(st + 1, (st + 1) & 1);
-    const u16* Yh = smem16 + (st & 1) * BUF;
-    const u16* Yl = Yh + PK * SY;
-    const u16* Xh = Yh + 2 * PK * SY;
-    const u16* Xl = Xh + XR * SX;
+    cst(0);
+    const bool fill = st + 1 < nst && !((DBG & 2) && st > 0);
+    if (fill) issue_prep((st + 1) & 1);
+    cst(1);
+    // byte addresses of this lane's first fragment row in the four planes of the stage
+    const int prow0 = 4 * g + tq;
+    const unsigned aYh = lds0 + (unsigned)(((st & 1) * BUF + prow0 * SY + 4 * tp) * 2);
+    const unsigned aYl = aYh + PK * SY * 2;
+    const unsigned aXh = lds0 + (unsigned)(((st & 1) * BUF + 2 * PK * SY + prow0 * SX + wave * 16 + 4 * tp) * 2);
+    const unsigned aXl = aXh + XR * SX * 2;
     const int c = st % nch;
-    const int nk = (min(PK, p.Wo - c * PK) + 31) / 32;    // 32-pixel MFMA k-steps with any valid pixel
-    for (int kk = 0; kk < nk; ++kk) {
-      const int prow = kk * 32 + 4 * g + tq;
-      bf16x8 yh[TM], yl[TM];
+    const int nk = (min(PK, p.Wo - c * PK) + 31) / 32;    // 32-pixel MFMA k-steps with any valid pixel (1 or 2)
+    // Software pipeline inside the wave (the first version read a k-step's fragments, waited, multiplied: a wave alone on
+    // its SIMD kept the matrix pipe 61 % busy): the x fragments of all KS taps stay in registers for a k-step and are
+    // replaced tap by tap during its last cout tile; the dy fragments are double-buffered one cout tile ahead.  The
+    // order of the MFMAs on every accumulator is unchanged (bit-identical results).
+    XwrRaw rxh[KS], rxl[KS], ryh[2], ryl[2];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        tr_read(Yh, SY, prow, i * 16, yh[i]);
-        tr_read(Yl, SY, prow, i * 16, yl[i]);
-      }
+    for (int t = 0; t < KS; ++t) {
+      xwr_tr_issue<16 * SX * 2>(aXh + t * SX * 2, rxh[t]);
+      xwr_tr_issue<16 * SX * 2>(aXl + t * SX * 2, rxl[t]);
+    }
+    xwr_tr_issue<16 * SY * 2>(aYh, ryh[0]);
+    xwr_tr_issue<16 * SY * 2>(aYl, ryl[0]);
+    bf16x8 xh[KS], xl[KS];
 #pragma unroll
-      for (int t = 0; t < KS; ++t) {
-        bf16x8 xh, xl;
-        tr_read(Xh, SX, prow + t, wave * 16, xh);
-        tr_read(Xl, SX, prow + t, wave * 16, xl);
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk < nk) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          if (DBG & 1) { asm volatile("" ::"v"(yl[i]), "v"(yh[i]), "v"(xh), "v"(xl)); continue; }
-          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl[i], xh, acc[t][i], 0, 0, 0);
-          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xl, acc[t][i], 0, 0, 0);
-          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xh, acc[t][i], 0, 0, 0);
+          const int cur = (kk * TM + i) & 1, nxt = cur ^ 1;
+          // everything issued so far has landed (the reads of this iteration were issued one iteration ago)
+          if (DBG & 8) {                               // (timing only: no wait for the fragments)
+            asm volatile("" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
+            if (i == 0) {
+#pragma unroll
+              for (int t = 0; t < KS; ++t) { xh[t] = xwr_cat(rxh[t]); xl[t] = xwr_cat(rxl[t]); }
+            }
+          } else if (i == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+              asm volatile("" : "+v"(rxh[t].a), "+v"(rxh[t].b), "+v"(rxl[t].a), "+v"(rxl[t].b));
+              xh[t] = xwr_cat(rxh[t]); xl[t] = xwr_cat(rxl[t]);
+            }
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
+          }
+          const bf16x8 yh = xwr_cat(ryh[cur]), yl = xwr_cat(ryl[cur]);
+          if (i + 1 < TM) {
+            xwr_tr_issue<16 * SY * 2>(aYh + (kk * 32 * SY + (i + 1) * 16) * 2, ryh[nxt]);
+            xwr_tr_issue<16 * SY * 2>(aYl + (kk * 32 * SY + (i + 1) * 16) * 2, ryl[nxt]);
+          } else if (kk + 1 < nk) {
+            xwr_tr_issue<16 * SY * 2>(aYh + ((kk + 1) * 32 * SY) * 2, ryh[nxt]);
+            xwr_tr_issue<16 * SY * 2>(aYl + ((kk + 1) * 32 * SY) * 2, ryl[nxt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);             // (the prefetch leaves before the MFMAs, not among them)
+#pragma unroll
+          for (int t = 0; t < KS; ++t) {
+            if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(xh[t]), "v"(xl[t])); }
+            else {
+              acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[t], acc[t][i], 0, 0, 0);
+              acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[t], acc[t][i], 0, 0, 0);
+              acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[t], acc[t][i], 0, 0, 0);
+            }
+            if (i == TM - 1 && kk + 1 < nk) {             // this tap's fragments of the next k-step
+              xwr_tr_issue<16 * SX * 2>(aXh + ((kk + 1) * 32 + t) * SX * 2, rxh[t]);
+              xwr_tr_issue<16 * SX * 2>(aXl + ((kk + 1) * 32 + t) * SX * 2, rxl[t]);
+            }
+          }
+          if (fill && kk * TM + i < NI) issue_one(kk * TM + i);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
+    if (fill) {                                          // what the MFMA stream had no slot for (one k-step, or NI > 2 TM)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        if (i >= nk * TM) issue_one(i);
+    }
+    cst(2);
   }
+  rts(2);
 
   if (DBG & 4) {     // clock probe: shader-clock ticks and 100 MHz ticks over the main loop
     const unsigned long long tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
@@ -2363,6 +2464,16 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
     }
     __syncthreads();
   }
+  if (DBG & 16) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    rts(3);
+    if (lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.dbg) + ((int64_t)blockIdx.x * NW + wave) * 8;
+      for (int i = 0; i < 4; ++i) o[i] = rt[i];
+      for (int i = 0; i < 3; ++i) o[4 + i] = cyc[i];
+      o[7] = (unsigned long long)nst;
+    }
+  }
 }
 
 template <int KS, int TM, int NW>
@@ -2386,10 +2497,10 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
   const dim3 grid((unsigned)(((q.S * q.coBlocks * q.ciBlocks + 7) / 8) * 8 * KS));
 #ifdef WCMC_DEBUG_BUILD        // `make debug` only: timing-only instances that compute WRONG results are not in the release library
   if (KS == 5 && TM == 7 && NW == 7) {
-    static int ab = -1;                 // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills, 4 = clock probe)
-    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
-    if (ab == 1 || ab == 2 || ab == 3 || ab == 4 || ab == 8) {
-      auto kfn = ab == 1 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 1> : ab == 2 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 2>
+    int ab;                             // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills, 4 = clock probe)
+    { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    if (ab == 1 || ab == 2 || ab == 3 || ab == 4 || ab == 8 || ab == 16) {
+      auto kfn = ab == 16 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 16> : ab == 1 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 1> : ab == 2 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 2>
                  : ab == 3 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 3> : ab == 4 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 4>
                  : &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 8>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2751,7 +2862,9 @@ static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream
   return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
 }
 template <int NT>
-static int launch_xhalo64(const XIgemmParams& p, hipStream_t stream) {
+static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
+  XIgemmParams p = p0;
+  if (x_env_on("WCMC_HALO64_PRIO")) p.SPS |= 0x100;
   const int HP = (16 + p.ks - 1) * (16 + p.ks - 1);
   const size_t halo = (size_t)((HP * p.PXS + 127) & ~127), bstage = (size_t)(2 * NT * 16 * XROW + 64) * sizeof(u16);
   const size_t out = p.ys ? (size_t)128 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)128 * (NT * 16 + 4) * sizeof(float);
