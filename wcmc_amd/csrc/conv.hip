@@ -630,7 +630,7 @@ extern "C" int wcmc_conv2d_wgrad(const float* x, int64_t xsn, int64_t xsh, int64
   const int64_t total = (int64_t)ks * ks * Cout * Cin;
   (void)total;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + WR_CI - 1) / WR_CI), (unsigned)Cout), dim3(256),
-                     (size_t)WR_CI * (ks * ks + 1) * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq, nullptr, 0, 0, nullptr);
+                     (size_t)WR_CI * (ks * ks + 1) * sizeof(float) + 256 * sizeof(float), st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq, nullptr, 0, 0, nullptr);
   rc = check_launch("conv2d_wgrad_reduce");
   if (rc || !db) return rc;
   float* partial = (float*)workspace + pl.slab_elems;

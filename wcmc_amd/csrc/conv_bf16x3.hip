@@ -2578,11 +2578,18 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
   const int rows_on = x_env_on("WCMC_WGRAD_ROWS");   // =0: A/B switch back to the one-tap-per-block kernel
   // filter-row kernel: (KS, TM, NW) instances below; TM / NW must divide the tile counts
   pl.R = N * Ho; pl.rps = 0; pl.rows = 0; pl.rTM = pl.rNW = 0;
-  if (rows_on && (ks == 5 || ks == 3) && (int64_t)N * Ho >= 64) {
+  if (rows_on && (ks == 5 || ks == 3 || (ks == 1 && x_env_on("WCMC_WGRAD_ROWS_1X1"))) && (int64_t)N * Ho >= 64) {
     // measured against the one-tap kernel (scripts/profile_layers.py): the 5x5 layers gain 1.9-2.7x; of the
     // 3x3 U-Net layers only those with >= 256 input channels gain (a filter row is 3 taps of reuse, not 5)
     int tm = 0, nw = 0;
     if (ks == 5) { tm = coT % 7 == 0 ? 7 : 0; nw = ciT % 7 == 0 ? 7 : ciT == 3 ? 3 : 0; }
+    else if (ks == 1) {
+      // the PathNet 1x1 layers: pure streaming (two operands read once); the stage ring of this kernel fills by LDS-DMA
+      // while the previous stage multiplies, the one-tap kernel stages through registers between two barriers
+      // (measured, scripts/time_wgrad_1x1.py: 128 -> 128 gains, 220 -> 184 us = 5.8 TB/s; 64 -> 64 is even and the narrow
+      // layers 36 -> 64 and 128 -> 3 lose 10-14 %: they stay on the one-tap kernel, which already streams them at 5.6-5.9 TB/s)
+      if (coT == 8 && ciT == 8) { tm = 8; nw = 8; }
+    }
     else if (coT % 8 == 0 && ciT % 8 == 0 && ciT >= 16) { tm = 8; nw = 8; }
     if (tm && nw) {
       pl.rows = 1; pl.rTM = tm; pl.rNW = nw;
@@ -3169,6 +3176,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
       case 577: rc = launch_xwgrad_rows<5, 7, 7>(q, st); break;
       case 573: rc = launch_xwgrad_rows<5, 7, 3>(q, st); break;
       case 388: rc = launch_xwgrad_rows<3, 8, 8>(q, st); break;
+      case 188: rc = launch_xwgrad_rows<1, 8, 8>(q, st); break;
       default: WCMC_REQUIRE(false, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: no filter-row instance for the plan");
     }
   } else if (phase != 2) {
@@ -3178,7 +3186,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
   // the slab reduction; with the column sums of dy at hand its launch also finishes the bias gradient (extra grid rows)
   const bool fuse_db = db && dy_colsum_partial;
   const int cs_rows = fuse_db ? (Cout + 63) / 64 : 0;
-  size_t red_lds = (size_t)WR_CI * (ks * ks + 1) * sizeof(float);
+  size_t red_lds = (size_t)WR_CI * (ks * ks + 1) * sizeof(float) + 256 * sizeof(float);   // (+ the group sums of the few-tap path)
   if (fuse_db && red_lds < (size_t)16 * 64 * sizeof(float)) red_lds = (size_t)16 * 64 * sizeof(float);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + WR_CI - 1) / WR_CI), (unsigned)(Cout + cs_rows)), dim3(256),
                      red_lds, st, p.slabs, dw, pl.S, ks * ks, Cout, Cin, pl.Np, pl.Cq, fuse_db ? dy_colsum_partial : nullptr,

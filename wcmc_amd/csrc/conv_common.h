@@ -51,6 +51,36 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
   const int co = blockIdx.y, ci0 = blockIdx.x * WR_CI;
   const int LD = taps + 1;
   const int64_t sstride = (int64_t)taps * Np * Cq;
+  if (taps * WR_CI * 2 <= 256) {
+    // few taps (the 1x1 layers: 32 sums of S = 512 slabs per block, i.e. 43 dependent round trips for 32 of the 256
+    // threads -- 80-130 us per layer, as long as the GEMM itself): the slab range is cut into SG contiguous groups, one
+    // per (taps * 32)-thread slice of the block, and the group sums are added in group order (fixed order -> reproducible)
+    const int TE = taps * WR_CI, SG = 256 / TE;
+    const int e = threadIdx.x % TE, sg = threadIdx.x / TE;
+    const int tap = e / WR_CI, cl = e - tap * WR_CI;
+    float* part = smem + WR_CI * LD;                    // [SG][TE]
+    float acc = 0.f;
+    if (sg < SG && ci0 + cl < Cin) {
+      const int chunk = (S + SG - 1) / SG, s0 = sg * chunk, s1 = min(S, s0 + chunk);
+      const float* q = slabs + ((int64_t)tap * Np + co) * Cq + ci0 + cl;
+      int s = s0;
+      for (; s + 12 <= s1; s += 12) {
+        float v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v[u] = q[(s + u) * sstride];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) acc += v[u];
+      }
+      for (; s < s1; ++s) acc += q[s * sstride];
+    }
+    if (sg < SG) part[sg * TE + e] = acc;
+    __syncthreads();
+    if (sg == 0) {
+      float t = part[e];
+      for (int g = 1; g < SG; ++g) t += part[g * TE + e];
+      smem[cl * LD + tap] = t;
+    }
+  } else
   for (int e = threadIdx.x; e < taps * WR_CI; e += 256) {
     const int tap = e / WR_CI, cl = e - tap * WR_CI;
     float acc = 0.f;
