@@ -323,6 +323,8 @@ static XKPlan x_plan_k(int kchan, int ks) {
   q.halo = enable && ks >= 3 && ks <= 5 && q.Kp >= 32;
   if (q.halo && ks == 5 && x_env_on("WCMC_HALO64")) {
     // conv_halo64_bf16x3_kernel: slabs of 16 channels (the last one 8 or 16), halo pixel stride 80 B, two taps per stage
+    // (5x5 only: on the U-Net's 3x3 layers it wins 4 % at 128^2 and loses 30-70 % on the 64^2 / 32^2 levels, whose 16x16
+    // tilings leave most CUs with one workgroup -- scripts/time_unet_layers.py)
     q.nslabs = (q.Kp + 15) / 16;
     q.CS = 16; q.CSl = q.Kp - (q.nslabs - 1) * 16;
     q.PXS = 80;
@@ -2590,7 +2592,14 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
       // layers 36 -> 64 and 128 -> 3 lose 10-14 %: they stay on the one-tap kernel, which already streams them at 5.6-5.9 TB/s)
       if (coT == 8 && ciT == 8) { tm = 8; nw = 8; }
     }
-    else if (coT % 8 == 0 && ciT % 8 == 0 && ciT >= 16) { tm = 8; nw = 8; }
+    else if (ks == 3) {
+      // (with the fill overlapped -- see the kernel -- the filter-row kernel also wins on the 128-channel levels: 128 -> 128 at
+      // 64^2 57 -> 36 us, 128 -> 256 at 32^2 32 -> 26; the 64-channel layers are even; WCMC_WGRAD_ROWS_3X3=0: A/B switch back
+      // to >= 256 input channels only -- scripts/time_wgrad_unet.py)
+      const int wide = x_env_on("WCMC_WGRAD_ROWS_3X3");
+      if (coT % 8 == 0 && ciT % 8 == 0 && (ciT >= 16 || wide)) { tm = 8; nw = 8; }
+      else if (wide && coT % 4 == 0 && ciT % 4 == 0) { tm = 4; nw = 4; }
+    }
     if (tm && nw) {
       pl.rows = 1; pl.rTM = tm; pl.rNW = nw;
       pl.coBlocks = coT / tm; pl.ciBlocks = ciT / nw;
@@ -3176,6 +3185,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
       case 577: rc = launch_xwgrad_rows<5, 7, 7>(q, st); break;
       case 573: rc = launch_xwgrad_rows<5, 7, 3>(q, st); break;
       case 388: rc = launch_xwgrad_rows<3, 8, 8>(q, st); break;
+      case 344: rc = launch_xwgrad_rows<3, 4, 4>(q, st); break;
       case 188: rc = launch_xwgrad_rows<1, 8, 8>(q, st); break;
       default: WCMC_REQUIRE(false, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: no filter-row instance for the plan");
     }
