@@ -222,9 +222,12 @@ __global__ __launch_bounds__(256) void split_dy_colsum_kernel(const float* __res
   const int c0 = v * 8;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (pl < PL) {
-    for (int64_t q = p0 + pl; q < p1; q += PL) {
-      const int xx = (int)(q % W); int64_t t = q / W;
-      const int y = (int)(t % H); const int n = (int)(t / H);
+    // pixel cursor (n, y, xx) of q, advanced by PL per iteration (the first version divided the 64-bit pixel index three
+    // times per pixel: the kernel ran at 1.7 TB/s on its address arithmetic)
+    int xx, y, n;
+    { const int64_t q0 = p0 + pl; xx = (int)(q0 % W); const int64_t t = q0 / W; y = (int)(t % H); n = (int)(t / H); }
+    for (int64_t q = p0 + pl; q < p1; q += PL, xx += PL) {
+      while (xx >= W) { xx -= W; if (++y == H) { y = 0; ++n; } }
       float f[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = 0.f;
@@ -252,9 +255,16 @@ __global__ __launch_bounds__(256) void split_dy_colsum_kernel(const float* __res
       }
       if (post) {
         const float* ps = post + n * psn + y * psh + xx * psw + c0;
+        if (whole) {
+          const float4 a = *reinterpret_cast<const float4*>(ps), b = *reinterpret_cast<const float4*>(ps + 4);
+          const float g[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (c0 + e < C) f[e] *= act_gate(ps[e], act, slope);
+          for (int e = 0; e < 8; ++e) f[e] *= act_gate(g[e], act, slope);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (c0 + e < C) f[e] *= act_gate(ps[e], act, slope);
+        }
       }
       u16 hi[8], lo[8];
 #pragma unroll
@@ -1245,9 +1255,10 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 // stage is then TWO filter taps x 16 channels (four taps x 8 in an 8-channel slab): k-group kg of the lanes reads tap
 // 2s + (kg >> 1); taps past ks*ks are slab padding (zero weights) and read the tile's first pixel.
 // Wave w owns tile rows w, w+4, w+8, w+12 (a tile that hangs over the image edge idles every wave equally).
-template <int NT, int NB, int DBG = 0>
+template <int NT, int NB, int PT = 4, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams p) {
-  constexpr int BN = NT * 16, TH = 16, TW = 16, NTHR = 256, NWV = 4, PT = 4;
+  constexpr int BN = NT * 16, TH = 4 * PT, TW = 16, NTHR = 256, NWV = 4;
+  constexpr int NG = (PT + 1) / 2;             // epilogue groups of two pixel tiles per wave (128 pixels of staging)
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
   constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
   const int HWd = TW + p.ks - 1, HHt = TH + p.ks - 1, HP = HWd * HHt;
@@ -1491,8 +1502,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   // ---- epilogue in two halves of 128 pixels (the staging tile of 256 split pixels would not fit beside a second
   // workgroup): half h = pixel tiles 2h, 2h+1 of every wave; staging row pr = 32 * wave + 16 * (i & 1) + column
   auto pix_of = [&](int h, int pr, int& oy, int& ox) {
-    oy = oy0 + (pr >> 5) + NWV * (2 * h + ((pr >> 4) & 1)); ox = ox0 + (pr & 15);
-    return oy < p.Ho && ox < p.Wo;
+    const int i = 2 * h + ((pr >> 4) & 1);             // (PT odd: the last group holds one pixel tile)
+    oy = oy0 + (pr >> 5) + NWV * i; ox = ox0 + (pr & 15);
+    return i < PT && oy < p.Ho && ox < p.Wo;
   };
   if (p.ys) {
     constexpr int OLD = 2 * BN + 8;
@@ -1501,7 +1513,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
     const int cc = tid % CW, rg = tid / CW;
     float csum = 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NG; ++h) {
       if (h) __syncthreads();                            // the first half has left the staging tile
 #pragma unroll
       for (int il = 0; il < 2; ++il) {
@@ -1509,11 +1521,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int co = n0 + j * 16 + fq;
-          float v[4];
-          x_epi_quad(acc[j][2 * h + il], bv[j], okp[2 * h + il], ak, gkind, gv[2 * h + il][j], co, gate_off, v);
-          unsigned h01, l01, h23, l23;
-          x_split2(v[0], v[1], h01, l01);
-          x_split2(v[2], v[3], h23, l23);
+          unsigned h01 = 0, l01 = 0, h23 = 0, l23 = 0;
+          if (2 * h + il < PT) {                           // (else: zeros, the column sums run over all 128 rows)
+            constexpr int dummy = 0; (void)dummy;
+            float v[4];
+            const int ti = 2 * h + il < PT ? 2 * h + il : 0;
+            x_epi_quad(acc[j][ti], bv[j], okp[ti], ak, gkind, gv[ti][j], co, gate_off, v);
+            x_split2(v[0], v[1], h01, l01);
+            x_split2(v[2], v[3], h23, l23);
+          }
           *reinterpret_cast<uint2*>(so + pr * OLD + j * 16 + fq) = make_uint2(h01, h23);
           *reinterpret_cast<uint2*>(so + pr * OLD + BN + j * 16 + fq) = make_uint2(l01, l23);
         }
@@ -1553,7 +1569,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
     constexpr int OLD = BN + 4;
     float* so = reinterpret_cast<float*>(smem16);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NG; ++h) {
       if (h) __syncthreads();
 #pragma unroll
       for (int il = 0; il < 2; ++il) {
@@ -1561,7 +1577,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int co = n0 + j * 16 + fq;
-          const f32x4 a4 = acc[j][2 * h + il];
+          const f32x4 a4 = acc[j][2 * h + il < PT ? 2 * h + il : 0];
           float v[4];
           x_epi_quad(a4, bv[j], true, ak, 0, u32x2{0u, 0u}, co, 1.f, v);
           *reinterpret_cast<float4*>(so + pr * OLD + j * 16 + fq) = make_float4(v[0], v[1], v[2], v[3]);
@@ -2865,35 +2881,43 @@ static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) 
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
-template <int NT, int NB>
+template <int NT, int NB, int PT>
 static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
-  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
 }
 template <int NT>
 static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   XIgemmParams p = p0;
   if (x_env_on("WCMC_HALO64_PRIO")) p.SPS |= 0x100;
-  const int HP = (16 + p.ks - 1) * (16 + p.ks - 1);
+  // Tile height 16 (four pixel tiles per wave) or 12 (three): 512 workgroups are resident (two per CU), a launch takes
+  // ceil(workgroups / 512) rounds of a time proportional to the tile height.  The KPCN layers of 100..108 output rows
+  // are 392 tiles of 16x16 (one round, a quarter of the slots empty) but 504 of 12x16 (one round of 3/4 the length).
+  const int gy = (p.Np / 16 + NT - 1) / NT;
+  auto rounds = [&](int th) { return ((int64_t)p.N * p.tilesX * ((p.Ho + th - 1) / th) * gy + 511) / 512 * th; };
+  const bool pt3 = x_env_on("WCMC_HALO64_PT3") && rounds(12) < rounds(16);
+  const int th = pt3 ? 12 : 16;
+  p.tilesY = (p.Ho + th - 1) / th;
+  const int HP = (th + p.ks - 1) * (16 + p.ks - 1);
   const size_t halo = (size_t)((HP * p.PXS + 127) & ~127), bstage = (size_t)(2 * NT * 16 * XROW + 64) * sizeof(u16);
   const size_t out = p.ys ? (size_t)128 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)128 * (NT * 16 + 4) * sizeof(float);
 #ifdef WCMC_DEBUG_BUILD
-  if (NT == 7) {
+  if (NT == 7 && !pt3) {
     const char* e = getenv("WCMC_DEBUG_ABLATE");
     const int ab = e ? atoi(e) : 0;
     if (ab) {
-      auto kfn = ab == 1 ? &conv_halo64_bf16x3_kernel<7, 3, 1> : ab == 2 ? &conv_halo64_bf16x3_kernel<7, 3, 2>
-                 : ab == 4 ? &conv_halo64_bf16x3_kernel<7, 3, 4> : ab == 8 ? &conv_halo64_bf16x3_kernel<7, 3, 8>
-                 : ab == 10 ? &conv_halo64_bf16x3_kernel<7, 3, 10> : ab == 14 ? &conv_halo64_bf16x3_kernel<7, 3, 14>
-                 : ab == 32 ? &conv_halo64_bf16x3_kernel<7, 3, 32> : ab == 46 ? &conv_halo64_bf16x3_kernel<7, 3, 46>
-                 : &conv_halo64_bf16x3_kernel<7, 3, 64>;
+      auto kfn = ab == 1 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 1> : ab == 2 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 2>
+                 : ab == 4 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 4> : ab == 8 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 8>
+                 : ab == 10 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 10> : ab == 14 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 14>
+                 : ab == 32 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 32> : ab == 46 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 46>
+                 : &conv_halo64_bf16x3_kernel<7, 3, 4, 64>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
       hipLaunchKernelGGL(kfn, grid, dim3(256), halo + 3 * bstage, stream, p);
@@ -2906,7 +2930,8 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   const int nb = (!(nbe && nbe[0] == '2') && halo + 3 * bstage <= 80 * 1024) ? 3 : 2;
   const size_t main_ = halo + nb * bstage;
   const size_t lds = main_ > out ? main_ : out;
-  return nb == 3 ? launch_xhalo64b<NT, 3>(p, lds, stream) : launch_xhalo64b<NT, 2>(p, lds, stream);
+  if (pt3) return nb == 3 ? launch_xhalo64b<NT, 3, 3>(p, lds, stream) : launch_xhalo64b<NT, 2, 3>(p, lds, stream);
+  return nb == 3 ? launch_xhalo64b<NT, 3, 4>(p, lds, stream) : launch_xhalo64b<NT, 2, 4>(p, lds, stream);
 }
 template <int NT>
 static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
