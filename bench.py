@@ -148,11 +148,13 @@ def pmc_traffic():
         d = json.load(f)
     pick = {}
     for k, v in d.items():
-        for tag, key in (("conv_halo_bf16x3_kernel<7", "conv_halo7"), ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
+        for tag, key in (("conv_halo_bf16x3_kernel<7, 8, 16", "conv_halo7"), ("conv_halo64_bf16x3_kernel<7, 3, 4", "conv_halo64_pt4"),
+                         ("conv_halo64_bf16x3_kernel<7, 3, 3", "conv_halo64_pt3"), ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("kernel_apply_strip_kernel<false", "kernel_apply_fwd"), ("kernel_apply_strip_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
                 shape = ("64x128x128 64->64 1x1 hidden layer (PathNet embedding): 536.9 MB algorithmic" if key == "conv_pw" else
+                         "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles)" if key == "conv_halo64_pt3" else
                          "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else "logits (8,441,92,92)")
                 pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "shape": shape,
                              "source": "profiles/r02_pmc_summary.json"}
@@ -375,6 +377,8 @@ def main():
                 # ~3.5x the counted FLOPs; for scale, the exact-fp32 MFMA peak is 157.3 TFLOP/s
                 extra = {"mfma_flops_per_algorithmic_flop": 3.0, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 3)}
             rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 8, 16, 0, 2>",
+                            "conv_halo64_pt4": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0>",
+                            "conv_halo64_pt3": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0>",
                             "conv_wgrad_rows": "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
                             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}.get(name, name + " (several kernels)")
             if ops.PRECISION == "fp32":
@@ -385,9 +389,11 @@ def main():
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "share_of_profiled_region": round(d["ms"] / (prof_elapsed * 1e3), 4)}
 
-        # classes = kernels: conv_halo7 is conv_halo_bf16x3_kernel<7,16,16> (KPCN 5x5 fwd + dgrad), conv_wgrad_rows
-        # is conv_wgrad_rows_bf16x3_kernel<5,7,7>; conv_igemm / conv_wgrad collect the other GEMM kernels
-        conv_keys = [k for k in ("conv_halo7", "conv_wgrad_rows", "conv_igemm", "conv_wgrad") if k in summ]
+        # classes = kernels: conv_halo64_pt4 / _pt3 are the two tile heights of conv_halo64_bf16x3_kernel<7,3,PT> (KPCN 5x5 fwd +
+        # dgrad; conv_halo7 = the 8x16 kernel it replaces, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows_bf16x3_kernel<5,7,7>;
+        # conv_igemm / conv_wgrad collect the other GEMM kernels
+        conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo7", "conv_wgrad_rows", "conv_igemm", "conv_wgrad")
+                     if k in summ]
         dominant = max(conv_keys, key=lambda k: summ[k]["ms"]) if conv_keys else None
         ka = kernel_apply_probe(device)
         traffic = pmc_traffic()

@@ -337,7 +337,13 @@ static XKPlan x_plan_k(int kchan, int ks) {
     // tilings leave most CUs with one workgroup -- scripts/time_unet_layers.py)
     q.nslabs = (q.Kp + 15) / 16;
     q.CS = 16; q.CSl = q.Kp - (q.nslabs - 1) * 16;
-    q.PXS = 80;
+    // halo pixel stride 80 B (5 slots of 16 B: hi 0-1, lo 2-3, one of pad).  The ds_read_b128 of the pixel fragments are
+    // 2-way bank conflicts with it (PMC: 23-26 % of the LDS cycles; the four 16-lane groups of a b128 read take k-groups 0
+    // and 1 of different pixel columns together and 5 f, 5 f' + 1 meet mod 16); 96 B is conflict-free for the 16-channel
+    // slabs and measured 0.7 % SLOWER (3.120 vs 3.097 ms per branch: the LDS pipe is not what the loop waits for, and the
+    // halo grows by a fifth) -- WCMC_HALO64_PXS=96 for the A/B
+    static const int pxs = [] { const char* e = getenv("WCMC_HALO64_PXS"); return e ? atoi(e) : 80; }();
+    q.PXS = pxs;
     q.Ks = round_up(ks * ks * q.CS, 32); q.Ksl = round_up(ks * ks * q.CSl, 32);
     q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
     return q;
@@ -2935,7 +2941,7 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
 }
 template <int NT>
 static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
-  if (p.PXS == 80 && p.ks == 5) return launch_xhalo64<NT>(p, stream);
+  if (p.CS == 16 && p.ks == 5) return launch_xhalo64<NT>(p, stream);
   constexpr int TH = 16, TW = 16;
   const int HP = (TH + p.ks - 1) * (TW + p.ks - 1);
   const size_t halo = (size_t)((HP * p.PXS + 127) & ~127), bstage = (size_t)(2 * NT * 16 * XROW + 64) * sizeof(u16);

@@ -466,16 +466,25 @@ def _pack_chain_x(weights, ks):
     return [keep[2 * i + 1] for i in range(n)]
 
 
-def _igemm_class(cin, cout, ks):
+def _igemm_class(cin, cout, ks, dims=None):
     """Profiler class of a split-bf16 GEMM launch = the kernel the library's plan picks for it
-    (csrc/conv_bf16x3.hip: x_plan_k, x_pick_nt), so that a class average is one kernel's average."""
+    (csrc/conv_bf16x3.hip: x_plan_k, x_pick_nt, launch_xhalo64), so that a class average is one kernel's average.
+    dims = (n, ho, wo) of the output selects between the two tile heights of the 5x5 kernel."""
     tiles = (cout + 15) // 16
     nt = min((7, 4, 2, 1), key=lambda t: (-(-tiles // t)) * (t + 2))
     halo = 3 <= ks <= 5 and (cin + 7) // 8 * 8 >= 32
     if ks == 1 and ((cin + 7) // 8 * 8, cout) in ((64, 64), (40, 64), (128, 128), (8, 128)) \
             and os.environ.get("WCMC_IGEMM_PW", "1") != "0":
         return "conv_pw"                    # x_plan_pw: the persistent pointwise kernel (HBM-bound class)
-    return "conv_halo7" if halo and nt == 7 and ks == 5 else "conv_igemm"     # conv_halo_bf16x3_kernel<7, 8, 16, 0, 2>
+    if not (halo and nt == 7 and ks == 5):
+        return "conv_igemm"
+    if dims is None or os.environ.get("WCMC_HALO64", "1") == "0" or os.environ.get("WCMC_IGEMM_HALO", "1") == "0":
+        return "conv_halo7"                 # conv_halo_bf16x3_kernel<7, 8, 16, 0, 2> (and the fp32 path's 5x5 class)
+    n, ho, wo = dims                        # conv_halo64_bf16x3_kernel<7, NB, PT>: 16x16 tiles (PT = 4) or 12x16 (PT = 3)
+    gy = -(-tiles // nt)
+    rounds = lambda th: -(-(n * (-(-wo // 16)) * (-(-ho // th)) * gy) // 512) * th
+    pt3 = os.environ.get("WCMC_HALO64_PT3", "1") != "0" and rounds(12) < rounds(16)
+    return "conv_halo64_pt3" if pt3 else "conv_halo64_pt4"
 
 
 def _wgrad_class(n, ho, cin, cout, ks):
@@ -505,7 +514,7 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     mask = None
     if mask_out:
         mask = torch.empty(n * ho * wo * ((cout + 7) // 8), device=dev, dtype=torch.uint8)
-    cls = _igemm_class(cin, cout, ks) if pad == 0 or ks > 1 else "conv_igemm"
+    cls = _igemm_class(cin, cout, ks, (n, ho, wo)) if pad == 0 or ks > 1 else "conv_igemm"
     if cls == "conv_pw":    # algorithmic bytes: the split input and the split / fp32 output, 4 B per channel and pixel
         work = (4.0 * n * pix * ((cin + 7) // 8 * 8 + cout), "byte")
     else:
