@@ -1,0 +1,19 @@
+set -x
+O=gpurun_out/r02f; mkdir -p $O
+export WCMC_DEBUG_LIB=1
+WCMC_HALO64=0 WCMC_DEBUG_ABLATE=64 timeout 200 python3 scripts/timeline_halo.py 124 116 100 2>&1 | grep -v amdgpu.ids > $O/halo8x16_timeline.txt
+WCMC_DEBUG_ABLATE=64 timeout 200 python3 scripts/timeline_halo.py 124 108 2>&1 | grep -v amdgpu.ids > $O/halo64_timeline.txt
+WCMC_HALO64=0 timeout 300 python3 scripts/time_halo_abl.py 124 0 1 2 4 8 16 32 10 26 2>&1 | grep -v amdgpu.ids > $O/halo8x16_ablations.txt
+timeout 300 python3 scripts/time_halo_abl.py 124 0 1 2 4 8 10 14 32 46 2>&1 | grep -v amdgpu.ids > $O/halo64_ablations.txt
+WCMC_DEBUG_ABLATE=16 timeout 200 python3 scripts/timeline_wgrad.py 124 108 2>&1 | grep -v amdgpu.ids > $O/wgrad_rows_timeline.txt
+timeout 300 python3 scripts/time_wgrad_abl.py 124 2>&1 | grep -v amdgpu.ids > $O/wgrad_rows_ablations.txt
+unset WCMC_DEBUG_LIB
+timeout 250 python3 scripts/time_conv_layers.py 2>&1 | grep -v amdgpu.ids > $O/conv_layers.txt
+WCMC_HALO64=0 timeout 250 python3 scripts/time_conv_layers.py 2>&1 | grep -v amdgpu.ids > $O/conv_layers_halo8x16.txt
+WCMC_HALO64_PT3=0 timeout 250 python3 scripts/time_conv_layers.py 2>&1 | grep -v amdgpu.ids > $O/conv_layers_pt4_only.txt
+timeout 200 python3 scripts/time_wgrad.py 2>&1 | grep -v amdgpu.ids > $O/wgrad_layers.txt
+timeout 300 python3 scripts/time_wgrad_1x1.py 2>&1 | grep -v amdgpu.ids > $O/wgrad_1x1.txt
+timeout 250 python3 scripts/time_wgrad_unet.py 2>&1 | grep -v amdgpu.ids > $O/wgrad_unet.txt
+WCMC_WGRAD_ROWS_3X3=0 timeout 250 python3 scripts/time_wgrad_unet.py 2>&1 | grep -v amdgpu.ids > $O/wgrad_unet_onetap.txt
+timeout 250 python3 scripts/time_unet_layers.py 2>&1 | grep -v amdgpu.ids > $O/unet_layers.txt
+ls -la $O
