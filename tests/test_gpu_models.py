@@ -579,6 +579,11 @@ _SWITCHES = [
     ("env", "WCMC_IGEMM_DBUF", "0", "exact"),            # single-buffered streaming igemm
     ("env", "WCMC_IGEMM_HALO", "0", "close"),            # streaming igemm for the 3x3 / 5x5 layers (another K order)
     ("env", "WCMC_WGRAD_ROWS", "0", "close"),            # one-tap weight-gradient kernel (another split-K order)
+    ("env", "WCMC_HALO64", "0", "close"),                # the 8x16 5x5 kernel (32-channel slabs: another K order)
+    ("env", "WCMC_HALO64_PT3", "0", "close"),            # 16x16 tiles only (bias sums group per tile)
+    ("env", "WCMC_HALO64_PRIO", "0", "exact"),           # no priority alternation between the workgroups of a CU
+    ("env", "WCMC_WGRAD_ROWS_3X3", "0", "close"),        # filter-row weight gradient only from 256 input channels up
+    ("env", "WCMC_WGRAD_ROWS_1X1", "0", "close"),        # one-tap kernel for the 128->128 1x1 weight gradient
 ]
 
 

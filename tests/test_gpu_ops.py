@@ -200,6 +200,61 @@ def test_gate_from_bit_mask_equals_gate_from_tensor(case):
         assert torch.equal(a, bb), act
 
 
+HALO5_CASES = [
+    # N, Cin, H, W, Cout, pad, split output -- ragged 16x16 / 12x16 tiles, the three slab structures (104 = 6 x 16 + 8,
+    # 40 = 16 + 16 + 8, 448 = 28 x 16), four cout blocks, the fp32-view output of the last KPCN layer
+    (2, 100, 40, 37, 100, 0, True),
+    (1, 100, 70, 75, 441, 0, False),
+    (2, 39, 29, 52, 100, 0, True),
+    (1, 441, 21, 26, 100, 4, True),
+    (3, 100, 20, 33, 39, 4, True),
+]
+
+
+@pytest.mark.parametrize("case", HALO5_CASES)
+def test_conv5x5_kernel_variants_agree_with_fp64(case, monkeypatch):
+    """The KPCN 5x5 forward / data-gradient launches through every variant of their kernel -- 12x16 tiles (what small
+    launches get), 16x16 tiles only, without the priority alternation, the 96-byte halo stride is a process-wide plan
+    (not switched here), and the 8x16 kernel they replaced -- against an fp64 convolution, gated by a bit mask and with
+    the column sums (the consumer's bias gradient) where the output is split."""
+    o = ops()
+    n, cin, h, w, cout, pad, split = case
+    ks = 5
+    ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+    x = gen(n, cin, h, w, seed=80)
+    wt = gen(cout, cin, ks, ks, seed=81, scale=(2.0 / (cin * ks * ks)) ** 0.5 * 1.7)
+    b = gen(cout, seed=82, scale=0.2)
+    keep = (gen(n, cout, ho, wo, seed=83) > -0.3)                     # the gate: ~65 % of the outputs pass
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=pad)) * keep.double()
+    xs = o.split_raw(o.to_nhwc_raw(x.to(DEV)))
+    cp = (cout + 7) // 8 * 8
+    bits = torch.zeros(n, ho, wo, cp, dtype=torch.bool)
+    bits[..., :cout] = keep.permute(0, 2, 3, 1)
+    mask = torch.from_numpy(np.packbits(bits.numpy().reshape(-1, cp), axis=1, bitorder="little").reshape(-1)).to(DEV)
+    outs = {}
+    for name, env in (("12x16 where it pays", {}), ("16x16 only", {"WCMC_HALO64_PT3": "0"}),
+                      ("no priority alternation", {"WCMC_HALO64_PRIO": "0"}), ("8x16 kernel", {"WCMC_HALO64": "0"})):
+        for k in ("WCMC_HALO64_PT3", "WCMC_HALO64_PRIO", "WCMC_HALO64"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        wp = o._pack_x(wt.to(DEV), 0)                                  # (the packing follows the kernel's slab plan)
+        if split:
+            y, part = o.conv2d_x_raw(xs, (n, cin, h, w), wp, b.to(DEV), cout, ks, pad, "relu", out_split=True,
+                                     gate_mask=mask, gate_act="relu", colsum=True)
+            yd = o.unsplit_debug(y, n, cout, ho, wo)
+            db = o.colsum_finish_raw(part, (n, cout, ho, wo))
+            assert_close(db, ref.sum(dim=(0, 2, 3)), tol=2e-5, what=name + ": column sums")
+        else:
+            yd = o.conv2d_x_raw(xs, (n, cin, h, w), wp, b.to(DEV), cout, ks, pad, "relu", out_split=False)
+            yd = yd * keep.to(DEV)
+        assert_close(yd, ref, tol=2e-5, what=name)
+        outs[name] = yd
+    # same kernel, same K order: the tile height and the priority do not change a single bit
+    assert torch.equal(outs["12x16 where it pays"], outs["16x16 only"])
+    assert torch.equal(outs["12x16 where it pays"], outs["no priority alternation"])
+
+
 PW_CASES = [
     # N, H, W, widths of a 1x1 chain, output activation -- the PathNet chains (support/networks.py:22-27)
     (5, 37, 41, (36, 64, 64, 64), "linear"),     # embedding: 7585 pixels = 118 tiles + 33 (ragged last tile)

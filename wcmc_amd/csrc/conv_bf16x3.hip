@@ -2993,7 +2993,9 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   // ... and for any launch whose 16x16 tiling has fewer workgroups than the chip has CUs (the deepest U-Net level: 32 tiles
   // x 4 cout blocks), where half-size tiles simply fill the machine (<= 4 cout tiles: one wave per weight row group pair)
   const int64_t blocks16 = (int64_t)p.N * p.tilesX * p.tilesY * ((p.Np / 16 + NT - 1) / NT);
-  const bool underfilled = NT <= 4 && blocks16 < 256 && p.Ho >= 16;
+  // ... and, measured (scripts/time_unet_layers.py), where the 16x16 tiling is two or more rounds (the 128^2 level: 512
+  // tiles): two 128-pixel workgroups per CU with their own stage barriers instead of one of 256 -- 46.8 -> 43.5 us
+  const bool underfilled = NT <= 4 && (blocks16 < 256 || blocks16 >= 512) && p.Ho >= 16;
   if ((p.PXS == 160 && p.ks == 5) || underfilled) {
     // WCMC_HALO_TH8_5X5 plan (32-channel slabs): 8x16-pixel tiles, four waves, TWO workgroups per CU -- their stage
     // barriers are independent, so the non-MFMA phases of one hide behind the MFMAs of the other
