@@ -7,18 +7,20 @@ import numpy as np, torch
 from wcmc_amd import ops as o
 assert os.environ.get("WCMC_DEBUG_ABLATE") == "64"
 dev = "cuda"
-n, cin, cout, ks = 8, 100, 100, 5
-for h in [int(a) for a in sys.argv[1:]] or [124, 116, 100]:
+unet = "--unet" in sys.argv                      # a U-Net 3x3 layer (64 -> 64, pad 1) instead of a KPCN 5x5 layer
+n, cin, cout, ks = (8, 64, 64, 3) if unet else (8, 100, 100, 5)
+pad = 1 if unet else 0
+for h in [int(a) for a in sys.argv[1:] if a != "--unet"] or [124, 116, 100]:
     x = o.to_nhwc_raw(torch.randn(n, cin, h, h, device=dev))
     w = torch.randn(cout, cin, ks, ks, device=dev) * 0.02
     b = torch.zeros(cout, device=dev)
     xs = o.split_raw(x); wp = o._pack_x(w, 0)
     for _ in range(3):
-        y, part = o.conv2d_x_raw(xs, (n, cin, h, h), wp, b, cout, ks, 0, "relu", out_split=True, colsum=True)
+        y, part = o.conv2d_x_raw(xs, (n, cin, h, h), wp, b, cout, ks, pad, "relu", out_split=True, colsum=True)
     torch.cuda.synchronize()
-    ho = h - ks + 1
-    th = 16 if os.environ.get("WCMC_HALO64", "1") != "0" else 8      # conv_halo64: 16x16 tiles; conv_halo<7,8,16>: 8x16
-    tiles, nw = n * ((ho + th - 1) // th) * ((ho + 15) // 16), 4
+    ho = h + 2 * pad - ks + 1
+    th = 8 if unet else 16 if os.environ.get("WCMC_HALO64", "1") != "0" else 8      # conv_halo64: 16x16 tiles; conv_halo<7,8,16>: 8x16
+    tiles, nw = n * ((ho + th - 1) // th) * ((ho + 15) // 16), (1 if unet else 4)     # (64 couts: room for one wave's record per tile)
     st = part.cpu().numpy().view(np.uint64)[: tiles * nw * 14].reshape(tiles, nw, 14)
     rt = st[:, :, 6:13].astype(np.float64) * 0.01          # us: entry, loop start, loop end, E0, E1, E2, exit
     t0 = rt[:, :, 0].min()
@@ -42,6 +44,13 @@ for h in [int(a) for a in sys.argv[1:]] or [124, 116, 100]:
         else:
             print("      epilogue: operand loads + drain + barrier %.1f  first half: act/split -> LDS %.1f, store issue %.1f  second half + store drain %.1f" %
                   ((e0 - lp1)[m].mean(), (e1 - e0)[m].mean(), (e2 - e1)[m].mean(), (ex - e2)[m].mean()))
+    if th == 8:      # the 8x16 kernel's s_memtime phase sums of the stage loop (cycles; the stamps themselves cost ~100 each)
+        ph = st[:, :, 0:6].astype(np.float64)
+        names = ["stage barrier", "halo DMA issue (slab ends)", "MFMAs + fragment reads", "stage tail (+ slab boundaries)",
+                 "wait for the wave's own weight DMA", "weight DMA issue"]
+        nstage = (ks * ks * (cin if unet else 32) + 31) // 32 if unet else 82
+        print("  stage loop, cycles per stage (%d stages): " % nstage + ", ".join("%s %.0f" % (nm, ph[:, :, i].mean() / nstage) for i, nm in enumerate(names))
+              + "; MFMA issue alone: %d" % ((4 if unet else 7) * 2 * 3 * 16))
     # occupancy over time: how many workgroups are inside their stage loop
     grid = np.arange(0, ex.max(), 5.0)
     inloop = [(int(((lp0 <= t) & (lp1 > t)).sum()), int(((ent <= t) & (ex > t)).sum())) for t in grid]

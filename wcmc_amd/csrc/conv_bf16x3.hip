@@ -873,6 +873,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
   constexpr int TPX = TH * TW, NTHR = TPX * 2, NWV = NTHR / 64;   // one wave per 32 pixels (two MFMA pixel tiles)
   constexpr int TPR = TW / 16;                 // MFMA pixel tiles per tile row
   static_assert(TPX % 32 == 0 && TW % 16 == 0, "a wave = 2 pixel tiles of 16");
+  constexpr int STW = BN * 4 >= NWV * 14 * 8 ? NWV : 1;    // (stamp builds: waves with a record in the tile's colsum row)
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
   constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
   const int HWd = TW + p.ks - 1, HHt = TH + p.ks - 1, HP = HWd * HHt;
@@ -1148,8 +1149,8 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     return;
   }
   if (DBG & 64) {
-    if (lane == 0) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * NWV + wave) * 14;
+    if (lane == 0 && wave < STW) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * STW + wave) * 14;
       for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
       for (int i = 0; i < 3; ++i) o[6 + i] = st_rt[i];
       unsigned hw;
@@ -1242,8 +1243,8 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
   if (DBG & 64) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the stores have left)
     rstamp(6);
-    if (lane == 0) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * NWV + wave) * 14;
+    if (lane == 0 && wave < STW) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + ((int64_t)tile * STW + wave) * 14;
       for (int i = 3; i < 7; ++i) o[6 + i] = st_rt[i];
     }
   }
@@ -2990,6 +2991,24 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
     }
   }
 #endif
+#ifdef WCMC_DEBUG_BUILD
+  if (NT == 4 && p.ks == 3) {        // wall-clock stamps of the U-Net 3x3 launches, 8x16 tiling (scripts/timeline_halo.py --unet)
+    const char* e = getenv("WCMC_DEBUG_ABLATE");
+    if (e && atoi(e) == 64) {
+      constexpr int TH8 = 8;
+      XIgemmParams q = p;
+      q.tilesY = (p.Ho + TH8 - 1) / TH8;
+      const size_t halo8 = (size_t)(((TH8 + p.ks - 1) * (TW + p.ks - 1) * p.PXS + 127) & ~127);
+      const size_t out8 = (size_t)TH8 * TW * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)32 * NT * 16 * sizeof(float);
+      const size_t main8 = halo8 + 2 * bstage;
+      const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)((q.Np / 16 + NT - 1) / NT));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<4, TH8, TW, 64, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      hipLaunchKernelGGL((conv_halo_bf16x3_kernel<4, TH8, TW, 64, 2>), grid, dim3(TH8 * TW * 2), main8 > out8 ? main8 : out8, stream, q);
+      return check_launch("conv2d_igemm_bf16x3(halo 8x16 3x3, stamps)");
+    }
+  }
+#endif
   // ... and for any launch whose 16x16 tiling has fewer workgroups than the chip has CUs (the deepest U-Net level: 32 tiles
   // x 4 cout blocks), where half-size tiles simply fill the machine (<= 4 cout tiles: one wave per weight row group pair)
   const int64_t blocks16 = (int64_t)p.N * p.tilesX * p.tilesY * ((p.Np / 16 + NT - 1) / NT);
@@ -3005,15 +3024,18 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
     const size_t halo8 = (size_t)(((TH8 + p.ks - 1) * (TW + p.ks - 1) * p.PXS + 127) & ~127);
     const size_t out8 = p.ys ? (size_t)TH8 * TW * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)32 * NT * 16 * sizeof(float)
                              : (size_t)TH8 * TW * (NT * 16 + 4) * sizeof(float);
+    // (three weight stages, which still fit beside the second workgroup for <= 4 cout tiles, measured no faster on the
+    // U-Net's 3x3 layers, nor five in the 16x16 tiling: wall-clock stamps show 15 us in the stage loop of 64 -> 64 at
+    // 128^2 for 7 us of MFMAs, but the DMA is not what the stages wait for -- scripts/timeline_halo.py --unet)
     const size_t main8 = halo8 + 2 * bstage;
     const size_t lds8 = main8 > out8 ? main8 : out8;
+    const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)((q.Np / 16 + NT - 1) / NT));
     static size_t attr8 = 0;
     if (lds8 > attr8) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
       attr8 = lds8;
     }
-    const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)((q.Np / 16 + NT - 1) / NT));
     hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>), grid, dim3(TH8 * TW * 2), lds8, stream, q);
     return check_launch("conv2d_igemm_bf16x3(halo, 8x16)");
   }
