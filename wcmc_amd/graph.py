@@ -45,6 +45,10 @@ class GraphedTrainStep:
         side = ops.USE_SIDE_STREAM
         ops.USE_SIDE_STREAM = side and side_stream        # forked capture: wgrad branches run beside dgrad in the graph
         self.static.pop('_wcmc_paths_nhwc', None)
+        # (Tried: the step as a SEQUENCE of three hipGraphs sharing one memory pool -- PathNet forwards | KPCN forward and losses |
+        # backward passes -- so that the host launches the later segments while the GPU runs the first: hipGraphLaunch of
+        # the ~410-node step costs the host 0.94 ms, scripts/diag_step_host.py.  Bit-identical, and no faster: 397.7 vs 400.9
+        # patches/s -- the runtime already feeds the GPU while it is still submitting.)
         self.graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(self.graph):
@@ -56,23 +60,31 @@ class GraphedTrainStep:
 
     def _draw(self):
         """Fresh pairings, in the reference's call order (diffuse: patch, batch; specular: patch, batch)."""
+        if self.fm.rng == 'device':                       # written in place: no sort, no copy; the keys of the step's
+            outs = [t for pair in self.perms for t in pair if t is not None]      # permutations in ONE draw (the same stream
+            seeds = torch.randint(0, 2 ** 62, (len(outs),)).tolist()              # of keys as one draw per permutation)
+            for t, seed in zip(outs, seeds):
+                ops.random_permutation(t.numel(), t.device, out=t, seed=seed)
+            return
         for ip, ib in self.perms:
-            if self.fm.rng == 'device':                   # written in place: no sort, no copy
-                ops.random_permutation(self.perm_sizes[0], ip.device, out=ip)
-                if ib is not None:
-                    ops.random_permutation(self.perm_sizes[1], ib.device, out=ib)
-            else:
-                ip.copy_(torch.randperm(self.perm_sizes[0]), non_blocking=True)
-                if ib is not None:
-                    ib.copy_(torch.randperm(self.perm_sizes[1]), non_blocking=True)
+            ip.copy_(torch.randperm(self.perm_sizes[0]), non_blocking=True)
+            if ib is not None:
+                ib.copy_(torch.randperm(self.perm_sizes[1]), non_blocking=True)
 
     def __call__(self, batch):
         itf = self.itf
         itf.preprocess(batch)                             # key asserts + iters += 1
+        dst, src = [], []
         for k in self.keys:
-            v, src = self.static[k], batch[k]
-            if src.data_ptr() != v.data_ptr():
-                v.copy_(src, non_blocking=True)
+            v, b = self.static[k], batch[k]
+            if b.data_ptr() != v.data_ptr():
+                dst.append(v); src.append(b)
+        if dst:                                           # one multi-tensor launch where torch can fuse it (same device / dtype)
+            if all(b.is_cuda and b.dtype == v.dtype and b.shape == v.shape for v, b in zip(dst, src)):
+                torch._foreach_copy_(dst, src)
+            else:
+                for v, b in zip(dst, src):
+                    v.copy_(b, non_blocking=True)
         if self.fm is not None:
             self._draw()
             self.fm._static_i = 0

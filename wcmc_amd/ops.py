@@ -1384,13 +1384,14 @@ def gradients(buf):
     return out
 
 
-def random_permutation(n, device, out=None):
+def random_permutation(n, device, out=None, seed=None):
     """A pseudo-random permutation of range(n) as an int64 device tensor, without the sort behind
     ``torch.randperm(n, device=...)`` (``wcmc_random_permutation``: keyed Feistel network).  The 62-bit key is drawn
     from torch's default CPU generator, so ``torch.manual_seed`` fixes the sequence of permutations."""
     if out is None:
         out = torch.empty(n, dtype=torch.int64, device=device)
     assert out.is_cuda and out.dtype == torch.int64 and out.numel() == n and out.is_contiguous()
-    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    check(lib().wcmc_random_permutation(_ptr(out), n, seed, _stream()), "random_permutation")
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    check(lib().wcmc_random_permutation(_ptr(out), n, int(seed), _stream()), "random_permutation")
     return out
