@@ -11,22 +11,17 @@ with open(f, newline="") as fh:
     for r in csv.DictReader(fh):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", ""), r.get("Stream_Id", "")))
 rows.sort()
-# steps: split at the first clip_adam launch of a step (the optimiser runs eagerly after every replay, 3 launches)
-marks = [i for i, r in enumerate(rows) if "clip_adam_kernel" in r[2]]
-steps = []
-prev = None
-for i in marks:
-    if prev is None or rows[i][0] - rows[prev][0] > 2_000_000:
-        steps.append(i)
-    prev = i
+# steps: the captured step begins with the one nchw_split launch (the shared `paths` conversion)
+steps = [i for i, r in enumerate(rows) if "nchw_split_kernel" in r[2]]
 print("kernels %d, steps found %d" % (len(rows), len(steps)))
-for a, b in list(zip(steps[:-1], steps[1:]))[-5:]:
+for a, b in list(zip(steps[:-1], steps[1:]))[8:14]:
     seg = rows[a:b]
-    t0, t1 = seg[0][0], max(r[1] for r in seg)
+    t0, t1 = seg[0][0], rows[b][0]                      # first kernel of this step -> first kernel of the next
     ev = []
     for s, e, *_ in seg:
         ev.append((s, 1)); ev.append((e, -1))
     ev.sort()
+    ev.append((t1, 0))
     busy = multi = 0; depth = 0; last = ev[0][0]; gaps = []
     for t, d in ev:
         if depth >= 1: busy += t - last
@@ -39,6 +34,7 @@ for a, b in list(zip(steps[:-1], steps[1:]))[-5:]:
           (len(seg), (t1 - t0) / 1e6, busy / 1e6, (t1 - t0 - busy) / 1e6, len(gaps), ", ".join("%.0f@%.1fms" % (g / 1e3, at / 1e6) for g, at in gaps[:6]), multi / 1e6, ksum / 1e6))
 if len(steps) > 12:
     a, b = steps[10], steps[11]
-    print("first kernels of one step (start offset us, duration us, name):")
-    for s_, e_, nm, *_ in rows[a:a + 40]:
+    a = max(0, b - 30)
+    print("the last kernels of one step and the first of the next (start offset us, duration us, name):")
+    for s_, e_, nm, *_ in rows[a:a + 60]:
         print("  %8.1f %7.1f  %s" % ((s_ - rows[a][0]) / 1e3, (e_ - s_) / 1e3, nm[:90]))

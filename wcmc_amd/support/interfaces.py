@@ -341,7 +341,12 @@ class KPCNInterface(BaseInterface):
         for key in loss_dict:
             if 'm_' + key not in self.m_losses:
                 self.m_losses['m_' + key] = torch.tensor(0.0, device=loss_dict[key].device)
-            self.m_losses['m_' + key] += loss_dict[key]
+        sums, vals = [self.m_losses['m_' + k] for k in keys], [loss_dict[k] for k in keys]
+        if all(a.shape == b.shape and a.device == b.device and a.dtype == b.dtype for a, b in zip(sums, vals)):
+            torch._foreach_add_(sums, vals)              # the running sums in one launch (seven tiny ones otherwise)
+        else:
+            for a, b in zip(sums, vals):
+                a += b
 
     @staticmethod
     def _raise_if_nonfinite(keys, finite):
