@@ -582,6 +582,7 @@ _SWITCHES = [
     ("env", "WCMC_HALO64", "0", "close"),                # the 8x16 5x5 kernel (32-channel slabs: another K order)
     ("env", "WCMC_HALO64_PT3", "0", "close"),            # 16x16 tiles only (bias sums group per tile)
     ("env", "WCMC_HALO64_PRIO", "0", "exact"),           # no priority alternation between the workgroups of a CU
+    ("env", "WCMC_HALO64_CS32", "0", "close"),           # 16-channel slabs for the 441-channel data gradient too (another K order)
     ("env", "WCMC_WGRAD_ROWS_3X3", "0", "close"),        # filter-row weight gradient only from 256 input channels up
     ("env", "WCMC_WGRAD_ROWS_1X1", "0", "close"),        # one-tap kernel for the 128->128 1x1 weight gradient
 ]

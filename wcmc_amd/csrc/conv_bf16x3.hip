@@ -335,6 +335,17 @@ static XKPlan x_plan_k(int kchan, int ks) {
     // conv_halo64_bf16x3_kernel: slabs of 16 channels (the last one 8 or 16), halo pixel stride 80 B, two taps per stage
     // (5x5 only: on the U-Net's 3x3 layers it wins 4 % at 128^2 and loses 30-70 % on the 64^2 / 32^2 levels, whose 16x16
     // tilings leave most CUs with one workgroup -- scripts/time_unet_layers.py)
+    if (q.Kp >= 256 && q.Kp % 32 == 0 && x_env_on("WCMC_HALO64_CS32")) {
+      // many input channels (the 441-cout layer's data gradient: 448): 32-channel slabs, one tap per stage -- half the
+      // halo reloads and no padded taps (14 x 800 k instead of 28 x 416); the 160-byte halo only fits the 12x16 tile
+      // beside a second workgroup, with two weight stages (launch_xhalo64)
+      q.nslabs = q.Kp / 32;
+      q.CS = q.CSl = 32;
+      q.PXS = 160;
+      q.Ks = q.Ksl = round_up(ks * ks * 32, 32);
+      q.Kt = q.nslabs * q.Ks;
+      return q;
+    }
     q.nslabs = (q.Kp + 15) / 16;
     q.CS = 16; q.CSl = q.Kp - (q.nslabs - 1) * 16;
     // halo pixel stride 80 B (5 slots of 16 B: hi 0-1, lo 2-3, one of pad).  The ds_read_b128 of the pixel fragments are
@@ -1366,9 +1377,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
     cs_cur = slab == p.nslabs - 1 ? p.CSl : p.CS;
     sps_cur = slab == p.nslabs - 1 ? p.SPSl : (p.SPS & 0xff);
     lo_off = cs_cur * 2;
-    tps = 32 / cs_cur;                                   // taps per stage: 2 (16 channels) or 4 (8)
+    tps = 32 / cs_cur;                                   // taps per stage: 1 (32 channels), 2 (16) or 4 (8)
     coff = ((kg * 8) & (cs_cur - 1)) * 2;
-    tdy = 0; tdx = cs_cur == 16 ? (kg >> 1) : kg;        // (< ks)
+    tdy = 0; tdx = cs_cur == 32 ? 0 : cs_cur == 16 ? (kg >> 1) : kg;        // (< ks)
   };
   bf16x8 ah[PT], al[PT], wh[NT], wl[NT];
   auto a_off = [&]() { return tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + coff : coff; };
@@ -2909,7 +2920,7 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   // are 392 tiles of 16x16 (one round, a quarter of the slots empty) but 504 of 12x16 (one round of 3/4 the length).
   const int gy = (p.Np / 16 + NT - 1) / NT;
   auto rounds = [&](int th) { return ((int64_t)p.N * p.tilesX * ((p.Ho + th - 1) / th) * gy + 511) / 512 * th; };
-  const bool pt3 = x_env_on("WCMC_HALO64_PT3") && rounds(12) < rounds(16);
+  const bool pt3 = p.PXS == 160 || (x_env_on("WCMC_HALO64_PT3") && rounds(12) < rounds(16));     // (32-channel slabs: 12x16 only)
   const int th = pt3 ? 12 : 16;
   p.tilesY = (p.Ho + th - 1) / th;
   const int HP = (th + p.ks - 1) * (16 + p.ks - 1);
@@ -2942,7 +2953,9 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
 }
 template <int NT>
 static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
-  if (p.CS == 16 && p.ks == 5) return launch_xhalo64<NT>(p, stream);
+  if ((p.CS == 16 || (p.CS == 32 && p.PXS == 160 && p.CSl == 32 && p.Kp >= 256 && x_env_on("WCMC_HALO64") && x_env_on("WCMC_HALO64_CS32"))) &&
+      p.ks == 5)
+    return launch_xhalo64<NT>(p, stream);
   constexpr int TH = 16, TW = 16;
   const int HP = (TH + p.ks - 1) * (TW + p.ks - 1);
   const size_t halo = (size_t)((HP * p.PXS + 127) & ~127), bstage = (size_t)(2 * NT * 16 * XROW + 64) * sizeof(u16);
