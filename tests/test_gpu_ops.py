@@ -255,6 +255,34 @@ def test_conv5x5_kernel_variants_agree_with_fp64(case, monkeypatch):
     assert torch.equal(outs["12x16 where it pays"], outs["no priority alternation"])
 
 
+@pytest.mark.parametrize("case", [(16, 36, 64, 64, 64, 1), (12, 128, 48, 40, 128, 1), (16, 128, 64, 64, 3, 1), (4, 128, 40, 37, 128, 3)])
+def test_weight_gradient_with_many_slabs_against_fp64(case, monkeypatch):
+    """Weight and bias gradients at sizes where the split-K plan has MANY slabs (the unit cases above have one or a few):
+    the 1x1 layers' slab reduction in groups, the filter-row kernel's KS = 1 instance (128 -> 128) and its 128-channel 3x3
+    one, against an fp64 reduction; and twice, bit for bit (fixed order of additions)."""
+    o = ops()
+    n, cin, h, w, cout, ks = case
+    pad = ks // 2
+    x = gen(n, cin, h, w, seed=90)
+    dy = gen(n, cout, h, w, seed=91)
+    xs = o.split_raw(o.to_nhwc_raw(x.to(DEV)))
+    dys = o.split_raw(o.to_nhwc_raw(dy.to(DEV)))
+    want = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, ks, ks), dy.double(), padding=pad)
+    got = {}
+    for name, env in (("shipped plan", {}), ("one-tap kernel", {"WCMC_WGRAD_ROWS": "0"})):
+        for k in ("WCMC_WGRAD_ROWS",):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dw, db = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, ks, pad, (cout, cin, ks, ks))
+        dw2, db2 = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, ks, pad, (cout, cin, ks, ks))
+        assert torch.equal(dw, dw2) and torch.equal(db, db2), name
+        assert_close(dw, want, tol=2e-5, what=name + ": dw")
+        assert_close(db, dy.double().sum(dim=(0, 2, 3)), tol=2e-5, what=name + ": db")
+        got[name] = dw
+    assert rel_err(got["shipped plan"], got["one-tap kernel"]) < 1e-5
+
+
 PW_CASES = [
     # N, H, W, widths of a 1x1 chain, output activation -- the PathNet chains (support/networks.py:22-27)
     (5, 37, 41, (36, 64, 64, 64), "linear"),     # embedding: 7585 pixels = 118 tiles + 33 (ragged last tile)
