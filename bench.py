@@ -149,7 +149,8 @@ def pmc_traffic():
     pick = {}
     for k, v in d.items():
         for tag, key in (("conv_halo_bf16x3_kernel<7, 8, 16", "conv_halo7"), ("conv_halo64_bf16x3_kernel<7, 3, 4", "conv_halo64_pt4"),
-                         ("conv_halo64_bf16x3_kernel<7, 3, 3", "conv_halo64_pt3"), ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
+                         ("conv_halo64_bf16x3_kernel<7, 3, 3", "conv_halo64_pt3"), ("conv_halo64_bf16x3_kernel<7, 2, 3", "conv_halo64_cs32"),
+                         ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("kernel_apply_strip_kernel<false", "kernel_apply_fwd"), ("kernel_apply_strip_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
@@ -379,6 +380,7 @@ def main():
             rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 8, 16, 0, 2>",
                             "conv_halo64_pt4": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0>",
                             "conv_halo64_pt3": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0>",
+                            "conv_halo64_cs32": "wcmc::conv_halo64_bf16x3_kernel<7, 2, 3, 0>",
                             "conv_wgrad_rows": "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
                             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}.get(name, name + " (several kernels)")
             if ops.PRECISION == "fp32":
@@ -389,12 +391,17 @@ def main():
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "share_of_profiled_region": round(d["ms"] / (prof_elapsed * 1e3), 4)}
 
-        # classes = kernels: conv_halo64_pt4 / _pt3 are the two tile heights of conv_halo64_bf16x3_kernel<7,3,PT> (KPCN 5x5 fwd +
-        # dgrad; conv_halo7 = the 8x16 kernel it replaces, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows_bf16x3_kernel<5,7,7>;
+        # classes = kernels: conv_halo64_pt4 / _pt3 / _cs32 are the instances of conv_halo64_bf16x3_kernel<7,NB,PT> (KPCN 5x5 fwd +
+        # dgrad: 16x16 tiles, 12x16 tiles, 12x16 with 32-channel slabs for the 441-channel data gradient; conv_halo7 = the 8x16
+        # kernel they replace, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows_bf16x3_kernel<5,7,7>;
         # conv_igemm / conv_wgrad collect the other GEMM kernels
-        conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo7", "conv_wgrad_rows", "conv_igemm", "conv_wgrad")
+        conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_cs32", "conv_halo7", "conv_wgrad_rows", "conv_igemm",
+                                 "conv_wgrad")
                      if k in summ]
-        dominant = max(conv_keys, key=lambda k: summ[k]["ms"]) if conv_keys else None
+        # the roofline kernel: the single kernel (one rocprof name) with the most time per step; the two catch-all classes
+        # collect several kernels and are reported under roofline_other_conv
+        single = [k for k in conv_keys if k not in ("conv_igemm", "conv_wgrad")] or conv_keys
+        dominant = max(single, key=lambda k: summ[k]["ms"]) if conv_keys else None
         ka = kernel_apply_probe(device)
         traffic = pmc_traffic()
         for nm in ("fwd", "bwd"):

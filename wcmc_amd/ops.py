@@ -481,6 +481,9 @@ def _igemm_class(cin, cout, ks, dims=None):
     if dims is None or os.environ.get("WCMC_HALO64", "1") == "0" or os.environ.get("WCMC_IGEMM_HALO", "1") == "0":
         return "conv_halo7"                 # conv_halo_bf16x3_kernel<7, 8, 16, 0, 2> (and the fp32 path's 5x5 class)
     n, ho, wo = dims                        # conv_halo64_bf16x3_kernel<7, NB, PT>: 16x16 tiles (PT = 4) or 12x16 (PT = 3)
+    kp = (cin + 7) // 8 * 8
+    if kp >= 256 and kp % 32 == 0 and os.environ.get("WCMC_HALO64_CS32", "1") != "0":
+        return "conv_halo64_cs32"           # 32-channel slabs: <7, 2, 3> (two weight stages, 12x16 tiles)
     gy = -(-tiles // nt)
     rounds = lambda th: -(-(n * (-(-wo // 16)) * (-(-ho // th)) * gy) // 512) * th
     pt3 = os.environ.get("WCMC_HALO64_PT3", "1") != "0" and rounds(12) < rounds(16)
