@@ -399,8 +399,8 @@ def main():
                                  "conv_wgrad")
                      if k in summ]
         # the roofline kernel: the single kernel (one rocprof name) with the most time per step; the two catch-all classes
-        # collect several kernels and are reported under roofline_other_conv
-        single = [k for k in conv_keys if k not in ("conv_igemm", "conv_wgrad")] or conv_keys
+        # collect several kernels and are reported under roofline_other_conv (exact-fp32 mode: one kernel per class anyway)
+        single = ([k for k in conv_keys if k not in ("conv_igemm", "conv_wgrad")] or conv_keys) if ops.PRECISION == "bf16x3" else conv_keys
         dominant = max(single, key=lambda k: summ[k]["ms"]) if conv_keys else None
         ka = kernel_apply_probe(device)
         traffic = pmc_traffic()
