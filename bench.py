@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
+_ROWS8 = os.environ.get("WCMC_WGRAD_ROWS8", "1")[:1] != "0"     # which filter-row weight-gradient kernel the library launches
 B_PER_GPU, SPP, PATCH = 8, 8, 128
 
 
@@ -150,7 +151,7 @@ def pmc_traffic():
     for k, v in d.items():
         for tag, key in (("conv_halo_bf16x3_kernel<7, 8, 16", "conv_halo7"), ("conv_halo64_bf16x3_kernel<7, 3, 4", "conv_halo64_pt4"),
                          ("conv_halo64_bf16x3_kernel<7, 3, 3", "conv_halo64_pt3"), ("conv_halo64_bf16x3_kernel<7, 2, 3", "conv_halo64_cs32"),
-                         ("conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
+                         ("conv_wgrad_rows8_bf16x3_kernel<0>" if _ROWS8 else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("kernel_apply_strip_kernel<false", "kernel_apply_fwd"), ("kernel_apply_strip_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
@@ -381,7 +382,7 @@ def main():
                             "conv_halo64_pt4": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0>",
                             "conv_halo64_pt3": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0>",
                             "conv_halo64_cs32": "wcmc::conv_halo64_bf16x3_kernel<7, 2, 3, 0>",
-                            "conv_wgrad_rows": "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
+                            "conv_wgrad_rows": "wcmc::conv_wgrad_rows8_bf16x3_kernel<0>" if _ROWS8 else "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
                             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}.get(name, name + " (several kernels)")
             if ops.PRECISION == "fp32":
                 rocprof_name = ("wcmc::conv_wgrad_kernel" if "wgrad" in name else "wcmc::conv_igemm_kernel") + \
@@ -393,7 +394,7 @@ def main():
 
         # classes = kernels: conv_halo64_pt4 / _pt3 / _cs32 are the instances of conv_halo64_bf16x3_kernel<7,NB,PT> (KPCN 5x5 fwd +
         # dgrad: 16x16 tiles, 12x16 tiles, 12x16 with 32-channel slabs for the 441-channel data gradient; conv_halo7 = the 8x16
-        # kernel they replace, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows_bf16x3_kernel<5,7,7>;
+        # kernel they replace, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows8_bf16x3_kernel (WCMC_WGRAD_ROWS8=0: ..._rows_bf16x3_kernel<5,7,7>);
         # conv_igemm / conv_wgrad collect the other GEMM kernels
         conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_cs32", "conv_halo7", "conv_wgrad_rows", "conv_igemm",
                                  "conv_wgrad")

@@ -6,6 +6,7 @@ import numpy as np, torch
 from wcmc_amd import ops as o
 from wcmc_amd.ops import _ptr, _stream, lib, check
 assert os.environ.get("WCMC_DEBUG_ABLATE") == "16"
+NWV = 7 if os.environ.get("WCMC_WGRAD_ROWS8", "1")[:1] == "0" else 8     # waves per block of the instance that runs
 dev = "cuda"
 n, cin, cout, ks = 8, 100, 100, 5
 for h in [int(a) for a in sys.argv[1:]] or [124, 108]:
@@ -24,7 +25,7 @@ for h in [int(a) for a in sys.argv[1:]] or [124, 108]:
     for S_try in range(S, 0, -1):
         st = raw[S_try * 25 * 112 * 112:].view(np.uint64)
         nb = ((S_try + 7) // 8) * 8 * 5
-        rec = st[: nb * 7 * 8].reshape(nb, 7, 8)
+        rec = st[: nb * NWV * 8].reshape(nb, NWV, 8)
         live = rec[:, 0, 7] > 0
         if live.sum() == S_try * 5 and rec[live][:, 0, 7].max() < 1000:
             break
@@ -38,7 +39,8 @@ for h in [int(a) for a in sys.argv[1:]] or [124, 108]:
            rt[:, :, 3].min(), rt[:, :, 3].max()))
     cyc = rec[:, :, 4:7]
     tot = cyc.sum(axis=2)
-    print("  stage loop cycles per stage: %.0f = wait (DMA + barrier) %.0f + issue %.0f + MFMA/fragment reads %.0f   (105 MFMAs x 2 k-steps x 16 = 3360)" %
-          (tot.mean() / rec[0, 0, 7], cyc[:, :, 0].mean() / rec[0, 0, 7], cyc[:, :, 1].mean() / rec[0, 0, 7], cyc[:, :, 2].mean() / rec[0, 0, 7]))
-    for w in range(7):
+    print("  stage loop cycles per stage: %.0f = wait (DMA + barrier) %.0f + issue %.0f + MFMA/fragment reads %.0f   (%d MFMAs x 2 k-steps x 16 = %d)" %
+          (tot.mean() / rec[0, 0, 7], cyc[:, :, 0].mean() / rec[0, 0, 7], cyc[:, :, 1].mean() / rec[0, 0, 7], cyc[:, :, 2].mean() / rec[0, 0, 7],
+           105 if NWV == 7 else 93, 3360 if NWV == 7 else 2976))
+    for w in range(NWV):
         print("    wave %d: wait %.0f issue %.0f mfma %.0f" % (w, cyc[:, w, 0].mean() / rec[0, 0, 7], cyc[:, w, 1].mean() / rec[0, 0, 7], cyc[:, w, 2].mean() / rec[0, 0, 7]))

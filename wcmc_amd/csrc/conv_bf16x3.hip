@@ -2219,6 +2219,7 @@ struct XWRowsParams {
   int pad;
   float* slabs; int S, rps, R;
   float* dbg;                       // clock-probe build only
+  int prio;                         // rows8: iteration (of 14 per stage) at which waves 0-3 hand the priority to waves 4-7; 0 = off
   int Np, Cq, coBlocks, ciBlocks;
   unsigned x_bytes, dy_bytes;
 };
@@ -2329,6 +2330,7 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
     }
   };
   auto issue_one = [&](int i) {
+    if ((i + 1) * NW * 64 > NVEC && (i * NW + wave) * 64 >= NVEC) return;   // (the tail of the last instruction row: nothing to fetch)
     // 2*YV is a multiple of 64: a wave-instruction is all dy or all x (wave-uniform choice of descriptor and base)
     const bool isx = (2 * VY) % NW == 0 ? i >= (2 * VY) / NW : (i * NW + wave) * 64 >= 2 * YV;
     const unsigned base = isx ? f_xbase : f_ybase, cnt = isx ? f_xn : f_yn;
@@ -2512,6 +2514,306 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
   }
 }
 
+template <int OFF1, int OFF2>
+__device__ __forceinline__ void xwr_tr_issue_at(unsigned addr, XwrRaw& r) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(r.a), "=&v"(r.b) : "v"(addr), "n"(OFF1), "n"(OFF2));
+}
+
+// The KPCN instance (5x5, 7 x 7 channel tiles) of the filter-row kernel on EIGHT waves.  conv_wgrad_rows_bf16x3_kernel
+// <5, 7, 7> gives wave w the input-channel tile w: seven waves on four SIMDs, 105 MFMAs per wave and k-step -- three SIMDs
+// carry two waves (210 MFMAs per k-step), the fourth one (scripts/timeline_wgrad.py: waves 0-3 wait 3100 of 9060 cycles
+// per stage for waves 4-6).  Here the 245 accumulator tiles (5 taps x 7 cin tiles x 7 cout tiles) are dealt evenly:
+// (tap, cin tile) pair q = 7 tap + ci, wave w owns pairs 4w .. 4w+3 with all seven cout tiles (28 tiles) and, of the
+// three pairs left over (tap 4, cin tiles 4..6), the cout tile w (wave 7 multiplies wave 0's again and drops it: no
+// branch in the MFMA stream) -- 93 MFMAs per wave and k-step, 186 per SIMD.  Stage layout, fill, slab layout and the
+// order of the MFMAs on every accumulator are those of the seven-wave kernel: the slabs are bit-identical.
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsParams p) {
+  constexpr int KS = 5, TM = 7, NCI = 7, NW = 8, NS = 4, NE = 3;
+  constexpr int CHY = TM * 16, CHX = NCI * 16, PK = 64, XR = PK + KS - 1;
+  constexpr int SY = xwr_stride(CHY), SX = xwr_stride(CHX);
+  constexpr int VY = SY / 8, VX = SX / 8;
+  constexpr int YV = PK * VY, XV = XR * VX;
+  constexpr int NVEC = 2 * YV + 2 * XV;
+  constexpr int NI = (NVEC + NW * 64 - 1) / (NW * 64);
+  constexpr int BUF = NI * NW * 64 * 8;
+  constexpr int XLO = XR * SX * 2;                          // byte offset of the lo plane of x (and below: of dy)
+  constexpr int YLO = PK * SY * 2;
+  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int unit = (local / KS) * 8 + xcd;
+  const int upb = p.coBlocks * p.ciBlocks;
+  if (unit >= p.S * upb) return;
+  const int trow = local % KS;
+  const int s = unit / upb, ub = unit - s * upb;
+  const int cob = ub / p.ciBlocks, cib = ub - cob * p.ciBlocks;
+  const int co0 = cob * CHY, ci0 = cib * CHX;
+  const int r0 = s * p.rps, r1 = min(p.R, r0 + p.rps);
+  const int nch = (p.Wo + PK - 1) / PK;
+  const int nrows = r1 - r0;
+  const int nst = nrows * nch;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+
+  // ---- stage fill: as conv_wgrad_rows_bf16x3_kernel (one linear run of 16-byte vectors [Yh | Yl | Xh | Xl])
+  unsigned relv[NI]; int rowv[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int v = (i * NW + wave) * 64 + lane;
+    unsigned rel = 0; int rw = 127;
+    if (v < 2 * YV) {
+      const int plane = v >= YV, vv = v - plane * YV;
+      const int row = vv / VY, vec = vv - row * VY;
+      const int co = co0 + vec * 8;
+      if (vec * 8 < CHY && co < p.Cpo) { rel = (unsigned)(row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2); rw = row; }
+    } else if (v < NVEC) {
+      const int u = v - 2 * YV;
+      const int plane = u >= XV, uu = u - plane * XV;
+      const int row = uu / VX, vec = uu - row * VX;
+      const int ci = ci0 + vec * 8;
+      if (vec * 8 < CHX && ci < p.Cpi) { rel = (unsigned)(row * 4 * p.Cpi + plane * 2 * p.Cpi + ci * 2); rw = row; }
+    }
+    relv[i] = rel; rowv[i] = rw;
+  }
+  unsigned f_ybase = 0, f_xbase = 0, f_yn = 0, f_xn = 0; int f_xlo = 0, f_buf = 0;
+  int f_c = 0, f_rs = nrows > 0 ? (nrows - trow % nrows) % nrows : 0, f_n, f_oy;
+  const int f_n0 = r0 / p.Ho, f_oy0 = r0 - f_n0 * p.Ho;
+  { const int r = r0 + f_rs; f_n = r / p.Ho; f_oy = r - f_n * p.Ho; }
+  auto issue_prep = [&](int buf) {
+    const int ox0 = f_c * PK;
+    const int iy = f_oy + trow - p.pad;
+    const bool rowok = (unsigned)iy < (unsigned)p.H;
+    f_ybase = (unsigned)(((f_n * p.Ho + f_oy) * p.Wo + ox0) * 4 * p.Cpo);
+    f_xbase = (unsigned)(((f_n * p.H + iy) * p.W + ox0 - p.pad) * 4 * p.Cpi);   // may wrap: only used when valid
+    f_yn = (unsigned)max(0, p.Wo - ox0);
+    f_xlo = p.pad - ox0;
+    f_xn = rowok ? (unsigned)p.W : 0u;
+    f_buf = buf;
+    if (++f_c == nch) {
+      f_c = 0;
+      if (++f_rs == nrows) { f_rs = 0; f_n = f_n0; f_oy = f_oy0; }
+      else if (++f_oy == p.Ho) { f_oy = 0; ++f_n; }
+    }
+  };
+  auto issue_one = [&](int i) {
+    // the last instruction row is mostly past the stage's 3696 vectors: six of the eight waves have nothing to fetch there
+    // (an LDS-DMA instruction holds the SIMD's vector issue for 60-100 cycles whether or not its lanes are in range)
+    if ((i + 1) * NW * 64 > NVEC && (i * NW + wave) * 64 >= NVEC) return;
+    const bool isx = (i * NW + wave) * 64 >= 2 * YV;        // 2*YV is a multiple of 64: all dy or all x (wave-uniform)
+    const unsigned base = isx ? f_xbase : f_ybase, cnt = isx ? f_xn : f_yn;
+    const int lo = isx ? f_xlo : 0;
+    const unsigned off = (unsigned)(rowv[i] - lo) < cnt ? base + relv[i] : XOOB;
+    __attribute__((address_space(3))) void* dst =
+        (__attribute__((address_space(3))) void*)(smem16 + f_buf * BUF + (i * NW + wave) * 512);
+    if (!isx) __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, dst, 16, off, 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, off, 0, 0, 0);
+  };
+
+  // this wave's pairs: byte offset of the pair's fragment column (tap row + cin tile) inside an x plane, and the
+  // cout tile of loop slot i (rotated by the wave: slot 0 is the tile of the wave's three extra accumulators)
+  int ptap[NS], pci[NS], xoff[NS], ycol[TM];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const int pr = NS * wave + q;
+    ptap[q] = pr / NCI; pci[q] = pr - ptap[q] * NCI;
+    xoff[q] = (ptap[q] * SX + pci[q] * 16) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ycol[i] = (wave + i) % TM;
+  constexpr int ETAP = KS - 1, ECI0 = NCI - NE;              // the left-over pairs: tap 4, cin tiles 4..6
+
+  f32x4 acc[NS][TM], ace[NE];
+#pragma unroll
+  for (int q = 0; q < NS; ++q)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < NE; ++e) ace[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) u16*)smem16);
+
+  unsigned long long rt[4] = {0, 0, 0, 0}, cyc[3] = {0, 0, 0}, tprev = 0;
+  auto rts = [&](int i) {
+    if (DBG & 16) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      rt[i] = t;
+    }
+  };
+  auto cst = [&](int i) {
+    if (DBG & 16) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (i >= 0) cyc[i] += t - tprev;
+      tprev = t;
+    }
+  };
+  rts(0);
+  if (nst > 0) {
+    issue_prep(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) issue_one(i);
+  }
+  rts(1);
+  cst(-1);
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cst(0);
+    const bool fill = st + 1 < nst;
+    if (fill) issue_prep((st + 1) & 1);
+    cst(1);
+    // Two waves share a SIMD (w and w + 4) and of two ready waves the older one issues: waves 0-3 ran ahead and then
+    // waited ~2800 of 8200 cycles per stage at the barrier while waves 4-7 finished alone, a lone wave keeping the matrix
+    // pipe ~60 % busy against ~86 % for a pair (scripts/timeline_wgrad.py).  Waves 0-3 take priority 2 for the first
+    // p.prio iterations of the stage and 0 afterwards, waves 4-7 stay at 1: both reach the barrier together.
+    if (p.prio) { if (wave < 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+    const int prow0 = 4 * g + tq;
+    const unsigned aY = lds0 + (unsigned)(((st & 1) * BUF + prow0 * SY + 4 * tp) * 2);
+    const unsigned aX = lds0 + (unsigned)(((st & 1) * BUF + 2 * PK * SY + prow0 * SX + 4 * tp) * 2);
+    unsigned ax[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) ax[q] = aX + (unsigned)xoff[q];
+    const int c = st % nch;
+    const int nk = (min(PK, p.Wo - c * PK) + 31) / 32;
+    XwrRaw rxh[NS], rxl[NS], reh[NE], rel_[NE], ryh[2], ryl[2];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      xwr_tr_issue_at<0, 16 * SX * 2>(ax[q], rxh[q]);
+      xwr_tr_issue_at<XLO, XLO + 16 * SX * 2>(ax[q], rxl[q]);
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      constexpr int EO = 0;
+      xwr_tr_issue_at<0, 16 * SX * 2>(aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2 + EO), reh[e]);
+      xwr_tr_issue_at<XLO, XLO + 16 * SX * 2>(aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2 + EO), rel_[e]);
+    }
+    {
+      const unsigned ay = aY + (unsigned)(ycol[0] * 32);
+      xwr_tr_issue_at<0, 16 * SY * 2>(ay, ryh[0]);
+      xwr_tr_issue_at<YLO, YLO + 16 * SY * 2>(ay, ryl[0]);
+    }
+    bf16x8 xh[NS], xl[NS], eh[NE], el[NE];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk < nk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int cur = (kk * TM + i) & 1, nxt = cur ^ 1;
+          if (kk * TM + i > 0 && p.prio == kk * TM + i && wave < 4) __builtin_amdgcn_s_setprio(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
+          if (i == 0) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+              asm volatile("" : "+v"(rxh[q].a), "+v"(rxh[q].b), "+v"(rxl[q].a), "+v"(rxl[q].b));
+              xh[q] = xwr_cat(rxh[q]); xl[q] = xwr_cat(rxl[q]);
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+              asm volatile("" : "+v"(reh[e].a), "+v"(reh[e].b), "+v"(rel_[e].a), "+v"(rel_[e].b));
+              eh[e] = xwr_cat(reh[e]); el[e] = xwr_cat(rel_[e]);
+            }
+          }
+          const bf16x8 yh = xwr_cat(ryh[cur]), yl = xwr_cat(ryl[cur]);
+          if (i + 1 < TM) {
+            const unsigned ay = aY + (unsigned)(kk * 32 * SY * 2 + ycol[i + 1] * 32);
+            xwr_tr_issue_at<0, 16 * SY * 2>(ay, ryh[nxt]);
+            xwr_tr_issue_at<YLO, YLO + 16 * SY * 2>(ay, ryl[nxt]);
+          } else if (kk + 1 < nk) {
+            const unsigned ay = aY + (unsigned)((kk + 1) * 32 * SY * 2 + ycol[0] * 32);
+            xwr_tr_issue_at<0, 16 * SY * 2>(ay, ryh[nxt]);
+            xwr_tr_issue_at<YLO, YLO + 16 * SY * 2>(ay, ryl[nxt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (i == 0) {                                   // the left-over pairs: cout tile ycol[0] = wave
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+              ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, eh[e], ace[e], 0, 0, 0);
+              ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, el[e], ace[e], 0, 0, 0);
+              ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, eh[e], ace[e], 0, 0, 0);
+              if (kk + 1 < nk) {
+                const unsigned ae = aX + (unsigned)((((kk + 1) * 32 + ETAP) * SX + (ECI0 + e) * 16) * 2);
+                xwr_tr_issue_at<0, 16 * SX * 2>(ae, reh[e]);
+                xwr_tr_issue_at<XLO, XLO + 16 * SX * 2>(ae, rel_[e]);
+              }
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < NS; ++q) {
+            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[q], acc[q][i], 0, 0, 0);
+            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[q], acc[q][i], 0, 0, 0);
+            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[q], acc[q][i], 0, 0, 0);
+            if (i == TM - 1 && kk + 1 < nk) {
+              constexpr int K1 = 32 * SX * 2;              // (kk + 1 < nk <= 2: the second k-step)
+              xwr_tr_issue_at<K1, K1 + 16 * SX * 2>(ax[q], rxh[q]);
+              xwr_tr_issue_at<K1 + XLO, K1 + XLO + 16 * SX * 2>(ax[q], rxl[q]);
+            }
+          }
+          if (fill && kk * TM + i < NI) issue_one(kk * TM + i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (fill) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        if (i >= nk * TM) issue_one(i);
+    }
+    cst(2);
+  }
+  rts(2);
+
+  // ---- slab write, tap by tap through LDS (as the seven-wave kernel): the wave stages the tiles of its pairs of this tap
+  __syncthreads();
+  constexpr int RS = CHX + 4;
+  float* red = reinterpret_cast<float*>(smem16);           // [CHY][RS]
+  const int fcol = lane & 15, fq = (lane >> 4) * 4;
+#pragma unroll
+  for (int t = 0; t < KS; ++t) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+      if (ptap[q] == t) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(ycol[i] * 16 + fq + r) * RS + pci[q] * 16 + fcol] = acc[q][i][r];
+      }
+    if (t == ETAP && wave < TM) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 16 + fq + r) * RS + (ECI0 + e) * 16 + fcol] = ace[e][r];
+    }
+    __syncthreads();
+    float* slab = p.slabs + (((int64_t)s * KS * KS + trow * KS + t) * p.Np + co0) * p.Cq + ci0;
+    for (int idx = tid; idx < CHY * (CHX / 4); idx += NW * 64) {
+      const int row = idx / (CHX / 4), v = idx - row * (CHX / 4);
+      if (co0 + row < p.Np && ci0 + v * 4 < p.Cq)
+        *reinterpret_cast<float4*>(slab + (int64_t)row * p.Cq + v * 4) = *reinterpret_cast<const float4*>(red + row * RS + v * 4);
+    }
+    __syncthreads();
+  }
+  if (DBG & 16) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    rts(3);
+    if (lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.dbg) + ((int64_t)blockIdx.x * NW + wave) * 8;
+      for (int i = 0; i < 4; ++i) o[i] = rt[i];
+      for (int i = 0; i < 3; ++i) o[4 + i] = cyc[i];
+      o[7] = (unsigned long long)nst;
+    }
+  }
+}
+
 template <int KS, int TM, int NW>
 static constexpr size_t xwr_lds_bytes() {
   constexpr int NVEC = 2 * 64 * (xwr_stride(TM * 16) / 8) + 2 * (64 + KS - 1) * (xwr_stride(NW * 16) / 8);
@@ -2531,6 +2833,25 @@ template <int KS, int TM, int NW>
 static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
   constexpr size_t lds = xwr_lds_bytes<KS, TM, NW>();
   const dim3 grid((unsigned)(((q.S * q.coBlocks * q.ciBlocks + 7) / 8) * 8 * KS));
+  if (KS == 5 && TM == 7 && NW == 7 && x_env_on("WCMC_WGRAD_ROWS8")) {   // =0: A/B switch back to the seven-wave kernel
+    constexpr size_t lds8 = (size_t)2 * 8 * 512 * 16;   // two stages of NI = 8 instructions x 8 waves x 1 KB (> the staging tile of the slab write)
+    static bool attr8_set = false;
+#ifdef WCMC_DEBUG_BUILD
+    { const char* e = getenv("WCMC_DEBUG_ABLATE");
+      if (e && atoi(e) == 16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+        hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<16>), grid, dim3(512), lds8, st, q);
+        return check_launch("conv2d_wgrad_bf16x3(rows8 stamps)");
+      } }
+#endif
+    if (!attr8_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+      attr8_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0>), grid, dim3(512), lds8, st, q);
+    return check_launch("conv2d_wgrad_bf16x3(rows8)");
+  }
 #ifdef WCMC_DEBUG_BUILD        // `make debug` only: timing-only instances that compute WRONG results are not in the release library
   if (KS == 5 && TM == 7 && NW == 7) {
     int ab;                             // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills, 4 = clock probe)
@@ -3246,6 +3567,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
     XWRowsParams q;
     q.x = p.x; q.N = N; q.H = H; q.W = W; q.Cpi = p.Cpi; q.dy = p.dy; q.Ho = Ho; q.Wo = Wo; q.Cpo = p.Cpo;
     q.dbg = (float*)workspace + pl.slab_elems;
+    { const char* e = getenv("WCMC_WGRAD_ROWS8_PRIO"); q.prio = e ? atoi(e) : 8; if (q.prio < 0 || q.prio > 13) q.prio = 0; }   // (scripts/time_wgrad_rows8.py: 6-8 of 14 best)
     q.pad = pad; q.slabs = p.slabs; q.S = pl.S; q.rps = pl.rps; q.R = pl.R; q.Np = pl.Np; q.Cq = pl.Cq;
     q.coBlocks = pl.coBlocks; q.ciBlocks = pl.ciBlocks; q.x_bytes = p.x_bytes; q.dy_bytes = p.dy_bytes;
     const int key = ks * 100 + pl.rTM * 10 + pl.rNW;
