@@ -81,27 +81,36 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
       smem[cl * LD + tap] = t;
     }
   } else
-  for (int e = threadIdx.x; e < taps * WR_CI; e += 256) {
-    const int tap = e / WR_CI, cl = e - tap * WR_CI;
-    float acc = 0.f;
-    if (ci0 + cl < Cin) {
+  // one thread = four neighbouring input channels of one tap (16-byte loads: a (tap, cout) row of the block is 128 B),
+  // 12 slabs in flight, every element summed in slab order as before (the scalar version of this loop moved the
+  // 60 MB of a KPCN layer's slabs at 1.3 TB/s: 47 us, a quarter of the GEMM that wrote them)
+  for (int e = threadIdx.x; e < taps * (WR_CI / 4); e += 256) {
+    const int tap = e / (WR_CI / 4), cl = (e - tap * (WR_CI / 4)) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ci0 + cl < Cq) {
       const float* q = slabs + ((int64_t)tap * Np + co) * Cq + ci0 + cl;
       int s = 0;
-      for (; s + 12 <= S; s += 12) {           // 12 independent loads in flight (48 slabs = 4 round trips), summed in slab order
-        float v[12];
+      for (; s + 12 <= S; s += 12) {
+        float4 v[12];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) v[u] = q[(s + u) * sstride];
+        for (int u = 0; u < 12; ++u) v[u] = *reinterpret_cast<const float4*>(q + (s + u) * sstride);
 #pragma unroll
-        for (int u = 0; u < 12; ++u) acc += v[u];
+        for (int u = 0; u < 12; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
       }
       for (; s + 4 <= S; s += 4) {
-        const float v0 = q[(s + 0) * sstride], v1 = q[(s + 1) * sstride];
-        const float v2 = q[(s + 2) * sstride], v3 = q[(s + 3) * sstride];
-        acc = (((acc + v0) + v1) + v2) + v3;
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(q + (s + u) * sstride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
       }
-      for (; s < S; ++s) acc += q[s * sstride];
+      for (; s < S; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(q + s * sstride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
     }
-    smem[cl * LD + tap] = acc;
+    smem[(cl + 0) * LD + tap] = acc.x; smem[(cl + 1) * LD + tap] = acc.y;
+    smem[(cl + 2) * LD + tap] = acc.z; smem[(cl + 3) * LD + tap] = acc.w;
   }
   __syncthreads();
   const int ncl = min(WR_CI, Cin - ci0);
