@@ -2391,7 +2391,6 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
     __syncthreads();                                      // ... everyone's; and everyone is done with stage st-1
     cst(0);
     const bool fill = st + 1 < nst && !((DBG & 2) && st > 0);
-    if (fill) issue_prep((st + 1) & 1);
     cst(1);
     // byte addresses of this lane's first fragment row in the four planes of the stage
     const int prow0 = 4 * g + tq;
@@ -2459,6 +2458,9 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
               xwr_tr_issue<16 * SX * 2>(aXl + ((kk + 1) * 32 + t) * SX * 2, rxl[t]);
             }
           }
+          // (the next stage's scalars are worked out behind the first MFMAs of the stage, not at the barrier where all
+          // waves of the block would do it at the same moment with the matrix pipe empty)
+          if (fill && kk * TM + i == 0) issue_prep((st + 1) & 1);
           if (fill && kk * TM + i < NI) issue_one(kk * TM + i);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -2670,7 +2672,6 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
     __syncthreads();
     cst(0);
     const bool fill = st + 1 < nst;
-    if (fill) issue_prep((st + 1) & 1);
     cst(1);
     // Two waves share a SIMD (w and w + 4) and of two ready waves the older one issues: waves 0-3 ran ahead and then
     // waited ~2800 of 8200 cycles per stage at the barrier while waves 4-7 finished alone, a lone wave keeping the matrix
@@ -2758,6 +2759,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
               xwr_tr_issue_at<K1 + XLO, K1 + XLO + 16 * SX * 2>(ax[q], rxl[q]);
             }
           }
+          // (the next stage's scalars are worked out here, behind the first MFMAs of the stage, not at the barrier where
+          // both waves of every SIMD would do it at the same moment with the matrix pipe empty)
+          if (fill && kk * TM + i == 0) issue_prep((st + 1) & 1);
           if (fill && kk * TM + i < NI) issue_one(kk * TM + i);
           __builtin_amdgcn_sched_barrier(0);
         }
