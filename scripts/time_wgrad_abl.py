@@ -1,6 +1,7 @@
 """Timing-only ablations of the filter-row weight-gradient kernel (debug library), interleaved inside one process:
    make -C wcmc_amd/csrc debug; WCMC_DEBUG_LIB=1 python3 scripts/time_wgrad_abl.py [h] [mode ...]
-Modes: 1 no MFMA, 2 no stage fills after the first, 3 both, 8 no wait for the fragment reads."""
+Modes: 1 no MFMA, 2 no stage fills after the first, 3 both, 8 no wait for the fragment reads; the eight-wave kernel (default;
+WCMC_WGRAD_ROWS8=0: the seven-wave one) also has 32 no fragment reads, 34 = 32 + 2 (MFMAs and barriers only), 35 = all three."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

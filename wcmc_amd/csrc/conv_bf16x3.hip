@@ -2532,6 +2532,7 @@ __device__ __forceinline__ void xwr_tr_issue_at(unsigned addr, XwrRaw& r) {
 // order of the MFMAs on every accumulator are those of the seven-wave kernel: the slabs are bit-identical.
 template <int DBG = 0>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsParams p) {
+#define XWR8_READ(O1, O2, ADDR, REG) do { if (DBG & 32) { asm volatile("" : "+v"((REG).a), "+v"((REG).b)); } else xwr_tr_issue_at<O1, O2>(ADDR, REG); } while (0)
   constexpr int KS = 5, TM = 7, NCI = 7, NW = 8, NS = 4, NE = 3;
   constexpr int CHY = TM * 16, CHX = NCI * 16, PK = 64, XR = PK + KS - 1;
   constexpr int SY = xwr_stride(CHY), SX = xwr_stride(CHX);
@@ -2671,7 +2672,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cst(0);
-    const bool fill = st + 1 < nst;
+    const bool fill = st + 1 < nst && !((DBG & 2) && st > 0);   // (DBG: timing-only ablations, wrong results -- 1 no MFMA, 2 no fills after the first, 8 no fragment waits, 32 no fragment reads)
     cst(1);
     // Two waves share a SIMD (w and w + 4) and of two ready waves the older one issues: waves 0-3 ran ahead and then
     // waited ~2800 of 8200 cycles per stage at the barrier while waves 4-7 finished alone, a lone wave keeping the matrix
@@ -2689,19 +2690,19 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
     XwrRaw rxh[NS], rxl[NS], reh[NE], rel_[NE], ryh[2], ryl[2];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-      xwr_tr_issue_at<0, 16 * SX * 2>(ax[q], rxh[q]);
-      xwr_tr_issue_at<XLO, XLO + 16 * SX * 2>(ax[q], rxl[q]);
+      XWR8_READ(0, 16 * SX * 2, ax[q], rxh[q]);
+      XWR8_READ(XLO, XLO + 16 * SX * 2, ax[q], rxl[q]);
     }
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       constexpr int EO = 0;
-      xwr_tr_issue_at<0, 16 * SX * 2>(aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2 + EO), reh[e]);
-      xwr_tr_issue_at<XLO, XLO + 16 * SX * 2>(aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2 + EO), rel_[e]);
+      XWR8_READ(0, 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2 + EO), reh[e]);
+      XWR8_READ(XLO, XLO + 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2 + EO), rel_[e]);
     }
     {
       const unsigned ay = aY + (unsigned)(ycol[0] * 32);
-      xwr_tr_issue_at<0, 16 * SY * 2>(ay, ryh[0]);
-      xwr_tr_issue_at<YLO, YLO + 16 * SY * 2>(ay, ryl[0]);
+      XWR8_READ(0, 16 * SY * 2, ay, ryh[0]);
+      XWR8_READ(YLO, YLO + 16 * SY * 2, ay, ryl[0]);
     }
     bf16x8 xh[NS], xl[NS], eh[NE], el[NE];
 #pragma unroll
@@ -2711,7 +2712,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
         for (int i = 0; i < TM; ++i) {
           const int cur = (kk * TM + i) & 1, nxt = cur ^ 1;
           if (kk * TM + i > 0 && p.prio == kk * TM + i && wave < 4) __builtin_amdgcn_s_setprio(0);
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
+          if (DBG & 8) { asm volatile("" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b)); }
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
           if (i == 0) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
@@ -2727,36 +2729,42 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
           const bf16x8 yh = xwr_cat(ryh[cur]), yl = xwr_cat(ryl[cur]);
           if (i + 1 < TM) {
             const unsigned ay = aY + (unsigned)(kk * 32 * SY * 2 + ycol[i + 1] * 32);
-            xwr_tr_issue_at<0, 16 * SY * 2>(ay, ryh[nxt]);
-            xwr_tr_issue_at<YLO, YLO + 16 * SY * 2>(ay, ryl[nxt]);
+            XWR8_READ(0, 16 * SY * 2, ay, ryh[nxt]);
+            XWR8_READ(YLO, YLO + 16 * SY * 2, ay, ryl[nxt]);
           } else if (kk + 1 < nk) {
             const unsigned ay = aY + (unsigned)((kk + 1) * 32 * SY * 2 + ycol[0] * 32);
-            xwr_tr_issue_at<0, 16 * SY * 2>(ay, ryh[nxt]);
-            xwr_tr_issue_at<YLO, YLO + 16 * SY * 2>(ay, ryl[nxt]);
+            XWR8_READ(0, 16 * SY * 2, ay, ryh[nxt]);
+            XWR8_READ(YLO, YLO + 16 * SY * 2, ay, ryl[nxt]);
           }
           __builtin_amdgcn_sched_barrier(0);
           if (i == 0) {                                   // the left-over pairs: cout tile ycol[0] = wave
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-              ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, eh[e], ace[e], 0, 0, 0);
-              ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, el[e], ace[e], 0, 0, 0);
-              ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, eh[e], ace[e], 0, 0, 0);
+              if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(eh[e]), "v"(el[e])); }
+              else {
+                ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, eh[e], ace[e], 0, 0, 0);
+                ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, el[e], ace[e], 0, 0, 0);
+                ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, eh[e], ace[e], 0, 0, 0);
+              }
               if (kk + 1 < nk) {
                 const unsigned ae = aX + (unsigned)((((kk + 1) * 32 + ETAP) * SX + (ECI0 + e) * 16) * 2);
-                xwr_tr_issue_at<0, 16 * SX * 2>(ae, reh[e]);
-                xwr_tr_issue_at<XLO, XLO + 16 * SX * 2>(ae, rel_[e]);
+                XWR8_READ(0, 16 * SX * 2, ae, reh[e]);
+                XWR8_READ(XLO, XLO + 16 * SX * 2, ae, rel_[e]);
               }
             }
           }
 #pragma unroll
           for (int q = 0; q < NS; ++q) {
-            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[q], acc[q][i], 0, 0, 0);
-            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[q], acc[q][i], 0, 0, 0);
-            acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[q], acc[q][i], 0, 0, 0);
+            if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(xh[q]), "v"(xl[q])); }
+            else {
+              acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[q], acc[q][i], 0, 0, 0);
+              acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[q], acc[q][i], 0, 0, 0);
+              acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[q], acc[q][i], 0, 0, 0);
+            }
             if (i == TM - 1 && kk + 1 < nk) {
               constexpr int K1 = 32 * SX * 2;              // (kk + 1 < nk <= 2: the second k-step)
-              xwr_tr_issue_at<K1, K1 + 16 * SX * 2>(ax[q], rxh[q]);
-              xwr_tr_issue_at<K1 + XLO, K1 + XLO + 16 * SX * 2>(ax[q], rxl[q]);
+              XWR8_READ(K1, K1 + 16 * SX * 2, ax[q], rxh[q]);
+              XWR8_READ(K1 + XLO, K1 + XLO + 16 * SX * 2, ax[q], rxl[q]);
             }
           }
           // (the next stage's scalars are worked out here, behind the first MFMAs of the stage, not at the barrier where
@@ -2817,6 +2825,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
     }
   }
 }
+#undef XWR8_READ
 
 template <int KS, int TM, int NW>
 static constexpr size_t xwr_lds_bytes() {
@@ -2842,10 +2851,14 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
     static bool attr8_set = false;
 #ifdef WCMC_DEBUG_BUILD
     { const char* e = getenv("WCMC_DEBUG_ABLATE");
-      if (e && atoi(e) == 16) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-        hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<16>), grid, dim3(512), lds8, st, q);
-        return check_launch("conv2d_wgrad_bf16x3(rows8 stamps)");
+      const int ab = e ? atoi(e) : 0;
+      auto kfn = ab == 16 ? &conv_wgrad_rows8_bf16x3_kernel<16> : ab == 1 ? &conv_wgrad_rows8_bf16x3_kernel<1> : ab == 2 ? &conv_wgrad_rows8_bf16x3_kernel<2>
+                 : ab == 3 ? &conv_wgrad_rows8_bf16x3_kernel<3> : ab == 8 ? &conv_wgrad_rows8_bf16x3_kernel<8> : ab == 32 ? &conv_wgrad_rows8_bf16x3_kernel<32>
+                 : ab == 34 ? &conv_wgrad_rows8_bf16x3_kernel<34> : ab == 35 ? &conv_wgrad_rows8_bf16x3_kernel<35> : nullptr;
+      if (kfn) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+        hipLaunchKernelGGL(kfn, grid, dim3(512), lds8, st, q);
+        return check_launch("conv2d_wgrad_bf16x3(rows8 ablation / stamps)");
       } }
 #endif
     if (!attr8_set) {
