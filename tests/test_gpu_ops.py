@@ -172,24 +172,30 @@ def test_conv_wgrad_is_bitwise_reproducible():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
-@pytest.mark.parametrize("geom", [(8, 44, 44, 0), (4, 37, 70, 0), (3, 30, 101, 2), (16, 8, 8, 0)])
+@pytest.mark.parametrize("geom", [(8, 44, 44, 0), (4, 37, 70, 0), (3, 30, 101, 2), (16, 8, 8, 0), (8, 124, 124, 0),
+                                  (2, 40, 40, 0, 100, 441), (2, 36, 52, 1, 224, 112), (2, 24, 24, 0, 210, 212)])
 def test_eight_wave_filter_row_kernel_equals_seven_wave(geom, monkeypatch):
     """conv_wgrad_rows8_bf16x3_kernel (245 accumulator tiles dealt over eight waves, priority hand-over inside a stage)
     writes the slabs of conv_wgrad_rows_bf16x3_kernel<5, 7, 7> bit for bit: ragged chunks (Wo % 64 in {40, 2, 37, 4}),
     short last splits, padding, and every hand-over point."""
     o = ops()
-    n, h, w, pad = geom
+    n, h, w, pad = geom[:4]
+    cin, cout = geom[4:] if len(geom) > 4 else (100, 100)     # (several cout / cin blocks of 7 tiles: the 441-cout layer, 14 x 14 tiles)
     ho, wo = h + 2 * pad - 4, w + 2 * pad - 4
-    xs = o.split_raw(o.to_nhwc_raw(gen(n, 100, h, w, seed=90).to(DEV)))
-    dys = o.split_raw(o.to_nhwc_raw(gen(n, 100, ho, wo, seed=91).to(DEV)))
+    xs = o.split_raw(o.to_nhwc_raw(gen(n, cin, h, w, seed=90).to(DEV)))
+    dys = o.split_raw(o.to_nhwc_raw(gen(n, cout, ho, wo, seed=91).to(DEV)))
     monkeypatch.setenv("WCMC_WGRAD_ROWS8", "0")
-    want = o.conv2d_wgrad_x_raw(xs, (n, 100, h, w), dys, 100, 5, pad, (100, 100, 5, 5))
+    want = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5))
     for prio in ("0", "1", "7", "9", "13"):
         monkeypatch.setenv("WCMC_WGRAD_ROWS8", "1")
         monkeypatch.setenv("WCMC_WGRAD_ROWS8_PRIO", prio)
-        got = o.conv2d_wgrad_x_raw(xs, (n, 100, h, w), dys, 100, 5, pad, (100, 100, 5, 5))
+        got = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5))
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), prio
     assert want[0].abs().max().item() > 0
+    if len(geom) > 4:                                   # the new block shapes against fp64 as well
+        ref = torch.nn.grad.conv2d_weight(gen(n, cin, h, w, seed=90).double(), (cout, cin, 5, 5), gen(n, cout, ho, wo, seed=91).double(),
+                                          padding=pad)
+        assert_close(want[0], ref, tol=2e-5, what="dw of %d -> %d" % (cin, cout))
 
 
 @pytest.mark.parametrize("case", [(2, 100, 40, 37, 100, 5, 0), (3, 36, 9, 10, 64, 1, 0), (2, 64, 16, 16, 128, 3, 1)])
