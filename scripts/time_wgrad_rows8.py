@@ -1,6 +1,6 @@
 """Eight-wave vs seven-wave filter-row weight gradient of the KPCN 5x5 layers (WCMC_WGRAD_ROWS8) and the priority
 hand-over point of the eight-wave kernel (WCMC_WGRAD_ROWS8_PRIO), interleaved inside one process, with the bit-identity
-of the results:  [PRIOS=0,8,9,10] python3 scripts/time_wgrad_rows8.py [h ...]"""
+of the results:  [PRIOS=0,8,9,10] [XES=0,1] python3 scripts/time_wgrad_rows8.py [h ...]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +9,8 @@ from wcmc_amd.ops import _ptr, _stream, lib, check
 dev = "cuda"
 hs = [int(a) for a in sys.argv[1:]] or [124, 116, 108, 100]
 prios = os.environ.get("PRIOS", "").split(",") if os.environ.get("PRIOS") else [None]
-cfgs = [("0", None)] + [("1", q) for q in prios]
+xes = os.environ.get("XES", "").split(",") if os.environ.get("XES") else [None]     # WCMC_WGRAD_ROWS8_XE values to compare
+cfgs = [("0", None, None)] + [("1", q, x) for q in prios for x in xes]
 n, cin, cout, ks = 8, 100, 100, 5
 for h in hs:
     ho = h - ks + 1
@@ -22,6 +23,7 @@ for h in hs:
     def run(cfg, phase=1):
         os.environ["WCMC_WGRAD_ROWS8"] = cfg[0]
         if cfg[1] is not None: os.environ["WCMC_WGRAD_ROWS8_PRIO"] = cfg[1]
+        if cfg[2] is not None: os.environ["WCMC_WGRAD_ROWS8_XE"] = cfg[2]
         dw = torch.empty(cout, cin, ks, ks, device=dev); db = torch.empty(cout, device=dev)
         check(lib().wcmc_conv2d_wgrad_bf16x3(_ptr(xs), n, h, h, cin, _ptr(dys), cout, ks, 0, _ptr(dw), _ptr(db), _ptr(ws),
                                               ws.numel() * 4, phase, None, _stream()), "wgrad")
@@ -41,4 +43,4 @@ for h in hs:
         for c in cfgs:
             res[c].append(once(c))
     print("h=%d  rows7 %.1f us  rows8 %s  (the split-K kernel alone: phase 1 of the call)  bit-identical: %s"
-          % (h, np.median(res[cfgs[0]]), "  ".join("%s%.1f us" % ("" if c[1] is None else "prio=%s: " % c[1], np.median(res[c])) for c in cfgs[1:]), same))
+          % (h, np.median(res[cfgs[0]]), "  ".join("%s%s%.1f us" % ("" if c[1] is None else "prio=%s " % c[1], "" if c[2] is None else "xe=%s " % c[2], np.median(res[c])) for c in cfgs[1:]), same))

@@ -587,6 +587,7 @@ _SWITCHES = [
     ("env", "WCMC_WGRAD_ROWS_1X1", "0", "close"),        # one-tap kernel for the 128->128 1x1 weight gradient
     ("env", "WCMC_WGRAD_ROWS8", "0", "exact"),           # seven-wave filter-row kernel for the 100 -> 100 5x5 layers (same slabs)
     ("env", "WCMC_WGRAD_ROWS8_PRIO", "0", "exact"),      # no priority hand-over between the two waves of a SIMD
+    ("env", "WCMC_WGRAD_ROWS8_XE", "0", "exact"),        # left-over tiles as three pairs x one cout tile per wave
 ]
 
 

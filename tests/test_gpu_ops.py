@@ -186,11 +186,12 @@ def test_eight_wave_filter_row_kernel_equals_seven_wave(geom, monkeypatch):
     dys = o.split_raw(o.to_nhwc_raw(gen(n, cout, ho, wo, seed=91).to(DEV)))
     monkeypatch.setenv("WCMC_WGRAD_ROWS8", "0")
     want = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5))
-    for prio in ("0", "1", "7", "9", "13"):
+    for prio, xe in (("0", "1"), ("1", "1"), ("7", "0"), ("9", "1"), ("13", "0"), ("8", "1"), ("8", "0")):
         monkeypatch.setenv("WCMC_WGRAD_ROWS8", "1")
         monkeypatch.setenv("WCMC_WGRAD_ROWS8_PRIO", prio)
+        monkeypatch.setenv("WCMC_WGRAD_ROWS8_XE", xe)           # both dealings of the 21 left-over tiles
         got = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5))
-        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), prio
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (prio, xe)
     assert want[0].abs().max().item() > 0
     if len(geom) > 4:                                   # the new block shapes against fp64 as well
         ref = torch.nn.grad.conv2d_weight(gen(n, cin, h, w, seed=90).double(), (cout, cin, 5, 5), gen(n, cout, ho, wo, seed=91).double(),

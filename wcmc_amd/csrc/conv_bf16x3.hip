@@ -2530,7 +2530,7 @@ __device__ __forceinline__ void xwr_tr_issue_at(unsigned addr, XwrRaw& r) {
 // three pairs left over (tap 4, cin tiles 4..6), the cout tile w (wave 7 multiplies wave 0's again and drops it: no
 // branch in the MFMA stream) -- 93 MFMAs per wave and k-step, 186 per SIMD.  Stage layout, fill, slab layout and the
 // order of the MFMAs on every accumulator are those of the seven-wave kernel: the slabs are bit-identical.
-template <int DBG = 0>
+template <int DBG = 0, int XE = 1>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsParams p) {
 #define XWR8_READ(O1, O2, ADDR, REG) do { if (DBG & 32) { asm volatile("" : "+v"((REG).a), "+v"((REG).b)); } else xwr_tr_issue_at<O1, O2>(ADDR, REG); } while (0)
   constexpr int KS = 5, TM = 7, NCI = 7, NW = 8, NS = 4, NE = 3;
@@ -2606,7 +2606,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
     // the last instruction row is mostly past the stage's 3696 vectors: six of the eight waves have nothing to fetch there
     // (an LDS-DMA instruction holds the SIMD's vector issue for 60-100 cycles whether or not its lanes are in range)
     if ((i + 1) * NW * 64 > NVEC && (i * NW + wave) * 64 >= NVEC) return;
-    const bool isx = (i * NW + wave) * 64 >= 2 * YV;        // 2*YV is a multiple of 64: all dy or all x (wave-uniform)
+    // 2*YV is a multiple of 64: a wave-instruction is all dy or all x; only one instruction row straddles the two (written
+    // out so that the others are compile-time choices and not wave-uniform masks kept in spilled scalar registers)
+    const bool isx = (i * NW + NW - 1) * 64 < 2 * YV ? false : i * NW * 64 >= 2 * YV ? true : (i * NW + wave) * 64 >= 2 * YV;
     const unsigned base = isx ? f_xbase : f_ybase, cnt = isx ? f_xn : f_yn;
     const int lo = isx ? f_xlo : 0;
     const unsigned off = (unsigned)(rowv[i] - lo) < cnt ? base + relv[i] : XOOB;
@@ -2618,24 +2620,35 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
 
   // this wave's pairs: byte offset of the pair's fragment column (tap row + cin tile) inside an x plane, and the
   // cout tile of loop slot i (rotated by the wave: slot 0 is the tile of the wave's three extra accumulators)
-  int ptap[NS], pci[NS], xoff[NS], ycol[TM];
+  int xoff[NS], ycol[TM];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
-    const int pr = NS * wave + q;
-    ptap[q] = pr / NCI; pci[q] = pr - ptap[q] * NCI;
-    xoff[q] = (ptap[q] * SX + pci[q] * 16) * 2;
+    const int pr = NS * wave + q, pt = pr / NCI, pc = pr - pt * NCI;
+    xoff[q] = (pt * SX + pc * 16) * 2;
   }
+  // XE = 1 (shipped; WCMC_WGRAD_ROWS8_XE=0 for the A/B): the 21 left-over tiles are dealt as ONE pair per wave x 2..4
+  // consecutive cout tiles -- pair 32: waves 0-2 (cout tiles {0,1}, {2,3}, {4,5,6}), pair 33: waves 3-5 alike, pair 34: waves
+  // 6, 7 ({0,1,2}, {3,4,5,6}); 4 / 5 / 6 / 6 extra tiles per SIMD (waves w, w + 4) -- so that a wave reads ONE extra x
+  // fragment per k-step instead of three (48 instead of 56 transposing reads per 90-96 MFMAs; the kernel is bound by the
+  // issue of its non-MFMA instructions: DESIGN.md 6.1).  The extras sit in loop slots 0 .. nex-1 (slots 2, 3 behind a
+  // wave-uniform test); XE = 0: three pairs x cout tile `wave` in slot 0, wave 7 multiplies wave 0's again and drops them.
+  const int er = wave % 3;
+  const int epair = XE ? (wave < 6 ? wave / 3 : 2) : 0;
+  const int ebase = XE ? (wave < 6 ? 2 * er : wave == 6 ? 0 : 3) : wave;
+  const int nex = XE ? (wave < 6 ? (er == 2 ? 3 : 2) : wave == 6 ? 3 : 4) : 1;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) ycol[i] = (wave + i) % TM;
+  for (int i = 0; i < TM; ++i) ycol[i] = (ebase + i) % TM;
   constexpr int ETAP = KS - 1, ECI0 = NCI - NE;              // the left-over pairs: tap 4, cin tiles 4..6
+  constexpr int NA = XE ? 4 : NE, NF = XE ? 1 : NE;          // extra accumulators / extra x fragments per wave
+  const int exoff = (ETAP * SX + (ECI0 + epair) * 16) * 2;   // (XE) byte offset of the wave's extra pair inside an x plane
 
-  f32x4 acc[NS][TM], ace[NE];
+  f32x4 acc[NS][TM], ace[NA];
 #pragma unroll
   for (int q = 0; q < NS; ++q)
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int e = 0; e < NE; ++e) ace[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int e = 0; e < NA; ++e) ace[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) u16*)smem16);
@@ -2687,24 +2700,29 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
     for (int q = 0; q < NS; ++q) ax[q] = aX + (unsigned)xoff[q];
     const int c = st % nch;
     const int nk = (min(PK, p.Wo - c * PK) + 31) / 32;
-    XwrRaw rxh[NS], rxl[NS], reh[NE], rel_[NE], ryh[2], ryl[2];
+    XwrRaw rxh[NS], rxl[NS], reh[NF], rel_[NF], ryh[2], ryl[2];
+    const unsigned aE = aX + (unsigned)exoff;
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       XWR8_READ(0, 16 * SX * 2, ax[q], rxh[q]);
       XWR8_READ(XLO, XLO + 16 * SX * 2, ax[q], rxl[q]);
     }
+    if (XE) {
+      XWR8_READ(0, 16 * SX * 2, aE, reh[0]);
+      XWR8_READ(XLO, XLO + 16 * SX * 2, aE, rel_[0]);
+    } else {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      constexpr int EO = 0;
-      XWR8_READ(0, 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2 + EO), reh[e]);
-      XWR8_READ(XLO, XLO + 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2 + EO), rel_[e]);
+      for (int e = 0; e < NF; ++e) {
+        XWR8_READ(0, 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2), reh[e]);
+        XWR8_READ(XLO, XLO + 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2), rel_[e]);
+      }
     }
     {
       const unsigned ay = aY + (unsigned)(ycol[0] * 32);
       XWR8_READ(0, 16 * SY * 2, ay, ryh[0]);
       XWR8_READ(YLO, YLO + 16 * SY * 2, ay, ryl[0]);
     }
-    bf16x8 xh[NS], xl[NS], eh[NE], el[NE];
+    bf16x8 xh[NS], xl[NS], eh[NF], el[NF];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if (kk < nk) {
@@ -2721,7 +2739,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
               xh[q] = xwr_cat(rxh[q]); xl[q] = xwr_cat(rxl[q]);
             }
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
+            for (int e = 0; e < NF; ++e) {
               asm volatile("" : "+v"(reh[e].a), "+v"(reh[e].b), "+v"(rel_[e].a), "+v"(rel_[e].b));
               eh[e] = xwr_cat(reh[e]); el[e] = xwr_cat(rel_[e]);
             }
@@ -2737,9 +2755,25 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
             XWR8_READ(YLO, YLO + 16 * SY * 2, ay, ryl[nxt]);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (i == 0) {                                   // the left-over pairs: cout tile ycol[0] = wave
+          if (XE) {                                       // the left-over pair of this wave: cout tiles ycol[0 .. nex-1]
+            if (i < 4) {
+              if (i < 2 || i < nex) {
+                if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(eh[0]), "v"(el[0])); }
+                else {
+                  ace[i < NA ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, eh[0], ace[i < NA ? i : 0], 0, 0, 0);
+                  ace[i < NA ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, el[0], ace[i < NA ? i : 0], 0, 0, 0);
+                  ace[i < NA ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, eh[0], ace[i < NA ? i : 0], 0, 0, 0);
+                }
+              }
+              if (i == 3 && kk + 1 < nk) {
+                constexpr int K1 = 32 * SX * 2;
+                XWR8_READ(K1, K1 + 16 * SX * 2, aE, reh[0]);
+                XWR8_READ(K1 + XLO, K1 + XLO + 16 * SX * 2, aE, rel_[0]);
+              }
+            }
+          } else if (i == 0) {                            // the left-over pairs: cout tile ycol[0] = wave
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
+            for (int e = 0; e < NF; ++e) {
               if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(eh[e]), "v"(el[e])); }
               else {
                 ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, eh[e], ace[e], 0, 0, 0);
@@ -2789,19 +2823,31 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
   constexpr int RS = CHX + 4;
   float* red = reinterpret_cast<float*>(smem16);           // [CHY][RS]
   const int fcol = lane & 15, fq = (lane >> 4) * 4;
+  int etap[NS], eci[NS];                                   // (recomputed: not kept live through the stage loop)
+#pragma unroll
+  for (int q = 0; q < NS; ++q) { const int pr = NS * wave + q; etap[q] = pr / NCI; eci[q] = pr - etap[q] * NCI; }
 #pragma unroll
   for (int t = 0; t < KS; ++t) {
 #pragma unroll
     for (int q = 0; q < NS; ++q)
-      if (ptap[q] == t) {
+      if (etap[q] == t) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) red[(ycol[i] * 16 + fq + r) * RS + pci[q] * 16 + fcol] = acc[q][i][r];
+          for (int r = 0; r < 4; ++r) red[(ycol[i] * 16 + fq + r) * RS + eci[q] * 16 + fcol] = acc[q][i][r];
       }
-    if (t == ETAP && wave < TM) {
+    if (XE) {
+      if (t == ETAP) {
 #pragma unroll
-      for (int e = 0; e < NE; ++e)
+        for (int j = 0; j < NA; ++j)
+          if (j < nex) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(ycol[j] * 16 + fq + r) * RS + (ECI0 + epair) * 16 + fcol] = ace[j][r];
+          }
+      }
+    } else if (t == ETAP && wave < TM) {
+#pragma unroll
+      for (int e = 0; e < NF; ++e)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[(wave * 16 + fq + r) * RS + (ECI0 + e) * 16 + fcol] = ace[e][r];
     }
@@ -2862,11 +2908,14 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
       } }
 #endif
     if (!attr8_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
       attr8_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0>), grid, dim3(512), lds8, st, q);
+    if (x_env_on("WCMC_WGRAD_ROWS8_XE")) hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0, 1>), grid, dim3(512), lds8, st, q);
+    else hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0, 0>), grid, dim3(512), lds8, st, q);
     return check_launch("conv2d_wgrad_bf16x3(rows8)");
   }
 #ifdef WCMC_DEBUG_BUILD        // `make debug` only: timing-only instances that compute WRONG results are not in the release library
