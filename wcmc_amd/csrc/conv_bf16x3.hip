@@ -2681,7 +2681,27 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
   }
   rts(1);
   cst(-1);
-  for (int st = 0; st < nst; ++st) {
+  // The stage loop is unrolled by two so that the buffer of a stage is a compile-time choice: this lane's fragment
+  // addresses in either buffer (7 dy cout tiles, 4 + 1 x slots) are worked out ONCE and every transposing read is an
+  // address register plus an immediate -- the loop had ~30 address additions per stage and wave, and it is bound by the
+  // issue of exactly such instructions.
+  unsigned ayv[2][TM], axv[2][NS], aEv[2], aXv[2];
+  {
+    const int prow0 = 4 * g + tq;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const unsigned by = lds0 + (unsigned)((bb * BUF + prow0 * SY + 4 * tp) * 2);
+      const unsigned bx = lds0 + (unsigned)((bb * BUF + 2 * PK * SY + prow0 * SX + 4 * tp) * 2);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) { ayv[bb][i] = by + (unsigned)(ycol[i] * 32); asm volatile("" : "+v"(ayv[bb][i])); }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) { axv[bb][q] = bx + (unsigned)xoff[q]; asm volatile("" : "+v"(axv[bb][q])); }
+      aEv[bb] = bx + (unsigned)exoff; asm volatile("" : "+v"(aEv[bb]));
+      aXv[bb] = bx; asm volatile("" : "+v"(aXv[bb]));
+    }
+  }
+  auto stage = [&](const int st, auto PAR) __attribute__((always_inline)) {
+    constexpr int par = decltype(PAR)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cst(0);
@@ -2692,16 +2712,13 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
     // pipe ~60 % busy against ~86 % for a pair (scripts/timeline_wgrad.py).  Waves 0-3 take priority 2 for the first
     // p.prio iterations of the stage and 0 afterwards, waves 4-7 stay at 1: both reach the barrier together.
     if (p.prio) { if (wave < 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
-    const int prow0 = 4 * g + tq;
-    const unsigned aY = lds0 + (unsigned)(((st & 1) * BUF + prow0 * SY + 4 * tp) * 2);
-    const unsigned aX = lds0 + (unsigned)(((st & 1) * BUF + 2 * PK * SY + prow0 * SX + 4 * tp) * 2);
-    unsigned ax[NS];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) ax[q] = aX + (unsigned)xoff[q];
+    const unsigned aX = aXv[par];
+    const unsigned (&ax)[NS] = axv[par];
+    const unsigned (&ayp)[TM] = ayv[par];
     const int c = st % nch;
     const int nk = (min(PK, p.Wo - c * PK) + 31) / 32;
     XwrRaw rxh[NS], rxl[NS], reh[NF], rel_[NF], ryh[2], ryl[2];
-    const unsigned aE = aX + (unsigned)exoff;
+    const unsigned aE = aEv[par];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       XWR8_READ(0, 16 * SX * 2, ax[q], rxh[q]);
@@ -2717,11 +2734,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
         XWR8_READ(XLO, XLO + 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2), rel_[e]);
       }
     }
-    {
-      const unsigned ay = aY + (unsigned)(ycol[0] * 32);
-      XWR8_READ(0, 16 * SY * 2, ay, ryh[0]);
-      XWR8_READ(YLO, YLO + 16 * SY * 2, ay, ryl[0]);
-    }
+    XWR8_READ(0, 16 * SY * 2, ayp[0], ryh[0]);
+    XWR8_READ(YLO, YLO + 16 * SY * 2, ayp[0], ryl[0]);
     bf16x8 xh[NS], xl[NS], eh[NF], el[NF];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -2745,14 +2759,18 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
             }
           }
           const bf16x8 yh = xwr_cat(ryh[cur]), yl = xwr_cat(ryl[cur]);
+          constexpr int KY = 32 * SY * 2;                 // the second k-step of the dy planes
           if (i + 1 < TM) {
-            const unsigned ay = aY + (unsigned)(kk * 32 * SY * 2 + ycol[i + 1] * 32);
-            XWR8_READ(0, 16 * SY * 2, ay, ryh[nxt]);
-            XWR8_READ(YLO, YLO + 16 * SY * 2, ay, ryl[nxt]);
+            if (kk == 0) {
+              XWR8_READ(0, 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryh[nxt]);
+              XWR8_READ(YLO, YLO + 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryl[nxt]);
+            } else {
+              XWR8_READ(KY, KY + 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryh[nxt]);
+              XWR8_READ(KY + YLO, KY + YLO + 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryl[nxt]);
+            }
           } else if (kk + 1 < nk) {
-            const unsigned ay = aY + (unsigned)((kk + 1) * 32 * SY * 2 + ycol[0] * 32);
-            XWR8_READ(0, 16 * SY * 2, ay, ryh[nxt]);
-            XWR8_READ(YLO, YLO + 16 * SY * 2, ay, ryl[nxt]);
+            XWR8_READ(KY, KY + 16 * SY * 2, ayp[0], ryh[nxt]);
+            XWR8_READ(KY + YLO, KY + YLO + 16 * SY * 2, ayp[0], ryl[nxt]);
           }
           __builtin_amdgcn_sched_barrier(0);
           if (XE) {                                       // the left-over pair of this wave: cout tiles ycol[0 .. nex-1]
@@ -2803,7 +2821,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
           }
           // (the next stage's scalars are worked out here, behind the first MFMAs of the stage, not at the barrier where
           // both waves of every SIMD would do it at the same moment with the matrix pipe empty)
-          if (fill && kk * TM + i == 0) issue_prep((st + 1) & 1);
+          if (fill && kk * TM + i == 0) issue_prep(par ^ 1);
           if (fill && kk * TM + i < NI) issue_one(kk * TM + i);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -2815,6 +2833,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
         if (i >= nk * TM) issue_one(i);
     }
     cst(2);
+  };
+  for (int st = 0; st < nst; st += 2) {
+    stage(st, std::integral_constant<int, 0>{});
+    if (st + 1 < nst) stage(st + 1, std::integral_constant<int, 1>{});
   }
   rts(2);
 
