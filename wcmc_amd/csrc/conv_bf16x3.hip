@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void conv_igemm_bf16x3_kernel(XI
   constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
   constexpr int BUF = A_ELEMS + B_ELEMS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: wave-uniform tests and LDS-DMA destinations stay scalar code)
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private 4 MB L2 each), so
   // give each XCD one contiguous run of pixel tiles (speed only, any placement is correct).
   int tile;
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
   char* const halo = reinterpret_cast<char*>(smem16);
   u16* const bsm = smem16 + ((HP * p.PXS + 127) & ~127) / 2;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: wave-uniform tests and LDS-DMA destinations stay scalar code)
   int tile;
   {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -1273,8 +1273,12 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 // stage is then TWO filter taps x 16 channels (four taps x 8 in an 8-channel slab): k-group kg of the lanes reads tap
 // 2s + (kg >> 1); taps past ks*ks are slab padding (zero weights) and read the tile's first pixel.
 // Wave w owns tile rows w, w+4, w+8, w+12 (a tile that hangs over the image edge idles every wave equally).
-template <int NT, int NB, int PT = 4, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams p) {
+// PXST: the halo pixel stride as a compile-time constant (80 or 160; 0 = p.PXS, the WCMC_HALO64_PXS experiments) -- with it the
+// pixel tiles of a wave sit at immediate offsets of ONE address register per stage (the kernel is launched for ks == 5 only).
+template <int NT, int NB, int PT = 4, int DBG = 0, int PXST = 0>
+__global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams p0) {
+  XIgemmParams p = p0;
+  if (PXST) { p.PXS = PXST; p.ks = 5; }
   constexpr int BN = NT * 16, TH = 4 * PT, TW = 16, NTHR = 256, NWV = 4;
   constexpr int NG = (PT + 1) / 2;             // epilogue groups of two pixel tiles per wave (128 pixels of staging)
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
@@ -1283,7 +1287,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   char* const halo = reinterpret_cast<char*>(smem16);
   u16* const bsm = smem16 + ((HP * p.PXS + 127) & ~127) / 2;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (wave as a SCALAR: the weight ring's LDS destinations, the group tests and the wait counts become scalar code -- as a
+  // vector value they cost ~10 vector instructions and 4 v_readfirstlane per stage in a loop bound by vector issue)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // DBG (debug library, timing only, WRONG results): 1 no MFMA, 2 no weight DMA in the stage loop, 4 one halo per tile,
   // 8 no fragment reads, 32 no epilogue; 64 = wall-clock stamps (scripts/timeline_halo.py)
   unsigned long long st_rt[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -1337,21 +1343,23 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   const int nstages = p.Kt / XKC;
   constexpr int NGMAX = (NT + NWV - 1) / NWV;
   const int ngroups = wave < NT ? (NT - wave + NWV - 1) / NWV : 0;       // wave-uniform
-  unsigned dbase[NGMAX];
+  unsigned dbase[NGMAX], dbase2[NGMAX];                  // hi / lo plane of this lane's 16 bytes of a stage's row group
 #pragma unroll
   for (int q = 0; q < NGMAX; ++q) {
     const int drow = 16 * (wave + q * NWV) + (lane >> 2);
     const int dvq = (lane & 3) ^ ((drow >> 1) & 3);
     dbase[q] = (q < ngroups && n0 + drow < p.Np) ? (unsigned)(((n0 + drow) * 2 * p.Kt + dvq * 8) * 2) : XOOB;
+    dbase2[q] = dbase[q] >= XOOB ? XOOB : dbase[q] + (unsigned)(p.Kt * 2);
   }
   auto dma_b = [&](int g, int buf) {
+    // one addition per instruction: the stage's byte offset is a scalar; stages past the end add 2^30 instead, which puts
+    // valid rows (< 2^30: the packed weights are a few MB) and invalid ones (2^31) alike beyond the buffer without wrapping
+    const unsigned sg = g < nstages ? (unsigned)(g * XKC * 2) : 0x40000000u;
 #pragma unroll
     for (int q = 0; q < NGMAX; ++q) {
       if (q < ngroups) {
-        const unsigned kill = g < nstages ? 0u : XOOB;
-        const unsigned db = dbase[q];
-        const unsigned off = (db + (unsigned)(g * XKC * 2)) | kill;
-        const unsigned off2 = db >= XOOB ? XOOB : (off + (unsigned)(p.Kt * 2)) | kill;
+        const unsigned off = dbase[q] + sg;
+        const unsigned off2 = dbase2[q] + sg;
         u16* d = bsm + buf * B_ELEMS + 16 * (wave + q * NWV) * XROW;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, off, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, off2, 0, 0, 0);
@@ -1368,9 +1376,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   // ---- fragments: lane = pixel column (lane & 15) of its four tile rows, k group kg = lane >> 4 (8 k each)
   const int frow = lane & 15, kg = lane >> 4;
   const int fslot = (kg ^ ((frow >> 1) & 3)) * 8;
-  int abase[PT];
-#pragma unroll
-  for (int i = 0; i < PT; ++i) abase[i] = ((wave + NWV * i) * HWd + frow) * p.PXS;
+  const int abase0 = (wave * HWd + frow) * p.PXS, dA = NWV * HWd * p.PXS;   // tile row i of the wave: + i * dA (a constant with PXST)
   // this lane's (tap, channel) of the stage whose A fragments are read next
   int cs_cur, sps_cur, lo_off, tps, coff, tdx, tdy;
   auto slab_begin = [&](int slab) {
@@ -1382,11 +1388,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
     tdy = 0; tdx = cs_cur == 32 ? 0 : cs_cur == 16 ? (kg >> 1) : kg;        // (< ks)
   };
   bf16x8 ah[PT], al[PT], wh[NT], wl[NT];
-  auto a_off = [&]() { return tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + coff : coff; };
+  // (24-bit multiplies: full-rate v_mad_u32_u24 instead of two 64-bit multiply-adds per stage)
+  auto a_off = [&]() { return tdy < p.ks ? (int)__umul24(__umul24((unsigned)tdy, (unsigned)HWd) + (unsigned)tdx, (unsigned)p.PXS) + coff : coff; };
   auto a_advance = [&]() { tdx += tps; if (tdx >= p.ks) { tdx -= p.ks; ++tdy; } };
   auto read_a1 = [&](int i, int aoff) {
-    ah[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
-    al[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
+    const char* pa = halo + abase0 + aoff;
+    ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * dA);
+    al[i] = *reinterpret_cast<const bf16x8*>(pa + lo_off + i * dA);
   };
   const u16* const bfrag = bsm + frow * XROW + fslot;
   auto read_b = [&](int buf, int j) {
@@ -2043,7 +2051,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
   u16* Ys = smem16;                        // [2][PK][SA]
   u16* Xs = smem16 + 2 * PK * SA;          // [2][PK][SB]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: wave-uniform tests and LDS-DMA destinations stay scalar code)
   // block -> (split, tap, tile): XCD x (= blockIdx & 7) owns splits s = x, x+8, ...; its consecutive
   // blocks sweep the taps and tiles of one split.
   const int taps = p.ks * p.ks;
@@ -3308,17 +3316,25 @@ static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) 
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
-template <int NT, int NB, int PT>
-static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream) {
+template <int NT, int NB, int PT, int PXST>
+static int launch_xhalo64c(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
-  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
+}
+template <int NT, int NB, int PT>
+static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream) {
+  // the halo pixel stride as a template constant for the two shipped values (NB = 3: 16-channel slabs, 80 B; NB = 2 with
+  // 12x16 tiles: 32-channel slabs, 160 B); anything else (WCMC_HALO64_PXS, WCMC_HALO_NB experiments) reads it from the params
+  if (p.ks == 5 && p.PXS == 80 && NB == 3) return launch_xhalo64c<NT, NB, PT, NB == 3 ? 80 : 0>(p, lds, stream);
+  if (p.ks == 5 && p.PXS == 160 && NB == 2 && PT == 3) return launch_xhalo64c<NT, NB, PT, (NB == 2 && PT == 3) ? 160 : 0>(p, lds, stream);
+  return launch_xhalo64c<NT, NB, PT, 0>(p, lds, stream);
 }
 template <int NT>
 static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
@@ -3336,15 +3352,15 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   const size_t halo = (size_t)((HP * p.PXS + 127) & ~127), bstage = (size_t)(2 * NT * 16 * XROW + 64) * sizeof(u16);
   const size_t out = p.ys ? (size_t)128 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)128 * (NT * 16 + 4) * sizeof(float);
 #ifdef WCMC_DEBUG_BUILD
-  if (NT == 7 && !pt3) {
+  if (NT == 7 && !pt3 && p.PXS == 80 && p.ks == 5) {
     const char* e = getenv("WCMC_DEBUG_ABLATE");
     const int ab = e ? atoi(e) : 0;
     if (ab) {
-      auto kfn = ab == 1 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 1> : ab == 2 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 2>
-                 : ab == 4 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 4> : ab == 8 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 8>
-                 : ab == 10 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 10> : ab == 14 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 14>
-                 : ab == 32 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 32> : ab == 46 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 46>
-                 : &conv_halo64_bf16x3_kernel<7, 3, 4, 64>;
+      auto kfn = ab == 1 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 1, 80> : ab == 2 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 2, 80>
+                 : ab == 4 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 4, 80> : ab == 8 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 8, 80>
+                 : ab == 10 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 10, 80> : ab == 14 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 14, 80>
+                 : ab == 32 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 32, 80> : ab == 46 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 46, 80>
+                 : &conv_halo64_bf16x3_kernel<7, 3, 4, 64, 80>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
       hipLaunchKernelGGL(kfn, grid, dim3(256), halo + 3 * bstage, stream, p);
