@@ -2252,6 +2252,19 @@ __device__ __forceinline__ bf16x8 xwr_cat(const XwrRaw& r) {
   return __builtin_bit_cast(bf16x8, c);
 }
 
+template <int OFF1, int OFF2>
+__device__ __forceinline__ void xwr_tr_issue_at(unsigned addr, XwrRaw& r) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(r.a), "=&v"(r.b) : "v"(addr), "n"(OFF1), "n"(OFF2));
+}
+
+// loops whose index must be a constant expression (immediate offsets of the transposing reads: an address that is a register
+// plus a constant costs a vector addition per read as a plain unrolled loop, and these kernels are bound by vector issue)
+template <class F, int... I>
+__device__ __forceinline__ void xstatic_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void xstatic_for(F&& f) { xstatic_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
 template <int KS, int TM, int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf16x3_kernel(XWRowsParams p) {
   constexpr int CHY = TM * 16, CHX = NW * 16, PK = 64, XR = PK + KS - 1;
@@ -2403,9 +2416,7 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
     // byte addresses of this lane's first fragment row in the four planes of the stage
     const int prow0 = 4 * g + tq;
     const unsigned aYh = lds0 + (unsigned)(((st & 1) * BUF + prow0 * SY + 4 * tp) * 2);
-    const unsigned aYl = aYh + PK * SY * 2;
     const unsigned aXh = lds0 + (unsigned)(((st & 1) * BUF + 2 * PK * SY + prow0 * SX + wave * 16 + 4 * tp) * 2);
-    const unsigned aXl = aXh + XR * SX * 2;
     const int c = st % nch;
     const int nk = (min(PK, p.Wo - c * PK) + 31) / 32;    // 32-pixel MFMA k-steps with any valid pixel (1 or 2)
     // Software pipeline inside the wave (the first version read a k-step's fragments, waited, multiplied: a wave alone on
@@ -2413,20 +2424,21 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
     // replaced tap by tap during its last cout tile; the dy fragments are double-buffered one cout tile ahead.  The
     // order of the MFMAs on every accumulator is unchanged (bit-identical results).
     XwrRaw rxh[KS], rxl[KS], ryh[2], ryl[2];
-#pragma unroll
-    for (int t = 0; t < KS; ++t) {
-      xwr_tr_issue<16 * SX * 2>(aXh + t * SX * 2, rxh[t]);
-      xwr_tr_issue<16 * SX * 2>(aXl + t * SX * 2, rxl[t]);
-    }
-    xwr_tr_issue<16 * SY * 2>(aYh, ryh[0]);
-    xwr_tr_issue<16 * SY * 2>(aYl, ryl[0]);
+    constexpr int XLOB = XR * SX * 2, YLOB = PK * SY * 2;   // lo planes; every read below = aXh / aYh + an immediate
+    xstatic_for<KS>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      xwr_tr_issue_at<t * SX * 2, t * SX * 2 + 16 * SX * 2>(aXh, rxh[t]);
+      xwr_tr_issue_at<XLOB + t * SX * 2, XLOB + t * SX * 2 + 16 * SX * 2>(aXh, rxl[t]);
+    });
+    xwr_tr_issue_at<0, 16 * SY * 2>(aYh, ryh[0]);
+    xwr_tr_issue_at<YLOB, YLOB + 16 * SY * 2>(aYh, ryl[0]);
     bf16x8 xh[KS], xl[KS];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    xstatic_for<2>([&](auto K_) {
+      constexpr int kk = decltype(K_)::value;
       if (kk < nk) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int cur = (kk * TM + i) & 1, nxt = cur ^ 1;
+        xstatic_for<TM>([&](auto I_) {
+          constexpr int i = decltype(I_)::value;
+          constexpr int cur = (kk * TM + i) & 1, nxt = cur ^ 1;
           // everything issued so far has landed (the reads of this iteration were issued one iteration ago)
           if (DBG & 8) {                               // (timing only: no wait for the fragments)
             asm volatile("" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
@@ -2445,16 +2457,18 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
           }
           const bf16x8 yh = xwr_cat(ryh[cur]), yl = xwr_cat(ryl[cur]);
-          if (i + 1 < TM) {
-            xwr_tr_issue<16 * SY * 2>(aYh + (kk * 32 * SY + (i + 1) * 16) * 2, ryh[nxt]);
-            xwr_tr_issue<16 * SY * 2>(aYl + (kk * 32 * SY + (i + 1) * 16) * 2, ryl[nxt]);
+          if constexpr (i + 1 < TM) {
+            constexpr int O = (kk * 32 * SY + (i + 1) * 16) * 2;
+            xwr_tr_issue_at<O, O + 16 * SY * 2>(aYh, ryh[nxt]);
+            xwr_tr_issue_at<YLOB + O, YLOB + O + 16 * SY * 2>(aYh, ryl[nxt]);
           } else if (kk + 1 < nk) {
-            xwr_tr_issue<16 * SY * 2>(aYh + ((kk + 1) * 32 * SY) * 2, ryh[nxt]);
-            xwr_tr_issue<16 * SY * 2>(aYl + ((kk + 1) * 32 * SY) * 2, ryl[nxt]);
+            constexpr int O = (kk + 1) * 32 * SY * 2;
+            xwr_tr_issue_at<O, O + 16 * SY * 2>(aYh, ryh[nxt]);
+            xwr_tr_issue_at<YLOB + O, YLOB + O + 16 * SY * 2>(aYh, ryl[nxt]);
           }
           __builtin_amdgcn_sched_barrier(0);             // (the prefetch leaves before the MFMAs, not among them)
-#pragma unroll
-          for (int t = 0; t < KS; ++t) {
+          xstatic_for<KS>([&](auto T_) {
+            constexpr int t = decltype(T_)::value;
             if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(xh[t]), "v"(xl[t])); }
             else {
               acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[t], acc[t][i], 0, 0, 0);
@@ -2462,18 +2476,19 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
               acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[t], acc[t][i], 0, 0, 0);
             }
             if (i == TM - 1 && kk + 1 < nk) {             // this tap's fragments of the next k-step
-              xwr_tr_issue<16 * SX * 2>(aXh + ((kk + 1) * 32 + t) * SX * 2, rxh[t]);
-              xwr_tr_issue<16 * SX * 2>(aXl + ((kk + 1) * 32 + t) * SX * 2, rxl[t]);
+              constexpr int O = ((kk + 1) * 32 + t) * SX * 2;
+              xwr_tr_issue_at<O, O + 16 * SX * 2>(aXh, rxh[t]);
+              xwr_tr_issue_at<XLOB + O, XLOB + O + 16 * SX * 2>(aXh, rxl[t]);
             }
-          }
+          });
           // (the next stage's scalars are worked out behind the first MFMAs of the stage, not at the barrier where all
           // waves of the block would do it at the same moment with the matrix pipe empty)
           if (fill && kk * TM + i == 0) issue_prep((st + 1) & 1);
           if (fill && kk * TM + i < NI) issue_one(kk * TM + i);
           __builtin_amdgcn_sched_barrier(0);
-        }
+        });
       }
-    }
+    });
     if (fill) {                                          // what the MFMA stream had no slot for (one k-step, or NI > 2 TM)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
@@ -2522,12 +2537,6 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
       o[7] = (unsigned long long)nst;
     }
   }
-}
-
-template <int OFF1, int OFF2>
-__device__ __forceinline__ void xwr_tr_issue_at(unsigned addr, XwrRaw& r) {
-  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-               : "=&v"(r.a), "=&v"(r.b) : "v"(addr), "n"(OFF1), "n"(OFF2));
 }
 
 // The KPCN instance (5x5, 7 x 7 channel tiles) of the filter-row kernel on EIGHT waves.  conv_wgrad_rows_bf16x3_kernel
