@@ -33,6 +33,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
 _ROWS8 = os.environ.get("WCMC_WGRAD_ROWS8", "1")[:1] != "0"     # which filter-row weight-gradient kernel the library launches
+_ROWS8_XE = 0 if os.environ.get("WCMC_WGRAD_ROWS8_XE", "1")[:1] == "0" else 1
 B_PER_GPU, SPP, PATCH = 8, 8, 128
 
 
@@ -151,7 +152,7 @@ def pmc_traffic():
     for k, v in d.items():
         for tag, key in (("conv_halo_bf16x3_kernel<7, 8, 16", "conv_halo7"), ("conv_halo64_bf16x3_kernel<7, 3, 4", "conv_halo64_pt4"),
                          ("conv_halo64_bf16x3_kernel<7, 3, 3", "conv_halo64_pt3"), ("conv_halo64_bf16x3_kernel<7, 2, 3", "conv_halo64_cs32"),
-                         ("conv_wgrad_rows8_bf16x3_kernel<0>" if _ROWS8 else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
+                         ("conv_wgrad_rows8_bf16x3_kernel<0, " if _ROWS8 else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("kernel_apply_strip_kernel<false", "kernel_apply_fwd"), ("kernel_apply_strip_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
@@ -379,10 +380,10 @@ def main():
                 # ~3.5x the counted FLOPs; for scale, the exact-fp32 MFMA peak is 157.3 TFLOP/s
                 extra = {"mfma_flops_per_algorithmic_flop": 3.0, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 3)}
             rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 8, 16, 0, 2>",
-                            "conv_halo64_pt4": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0>",
-                            "conv_halo64_pt3": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0>",
-                            "conv_halo64_cs32": "wcmc::conv_halo64_bf16x3_kernel<7, 2, 3, 0>",
-                            "conv_wgrad_rows": "wcmc::conv_wgrad_rows8_bf16x3_kernel<0>" if _ROWS8 else "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
+                            "conv_halo64_pt4": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80>",
+                            "conv_halo64_pt3": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80>",
+                            "conv_halo64_cs32": "wcmc::conv_halo64_bf16x3_kernel<7, 2, 3, 0, 160>",
+                            "conv_wgrad_rows": "wcmc::conv_wgrad_rows8_bf16x3_kernel<0, %d>" % _ROWS8_XE if _ROWS8 else "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
                             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}.get(name, name + " (several kernels)")
             if ops.PRECISION == "fp32":
                 rocprof_name = ("wcmc::conv_wgrad_kernel" if "wgrad" in name else "wcmc::conv_igemm_kernel") + \

@@ -12,7 +12,7 @@ timeout 300 python3 scripts/time_halo_abl.py 124 0 1 2 4 8 10 14 32 46 2>&1 | gr
  echo "# WCMC_WGRAD_ROWS8=0: conv_wgrad_rows_bf16x3_kernel<5, 7, 7> (seven waves)"; WCMC_WGRAD_ROWS8=0 WCMC_DEBUG_ABLATE=16 timeout 200 python3 scripts/timeline_wgrad.py 124 108 2>&1 | grep -v amdgpu.ids) > $O/wgrad_rows_timeline.txt
 (echo "# WCMC_WGRAD_ROWS8=0: the ablation instances are those of the seven-wave kernel"; WCMC_WGRAD_ROWS8=0 timeout 300 python3 scripts/time_wgrad_abl.py 124 2>&1 | grep -v amdgpu.ids) > $O/wgrad_rows_ablations.txt
 (echo "# conv_wgrad_rows8_bf16x3_kernel: 1 no MFMA, 2 no fills after the first, 3 both, 8 no fragment waits, 32 no fragment reads, 34 = 32 + 2, 35 = all"; timeout 300 python3 scripts/time_wgrad_abl.py 124 0 1 2 3 8 32 34 35 2>&1 | grep -v amdgpu.ids) > $O/wgrad_rows8_ablations.txt
-WCMC_DEBUG_LIB= PRIOS=0,6,8,10 timeout 300 python3 scripts/time_wgrad_rows8.py 2>&1 | grep -v amdgpu.ids > $O/wgrad_rows8.txt
+WCMC_DEBUG_LIB= PRIOS=0,8 XES=0,1 timeout 300 python3 scripts/time_wgrad_rows8.py 2>&1 | grep -v amdgpu.ids > $O/wgrad_rows8.txt
 unset WCMC_DEBUG_LIB
 timeout 250 python3 scripts/time_conv_layers.py 2>&1 | grep -v amdgpu.ids > $O/conv_layers.txt
 WCMC_HALO64=0 timeout 250 python3 scripts/time_conv_layers.py 2>&1 | grep -v amdgpu.ids > $O/conv_layers_halo8x16.txt
