@@ -939,20 +939,22 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
   // row group = 16 cout rows; wave w fills groups w, w + NWV, ... (one each with 8 waves; up to two with 4)
   constexpr int NGMAX = (NT + NWV - 1) / NWV;
   const int ngroups = wave < NT ? (NT - wave + NWV - 1) / NWV : 0;       // wave-uniform
-  unsigned dbase[NGMAX];
+  unsigned dbase[NGMAX], dbase2[NGMAX];
 #pragma unroll
   for (int q = 0; q < NGMAX; ++q) {
     const int drow = 16 * (wave + q * NWV) + (lane >> 2);
     const int dvq = (lane & 3) ^ ((drow >> 1) & 3);
     dbase[q] = (q < ngroups && n0 + drow < p.Np) ? (unsigned)(((n0 + drow) * 2 * p.Kt + dvq * 8) * 2) : XOOB;
+    dbase2[q] = dbase[q] >= XOOB ? XOOB : dbase[q] + (unsigned)(p.Kt * 2);
   }
-  // one row group (hi + lo plane: two wave instructions) of stage g's weights
+  // one row group (hi + lo plane: two wave instructions) of stage g's weights; one addition per instruction (the stage's
+  // byte offset is a scalar; stages past the end add 2^30: valid rows -- the packed weights are a few MB -- and invalid
+  // ones (2^31) alike land beyond the buffer, without wrapping)
   auto dma_b_group = [&](int g, int buf, int q) {
     if (q < ngroups) {
-      const unsigned kill = g < nstages ? 0u : XOOB;
-      const unsigned db = dbase[q];
-      const unsigned off = (db + (unsigned)(g * XKC * 2)) | kill;
-      const unsigned off2 = db >= XOOB ? XOOB : (off + (unsigned)(p.Kt * 2)) | kill;
+      const unsigned sg = g < nstages ? (unsigned)(g * XKC * 2) : 0x40000000u;
+      const unsigned off = dbase[q] + sg;
+      const unsigned off2 = dbase2[q] + sg;
       u16* d = bsm + buf * B_ELEMS + 16 * (wave + q * NWV) * XROW;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, off, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, off2, 0, 0, 0);
@@ -1019,7 +1021,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     // padding, zero weights) read the tile's first pixels
     cl += XKC;
     if (cl >= cs_cur) { cl -= cs_cur; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
-    aoff = tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0;
+    aoff = tdy < p.ks ? (int)__umul24(__umul24((unsigned)tdy, (unsigned)HWd) + (unsigned)tdx, (unsigned)p.PXS) + cl * 2 : 0;
   };
   const u16* const bfrag = bsm + frow * XROW + fslot;
   auto read_b = [&](int buf, int j) {
@@ -1054,6 +1056,12 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     // halo: the next slab's halo lands while this stage multiplies
     if (last_of_slab && slab + 1 < p.nslabs && !(DBG & 4)) dma_halo(slab + 1);      // (DBG & 4, timing only: one halo per tile)
     stamp(1);
+    // A fragments of stage g+1: with two workgroups per CU (8x16 tiles) they replace a pixel tile's registers as soon as its
+    // last MFMAs of this stage have issued (LATE; reading them into a second register set during the first cout tile and
+    // copying costs 8 v_mov_b64 per stage in a loop of 24 MFMAs that is bound by vector issue: 64 -> 64 at 128^2 43.3 -> 41.9
+    // us); with ONE workgroup per CU (16x16 tiles, all eight waves in step) the early read hides the LDS latency that
+    // nothing else covers there and stays (128 -> 128 at 64^2: 37 us early, 39-40 late).
+    constexpr bool LATE = TH * TW <= 128;
     bf16x8 ahn[2], aln[2];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1065,9 +1073,13 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
         }
+        if (LATE && j == NT - 1 && !last_of_slab && !(DBG & 8)) {
+          ah[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
+          al[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
+        }
       }
       if (!(DBG & 8)) read_b(b1, j);             // stage g+1, same cout tile, into the registers just consumed
-      if (j == 0 && !last_of_slab && !(DBG & 8)) {
+      if (!LATE && j == 0 && !last_of_slab && !(DBG & 8)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           ahn[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
@@ -1078,11 +1090,13 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     }
     stamp(2);
     if (!last_of_slab) {
+      if (!LATE) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { ah[i] = ahn[i]; al[i] = aln[i]; }
+        for (int i = 0; i < 2; ++i) { ah[i] = ahn[i]; al[i] = aln[i]; }
+      }
       cl += XKC;
       if (cl >= cs_cur) { cl -= cs_cur; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
-      aoff = tdy < p.ks ? (tdy * HWd + tdx) * p.PXS + cl * 2 : 0;
+      aoff = tdy < p.ks ? (int)__umul24(__umul24((unsigned)tdy, (unsigned)HWd) + (unsigned)tdx, (unsigned)p.PXS) + cl * 2 : 0;
       ++s_in;
     } else {                                     // slab boundary: the next A fragments come from the next halo
       s_in = 0;
