@@ -3549,6 +3549,8 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   const size_t xb = wcmc_split_elems(N, H, W, Cin) * sizeof(u16), wb = (size_t)p.Np * 2 * p.Kt * sizeof(u16);
   WCMC_REQUIRE(xb < 0x7ff00000u && wb < 0x7ff00000u, WCMC_ERR_BAD_ARG,
                "conv2d_igemm_bf16x3: operand larger than 2 GiB (split the batch)");
+  // (the halo kernels push the weight-DMA offsets of stages past the end out of range by adding 2^30: see dma_b)
+  WCMC_REQUIRE(!q.halo || wb < 0x40000000u, WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: packed weights of 1 GiB or more");
   p.x_bytes = (unsigned)xb; p.wp_bytes = (unsigned)wb;
   p.colsum = colsum_partial;
 #ifdef WCMC_DEBUG_BUILD
