@@ -1335,7 +1335,51 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   const int VP = p.PXS / 16;
   const int hvecs = HP * VP;
   const float invVP = 1.0f / (float)VP, invHW = 1.0f / (float)HWd;
+  // With the stride a template constant the per-lane source offsets of the halo's 16-byte vectors are worked out ONCE, for a
+  // regular slab and for the last (narrower) one; a slab's fill is then one addition per instruction (+ slab * CS * 2, a
+  // scalar).  Decoding them again for every slab cost ~25 vector instructions per vector, ~800 cycles of vector issue per
+  // wave in front of the MFMAs of each slab's last stage (the "six halo reloads per tile: 4 %" of the ablations).
+  constexpr int NHV = PXST ? (((TH + 4) * (TW + 4) * (PXST / 16) + 63) / 64 + NWV - 1) / NWV : 0;
+  unsigned hoff[NHV ? NHV : 1], hoffl[NHV ? NHV : 1];
+  if (PXST) {
+#pragma unroll
+    for (int kq = 0; kq < NHV; ++kq) {
+      const int v = (wave + NWV * kq) * 64 + lane;
+      hoff[kq] = XOOB; hoffl[kq] = XOOB;
+      if (v < hvecs) {
+        const int px = (int)(((float)v + 0.5f) * invVP), part = v - px * VP;     // exact: v < 2^13
+        const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
+        const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+          const unsigned pbase = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb);
+          {
+            const int V = p.CS / 4, plane = part >= (V >> 1), vec = part - plane * (V >> 1);
+            // (channel test against the widest regular slab, nslabs - 2: it then holds for every regular slab)
+            if (part < V && (p.nslabs - 2) * p.CS + vec * 8 < p.Cpi) hoff[kq] = pbase + (unsigned)(plane * 2 * p.Cpi + vec * 16);
+          }
+          {
+            const int V = p.CSl / 4, plane = part >= (V >> 1), vec = part - plane * (V >> 1);
+            if (part < V && (p.nslabs - 1) * p.CS + vec * 8 < p.Cpi) hoffl[kq] = pbase + (unsigned)(plane * 2 * p.Cpi + vec * 16);
+          }
+        }
+      }
+    }
+  }
   auto dma_halo = [&](int slab) {
+    if (PXST) {
+      const unsigned so = (unsigned)(slab * p.CS * 2);
+      const bool lastslab = slab == p.nslabs - 1;
+#pragma unroll
+      for (int kq = 0; kq < NHV; ++kq) {
+        const int ii = wave + NWV * kq;
+        if (ii * 64 < hvecs) {
+          const unsigned off = (lastslab ? hoffl[kq] : hoff[kq]) + so;     // (invalid: 2^31 + a few hundred: out of range)
+          if (ii * 64 + lane < hvecs)                                      // (the tail of the last instruction would land in the weight ring)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(halo + ii * 1024), 16, off, 0, 0, 0);
+        }
+      }
+      return;
+    }
     const int V = (slab == p.nslabs - 1 ? p.CSl : p.CS) / 4;      // data vectors per halo pixel (2 planes x cs/8)
     for (int ii = wave; ii * 64 < hvecs; ii += NWV) {
       const int v = ii * 64 + lane;
