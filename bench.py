@@ -164,6 +164,43 @@ def pmc_traffic():
     return pick
 
 
+def c2_leg(device, steps, warmup):
+    """BASELINE configs[1] (BASELINE.md section 3 promises its number beside C3's): KPCN-Vanilla, diffuse + specular
+    (n_in = 34, no PathNet, no manifold loss), 128x128, batch 8 on one MI355X -- the same graphed step machinery, the
+    library's default arithmetic.  Parity of exactly this step: tests/test_gpu_bench_config.py::test_c2_vanilla_..."""
+    from wcmc_amd import KPCN, ops
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.optim import FusedClipAdam
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import RelativeMSE
+    from wcmc_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    models = {"dncnn": KPCN(34).to(device)}
+    optims = {"optim_dncnn": torch.optim.Adam(models["dncnn"].parameters(), lr=1e-4)}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(), "l_test": RelativeMSE()}
+    itf = KPCNInterface(models, optims, lf, types.SimpleNamespace(model_name="bench_c2"), train_branches=True)
+    itf.fused_optim = FusedClipAdam(models, optims)
+    itf.iters = 1
+    itf.to_train_mode()
+    batch = make_batch(B_PER_GPU, SPP, PATCH, seed=0, device=device, use_llpm=False)
+    graphed = GraphedTrainStep(itf, batch)
+    for _ in range(warmup):
+        graphed(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graphed(batch)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    flops = 374.0e9 * B_PER_GPU                       # SURVEY 8d: 3 x 124.7 GF per patch
+    peak = PEAK_BF16_MFMA_TFLOPS if ops.PRECISION != "fp32" else PEAK_FP32_MFMA_TFLOPS
+    return {"workload": "BASELINE configs[1]: KPCN-Vanilla diffuse+specular (n_in=34), 128x128, batch %d, 1 GPU" % B_PER_GPU,
+            "value": round(B_PER_GPU * steps / el, 3), "unit": "patches/s", "ms_per_step": round(el / steps * 1e3, 3),
+            "steps": steps, "warmup": warmup, "dtype": ops.PRECISION,
+            "whole_step_mfma_frac": round(flops / (el / steps) / 1e12 / peak, 4),
+            "losses_last_step": {k: round(float(v), 6) for k, v in itf.last_loss_dict.items()}}
+
+
 def cpu_baseline():
     """The oracle's step (same architecture, same losses) on the host cores: C3 shape at batch 1."""
     from oracle import step as ostep
@@ -291,6 +328,7 @@ def main():
         itf.train_batch(batch)
 
     prof = EventProfiler()
+    stream_defaults = (ops.USE_SIDE_STREAM, ops.USE_BRANCH_STREAM)      # (the per-kernel profile below switches them off)
 
     def eager_profiled_step():
         prof.next_step()
@@ -441,6 +479,9 @@ def main():
             "roofline_pointwise": (dict(roof("conv_pw", "hbm"), traffic=traffic.get("conv_pw")) if roof("conv_pw", "hbm") else None),
             "roofline_kernel_apply": ka,
         }
+        if world == 1 and not args.eager:
+            ops.USE_SIDE_STREAM, ops.USE_BRANCH_STREAM = stream_defaults
+            line["c2"] = c2_leg(device, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -759,3 +759,52 @@ def test_bench_roofline_names_match_the_committed_profiles():
     for p in printed:
         p = p.replace("%d", "1")
         assert any(p.replace("wcmc::", "") in n for n in names), p
+
+
+def test_kernel_apply_backward_start_up_waits_are_in_the_binary(tmp_path):
+    """the strip kernel's counted wait ``vmcnt(D*S + 7*(D-1))`` only holds in steady state; the first D rows of
+    a block have fewer stores behind them and need ``vmcnt(7*(D-1) + k*S)`` (k = rows already multiplied), or row c0 + 1 can
+    be read before its LDS-DMA has landed.  The source now writes those waits out; this checks that the gfx950 code of the
+    BACKWARD kernel (D = 2, S = 7) really carries the three counts in front of ring reads, and the forward its single one."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(ROOT, "wcmc_amd", "csrc", "kernel_apply.o")
+    if not (os.path.isfile(objdump) and os.path.isfile(obj)):
+        pytest.skip("needs the ROCm llvm-objdump and the built kernel_apply.o")
+    local = str(tmp_path / "kernel_apply.o")
+    shutil.copy(obj, local)
+    subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=str(tmp_path))
+    bundles = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
+    assert bundles, os.listdir(str(tmp_path))
+    asm = subprocess.run([objdump, "-d", str(tmp_path / bundles[0])], check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    cur = None
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+        elif cur is not None:
+            kernels[cur].append(line)
+    bwd = [v for k, v in kernels.items() if "kernel_apply_strip_kernelILb1ELi2E" in k]
+    fwd = [v for k, v in kernels.items() if "kernel_apply_strip_kernelILb0ELi2E" in k]
+    assert len(bwd) == 1 and len(fwd) == 1, list(kernels)
+
+    def waits_before_ring_reads(lines):
+        """vmcnt counts of the s_waitcnt that directly precede a group of ds_read_b128 (the ring reads are the only
+        b128 reads behind a counted, non-zero wait)."""
+        found = set()
+        for i, ln in enumerate(lines):
+            m = re.search(r"s_waitcnt vmcnt\((\d+)\)", ln)
+            if not m or m.group(1) == "0":
+                continue
+            for nxt in lines[i + 1:i + 24]:       # (the start-up waits are alternatives that branch to one read group)
+                if "ds_read_b128" in nxt:
+                    found.add(int(m.group(1)))
+                    break
+                if "buffer_" in nxt or "s_barrier" in nxt:
+                    break
+        return found
+    assert {7, 14, 21} <= waits_before_ring_reads(bwd[0]), waits_before_ring_reads(bwd[0])
+    assert 7 in waits_before_ring_reads(fwd[0])

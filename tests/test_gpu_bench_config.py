@@ -3,8 +3,8 @@
 ``bench.build_interface`` + ``GraphedTrainStep`` with the library's default switches (split-bf16 GEMMs, forked
 weight-gradient stream, forked specular stream, fused chain glue, fused 1x1 pairs, fused clip + Adam), BASELINE
 configs[2] at its per-GPU shape (8 patches of 128x128, S=8), for two consecutive steps, against
-``oracle.step.train_step`` on the same weights, inputs and FeatureMSE pairings (``rng='cpu'``: the reference's
-``torch.randperm`` stream, ``losses.py:35,50``).  What is compared, per step (``interfaces.py:122-251``):
+``oracle.step.train_step`` on the same weights, inputs and FeatureMSE pairings (``rng='device'``, the bench's switch:
+read back from the product; ``rng='cpu'``: the reference's ``torch.randperm`` stream, ``losses.py:35,50``).  What is compared, per step (``interfaces.py:122-251``):
 
   * every ``loss_dict`` scalar, 1e-3 relative (north star);
   * the denoised patches ``radiance / diffuse / specular`` (8,3,92,92), 1e-3 of the tensor's max (north star);
@@ -45,8 +45,11 @@ def _max_rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("rng_mode", ["cpu"])
+@pytest.mark.parametrize("rng_mode", ["device", "cpu"])
 def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
+    """``rng_mode='device'`` is the switch ``bench.py`` runs with (``config.feature_mse_rng``): the pairings come from the
+    keyed device bijection (``GraphedTrainStep._draw``), are read back from ``fm.static_perms`` after the replay and handed to
+    the oracle; ``'cpu'`` is the reference's ``torch.randperm`` stream (``losses.py:35,50``), drawn identically on both sides."""
     import bench
     from wcmc_amd import ops
     from wcmc_amd.graph import GraphedTrainStep
@@ -85,11 +88,26 @@ def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
     ograds = [{}, {}]
     lr = 1e-4
     p_prev = {mn: dict(d) for mn, d in p_start.items()}
+    fm = itf.loss_funcs["l_manif"]
+    assert fm.rng == rng_mode
     for step in range(2):
-        loss_o, out_o = ostep.train_step(omods, oopt, batches[step], cfg, perms[step])
-        graphed(dbatches[step])
-        torch.cuda.synchronize()
-        assert torch.equal(itf.loss_funcs["l_manif"].static_perms[1][0].cpu(), perms[step][1][0])
+        if rng_mode == "device":
+            # the product draws; the oracle is handed what it drew (every permutation checked to be a bijection)
+            graphed(dbatches[step])
+            torch.cuda.synchronize()
+            perms[step] = [(ip.cpu().clone(), ib.cpu().clone()) for ip, ib in fm.static_perms]
+            for pair in perms[step]:
+                for t in pair:
+                    assert torch.equal(torch.sort(t).values, torch.arange(t.numel())), "device pairing is not a permutation"
+            assert not torch.equal(perms[step][0][0], perms[step][1][0]) and not torch.equal(perms[step][0][1], perms[step][1][1])
+            if step == 1:
+                assert not torch.equal(perms[0][0][0], perms[1][0][0]), "the pairings must change from step to step"
+            loss_o, out_o = ostep.train_step(omods, oopt, batches[step], cfg, perms[step])
+        else:
+            loss_o, out_o = ostep.train_step(omods, oopt, batches[step], cfg, perms[step])
+            graphed(dbatches[step])
+            torch.cuda.synchronize()
+            assert torch.equal(fm.static_perms[1][0].cpu(), perms[step][1][0])
         for k, v in loss_o.items():
             np.testing.assert_allclose(graphed.losses[k].item(), v.item(), rtol=1e-3, err_msg="step %d %s" % (step, k))
         for k in ("radiance", "diffuse", "specular"):
@@ -139,7 +157,7 @@ def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
                     p_prev[mn][k] = p.detach().cpu().clone()
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "bench_config_parity.txt"), "w") as f:
+    with open(os.path.join(out, "bench_config_parity_%s.txt" % rng_mode), "w") as f:
         for name, e, c, mx in sorted(report, key=lambda r: -r[1]):
             f.write("%-60s relL2/err %.3e%s%s\n" % (name, e, "" if c is None else "  1-cos %.2e" % c,
                                                     "" if mx is None else "  max-norm %.2e" % mx))

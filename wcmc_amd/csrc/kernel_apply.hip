@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256, D <= 2 ? 2 : 1) void kernel_apply_strip_kernel
   constexpr int S = BWD ? KA_MAXV : 0;        // global stores per row and wave (static; the forward parks its results in LDS)
   constexpr int NWAIT = D * S + 7 * (D - 1);  // vector-memory instructions younger than the DMA of the row being consumed
   static_assert(NWAIT < 64, "vmcnt is a 6-bit counter");
+  static_assert(D <= 4, "the start-up waits below are written out for up to four ring slots");
   constexpr float LOG2E = 1.4426950408889634f;
   // SEPARATE static arrays on purpose: hipcc (ROCm 7.2) makes every LDS read it cannot prove disjoint from an outstanding
   // LDS-DMA wait for vmcnt(0); reads of another __shared__ variable carry the alias scopes that prove it (one dynamic
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(256, D <= 2 ? 2 : 1) void kernel_apply_strip_kernel
   // inner loop contains no vector-memory instruction that returns into registers (only LDS-DMA and, in the backward,
   // stores), so the compiler's own wait counts stay out of it.
   int slot = 0;
+  int nrow = 0;                                             // rows multiplied since the block started (counted up to D)
   for (int c = c0; c < c1;) {
     const int seg_n = min(p.h - y, c1 - c);                 // rows of this strip the block owns (<= MAXROWS)
     if (c != c0) {                                          // the block enters another strip (at most twice per block)
@@ -480,8 +482,19 @@ __global__ __launch_bounds__(256, D <= 2 ? 2 : 1) void kernel_apply_strip_kernel
     }
    for (int sr_ = 0; sr_ < seg_n; ++sr_, ++c, ++y) {
     const int x0 = strip * KS_TX;
-    // this wave's row c has landed; the D - 1 rows behind it (and the stores of the last D rows) stay in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+    // this wave's row c has landed; the D - 1 rows behind it (and the stores of the last D rows) stay in flight.
+    // NWAIT is the steady state.  The first D rows of a block have fewer stores behind them: row k of the block is
+    // followed by the DMA of the D - 1 rows after it and by the S stores of each of the k rows already multiplied
+    // (after a strip change everything issued before it was drained, so the steady-state count is never too weak there).
+    if (S != 0 && nrow < D) {
+      if (nrow == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * (D - 1)) : "memory");
+      else if (nrow == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * (D - 1) + S) : "memory");
+      else if (nrow == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * (D - 1) + 2 * S) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * (D - 1) + 3 * S) : "memory");
+      ++nrow;
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
+    }
     float4 l4[KA_MAXV];
     {
       // (vector 111 of a pixel -- lane 15, i = 6 -- is the next pixel's first vector or DMA zero-fill: all four of its
