@@ -123,3 +123,57 @@ def train_step(models, optims, batch, cfg, perms=None, clip=1.0):
     for name in models:
         optims["optim_" + name].step()
     return loss_dict, out
+
+
+def sample_train_step(models, optims, batch, cfg, perms=None):
+    """One ``SBMCInterface`` / ``LBMCInterface`` step (``interfaces.py:360-464`` and ``:771-839``) around any base
+    denoiser honouring their batch contract (``radiance`` (B,S,3,H,W), ``features`` (B,S,C,H,W) -> (B,3,H',W')).
+
+    cfg: ``use_llpm_buf``, ``manif_learn``, ``w_manif``, ``disentangle``, ``recon`` (the ``l_recon`` module) and
+    ``clip_norm`` (1000 for SBMC ``:455``, 250 for LBMC ``:826``).  perms = (idx_patch, idx_batch) of the one FeatureMSE call.
+    Returns (loss_dict, out, p_buffer fed to the regression).  Pinned by tests/golden/interface_{sbmc,lbmc}_*.npz (the
+    REAL classes): tests/test_oracle_golden.py::test_oracle_sample_step_against_reference_golden."""
+    option = cfg.get("disentangle", "m11r11")
+    assert option in OPTIONS
+    for m in models.values():
+        m.zero_grad()
+    out_manif, p_buffer = None, None
+    if cfg.get("use_llpm_buf", False):
+        p_buffer = models["backbone"](batch)                     # (B,S,C,H,W)
+        s, c = p_buffer.shape[1], p_buffer.shape[2]
+        assert c >= 2
+        if option == "m11r11":
+            out_manif = p_buffer
+        elif option == "m10r01":
+            out_manif, p_buffer = p_buffer[:, :, c // 2:], p_buffer[:, :, :c // 2]
+        elif option == "m11r01":
+            out_manif, p_buffer = p_buffer, p_buffer[:, :, :c // 2]
+        else:                                                     # m10r11
+            out_manif = p_buffer[:, :, c // 2:]
+        p_var = p_buffer.var(1).mean(1, keepdim=True) / s        # :394-396 (unbiased over spp, mean over channels)
+        p_var = torch.stack([p_var] * s, 1).detach()
+        batch = {"target_image": batch["target_image"], "radiance": batch["radiance"],
+                 "features": torch.cat([batch["features"], p_buffer, p_var], 2)}
+    out = models["dncnn"](batch)
+    tgt = crop_like(batch["target_image"], out)
+    loss_dict = {}
+    total = cfg["recon"](out, tgt)
+    if cfg.get("manif_learn", False):
+        lm = feature_mse(crop_like(out_manif, out), tgt, perms[0], perms[1])
+        loss_dict["l_manif"] = lm.detach()
+        total = total + lm * cfg.get("w_manif", 0.1)
+        # reference quirk (:432-434): l_recon = L_total.detach() aliases the tensor `L_total += L_manif * w` updates in place
+        loss_dict["l_recon"] = total.detach()
+    loss_dict["l_total"] = total.detach()
+    total.backward()
+    with torch.no_grad():
+        loss_dict["rmse"] = RelativeMSE()(out, tgt)
+    for k, v in loss_dict.items():
+        if not torch.isfinite(v).all():
+            raise RuntimeError("%s: Non-finite loss at train time." % k)
+    norms = {}
+    for name, m in models.items():
+        norms[name] = nn.utils.clip_grad_norm_(m.parameters(), max_norm=cfg["clip_norm"])
+    for name in models:
+        optims["optim_" + name].step()
+    return loss_dict, out, p_buffer, norms

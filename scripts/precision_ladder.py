@@ -78,7 +78,7 @@ def q_split(t, dims, fmt):
     return torch.stack([hi, lo], 3).contiguous().view(torch.int16).view(-1)
 
 
-_wgrad, _igemm, _packx, _bwd = ops.conv2d_wgrad_x_raw, ops.conv2d_x_raw, ops._pack_x, ops._chainx_backward
+_wgrad, _igemm, _packx, _bwd, _pair = ops.conv2d_wgrad_x_raw, ops.conv2d_x_raw, ops._pack_x, ops._chainx_backward, ops.conv1x1_pair_x_raw
 
 
 def active():
@@ -100,6 +100,12 @@ def igemm(xs, dims, *a, **kw):
     return _igemm(xs, dims, *a, **kw)
 
 
+def pair(xs, dims, *a, **kw):          # the fused data gradient of PathNet.final's two layers (only its first GEMM's dy is rounded)
+    if active():
+        xs = q_split(xs, dims, FMT["dgrad_dy"])
+    return _pair(xs, dims, *a, **kw)
+
+
 def packx(weight, mode):
     if active() and mode == 1:
         weight = q_values(weight.detach(), FMT["dgrad_w"])
@@ -116,7 +122,7 @@ def bwd(ctx, *a, **kw):
         ctx.wp1 = wp1
 
 
-ops.conv2d_wgrad_x_raw, ops.conv2d_x_raw, ops._pack_x, ops._chainx_backward = wgrad, igemm, packx, bwd
+ops.conv2d_wgrad_x_raw, ops.conv2d_x_raw, ops._pack_x, ops._chainx_backward, ops.conv1x1_pair_x_raw = wgrad, igemm, packx, bwd, pair
 
 # ------------------------------------------------------------------ the step, three ways
 torch.manual_seed(0)
@@ -180,6 +186,8 @@ RUNGS = [
     ("C  dy full, x/W bf16 hi-only", dict(wgrad_dy="full", wgrad_x="bf16", dgrad_dy="full", dgrad_w="bf16"), (2, 2)),
     ("C' wgrad only: x bf16 hi-only", dict(wgrad_dy="full", wgrad_x="bf16", dgrad_dy="full", dgrad_w="full"), (2, 3)),
     ("D  all single bf16", dict(wgrad_dy="bf16", wgrad_x="bf16", dgrad_dy="bf16", dgrad_w="bf16"), (1, 1)),
+    ("H  wgrad single bf16 (dy hi x x hi), dgrad bf16x3", dict(wgrad_dy="bf16", wgrad_x="bf16", dgrad_dy="full", dgrad_w="full"), (1, 3)),
+    ("I  wgrad single bf16, dgrad dy bf16 hi x W full", dict(wgrad_dy="bf16", wgrad_x="bf16", dgrad_dy="bf16", dgrad_w="full"), (1, 2)),
     ("F  dy fp16 (scaled), x/W full [=fp16 two-term]", dict(wgrad_dy="fp16", wgrad_x="full", dgrad_dy="fp16", dgrad_w="full"), (2, 2)),
     ("G  dy full, x/W fp16 [=fp16 two-term]", dict(wgrad_dy="full", wgrad_x="fp16", dgrad_dy="full", dgrad_w="fp16"), (2, 2)),
     ("E  all single fp16 (dy scaled per tensor)", dict(wgrad_dy="fp16", wgrad_x="fp16", dgrad_dy="fp16", dgrad_w="fp16"), (1, 1)),
@@ -202,7 +210,7 @@ for name, fmt, cost in RUNGS:
           (name, cost[0], cost[1], max(v[0] for v in r.values()), st.median(v[0] for v in r.values()),
            max(v[1] for v in r.values()), st.median(v[1] for v in r.values()), max(v[2] for v in r.values()),
            worst[0], worst[1]), flush=True)
-    if name.startswith(("A", "E ")):
+    if name.startswith(("A", "E ", "I ")):
         kp = sorted((k for k in names if k[0] == "dncnn" and k[1].endswith("weight")), key=lambda k: k[1])
         print("     KPCN weight gradients vs fp64, layer 0..8: diffuse " +
               " ".join("%.1e" % r[k][0] for k in kp if "diffuse" in k[1]) + " | specular " +

@@ -152,3 +152,39 @@ def test_patch_loader_item_golden(golden_dir):
             assert keys == set(item)
             for k in keys:
                 np.testing.assert_array_equal(item[k], d["%s/%d/%s" % (tag, i, k)], err_msg="%s %d %s" % (tag, i, k))
+
+
+@pytest.mark.parametrize("case", list(mg.SAMPLE_CASES))
+def test_oracle_sample_step_against_reference_golden(golden_dir, case):
+    """``oracle.step.sample_train_step`` -- the restatement of ``SBMCInterface`` / ``LBMCInterface.train_batch``
+    (``interfaces.py:360-464,771-839``) that the full-size configs[3] / configs[4] GPU test compares with -- against the
+    fixtures of the REAL classes: logged losses, gradients after the norm clamp, gradient norms, parameters after Adam."""
+    from oracle.models import SampleDenoiserStandIn
+    from oracle.networks import PathNet
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    kind, use_llpm, manif, option, pout, recon, nfeat = mg.SAMPLE_CASES[case]
+    G = mg.G7_GEOM
+    c_r = ((pout // 2 if option in ("m10r01", "m11r01") else pout) + 1) if use_llpm else 0
+    models = {"dncnn": SampleDenoiserStandIn(nfeat + c_r, width=G["WIDTH"], depth=G["DEPTH"])}
+    if use_llpm:
+        models["backbone"] = PathNet(36, intermc=G["INTERMC"], outc=pout)
+    for mn, m in models.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3) for mn, m in models.items()}
+    cfg = dict(use_llpm_buf=use_llpm, manif_learn=manif, w_manif=0.1, disentangle=option,
+               recon=torch.nn.L1Loss() if recon == "L1Loss" else getattr(ol, recon)(),
+               clip_norm=1000 if kind == "SBMCInterface" else 250)
+    batch = {k[len("batch/"):]: T(d[k]) for k in d.files if k.startswith("batch/")}
+    perms = (T(d["perm/patch"]), T(d["perm/batch"])) if manif else None
+    loss, out, pb, norms = ostep.sample_train_step(models, optims, batch, cfg, perms)
+    for k in d.files:
+        if k.startswith("m_losses/") and k != "m_losses/m_val":
+            np.testing.assert_allclose(loss[k[len("m_losses/m_"):]].item(), d[k], rtol=1e-5, err_msg=k)
+    for mn, m in models.items():
+        post = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))     # (the fixture holds the norm AFTER the clamp)
+        np.testing.assert_allclose(post, d["gradnorm/" + mn], rtol=1e-4)
+        assert float(norms[mn]) >= post * (1 - 1e-6)
+        for k, p in m.named_parameters():
+            np.testing.assert_allclose(p.grad.numpy(), d["grad/%s/%s" % (mn, k)], rtol=1e-4, atol=1e-7, err_msg="%s %s" % (mn, k))
+        for k, v in m.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), d["after/%s/%s" % (mn, k)], rtol=1e-4, atol=1e-6, err_msg="after %s %s" % (mn, k))
