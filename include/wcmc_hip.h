@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WCMC_ABI_VERSION 1
+#define WCMC_ABI_VERSION 2     /* 2: `terms` of the GEMM entry points, packing mode 2 (round 3) */
 
 enum wcmc_status {
   WCMC_OK = 0,
@@ -153,11 +153,14 @@ int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t dsh, int64_t
                               const float* post, int64_t psn, int64_t psh, int64_t psw, int act, float slope,
                               const float* gm, int64_t msn, int64_t msh, int64_t msw, int S, float scale,
                               void* out_split, float* colsum_partial, int N, int H, int W, int C, void* stream);
-size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks);
+/* mode: 0 = forward orientation (rows = Cout, k over Cin x taps); 1 = data-gradient orientation (rows = Cin, k over
+ * Cout x flipped taps) for a three-term launch; 2 = the same orientation in the K order of a TWO-term launch
+ * (wcmc_conv2d_igemm_bf16x3 with terms = 2: the channel slabs are twice as wide, see there). */
+size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks, int mode);
 int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
                                    void* stream);
 /* The same for up to 20 (layer, mode) pairs of one chain in ONE launch: w[i] OIHW (Cout[i], Cin[i], ks, ks) ->
- * wp[i] (wcmc_conv2d_packed_elems_bf16x3(rows, kchan, ks) u16 each), mode[i] as above; host arrays of n_entries items. */
+ * wp[i] (wcmc_conv2d_packed_elems_bf16x3(rows, kchan, ks, mode) u16 each), mode[i] as above; host arrays of n_entries items. */
 int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* w, void* const* wp, const int* Cout,
                                   const int* Cin, const int* mode, int ks, void* stream);
 /* Exactly one of y (fp32 NHWC view) and y_split (dense split tensor) receives the result.
@@ -165,13 +168,18 @@ int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* w, void* co
  * mask evaluated from the hi plane of the post-activation tensor.
  * mask_out (optional, with y_split): uint8 [N*Ho*Wo][round_up(Cout,8)/8], bit c%8 of byte c/8 = (hi plane of
  * output channel c > 0) -- the same predicate at 1/16 of the bytes; gate_mask (optional, instead of gate_split):
- * such a mask of a tensor with the output's geometry. */
+ * such a mask of a tensor with the output's geometry.
+ * terms: bf16 MFMAs per product -- 3 = W_lo*x_hi + W_hi*x_lo + W_hi*x_hi (the forward); 2 = W_lo*x_hi + W_hi*x_hi, i.e.
+ * x rounded to its hi plane (8 mantissa bits), W exact to 16 -- the data gradient of the default mode, whose x operand is
+ * dy (wp then packed with mode 2).  Where no two-term kernel instance exists for the shape the launch runs three terms
+ * (the packing of mode 2 follows the same rule, so the pair stays consistent).  Replaces the data gradient of
+ * `nn.Conv2d` under cuDNN (train_kpcn.py:349; TF32 by default on the reference's hardware: 10 bits on BOTH operands). */
 int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              const void* wp, const float* bias,
                              float* y, int64_t ysn, int64_t ysh, int64_t ysw, void* y_split, int Cout,
                              int ks, int pad, int act, float slope,
                              const void* gate_split, int gate_act, float gate_slope,
-                             float* colsum_partial, const void* gate_mask, void* mask_out, void* stream);
+                             float* colsum_partial, const void* gate_mask, void* mask_out, int terms, void* stream);
 /* colsum_partial (optional, with y_split): [wcmc_conv2d_igemm_colsum_elems] floats that receive the
  * per-pixel-tile column sums of the result -- the bias gradient of the layer that consumes this
  * data gradient, finished by wcmc_colsum_finish (saves a pass over dy per layer).  The buffer ends with a trailer
@@ -197,11 +205,14 @@ size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout,
  * dy_colsum_partial (optional): the per-tile column sums of dy that the launch which PRODUCED dy left
  * (wcmc_conv2d_igemm_bf16x3 / wcmc_conv1x1_pair_bf16x3 colsum output, wcmc_conv2d_igemm_colsum_elems floats): the bias
  * gradient db is then finished from them by extra blocks of the slab-reduction launch -- same sums, same order as
- * wcmc_colsum_finish, bit for bit -- instead of a column-sum pass over dy plus a finish launch. */
+ * wcmc_colsum_finish, bit for bit -- instead of a column-sum pass over dy plus a finish launch.
+ * terms: bf16 MFMAs per product -- 3 = dy_lo*x_hi + dy_hi*x_lo + dy_hi*x_hi; 1 = dy_hi*x_hi only (the lo planes are not
+ * read: half the operand bytes).  The reference's counterpart is cuDNN's weight gradient under
+ * `torch.backends.cudnn.allow_tf32` (train_kpcn.py:349 leaves the default, TF32 = 10 mantissa bits per operand). */
 int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              const void* dy_split, int Cout, int ks, int pad, float* dw, float* db,
                              void* workspace, size_t workspace_bytes, int phase, const float* dy_colsum_partial,
-                             void* stream);
+                             int terms, void* stream);
 
 /* dx = dy * act'(y) from the post-activation value y (NHWC views of equal geometry). */
 int wcmc_act_backward(const float* dy, int64_t dsn, int64_t dsh, int64_t dsw,

@@ -5,6 +5,7 @@ builds, and the time of the slab reduction (phase 2 of the call):
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+TERMS = int(os.environ.get("WCMC_WGRAD_TERMS", "1"))      # bf16 MFMAs per product of the weight gradient: 1 (hi planes only) or 3
 if sys.argv[1] == "--compare":
     a, b = torch.load(sys.argv[2]), torch.load(sys.argv[3])
     for k in a:
@@ -26,7 +27,7 @@ for n, cin, cout, ks, pad, h in LAYERS:
     ws = torch.empty((nbytes + 3) // 4, device=dev)
     dw = torch.empty(cout, cin, ks, ks, device=dev); db = torch.empty(cout, device=dev)
     call = lambda ph: check(lib().wcmc_conv2d_wgrad_bf16x3(_ptr(xs), n, h, h, cin, _ptr(dys), cout, ks, pad, _ptr(dw), _ptr(db), _ptr(ws),
-                                                            ws.numel() * 4, ph, None, _stream()), "wgrad")
+                                                            ws.numel() * 4, ph, None, TERMS, _stream()), "wgrad")
     call(0)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()

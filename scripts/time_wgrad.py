@@ -3,6 +3,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+TERMS = int(os.environ.get("WCMC_WGRAD_TERMS", "1"))      # bf16 MFMAs per product of the weight gradient: 1 (hi planes only) or 3
 from wcmc_amd import ops as o
 from wcmc_amd.ops import _ptr, _stream, lib, check
 dev = "cuda"
@@ -20,8 +21,8 @@ def case(n, cin, h, cout, ks):
     nbytes = lib().wcmc_conv2d_wgrad_bf16x3_workspace_bytes(n, ho, ho, cout, cin, ks)
     ws = torch.empty((nbytes + 3) // 4, device=dev); dw = torch.empty(cout, cin, ks, ks, device=dev); db = torch.empty(cout, device=dev)
     args = (_ptr(xs), n, h, h, cin, _ptr(dys), cout, ks, 0, _ptr(dw), _ptr(db), _ptr(ws), ws.numel() * 4)
-    t1 = timeit(lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, None, _stream()), "wgrad"))
-    t2 = timeit(lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 2, None, _stream()), "wgrad"))
+    t1 = timeit(lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, None, TERMS, _stream()), "wgrad"))
+    t2 = timeit(lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 2, None, TERMS, _stream()), "wgrad"))
     fl = 2.0 * n * ho * ho * cout * cin * ks * ks
     print("%3d->%3d out %3d: gemm %7.1f us (%6.1f TF/s)  finish %6.1f us  workspace %.1f MB" % (cin, cout, ho, t1, fl / t1 / 1e6, t2, nbytes / 1e6))
 for h in (128, 124, 120, 116, 112, 108, 104):

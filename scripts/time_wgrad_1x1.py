@@ -3,6 +3,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+TERMS = int(os.environ.get("WCMC_WGRAD_TERMS", "1"))      # bf16 MFMAs per product of the weight gradient: 1 (hi planes only) or 3
 from wcmc_amd import ops as o
 from wcmc_amd.ops import _ptr, _stream, lib, check
 dev = "cuda"
@@ -23,9 +24,9 @@ def case(n, cin, h, cout):
         nbytes = lib().wcmc_conv2d_wgrad_bf16x3_workspace_bytes(n, h, h, cout, cin, 1)
         ws = torch.empty((nbytes + 3) // 4, device=dev); dw = torch.empty(cout, cin, 1, 1, device=dev); db = torch.empty(cout, device=dev)
         args = (_ptr(xs), n, h, h, cin, _ptr(dys), cout, 1, 0, _ptr(dw), _ptr(db), _ptr(ws), ws.numel() * 4)
-        t1 = timeit(lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, None, _stream()), "wgrad"))
-        t2 = timeit(lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 2, None, _stream()), "wgrad"))
-        check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 0, None, _stream()), "wgrad")
+        t1 = timeit(lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, None, TERMS, _stream()), "wgrad"))
+        t2 = timeit(lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 2, None, TERMS, _stream()), "wgrad"))
+        check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 0, None, TERMS, _stream()), "wgrad")
         res[mode] = dw.clone()
         out.append((t1, t2, nbytes))
     gb = 4.0 * n * h * h * ((cin + 7) // 8 * 8 + (cout + 7) // 8 * 8) / 1e9

@@ -5,6 +5,7 @@ WCMC_WGRAD_ROWS8=0: the seven-wave one) also has 32 no fragment reads, 34 = 32 +
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+TERMS = int(os.environ.get("WCMC_WGRAD_TERMS", "1"))      # bf16 MFMAs per product of the weight gradient: 1 (hi planes only) or 3
 from wcmc_amd import ops as o
 from wcmc_amd.ops import _ptr, _stream, lib, check
 dev = "cuda"
@@ -17,7 +18,7 @@ dys = o.split_raw(o.to_nhwc_raw(torch.randn(n, cout, ho, ho, device=dev)))
 nbytes = lib().wcmc_conv2d_wgrad_bf16x3_workspace_bytes(n, ho, ho, cout, cin, ks)
 ws = torch.empty((nbytes + 3) // 4, device=dev); dw = torch.empty(cout, cin, ks, ks, device=dev); db = torch.empty(cout, device=dev)
 args = (_ptr(xs), n, h, h, cin, _ptr(dys), cout, ks, 0, _ptr(dw), _ptr(db), _ptr(ws), ws.numel() * 4)
-fn = lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, None, _stream()), "wgrad")
+fn = lambda: check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, None, TERMS, _stream()), "wgrad")
 def once(mode, reps=10):
     os.environ["WCMC_DEBUG_ABLATE"] = str(mode)
     fn()

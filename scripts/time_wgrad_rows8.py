@@ -4,6 +4,7 @@ of the results:  [PRIOS=0,8,9,10] [XES=0,1] python3 scripts/time_wgrad_rows8.py 
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+TERMS = int(os.environ.get("WCMC_WGRAD_TERMS", "1"))      # bf16 MFMAs per product of the weight gradient: 1 (hi planes only) or 3
 from wcmc_amd import ops as o
 from wcmc_amd.ops import _ptr, _stream, lib, check
 dev = "cuda"
@@ -26,7 +27,7 @@ for h in hs:
         if cfg[2] is not None: os.environ["WCMC_WGRAD_ROWS8_XE"] = cfg[2]
         dw = torch.empty(cout, cin, ks, ks, device=dev); db = torch.empty(cout, device=dev)
         check(lib().wcmc_conv2d_wgrad_bf16x3(_ptr(xs), n, h, h, cin, _ptr(dys), cout, ks, 0, _ptr(dw), _ptr(db), _ptr(ws),
-                                              ws.numel() * 4, phase, None, _stream()), "wgrad")
+                                              ws.numel() * 4, phase, None, TERMS, _stream()), "wgrad")
         return dw, db
     def once(sw, reps=10):
         run(sw)

@@ -3,6 +3,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+TERMS = int(os.environ.get("WCMC_WGRAD_TERMS", "1"))      # bf16 MFMAs per product of the weight gradient: 1 (hi planes only) or 3
 from wcmc_amd import ops as o
 from wcmc_amd.ops import _ptr, _stream, lib, check
 assert os.environ.get("WCMC_DEBUG_ABLATE") == "16"
@@ -17,7 +18,7 @@ for h in [int(a) for a in sys.argv[1:]] or [124, 108]:
     ws = torch.zeros((nbytes + 3) // 4, device=dev); dw = torch.empty(cout, cin, ks, ks, device=dev); db = torch.empty(cout, device=dev)
     args = (_ptr(xs), n, h, h, cin, _ptr(dys), cout, ks, 0, _ptr(dw), _ptr(db), _ptr(ws), ws.numel() * 4)
     for _ in range(3):
-        check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, None, _stream()), "wgrad")
+        check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, None, TERMS, _stream()), "wgrad")
     torch.cuda.synchronize()
     # slabs: S x 25 x 112 x 112 floats; the stamps sit behind them
     S = (nbytes // 4 - 0) // (25 * 112 * 112)

@@ -24,9 +24,10 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(params=["fp32", "bf16x3"])
+@pytest.fixture(params=["fp32", "bf16x3", "bf16x321"])
 def precision(request):
-    """Runs a GPU test once per conv arithmetic: exact fp32 MFMA and split-bf16 (3 bf16 MFMAs / product)."""
+    """Runs a GPU test once per conv arithmetic: exact fp32 MFMA, split-bf16 with 3 bf16 MFMAs per product everywhere, and the
+    default mode (forward 3, data gradient 2, weight gradient 1: wcmc_amd/ops.py)."""
     from wcmc_amd import ops
     old = ops.PRECISION
     ops.set_precision(request.param)
@@ -36,6 +37,16 @@ def precision(request):
 
 def ptol(precision, fp32_tol, x3_tol):
     return fp32_tol if precision == "fp32" else x3_tol
+
+
+def gtol(precision, fp32_tol, x3_tol, x321_tol=8e-3):
+    """Max-norm bar of a GRADIENT of one conv op on random operands.  In the "bf16x321" mode the backward GEMMs round dy (and,
+    in the weight gradient, x) to bf16: 2^-9 per rounded operand, uncorrelated from pixel to pixel -- on the i.i.d. test
+    operands that shows in full (the sums are random walks too), hence 8e-3 of the tensor's max; in the networks it averages
+    out (profiles/r03_precision_ladder.txt: 1.09e-3 -> 1.22e-3 on the benchmarked step).  That each reduced-term kernel
+    computes EXACTLY the gradient of the rounded operands is pinned separately (tests/test_gpu_ops.py::test_one_term_...,
+    test_two_term_...)."""
+    return x321_tol if precision == "bf16x321" else ptol(precision, fp32_tol, x3_tol)
 
 
 def rel_l2(a, b):

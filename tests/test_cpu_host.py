@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     h = lib()
     for name in declared:
         assert getattr(h, name) is not None
-    assert h.wcmc_abi_version() == 1
+    assert h.wcmc_abi_version() == 2
     # pure host-side size queries work without a GPU
     assert h.wcmc_conv2d_packed_elems(100, 100, 5) == 112 * 2528
     assert h.wcmc_conv2d_packed_elems(441, 100, 5) == 448 * 2528
@@ -70,7 +70,8 @@ def test_abi_rejects_bad_arguments_without_touching_the_gpu():
         "wcmc_cat_broadcast_split": (one, 64, 16, 4, one, 64, 16, 4, one, 1, 2, 4, 4, 12, 8, null),   # C1 % 8 != 0
         "wcmc_add_broadcast_split": (null, 0, 0, 0, null, 0, 0, 0, 1.0, one, 1, 2, 4, 4, 8, null),   # both gradients null
         "wcmc_conv2d_igemm_bf16x3": (one, 1, 8, 8, 8, one, null, null, 0, 0, 0, null, 8, 3, 1, 0, 0.0,
-                                     null, 0, 0.0, null, null, null, null),               # neither y nor y_split
+                                     null, 0, 0.0, null, null, null, 3, null),            # neither y nor y_split
+        "wcmc_conv2d_wgrad_bf16x3": (one, 1, 8, 8, 8, one, 8, 3, 1, one, null, one, 1 << 20, 0, null, 2, null),   # terms must be 3 or 1
         "wcmc_clip_adam": (null, one, one, one, 4, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, null, null),
         # no fused instance for 100 -> 128 -> 3 channels
         "wcmc_conv1x1_pair_bf16x3": (one, 1, 8, 8, 100, one, null, 128, 1, 0.0, one, null, null, 0, 0.0, null, one, null, 3,

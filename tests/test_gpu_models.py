@@ -156,6 +156,10 @@ def golden_l2(precision, flips=None):
         return 1e-4
     if flips is None:          # (tests that do not run the oracle forward beside the step: <= 1.7e-2 measured)
         return 1e-1
+    if precision == "bf16x321" and flips == 0:
+        # the backward GEMMs round dy (and x in the weight gradient) to bf16, 2^-9 each: with 800 pixels per golden batch
+        # there is little to average over (the benchmarked step has 107k per layer: profiles/r03_precision_ladder.txt)
+        return 8e-3
     return 2e-4 if flips == 0 else 8e-2 * flips
 
 
@@ -400,7 +404,7 @@ def test_full_size_step_against_oracle(precision):
     for k, v in loss_o.items():
         np.testing.assert_allclose(itf.m_losses["m_" + k].item(), v.item(), rtol=1e-3, err_msg=k)
     for k in ("radiance", "diffuse", "specular"):        # the denoised patches (north star: 1e-3)
-        assert_close(itf.last_out[k], out_o[k], tol=1e-3 if precision == "bf16x3" else 1e-4, what="denoised " + k)
+        assert_close(itf.last_out[k], out_o[k], tol=1e-4 if precision == "fp32" else 1e-3, what="denoised " + k)
     for mn in omods:
         for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
             # one patch: 1/8 of the benchmark's units, so sqrt(8) x its relative L2 (tests/test_gpu_bench_config.py holds

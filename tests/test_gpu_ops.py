@@ -43,7 +43,7 @@ def gen(*shape, seed=0, scale=1.0):
 
 def test_library_loaded_is_in_tree():
     from wcmc_amd._lib import LIB_PATH, lib
-    assert lib().wcmc_abi_version() == 1
+    assert lib().wcmc_abi_version() == 2
     assert os.path.isfile(LIB_PATH)
     with open("/proc/self/maps") as f:
         assert "libwcmc_hip.so" in f.read()
@@ -99,8 +99,9 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_chain_single_layer_fwd_bwd(case, precision):
-    from conftest import ptol
+    from conftest import gtol, ptol
     tol = ptol(precision, 2e-5, 1e-4)        # split-bf16 operands: ~2^-17 per operand
+    gt = gtol(precision, 2e-5, 1e-4)         # gradients: the default mode rounds dy (and x in the weight gradient) to bf16
     n, cin, h, w, cout, ks, pad, act = case
     o = ops()
     x = gen(n, cin, h, w, seed=2)
@@ -119,14 +120,15 @@ def test_conv_chain_single_layer_fwd_bwd(case, precision):
     assert o.is_nhwc_view(y)
     y.backward(gy.to(DEV))
     assert_close(y, yr, tol=tol, what="conv fwd")
-    assert_close(xd.grad, xr.grad, tol=tol, what="conv dgrad")
-    assert_close(wd.grad, wr.grad, tol=tol, what="conv wgrad")
+    assert_close(xd.grad, xr.grad, tol=gt, what="conv dgrad")
+    assert_close(wd.grad, wr.grad, tol=gt, what="conv wgrad")
     assert_close(bd.grad, br.grad, tol=tol, what="conv bias grad")
 
 
 def test_conv_chain_deep_matches_oracle_chain(precision):
-    from conftest import ptol
+    from conftest import gtol, ptol
     tol = ptol(precision, 2e-5, 2e-4)
+    gt = gtol(precision, 2e-5, 2e-4)
     torch.manual_seed(11)
     ref = om.ConvChain(13, 25, ksize=5, width=20, depth=4, pad=False, output_type="linear").double()
     from wcmc_amd.modules import ConvChain
@@ -148,9 +150,9 @@ def test_conv_chain_deep_matches_oracle_chain(precision):
     yr.backward(g.double())
     y.backward(g.to(DEV))
     assert_close(y, yr, tol=tol, what="chain fwd")
-    fc.check(xd.grad, xr.grad, tol, what="chain dx", l2=2e-2)                # 20-channel test chain: ~10k units / layer
+    fc.check(xd.grad, xr.grad, gt, what="chain dx", l2=2e-2)                 # 20-channel test chain: ~10k units / layer
     for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
-        fc.check(p.grad, q.grad, tol, what="chain grad " + k, l2=2e-2)
+        fc.check(p.grad, q.grad, gt, what="chain grad " + k, l2=2e-2)
 
 
 def test_conv_wgrad_is_bitwise_reproducible():
@@ -185,13 +187,17 @@ def test_eight_wave_filter_row_kernel_equals_seven_wave(geom, monkeypatch):
     xs = o.split_raw(o.to_nhwc_raw(gen(n, cin, h, w, seed=90).to(DEV)))
     dys = o.split_raw(o.to_nhwc_raw(gen(n, cout, ho, wo, seed=91).to(DEV)))
     monkeypatch.setenv("WCMC_WGRAD_ROWS8", "0")
-    want = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5))
+    want = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5), terms=3)
+    want1 = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5), terms=1)    # the one-plane instances alike
     for prio, xe in (("0", "1"), ("1", "1"), ("7", "0"), ("9", "1"), ("13", "0"), ("8", "1"), ("8", "0")):
         monkeypatch.setenv("WCMC_WGRAD_ROWS8", "1")
         monkeypatch.setenv("WCMC_WGRAD_ROWS8_PRIO", prio)
         monkeypatch.setenv("WCMC_WGRAD_ROWS8_XE", xe)           # both dealings of the 21 left-over tiles
-        got = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5))
+        got = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5), terms=3)
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (prio, xe)
+        if xe == "1":
+            got = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, 5, pad, (cout, cin, 5, 5), terms=1)
+            assert torch.equal(got[0], want1[0]) and torch.equal(got[1], want1[1]), (prio, "one plane")
     assert want[0].abs().max().item() > 0
     if len(geom) > 4:                                   # the new block shapes against fp64 as well
         ref = torch.nn.grad.conv2d_weight(gen(n, cin, h, w, seed=90).double(), (cout, cin, 5, 5), gen(n, cout, ho, wo, seed=91).double(),
@@ -301,13 +307,102 @@ def test_weight_gradient_with_many_slabs_against_fp64(case, monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        dw, db = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, ks, pad, (cout, cin, ks, ks))
-        dw2, db2 = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, ks, pad, (cout, cin, ks, ks))
+        dw, db = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, ks, pad, (cout, cin, ks, ks), terms=3)
+        dw2, db2 = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, ks, pad, (cout, cin, ks, ks), terms=3)
         assert torch.equal(dw, dw2) and torch.equal(db, db2), name
         assert_close(dw, want, tol=2e-5, what=name + ": dw")
         assert_close(db, dy.double().sum(dim=(0, 2, 3)), tol=2e-5, what=name + ": db")
         got[name] = dw
     assert rel_err(got["shipped plan"], got["one-tap kernel"]) < 1e-5
+
+
+def _bf16_round(t):
+    return t.bfloat16().float()
+
+
+WGRAD_TERM_CASES = [
+    # N, Cin, H, W, Cout, ks, pad -- one per weight-gradient kernel instance the plan can pick
+    (8, 100, 44, 44, 100, 5, 0),     # conv_wgrad_rows8 (eight waves), one chunk per row
+    (2, 100, 30, 101, 100, 5, 2),    # conv_wgrad_rows8, two chunks per row (Wo = 101), padding
+    (2, 100, 40, 40, 441, 5, 0),     # conv_wgrad_rows8, four cout blocks
+    (2, 39, 40, 37, 100, 5, 0),      # conv_wgrad_rows<5,7,3>
+    (1, 256, 70, 35, 128, 3, 1),     # conv_wgrad_rows<3,8,8>, two cin blocks
+    (2, 64, 40, 37, 64, 3, 1),       # conv_wgrad_rows<3,4,4> / one-tap kernel (TM = 4)
+    (12, 128, 48, 40, 128, 1, 0),    # conv_wgrad_rows<1,8,8>
+    (16, 36, 64, 64, 64, 1, 0),      # one-tap kernel, TM = 4, many slabs
+    (2, 34, 11, 13, 100, 5, 0),      # one-tap kernel, TM = 7 (22 vectors per pixel over 4 threads: ragged)
+    (3, 128, 9, 10, 3, 1, 0),        # one-tap kernel, 3 couts
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_TERM_CASES)
+def test_one_term_weight_gradient_is_the_three_term_one_on_bf16_operands(case, monkeypatch):
+    """terms = 1 of wcmc_conv2d_wgrad_bf16x3 multiplies the hi planes only.  On operands that ARE bf16 numbers the lo planes
+    are zero, the two dropped MFMAs add exact zeros, and every remaining MFMA and slab addition is the same: the result must
+    equal the three-term kernel's BIT FOR BIT -- for every kernel instance (eight-wave / generic filter-row / one-tap), and
+    both must sit on the fp64 value.  On general operands the one-term result is the exact gradient of the rounded operands:
+    checked against fp64 on the rounded values at the same tolerance."""
+    o = ops()
+    n, cin, h, w, cout, ks, pad = case
+    ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+    x, dy = gen(n, cin, h, w, seed=190), gen(n, cout, ho, wo, seed=191)
+    xb, dyb = _bf16_round(x), _bf16_round(dy)
+    xs, dys = o.split_raw(o.to_nhwc_raw(xb.to(DEV))), o.split_raw(o.to_nhwc_raw(dyb.to(DEV)))
+    want = torch.nn.grad.conv2d_weight(xb.double(), (cout, cin, ks, ks), dyb.double(), padding=pad)
+    for env in ({}, {"WCMC_WGRAD_ROWS": "0"}):
+        monkeypatch.delenv("WCMC_WGRAD_ROWS", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dw3, db3 = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, ks, pad, (cout, cin, ks, ks), terms=3)
+        dw1, db1 = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, ks, pad, (cout, cin, ks, ks), terms=1)
+        assert torch.equal(dw1, dw3) and torch.equal(db1, db3), env
+        assert_close(dw1, want, tol=2e-5, what="dw on bf16 operands")
+    # general operands: one term == the gradient of the ROUNDED operands; the bias gradient still sums hi + lo of dy
+    xs, dys = o.split_raw(o.to_nhwc_raw(x.to(DEV))), o.split_raw(o.to_nhwc_raw(dy.to(DEV)))
+    dw1, db1 = o.conv2d_wgrad_x_raw(xs, (n, cin, h, w), dys, cout, ks, pad, (cout, cin, ks, ks), terms=1)
+    assert_close(dw1, want, tol=2e-5, what="dw of general operands = dw of their hi planes")
+    assert_close(db1, dy.double().sum(dim=(0, 2, 3)), tol=2e-5, what="db")
+    full = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, ks, ks), dy.double(), padding=pad)
+    assert rel_err(dw1, full) < 1.5e-2          # (2^-9 per operand, uncorrelated from pixel to pixel)
+
+
+@pytest.mark.parametrize("case", [(8, 100, 44, 44, 100, 0), (2, 100, 36, 36, 100, 4), (1, 441, 40, 37, 100, 4), (2, 232, 24, 24, 100, 4),
+                                  (2, 100, 30, 29, 39, 4), (2, 120, 24, 24, 100, 4)])
+def test_two_term_data_gradient_against_fp64(case):
+    """terms = 2 of wcmc_conv2d_igemm_bf16x3: x (= dy in the data gradient) rounded to its hi plane, W exact to 16 bits,
+    weights packed with mode 2 (32-channel slabs in the hi-plane-only halo).  Against fp64 on the rounded x at the kernel's
+    usual tolerance, gated and ungated, split and fp32 outputs; and against the three-term launch on bf16 operands.  The last
+    two cases have no two-term instance (39 couts: NT = 4; 120 channels: a 24-channel last slab): packing and launch must fall
+    back to the three-term plan TOGETHER (the result is then the exact data gradient)."""
+    o = ops()
+    n, cin, h, w, cout, pad = case
+    ks = 5
+    ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+    x = gen(n, cin, h, w, seed=290)
+    wt = gen(cin, cout, ks, ks, seed=291, scale=(2.0 / (cin * 25)) ** 0.5 * 1.7)      # layer weight (Cout_l = cin, Cin_l = cout)
+    xb = _bf16_round(x)
+    xs, xbs = o.split_raw(o.to_nhwc_raw(x.to(DEV))), o.split_raw(o.to_nhwc_raw(xb.to(DEV)))
+    wd = wt.to(DEV)
+    wp3, wp2 = o._pack_x(wd, 1), o._pack_x(wd, 2)
+    fallback = wp3.numel() == wp2.numel() and torch.equal(wp3, wp2)
+    assert fallback == (case in ((2, 100, 30, 29, 39, 4), (2, 120, 24, 24, 100, 4)))
+    # the data-gradient GEMM: conv of x with the flipped, channel-swapped filter
+    wf = wt.flip(2, 3).transpose(0, 1).contiguous()
+    want = F.conv2d((x if fallback else xb).double(), wf.double(), padding=pad)
+    y2 = o.conv2d_x_raw(xs, (n, cin, h, w), wp2, None, cout, ks, pad, "linear", out_split=False, terms=2)
+    assert_close(y2, want, tol=2e-5, what="two-term dgrad (general x = its hi plane)")
+    y2b = o.conv2d_x_raw(xbs, (n, cin, h, w), wp2, None, cout, ks, pad, "linear", out_split=False, terms=2)
+    assert torch.equal(y2, y2b) != fallback           # the lo plane of x is never read
+    y3b = o.conv2d_x_raw(xbs, (n, cin, h, w), wp3, None, cout, ks, pad, "linear", out_split=False, terms=3)
+    assert rel_err(y2b, y3b) < 2e-6                   # same products, another K order
+    gate = o.split_raw(o.to_nhwc_raw(gen(n, cout, ho, wo, seed=292).to(DEV)))
+    ys, part = o.conv2d_x_raw(xs, (n, cin, h, w), wp2, None, cout, ks, pad, "linear", out_split=True, gate=gate, gate_act="relu",
+                              colsum=True, terms=2)
+    g = (o.unsplit_debug(gate, n, cout, ho, wo) > 0).double().cpu()
+    assert_close(o.unsplit_debug(ys, n, cout, ho, wo), want * g, tol=2e-5, what="two-term dgrad, gated split output")
+    assert_close(o.colsum_finish_raw(part, (n, cout, ho, wo)), (want * g).sum(dim=(0, 2, 3)), tol=2e-5, what="its column sums")
+    full = F.conv2d(x.double(), wf.double(), padding=pad)
+    assert rel_err(y2, full) < 1e-2
 
 
 PW_CASES = [
@@ -407,17 +502,19 @@ def test_dma_fed_gemms_repeat_bitwise_at_benchmark_size():
     dys = o.split_raw(o.to_nhwc_raw(gen(n, 100, h - 4, h - 4, seed=31).to(DEV)))
     w = gen(100, c, 5, 5, seed=32, scale=0.02).to(DEV)
     b = gen(100, seed=33, scale=0.1).to(DEV)
-    wp, wpt = o._pack_x(w, 0), o._pack_x(w, 1)
+    wp, wpt, wpt2 = o._pack_x(w, 0), o._pack_x(w, 1), o._pack_x(w, 2)
     first = None
     for _ in range(12):
         y = o.conv2d_x_raw(xs, (n, c, h, h), wp, b, 100, 5, 0, "relu", out_split=True)
         dx = o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt, None, c, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu")
-        dw, db = o.conv2d_wgrad_x_raw(xs, (n, c, h, h), dys, 100, 5, 0, (100, c, 5, 5))
-        cur = (y.clone(), dx.clone(), dw.clone(), db.clone())
+        dx2 = o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt2, None, c, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu", terms=2)
+        dw, db = o.conv2d_wgrad_x_raw(xs, (n, c, h, h), dys, 100, 5, 0, (100, c, 5, 5), terms=3)
+        dw1, _ = o.conv2d_wgrad_x_raw(xs, (n, c, h, h), dys, 100, 5, 0, (100, c, 5, 5), terms=1)
+        cur = (y.clone(), dx.clone(), dw.clone(), db.clone(), dx2.clone(), dw1.clone())
         if first is None:
             first = cur
         else:
-            for a, bb, what in zip(first, cur, ("fwd", "dgrad", "wgrad", "bias grad")):
+            for a, bb, what in zip(first, cur, ("fwd", "dgrad", "wgrad", "bias grad", "two-term dgrad", "one-term wgrad")):
                 assert torch.equal(a, bb), "run-to-run difference in " + what
 
 

@@ -37,16 +37,16 @@ SIGNATURES = {
     "wcmc_cat_upsample_split": (I, [P, L, L, L, P, L, L, L, P, I, I, I, I, I, P]),
     "wcmc_add_broadcast_split": (I, [P, L, L, L, P, L, L, L, F, P, I, I, I, I, I, P]),
     "wcmc_split_dy_colsum_bf16": (I, [P, L, L, L, P, L, L, L, I, F, P, L, L, L, I, F, P, P, I, I, I, I, P]),
-    "wcmc_conv2d_packed_elems_bf16x3": (Z, [I, I, I]),
+    "wcmc_conv2d_packed_elems_bf16x3": (Z, [I, I, I, I]),
     "wcmc_conv2d_pack_weight_bf16x3": (I, [P, P, I, I, I, I, P]),
     "wcmc_conv2d_pack_chain_bf16x3": (I, [I, P, P, P, P, P, I, P]),
-    "wcmc_conv2d_igemm_bf16x3": (I, [P, I, I, I, I, P, P, P, L, L, L, P, I, I, I, I, F, P, I, F, P, P, P, P]),
+    "wcmc_conv2d_igemm_bf16x3": (I, [P, I, I, I, I, P, P, P, L, L, L, P, I, I, I, I, F, P, I, F, P, P, P, I, P]),
     "wcmc_conv1x1_pair_supported": (I, [I, I, I]),
     "wcmc_conv1x1_pair_bf16x3": (I, [P, I, I, I, I, P, P, I, I, F, P, P, P, I, F, P, P, P, I, I, F, P, L, L, L, P]),
     "wcmc_conv2d_igemm_colsum_elems": (Z, [I, I, I, I]),
     "wcmc_colsum_finish": (I, [P, I, I, I, I, P, P]),
     "wcmc_conv2d_wgrad_bf16x3_workspace_bytes": (Z, [I, I, I, I, I, I]),
-    "wcmc_conv2d_wgrad_bf16x3": (I, [P, I, I, I, I, P, I, I, I, P, P, P, Z, I, P, P]),
+    "wcmc_conv2d_wgrad_bf16x3": (I, [P, I, I, I, I, P, I, I, I, P, P, P, Z, I, P, I, P]),
     "wcmc_act_backward": (I, [P, L, L, L, P, L, L, L, P, L, L, L, I, I, I, I, I, F, P]),
     "wcmc_kernel_apply_fwd": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, I, I, I, I, I, P]),
     "wcmc_kernel_apply_bwd": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P,
@@ -95,7 +95,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        if h.wcmc_abi_version() != 1:
+        if h.wcmc_abi_version() != 2:
             raise RuntimeError("wcmc_amd: ABI version mismatch in %s" % LIB_PATH)
         _lib = h
     return _lib

@@ -324,13 +324,32 @@ static int x_env_on(const char* name) {           // switch is ON unless the var
   const char* e = getenv(name);
   return (e && e[0] == '0') ? 0 : 1;
 }
-struct XKPlan { bool halo; int Kp, CS, nslabs, Ks, Kt, PXS, CSl, Ksl; };     // CSl / Ksl: the last (narrower) slab
-static XKPlan x_plan_k(int kchan, int ks) {
+struct XKPlan { bool halo; int Kp, CS, nslabs, Ks, Kt, PXS, CSl, Ksl, ap; };     // CSl / Ksl: the last (narrower) slab
+static int x_pick_nt(int tiles);
+// ap_req: planes of the A operand (the pixels) the caller wants multiplied -- 2 = hi + lo (three MFMAs per product), 1 = hi only
+// (two: W_lo*A_hi + W_hi*A_hi; the data gradient of the "bf16x321" mode).  q.ap is what the plan grants: 1 only where a
+// kernel instance for it exists (rows = the GEMM's output channels pick the instance), else the three-term plan.  The K
+// order of the packed weights follows the plan, so packing and launch must ask with the same (kchan, ks, ap_req, rows).
+static XKPlan x_plan_k(int kchan, int ks, int ap_req = 2, int rows = 0) {
   // (A/B switches are read per call -- a getenv per launch -- so that tests/test_gpu_models.py can flip them in one process)
   const int enable = x_env_on("WCMC_IGEMM_HALO");
   XKPlan q;
+  q.ap = 2;
   q.Kp = round_up(kchan, 8);
   q.halo = enable && ks >= 3 && ks <= 5 && q.Kp >= 32;
+  if (ap_req == 1 && q.halo && ks == 5 && x_env_on("WCMC_HALO64") && rows > 0 && x_pick_nt(round_up(rows, 16) / 16) == 7 &&
+      q.Kp % 32 != 24 && x_env_on("WCMC_DGRAD_AP1")) {
+    // conv_halo64_bf16x3_kernel<7, 3, PT, 0, 80, 1>: the halo holds the hi plane only, so a pixel's 80 bytes carry 32 channels
+    // instead of 16 -- half the slabs (104 channels = 32 + 32 + 32 + 8: K = 3 x 800 + 224 = 2624 of 2500 useful, three halo
+    // reloads per tile instead of six), one tap per 32-k stage (four in the 8-channel slab)
+    q.ap = 1;
+    q.nslabs = (q.Kp + 31) / 32;
+    q.CS = 32; q.CSl = q.Kp - (q.nslabs - 1) * 32;            // 8, 16 or 32
+    q.PXS = 80;
+    q.Ks = round_up(ks * ks * q.CS, 32); q.Ksl = round_up(ks * ks * q.CSl, 32);
+    q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
+    return q;
+  }
   if (q.halo && ks == 5 && x_env_on("WCMC_HALO64")) {
     // conv_halo64_bf16x3_kernel: slabs of 16 channels (the last one 8 or 16), halo pixel stride 80 B, two taps per stage
     // (5x5 only: on the U-Net's 3x3 layers it wins 4 % at 128^2 and loses 30-70 % on the 64^2 / 32^2 levels, whose 16x16
@@ -512,6 +531,7 @@ struct XIgemmParams {
   int G;                                  // rows of colsum (tiles past the kernel's own are zero-filled)
   int CS, nslabs, SPS, PXS, tilesX, tilesY;   // halo kernel: channel slab, stages per slab, halo pixel stride
   int CSl, SPSl;                              // ... of the last slab
+  int ap;                                     // planes of x multiplied: 2 = hi + lo, 1 = hi only (two MFMAs per product)
   unsigned y_bytes, m_bytes;                  // pointwise kernel: extents of the output and of the 1-bit masks
   // pointwise kernel, optional tail layer (a second 1x1 conv of <= 4 couts applied to the tile while it is in LDS)
   const u16* wp2; const float* bias2; float* y2; int64_t y2sn, y2sh, y2sw;
@@ -1289,7 +1309,10 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 // Wave w owns tile rows w, w+4, w+8, w+12 (a tile that hangs over the image edge idles every wave equally).
 // PXST: the halo pixel stride as a compile-time constant (80 or 160; 0 = p.PXS, the WCMC_HALO64_PXS experiments) -- with it the
 // pixel tiles of a wave sit at immediate offsets of ONE address register per stage (the kernel is launched for ks == 5 only).
-template <int NT, int NB, int PT = 4, int DBG = 0, int PXST = 0>
+// AP: planes of the pixel operand that are multiplied -- 2: W_lo*A_hi + W_hi*A_lo + W_hi*A_hi; 1: the hi plane only (W_lo*A_hi +
+// W_hi*A_hi: the data gradient of the "bf16x321" mode, whose A operand is dy) -- the halo then holds no lo plane and a
+// pixel's PXS bytes carry twice the channels (x_plan_k).
+template <int NT, int NB, int PT = 4, int DBG = 0, int PXST = 0, int AP = 2>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams p0) {
   XIgemmParams p = p0;
   if (PXST) { p.PXS = PXST; p.ks = 5; }
@@ -1352,6 +1375,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
         const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
         if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
           const unsigned pbase = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb);
+          if (AP == 1) {                             // hi plane only: part = 16-byte unit of the slab's channels
+            if (part < p.CS / 8 && (p.nslabs - 2) * p.CS + part * 8 < p.Cpi) hoff[kq] = pbase + (unsigned)(part * 16);
+            if (part < p.CSl / 8 && (p.nslabs - 1) * p.CS + part * 8 < p.Cpi) hoffl[kq] = pbase + (unsigned)(part * 16);
+          } else {
           {
             const int V = p.CS / 4, plane = part >= (V >> 1), vec = part - plane * (V >> 1);
             // (channel test against the widest regular slab, nslabs - 2: it then holds for every regular slab)
@@ -1360,6 +1387,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
           {
             const int V = p.CSl / 4, plane = part >= (V >> 1), vec = part - plane * (V >> 1);
             if (part < V && (p.nslabs - 1) * p.CS + vec * 8 < p.Cpi) hoffl[kq] = pbase + (unsigned)(plane * 2 * p.Cpi + vec * 16);
+          }
           }
         }
       }
@@ -1380,14 +1408,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
       }
       return;
     }
-    const int V = (slab == p.nslabs - 1 ? p.CSl : p.CS) / 4;      // data vectors per halo pixel (2 planes x cs/8)
+    const int V = (slab == p.nslabs - 1 ? p.CSl : p.CS) / (AP == 1 ? 8 : 4);      // data vectors per halo pixel (AP planes x cs/8)
     for (int ii = wave; ii * 64 < hvecs; ii += NWV) {
       const int v = ii * 64 + lane;
       if (v < hvecs) {
         const int px = (int)(((float)v + 0.5f) * invVP), part = v - px * VP;     // exact: v < 2^13
         const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
         const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
-        const int plane = part >= (V >> 1), vec = part - plane * (V >> 1);
+        const int plane = AP == 1 ? 0 : part >= (V >> 1), vec = part - plane * (V >> 1);
         const int ch = slab * p.CS + vec * 8;
         unsigned off = XOOB;
         if (part < V && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Cpi)
@@ -1452,7 +1480,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   auto read_a1 = [&](int i, int aoff) {
     const char* pa = halo + abase0 + aoff;
     ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * dA);
-    al[i] = *reinterpret_cast<const bf16x8*>(pa + lo_off + i * dA);
+    if (AP == 2) al[i] = *reinterpret_cast<const bf16x8*>(pa + lo_off + i * dA);
   };
   const u16* const bfrag = bsm + frow * XROW + fslot;
   auto read_b = [&](int buf, int j) {
@@ -1499,7 +1527,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
       for (int i = 0; i < PT; ++i) {
         if (!(DBG & 1)) {
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
+          if (AP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
         }
         // the pixel tile's fragments of stage g+1 replace it as soon as its last MFMAs of this stage have issued
@@ -2094,20 +2122,26 @@ struct XWgradParams {
   float* slabs; int S; int64_t M, pix_per_split;
   int Np, Cq, coBlocks, ciBlocks;
   unsigned x_bytes, dy_bytes;
+  int xps, yps;                     // pixel stride (bytes) of x / dy: 4 * Cp for a split tensor, 2 * Cp for a single bf16 plane
 };
 
 constexpr int xw_stride(int ch) { return ((ch / 16) & 1) ? ch : ch + 16; }   // bf16 elements; bytes = odd * 32
 
-template <int TM>
+// PL = planes multiplied: 2 = hi + lo of both operands, three MFMAs per product (yl*xh + yh*xl + yh*xh); 1 = the hi planes
+// only, ONE MFMA per product (the round-3 precision ladder, profiles/r03_precision_ladder.txt: rounding dy and x to bf16 is
+// independent from pixel to pixel and averages out over the pixel sum -- the gradients of the benchmarked step move from
+// 1.09e-3 to 1.14e-3 of the fp32 oracle's in relative L2).  Half the stage bytes, half the fragment reads, a third of the MFMAs.
+template <int TM, int PL = 2>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams p) {
   constexpr int PK = 64;
   constexpr int YC = TM * 16, XC = 64;
   constexpr int SA = xw_stride(YC), SB = xw_stride(XC);
   constexpr int YV = YC / 8, XV = XC / 8;          // 16-byte vectors per plane per pixel
-  constexpr int NV = (2 * YV + 2 * XV) / 4;        // vectors per thread (4 threads share a pixel)
+  constexpr int TOTV = PL * YV + PL * XV;
+  constexpr int NV = (TOTV + 3) / 4;               // vectors per thread (4 threads share a pixel)
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
-  u16* Ys = smem16;                        // [2][PK][SA]
-  u16* Xs = smem16 + 2 * PK * SA;          // [2][PK][SB]
+  u16* Ys = smem16;                        // [PL][PK][SA]
+  u16* Xs = smem16 + PL * PK * SA;         // [PL][PK][SB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: wave-uniform tests and LDS-DMA destinations stay scalar code)
   // block -> (split, tap, tile): XCD x (= blockIdx & 7) owns splits s = x, x+8, ...; its consecutive
@@ -2141,19 +2175,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int v = lv0 + 4 * j;
-    if (v < 2 * YV) {
+    if (v < PL * YV) {
       const int plane = v >= YV, vec = v - plane * YV;
       const int co = co0 + vec * 8;
       isy[j] = true;
       voff[j] = co < p.Cpo ? (unsigned)((plane * p.Cpo + co) * 2) : XOOB;
       lds_off[j] = (plane * PK + lpx) * SA + vec * 8;
-    } else {
-      const int u = v - 2 * YV;
+    } else if (v < TOTV) {
+      const int u = v - PL * YV;
       const int plane = u >= XV, vec = u - plane * XV;
       const int ci = ci0 + vec * 8;
       isy[j] = false;
       voff[j] = ci < p.Cpi ? (unsigned)((plane * p.Cpi + ci) * 2) : XOOB;
-      lds_off[j] = 2 * PK * SA + (plane * PK + lpx) * SB + vec * 8;
+      lds_off[j] = PL * PK * SA + (plane * PK + lpx) * SB + vec * 8;
+    } else {                               // (TOTV not a multiple of 4: this thread has one vector less)
+      isy[j] = true; voff[j] = XOOB; lds_off[j] = -1;
     }
   }
   int cn, coy, cox; int64_t cp = pstart + lpx;
@@ -2168,8 +2204,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
     const bool pv = cp < pend;
     const int iy = coy + tdy, ix = cox + tdx;
     const bool xv = pv && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    const unsigned yb = pv ? (unsigned)((((int64_t)cn * p.Ho + coy) * p.Wo + cox) * 4 * p.Cpo) : XOOB;
-    const unsigned xb = xv ? (unsigned)((((int64_t)cn * p.H + iy) * p.W + ix) * 4 * p.Cpi) : XOOB;
+    const unsigned yb = pv ? (unsigned)((((int64_t)cn * p.Ho + coy) * p.Wo + cox) * p.yps) : XOOB;
+    const unsigned xb = xv ? (unsigned)((((int64_t)cn * p.H + iy) * p.W + ix) * p.xps) : XOOB;
 #pragma unroll
     for (int j = 0; j < NV; ++j)
       rv[j] = isy[j] ? __builtin_amdgcn_raw_buffer_load_b128(yr, (yb | voff[j]) >= XOOB ? XOOB : yb + voff[j], 0, 0)
@@ -2179,7 +2215,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
   };
   auto store_stage = [&]() {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) *reinterpret_cast<u32x4*>(smem16 + lds_off[j]) = rv[j];
+    for (int j = 0; j < NV; ++j)
+      if (TOTV % 4 == 0 || lds_off[j] >= 0) *reinterpret_cast<u32x4*>(smem16 + lds_off[j]) = rv[j];
   };
 
   f32x4 acc[MT][4];
@@ -2210,16 +2247,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
     store_stage();
     __syncthreads();
     if (st + 1 < nstages) load_stage();
-    bf16x8 xh[4], xl[4], yh[MT], yl[MT];
+    bf16x8 xh[4], xl[PL == 2 ? 4 : 1], yh[MT], yl[PL == 2 ? MT : 1];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       tr_read(Xs, SB, j * 16, xh[j]);
-      tr_read(Xs + PK * SB, SB, j * 16, xl[j]);
+      if constexpr (PL == 2) tr_read(Xs + PK * SB, SB, j * 16, xl[j]);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       tr_read(Ys, SA, (wm * MT + i) * 16, yh[i]);            // (a tile past TM reads the X region: unused)
-      tr_read(Ys + PK * SA, SA, (wm * MT + i) * 16, yl[i]);
+      if constexpr (PL == 2) tr_read(Ys + PK * SA, SA, (wm * MT + i) * 16, yl[i]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2228,8 +2265,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(XWgradParams 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (j < tn_valid) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl[i], xh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xl[j], acc[i][j], 0, 0, 0);
+            if constexpr (PL == 2) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl[i], xh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xl[j], acc[i][j], 0, 0, 0);
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh[i], xh[j], acc[i][j], 0, 0, 0);
           }
         }
@@ -2288,6 +2327,7 @@ struct XWRowsParams {
   int prio;                         // rows8: iteration (of 14 per stage) at which waves 0-3 hand the priority to waves 4-7; 0 = off
   int Np, Cq, coBlocks, ciBlocks;
   unsigned x_bytes, dy_bytes;
+  int xps, yps;                     // pixel stride (bytes) of x / dy: 4 * Cp for a split tensor, 2 * Cp for a single bf16 plane
 };
 
 // LDS row stride (u16) of a CH-channel tile: bytes = odd multiple of 32 (conflict-free transposing reads);
@@ -2323,13 +2363,14 @@ __device__ __forceinline__ void xstatic_for_impl(F&& f, std::integer_sequence<in
 template <int N, class F>
 __device__ __forceinline__ void xstatic_for(F&& f) { xstatic_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
-template <int KS, int TM, int NW, int DBG = 0>
+// PL: planes multiplied (see conv_wgrad_bf16x3_kernel): 2 = [Yh | Yl | Xh | Xl] stages, three MFMAs per product; 1 = [Yh | Xh], one.
+template <int KS, int TM, int NW, int DBG = 0, int PL = 2>
 __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf16x3_kernel(XWRowsParams p) {
   constexpr int CHY = TM * 16, CHX = NW * 16, PK = 64, XR = PK + KS - 1;
   constexpr int SY = xwr_stride(CHY), SX = xwr_stride(CHX);
   constexpr int VY = SY / 8, VX = SX / 8;                   // 16-byte vectors per row and plane (with pad)
   constexpr int YV = PK * VY, XV = XR * VX;
-  constexpr int NVEC = 2 * YV + 2 * XV;
+  constexpr int NVEC = PL * YV + PL * XV;
   constexpr int NI = (NVEC + NW * 64 - 1) / (NW * 64);      // LDS-DMA instructions per wave and stage
   constexpr int BUF = NI * NW * 64 * 8;                     // u16 per buffer (whole instructions)
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
@@ -2368,17 +2409,17 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
   for (int i = 0; i < NI; ++i) {
     const int v = (i * NW + wave) * 64 + lane;
     unsigned rel = 0; int rw = 127;
-    if (v < 2 * YV) {
+    if (v < PL * YV) {
       const int plane = v >= YV, vv = v - plane * YV;
       const int row = vv / VY, vec = vv - row * VY;
       const int co = co0 + vec * 8;
-      if (vec * 8 < CHY && co < p.Cpo) { rel = (unsigned)(row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2); rw = row; }
+      if (vec * 8 < CHY && co < p.Cpo) { rel = (unsigned)(row * p.yps + plane * 2 * p.Cpo + co * 2); rw = row; }
     } else if (v < NVEC) {
-      const int u = v - 2 * YV;
+      const int u = v - PL * YV;
       const int plane = u >= XV, uu = u - plane * XV;
       const int row = uu / VX, vec = uu - row * VX;
       const int ci = ci0 + vec * 8;
-      if (vec * 8 < CHX && ci < p.Cpi) { rel = (unsigned)(row * 4 * p.Cpi + plane * 2 * p.Cpi + ci * 2); rw = row; }
+      if (vec * 8 < CHX && ci < p.Cpi) { rel = (unsigned)(row * p.xps + plane * 2 * p.Cpi + ci * 2); rw = row; }
     }
     relv[i] = rel; rowv[i] = rw;
   }
@@ -2396,8 +2437,8 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
     const int ox0 = f_c * PK;
     const int iy = f_oy + trow - p.pad;
     const bool rowok = (unsigned)iy < (unsigned)p.H;
-    f_ybase = (unsigned)(((f_n * p.Ho + f_oy) * p.Wo + ox0) * 4 * p.Cpo);
-    f_xbase = (unsigned)(((f_n * p.H + iy) * p.W + ox0 - p.pad) * 4 * p.Cpi);   // may wrap: only used when valid
+    f_ybase = (unsigned)(((f_n * p.Ho + f_oy) * p.Wo + ox0) * p.yps);
+    f_xbase = (unsigned)(((f_n * p.H + iy) * p.W + ox0 - p.pad) * p.xps);       // may wrap: only used when valid
     f_yn = (unsigned)max(0, p.Wo - ox0);               // dy rows [0, yn) exist
     f_xlo = p.pad - ox0;                               // x rows [xlo, xlo + xn) are inside the image
     f_xn = rowok ? (unsigned)p.W : 0u;
@@ -2410,8 +2451,8 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
   };
   auto issue_one = [&](int i) {
     if ((i + 1) * NW * 64 > NVEC && (i * NW + wave) * 64 >= NVEC) return;   // (the tail of the last instruction row: nothing to fetch)
-    // 2*YV is a multiple of 64: a wave-instruction is all dy or all x (wave-uniform choice of descriptor and base)
-    const bool isx = (2 * VY) % NW == 0 ? i >= (2 * VY) / NW : (i * NW + wave) * 64 >= 2 * YV;
+    // PL*YV is a multiple of 64: a wave-instruction is all dy or all x (wave-uniform choice of descriptor and base)
+    const bool isx = (PL * VY) % NW == 0 ? i >= (PL * VY) / NW : (i * NW + wave) * 64 >= PL * YV;
     const unsigned base = isx ? f_xbase : f_ybase, cnt = isx ? f_xn : f_yn;
     const int lo = isx ? f_xlo : 0;
     const unsigned off = (unsigned)(rowv[i] - lo) < cnt ? base + relv[i] : XOOB;
@@ -2474,7 +2515,7 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
     // byte addresses of this lane's first fragment row in the four planes of the stage
     const int prow0 = 4 * g + tq;
     const unsigned aYh = lds0 + (unsigned)(((st & 1) * BUF + prow0 * SY + 4 * tp) * 2);
-    const unsigned aXh = lds0 + (unsigned)(((st & 1) * BUF + 2 * PK * SY + prow0 * SX + wave * 16 + 4 * tp) * 2);
+    const unsigned aXh = lds0 + (unsigned)(((st & 1) * BUF + PL * PK * SY + prow0 * SX + wave * 16 + 4 * tp) * 2);
     const int c = st % nch;
     const int nk = (min(PK, p.Wo - c * PK) + 31) / 32;    // 32-pixel MFMA k-steps with any valid pixel (1 or 2)
     // Software pipeline inside the wave (the first version read a k-step's fragments, waited, multiplied: a wave alone on
@@ -2486,10 +2527,10 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
     xstatic_for<KS>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
       xwr_tr_issue_at<t * SX * 2, t * SX * 2 + 16 * SX * 2>(aXh, rxh[t]);
-      xwr_tr_issue_at<XLOB + t * SX * 2, XLOB + t * SX * 2 + 16 * SX * 2>(aXh, rxl[t]);
+      if constexpr (PL == 2) xwr_tr_issue_at<XLOB + t * SX * 2, XLOB + t * SX * 2 + 16 * SX * 2>(aXh, rxl[t]);
     });
     xwr_tr_issue_at<0, 16 * SY * 2>(aYh, ryh[0]);
-    xwr_tr_issue_at<YLOB, YLOB + 16 * SY * 2>(aYh, ryl[0]);
+    if constexpr (PL == 2) xwr_tr_issue_at<YLOB, YLOB + 16 * SY * 2>(aYh, ryl[0]);
     bf16x8 xh[KS], xl[KS];
     xstatic_for<2>([&](auto K_) {
       constexpr int kk = decltype(K_)::value;
@@ -2498,7 +2539,16 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
           constexpr int i = decltype(I_)::value;
           constexpr int cur = (kk * TM + i) & 1, nxt = cur ^ 1;
           // everything issued so far has landed (the reads of this iteration were issued one iteration ago)
-          if (DBG & 8) {                               // (timing only: no wait for the fragments)
+          if constexpr (PL == 1) {                     // (the lo registers do not exist in this instance)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b));
+            if (i == 0) {
+#pragma unroll
+              for (int t = 0; t < KS; ++t) {
+                asm volatile("" : "+v"(rxh[t].a), "+v"(rxh[t].b));
+                xh[t] = xwr_cat(rxh[t]);
+              }
+            }
+          } else if (DBG & 8) {                        // (timing only: no wait for the fragments)
             asm volatile("" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
             if (i == 0) {
 #pragma unroll
@@ -2514,29 +2564,32 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
           } else {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
           }
-          const bf16x8 yh = xwr_cat(ryh[cur]), yl = xwr_cat(ryl[cur]);
+          bf16x8 yh = xwr_cat(ryh[cur]), yl = yh;
+          if constexpr (PL == 2) yl = xwr_cat(ryl[cur]);
           if constexpr (i + 1 < TM) {
             constexpr int O = (kk * 32 * SY + (i + 1) * 16) * 2;
             xwr_tr_issue_at<O, O + 16 * SY * 2>(aYh, ryh[nxt]);
-            xwr_tr_issue_at<YLOB + O, YLOB + O + 16 * SY * 2>(aYh, ryl[nxt]);
+            if constexpr (PL == 2) xwr_tr_issue_at<YLOB + O, YLOB + O + 16 * SY * 2>(aYh, ryl[nxt]);
           } else if (kk + 1 < nk) {
             constexpr int O = (kk + 1) * 32 * SY * 2;
             xwr_tr_issue_at<O, O + 16 * SY * 2>(aYh, ryh[nxt]);
-            xwr_tr_issue_at<YLOB + O, YLOB + O + 16 * SY * 2>(aYh, ryl[nxt]);
+            if constexpr (PL == 2) xwr_tr_issue_at<YLOB + O, YLOB + O + 16 * SY * 2>(aYh, ryl[nxt]);
           }
           __builtin_amdgcn_sched_barrier(0);             // (the prefetch leaves before the MFMAs, not among them)
           xstatic_for<KS>([&](auto T_) {
             constexpr int t = decltype(T_)::value;
             if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(xh[t]), "v"(xl[t])); }
             else {
-              acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[t], acc[t][i], 0, 0, 0);
-              acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[t], acc[t][i], 0, 0, 0);
+              if constexpr (PL == 2) {
+                acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[t], acc[t][i], 0, 0, 0);
+                acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[t], acc[t][i], 0, 0, 0);
+              }
               acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[t], acc[t][i], 0, 0, 0);
             }
             if (i == TM - 1 && kk + 1 < nk) {             // this tap's fragments of the next k-step
               constexpr int O = ((kk + 1) * 32 + t) * SX * 2;
               xwr_tr_issue_at<O, O + 16 * SX * 2>(aXh, rxh[t]);
-              xwr_tr_issue_at<XLOB + O, XLOB + O + 16 * SX * 2>(aXh, rxl[t]);
+              if constexpr (PL == 2) xwr_tr_issue_at<XLOB + O, XLOB + O + 16 * SX * 2>(aXh, rxl[t]);
             }
           });
           // (the next stage's scalars are worked out behind the first MFMAs of the stage, not at the barrier where all
@@ -2605,7 +2658,7 @@ __global__ __launch_bounds__(NW * 64, (NW <= 4 ? 2 : 1)) void conv_wgrad_rows_bf
 // three pairs left over (tap 4, cin tiles 4..6), the cout tile w (wave 7 multiplies wave 0's again and drops it: no
 // branch in the MFMA stream) -- 93 MFMAs per wave and k-step, 186 per SIMD.  Stage layout, fill, slab layout and the
 // order of the MFMAs on every accumulator are those of the seven-wave kernel: the slabs are bit-identical.
-template <int DBG = 0, int XE = 1>
+template <int DBG = 0, int XE = 1, int PL = 2>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsParams p) {
 #define XWR8_READ(O1, O2, ADDR, REG) do { if (DBG & 32) { asm volatile("" : "+v"((REG).a), "+v"((REG).b)); } else xwr_tr_issue_at<O1, O2>(ADDR, REG); } while (0)
   constexpr int KS = 5, TM = 7, NCI = 7, NW = 8, NS = 4, NE = 3;
@@ -2613,7 +2666,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
   constexpr int SY = xwr_stride(CHY), SX = xwr_stride(CHX);
   constexpr int VY = SY / 8, VX = SX / 8;
   constexpr int YV = PK * VY, XV = XR * VX;
-  constexpr int NVEC = 2 * YV + 2 * XV;
+  constexpr int NVEC = PL * YV + PL * XV;                   // PL = 1: [Yh | Xh] stages, one MFMA per product (see conv_wgrad_bf16x3_kernel)
   constexpr int NI = (NVEC + NW * 64 - 1) / (NW * 64);
   constexpr int BUF = NI * NW * 64 * 8;
   constexpr int XLO = XR * SX * 2;                          // byte offset of the lo plane of x (and below: of dy)
@@ -2643,17 +2696,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
   for (int i = 0; i < NI; ++i) {
     const int v = (i * NW + wave) * 64 + lane;
     unsigned rel = 0; int rw = 127;
-    if (v < 2 * YV) {
+    if (v < PL * YV) {
       const int plane = v >= YV, vv = v - plane * YV;
       const int row = vv / VY, vec = vv - row * VY;
       const int co = co0 + vec * 8;
-      if (vec * 8 < CHY && co < p.Cpo) { rel = (unsigned)(row * 4 * p.Cpo + plane * 2 * p.Cpo + co * 2); rw = row; }
+      if (vec * 8 < CHY && co < p.Cpo) { rel = (unsigned)(row * p.yps + plane * 2 * p.Cpo + co * 2); rw = row; }
     } else if (v < NVEC) {
-      const int u = v - 2 * YV;
+      const int u = v - PL * YV;
       const int plane = u >= XV, uu = u - plane * XV;
       const int row = uu / VX, vec = uu - row * VX;
       const int ci = ci0 + vec * 8;
-      if (vec * 8 < CHX && ci < p.Cpi) { rel = (unsigned)(row * 4 * p.Cpi + plane * 2 * p.Cpi + ci * 2); rw = row; }
+      if (vec * 8 < CHX && ci < p.Cpi) { rel = (unsigned)(row * p.xps + plane * 2 * p.Cpi + ci * 2); rw = row; }
     }
     relv[i] = rel; rowv[i] = rw;
   }
@@ -2665,8 +2718,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
     const int ox0 = f_c * PK;
     const int iy = f_oy + trow - p.pad;
     const bool rowok = (unsigned)iy < (unsigned)p.H;
-    f_ybase = (unsigned)(((f_n * p.Ho + f_oy) * p.Wo + ox0) * 4 * p.Cpo);
-    f_xbase = (unsigned)(((f_n * p.H + iy) * p.W + ox0 - p.pad) * 4 * p.Cpi);   // may wrap: only used when valid
+    f_ybase = (unsigned)(((f_n * p.Ho + f_oy) * p.Wo + ox0) * p.yps);
+    f_xbase = (unsigned)(((f_n * p.H + iy) * p.W + ox0 - p.pad) * p.xps);       // may wrap: only used when valid
     f_yn = (unsigned)max(0, p.Wo - ox0);
     f_xlo = p.pad - ox0;
     f_xn = rowok ? (unsigned)p.W : 0u;
@@ -2683,7 +2736,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
     if ((i + 1) * NW * 64 > NVEC && (i * NW + wave) * 64 >= NVEC) return;
     // 2*YV is a multiple of 64: a wave-instruction is all dy or all x; only one instruction row straddles the two (written
     // out so that the others are compile-time choices and not wave-uniform masks kept in spilled scalar registers)
-    const bool isx = (i * NW + NW - 1) * 64 < 2 * YV ? false : i * NW * 64 >= 2 * YV ? true : (i * NW + wave) * 64 >= 2 * YV;
+    const bool isx = (i * NW + NW - 1) * 64 < PL * YV ? false : i * NW * 64 >= PL * YV ? true : (i * NW + wave) * 64 >= PL * YV;
     const unsigned base = isx ? f_xbase : f_ybase, cnt = isx ? f_xn : f_yn;
     const int lo = isx ? f_xlo : 0;
     const unsigned off = (unsigned)(rowv[i] - lo) < cnt ? base + relv[i] : XOOB;
@@ -2766,7 +2819,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
       const unsigned by = lds0 + (unsigned)((bb * BUF + prow0 * SY + 4 * tp) * 2);
-      const unsigned bx = lds0 + (unsigned)((bb * BUF + 2 * PK * SY + prow0 * SX + 4 * tp) * 2);
+      const unsigned bx = lds0 + (unsigned)((bb * BUF + PL * PK * SY + prow0 * SX + 4 * tp) * 2);
 #pragma unroll
       for (int i = 0; i < TM; ++i) { ayv[bb][i] = by + (unsigned)(ycol[i] * 32); asm volatile("" : "+v"(ayv[bb][i])); }
 #pragma unroll
@@ -2797,20 +2850,20 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       XWR8_READ(0, 16 * SX * 2, ax[q], rxh[q]);
-      XWR8_READ(XLO, XLO + 16 * SX * 2, ax[q], rxl[q]);
+      if constexpr (PL == 2) XWR8_READ(XLO, XLO + 16 * SX * 2, ax[q], rxl[q]);
     }
     if (XE) {
       XWR8_READ(0, 16 * SX * 2, aE, reh[0]);
-      XWR8_READ(XLO, XLO + 16 * SX * 2, aE, rel_[0]);
+      if constexpr (PL == 2) XWR8_READ(XLO, XLO + 16 * SX * 2, aE, rel_[0]);
     } else {
 #pragma unroll
       for (int e = 0; e < NF; ++e) {
         XWR8_READ(0, 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2), reh[e]);
-        XWR8_READ(XLO, XLO + 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2), rel_[e]);
+        if constexpr (PL == 2) XWR8_READ(XLO, XLO + 16 * SX * 2, aX + (unsigned)((ETAP * SX + (ECI0 + e) * 16) * 2), rel_[e]);
       }
     }
     XWR8_READ(0, 16 * SY * 2, ayp[0], ryh[0]);
-    XWR8_READ(YLO, YLO + 16 * SY * 2, ayp[0], ryl[0]);
+    if constexpr (PL == 2) XWR8_READ(YLO, YLO + 16 * SY * 2, ayp[0], ryl[0]);
     bf16x8 xh[NS], xl[NS], eh[NF], el[NF];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -2819,6 +2872,15 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
         for (int i = 0; i < TM; ++i) {
           const int cur = (kk * TM + i) & 1, nxt = cur ^ 1;
           if (kk * TM + i > 0 && p.prio == kk * TM + i && wave < 4) __builtin_amdgcn_s_setprio(0);
+          if constexpr (PL == 1) {                        // (the lo registers do not exist in this instance)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b));
+            if (i == 0) {
+#pragma unroll
+              for (int q = 0; q < NS; ++q) { asm volatile("" : "+v"(rxh[q].a), "+v"(rxh[q].b)); xh[q] = xwr_cat(rxh[q]); }
+#pragma unroll
+              for (int e = 0; e < NF; ++e) { asm volatile("" : "+v"(reh[e].a), "+v"(reh[e].b)); eh[e] = xwr_cat(reh[e]); }
+            }
+          } else {
           if (DBG & 8) { asm volatile("" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b)); }
           else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ryh[cur].a), "+v"(ryh[cur].b), "+v"(ryl[cur].a), "+v"(ryl[cur].b));
           if (i == 0) {
@@ -2833,19 +2895,21 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
               eh[e] = xwr_cat(reh[e]); el[e] = xwr_cat(rel_[e]);
             }
           }
-          const bf16x8 yh = xwr_cat(ryh[cur]), yl = xwr_cat(ryl[cur]);
+          }
+          bf16x8 yh = xwr_cat(ryh[cur]), yl = yh;
+          if constexpr (PL == 2) yl = xwr_cat(ryl[cur]);
           constexpr int KY = 32 * SY * 2;                 // the second k-step of the dy planes
           if (i + 1 < TM) {
             if (kk == 0) {
               XWR8_READ(0, 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryh[nxt]);
-              XWR8_READ(YLO, YLO + 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryl[nxt]);
+              if constexpr (PL == 2) XWR8_READ(YLO, YLO + 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryl[nxt]);
             } else {
               XWR8_READ(KY, KY + 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryh[nxt]);
-              XWR8_READ(KY + YLO, KY + YLO + 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryl[nxt]);
+              if constexpr (PL == 2) XWR8_READ(KY + YLO, KY + YLO + 16 * SY * 2, ayp[i + 1 < TM ? i + 1 : 0], ryl[nxt]);
             }
           } else if (kk + 1 < nk) {
             XWR8_READ(KY, KY + 16 * SY * 2, ayp[0], ryh[nxt]);
-            XWR8_READ(KY + YLO, KY + YLO + 16 * SY * 2, ayp[0], ryl[nxt]);
+            if constexpr (PL == 2) XWR8_READ(KY + YLO, KY + YLO + 16 * SY * 2, ayp[0], ryl[nxt]);
           }
           __builtin_amdgcn_sched_barrier(0);
           if (XE) {                                       // the left-over pair of this wave: cout tiles ycol[0 .. nex-1]
@@ -2853,15 +2917,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
               if (i < 2 || i < nex) {
                 if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(eh[0]), "v"(el[0])); }
                 else {
-                  ace[i < NA ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, eh[0], ace[i < NA ? i : 0], 0, 0, 0);
-                  ace[i < NA ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, el[0], ace[i < NA ? i : 0], 0, 0, 0);
+                  if constexpr (PL == 2) {
+                    ace[i < NA ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, eh[0], ace[i < NA ? i : 0], 0, 0, 0);
+                    ace[i < NA ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, el[0], ace[i < NA ? i : 0], 0, 0, 0);
+                  }
                   ace[i < NA ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, eh[0], ace[i < NA ? i : 0], 0, 0, 0);
                 }
               }
               if (i == 3 && kk + 1 < nk) {
                 constexpr int K1 = 32 * SX * 2;
                 XWR8_READ(K1, K1 + 16 * SX * 2, aE, reh[0]);
-                XWR8_READ(K1 + XLO, K1 + XLO + 16 * SX * 2, aE, rel_[0]);
+                if constexpr (PL == 2) XWR8_READ(K1 + XLO, K1 + XLO + 16 * SX * 2, aE, rel_[0]);
               }
             }
           } else if (i == 0) {                            // the left-over pairs: cout tile ycol[0] = wave
@@ -2869,14 +2935,16 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
             for (int e = 0; e < NF; ++e) {
               if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(eh[e]), "v"(el[e])); }
               else {
-                ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, eh[e], ace[e], 0, 0, 0);
-                ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, el[e], ace[e], 0, 0, 0);
+                if constexpr (PL == 2) {
+                  ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, eh[e], ace[e], 0, 0, 0);
+                  ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, el[e], ace[e], 0, 0, 0);
+                }
                 ace[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, eh[e], ace[e], 0, 0, 0);
               }
               if (kk + 1 < nk) {
                 const unsigned ae = aX + (unsigned)((((kk + 1) * 32 + ETAP) * SX + (ECI0 + e) * 16) * 2);
                 XWR8_READ(0, 16 * SX * 2, ae, reh[e]);
-                XWR8_READ(XLO, XLO + 16 * SX * 2, ae, rel_[e]);
+                if constexpr (PL == 2) XWR8_READ(XLO, XLO + 16 * SX * 2, ae, rel_[e]);
               }
             }
           }
@@ -2884,14 +2952,16 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
           for (int q = 0; q < NS; ++q) {
             if (DBG & 1) { asm volatile("" ::"v"(yl), "v"(yh), "v"(xh[q]), "v"(xl[q])); }
             else {
-              acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[q], acc[q][i], 0, 0, 0);
-              acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[q], acc[q][i], 0, 0, 0);
+              if constexpr (PL == 2) {
+                acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[q], acc[q][i], 0, 0, 0);
+                acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[q], acc[q][i], 0, 0, 0);
+              }
               acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[q], acc[q][i], 0, 0, 0);
             }
             if (i == TM - 1 && kk + 1 < nk) {
               constexpr int K1 = 32 * SX * 2;              // (kk + 1 < nk <= 2: the second k-step)
               XWR8_READ(K1, K1 + 16 * SX * 2, ax[q], rxh[q]);
-              XWR8_READ(K1 + XLO, K1 + XLO + 16 * SX * 2, ax[q], rxl[q]);
+              if constexpr (PL == 2) XWR8_READ(K1 + XLO, K1 + XLO + 16 * SX * 2, ax[q], rxl[q]);
             }
           }
           // (the next stage's scalars are worked out here, behind the first MFMAs of the stage, not at the barrier where
@@ -2970,9 +3040,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
 }
 #undef XWR8_READ
 
-template <int KS, int TM, int NW>
+template <int KS, int TM, int NW, int PL = 2>
 static constexpr size_t xwr_lds_bytes() {
-  constexpr int NVEC = 2 * 64 * (xwr_stride(TM * 16) / 8) + 2 * (64 + KS - 1) * (xwr_stride(NW * 16) / 8);
+  constexpr int NVEC = PL * 64 * (xwr_stride(TM * 16) / 8) + PL * (64 + KS - 1) * (xwr_stride(NW * 16) / 8);
   constexpr int NI = (NVEC + NW * 64 - 1) / (NW * 64);
   constexpr size_t stage = (size_t)2 * NI * NW * 64 * 16;
   constexpr size_t red = (size_t)TM * 16 * (NW * 16 + 4) * sizeof(float);
@@ -2985,12 +3055,23 @@ static size_t xwr_lds_bytes_rt(int ks, int tm, int nw) {
   return stage > red ? stage : red;
 }
 
-template <int KS, int TM, int NW>
+template <int KS, int TM, int NW, int PL = 2>
 static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
-  constexpr size_t lds = xwr_lds_bytes<KS, TM, NW>();
+  constexpr size_t lds = xwr_lds_bytes<KS, TM, NW, PL>();
   const dim3 grid((unsigned)(((q.S * q.coBlocks * q.ciBlocks + 7) / 8) * 8 * KS));
   if (KS == 5 && TM == 7 && NW == 7 && x_env_on("WCMC_WGRAD_ROWS8")) {   // =0: A/B switch back to the seven-wave kernel
-    constexpr size_t lds8 = (size_t)2 * 8 * 512 * 16;   // two stages of NI = 8 instructions x 8 waves x 1 KB (> the staging tile of the slab write)
+    // two stages of NI = 8 (PL = 1: 4) instructions x 8 waves x 1 KB (> the 52 KB staging tile of the slab write)
+    constexpr size_t lds8 = (size_t)2 * ((PL * (64 * 14 + 68 * 14) + 511) / 512) * 512 * 16;
+    if (PL == 1) {
+      static bool attr81_set = false;
+      if (!attr81_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+        attr81_set = true;
+      }
+      hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>), grid, dim3(512), lds8, st, q);
+      return check_launch("conv2d_wgrad_bf16x3(rows8, one plane)");
+    }
     static bool attr8_set = false;
 #ifdef WCMC_DEBUG_BUILD
     { const char* e = getenv("WCMC_DEBUG_ABLATE");
@@ -3016,7 +3097,7 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
     return check_launch("conv2d_wgrad_bf16x3(rows8)");
   }
 #ifdef WCMC_DEBUG_BUILD        // `make debug` only: timing-only instances that compute WRONG results are not in the release library
-  if (KS == 5 && TM == 7 && NW == 7) {
+  if (KS == 5 && TM == 7 && NW == 7 && PL == 2) {
     int ab;                             // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills, 4 = clock probe)
     { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
     if (ab == 1 || ab == 2 || ab == 3 || ab == 4 || ab == 8 || ab == 16) {
@@ -3031,11 +3112,11 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
 #endif
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<KS, TM, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<KS, TM, NW, 0, PL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_rows_bf16x3_kernel<KS, TM, NW>), grid, dim3(NW * 64), lds, st, q);
+  hipLaunchKernelGGL((conv_wgrad_rows_bf16x3_kernel<KS, TM, NW, 0, PL>), grid, dim3(NW * 64), lds, st, q);
   return check_launch("conv2d_wgrad_bf16x3(rows)");
 }
 
@@ -3276,18 +3357,21 @@ extern "C" int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t d
   return check_launch("split_dy_colsum_bf16");
 }
 
-extern "C" size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks) {
-  if (rows <= 0 || kchan <= 0 || ks <= 0) return 0;
-  return (size_t)round_up(rows, 16) * 2 * x_plan_k(kchan, ks).Kt;
+// mode of a packed weight: 0 = forward orientation, 1 = data-gradient orientation (flipped taps, channels swapped), 2 = the
+// data-gradient orientation in the K order of a TWO-term launch (terms = 2 of wcmc_conv2d_igemm_bf16x3: x hi plane only)
+static inline int x_mode_ap(int mode) { return mode == 2 ? 1 : 2; }
+extern "C" size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks, int mode) {
+  if (rows <= 0 || kchan <= 0 || ks <= 0 || mode < 0 || mode > 2) return 0;
+  return (size_t)round_up(rows, 16) * 2 * x_plan_k(kchan, ks, x_mode_ap(mode), rows).Kt;
 }
 
 extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout, int Cin, int ks, int mode,
                                               void* stream) {
-  WCMC_REQUIRE(w && wp && Cout > 0 && Cin > 0 && ks > 0 && (mode == 0 || mode == 1), WCMC_ERR_BAD_ARG,
+  WCMC_REQUIRE(w && wp && Cout > 0 && Cin > 0 && ks > 0 && mode >= 0 && mode <= 2, WCMC_ERR_BAD_ARG,
                "conv2d_pack_weight_bf16x3: bad argument");
   const int rows = mode == 0 ? Cout : Cin, kchan = mode == 0 ? Cin : Cout;
   const int Np = round_up(rows, 16);
-  const XKPlan q = x_plan_k(kchan, ks);
+  const XKPlan q = x_plan_k(kchan, ks, x_mode_ap(mode), rows);
   const int64_t total = (int64_t)Np * q.Kt;
   hipLaunchKernelGGL(pack_weight_split_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, mode, rows, Np, q.CS, q.Ks, q.Kt, q.nslabs, q.CSl);
@@ -3302,14 +3386,14 @@ extern "C" int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* 
   t.n = n_entries; t.ks = ks;
   unsigned blocks = 0;
   for (int i = 0; i < n_entries; ++i) {
-    WCMC_REQUIRE(w[i] && wp[i] && Cout[i] > 0 && Cin[i] > 0 && (mode[i] == 0 || mode[i] == 1), WCMC_ERR_BAD_ARG,
+    WCMC_REQUIRE(w[i] && wp[i] && Cout[i] > 0 && Cin[i] > 0 && mode[i] >= 0 && mode[i] <= 2, WCMC_ERR_BAD_ARG,
                  "conv2d_pack_chain_bf16x3: bad entry %d", i);
     XPackEntry& e = t.e[i];
     e.w = w[i]; e.wp = (u16*)wp[i]; e.Cout = Cout[i]; e.Cin = Cin[i]; e.mode = mode[i];
     e.rows = mode[i] == 0 ? Cout[i] : Cin[i];
     const int kchan = mode[i] == 0 ? Cin[i] : Cout[i];
     e.Np = round_up(e.rows, 16);
-    const XKPlan q = x_plan_k(kchan, ks);
+    const XKPlan q = x_plan_k(kchan, ks, x_mode_ap(mode[i]), e.rows);
     e.CS = q.CS; e.Ks = q.Ks; e.Kt = q.Kt; e.nslabs = q.nslabs; e.CSl = q.CSl;
     e.block0 = blocks;
     blocks += (unsigned)ceil_div64((int64_t)e.Np * q.Kt, 256);
@@ -3383,22 +3467,25 @@ static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) 
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
-template <int NT, int NB, int PT, int PXST>
+template <int NT, int NB, int PT, int PXST, int AP = 2>
 static int launch_xhalo64c(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
-  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
 }
 template <int NT, int NB, int PT>
 static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   // the halo pixel stride as a template constant for the two shipped values (NB = 3: 16-channel slabs, 80 B; NB = 2 with
   // 12x16 tiles: 32-channel slabs, 160 B); anything else (WCMC_HALO64_PXS, WCMC_HALO_NB experiments) reads it from the params
+  if constexpr (NT == 7 && NB == 3) {
+    if (p.ap == 1) return launch_xhalo64c<NT, NB, PT, 80, 1>(p, lds, stream);          // (x_plan_k grants ap = 1 with PXS = 80, ks = 5 only)
+  }
   if (p.ks == 5 && p.PXS == 80 && NB == 3) return launch_xhalo64c<NT, NB, PT, NB == 3 ? 80 : 0>(p, lds, stream);
   if (p.ks == 5 && p.PXS == 160 && NB == 2 && PT == 3) return launch_xhalo64c<NT, NB, PT, (NB == 2 && PT == 3) ? 160 : 0>(p, lds, stream);
   return launch_xhalo64c<NT, NB, PT, 0>(p, lds, stream);
@@ -3437,7 +3524,7 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
 #endif
   // three weight stages where two workgroups still fit a CU (80 KB each), else two
   const char* nbe = getenv("WCMC_HALO_NB");
-  const int nb = (!(nbe && nbe[0] == '2') && halo + 3 * bstage <= 80 * 1024) ? 3 : 2;
+  const int nb = (p.ap == 1 || (!(nbe && nbe[0] == '2') && halo + 3 * bstage <= 80 * 1024)) ? 3 : 2;
   const size_t main_ = halo + nb * bstage;
   const size_t lds = main_ > out ? main_ : out;
   if (pt3) return nb == 3 ? launch_xhalo64b<NT, 3, 3>(p, lds, stream) : launch_xhalo64b<NT, 2, 3>(p, lds, stream);
@@ -3445,7 +3532,8 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
 }
 template <int NT>
 static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
-  if ((p.CS == 16 || (p.CS == 32 && p.PXS == 160 && p.CSl == 32 && p.Kp >= 256 && x_env_on("WCMC_HALO64") && x_env_on("WCMC_HALO64_CS32"))) &&
+  if ((p.CS == 16 || p.ap == 1 ||
+       (p.CS == 32 && p.PXS == 160 && p.CSl == 32 && p.Kp >= 256 && x_env_on("WCMC_HALO64") && x_env_on("WCMC_HALO64_CS32"))) &&
       p.ks == 5)
     return launch_xhalo64<NT>(p, stream);
   constexpr int TH = 16, TW = 16;
@@ -3557,9 +3645,11 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
                                         void* y_split, int Cout, int ks, int pad, int act, float slope,
                                         const void* gate_split, int gate_act, float gate_slope,
                                         float* colsum_partial, const void* gate_mask, void* mask_out,
-                                        void* stream) {
+                                        int terms, void* stream) {
   WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ks > 0 && pad >= 0 && x_split && wp,
                WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: bad argument");
+  WCMC_REQUIRE(terms == 3 || terms == 2, WCMC_ERR_BAD_ARG,
+               "conv2d_igemm_bf16x3: terms must be 3 or 2 (x hi plane only; wp packed with mode 2)");
   WCMC_REQUIRE(!colsum_partial || y_split, WCMC_ERR_BAD_ARG,
                "conv2d_igemm_bf16x3: column sums are produced with the split output only");
   WCMC_REQUIRE((y != nullptr) != (y_split != nullptr), WCMC_ERR_BAD_ARG,
@@ -3583,7 +3673,8 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   p.gate = (const u16*)gate_split; p.gate_act = gate_act; p.gate_slope = gate_slope;
   p.gate_mask = (const unsigned char*)gate_mask; p.mask_out = (unsigned char*)mask_out;
   p.ks = ks; p.pad = pad; p.act = act; p.slope = slope;
-  const XKPlan q = x_plan_k(Cin, ks);
+  const XKPlan q = x_plan_k(Cin, ks, terms == 2 ? 1 : 2, Cout);
+  p.ap = q.ap;
   p.Kp = p.Cpi; p.Kt = q.Kt; p.Np = round_up(Cout, 16);
   p.CS = q.CS; p.nslabs = q.nslabs; p.SPS = q.Ks / 32; p.PXS = q.halo ? q.PXS : 0;
   p.CSl = q.CSl; p.SPSl = q.Ksl / 32;
@@ -3662,7 +3753,7 @@ extern "C" int wcmc_conv1x1_pair_bf16x3(const void* x_split, int N, int H, int W
   p.mask_out = (unsigned char*)mask1;
   p.ks = 1; p.pad = 0; p.act = act1; p.slope = slope1;
   p.Kp = p.Cpi; p.Kt = round_up(p.Cpi, 32); p.Np = round_up(Cout1, 16);
-  p.CS = p.Kp; p.nslabs = 1; p.SPS = p.Kt / 32; p.PXS = 0; p.CSl = p.CS; p.SPSl = p.SPS;
+  p.CS = p.Kp; p.nslabs = 1; p.SPS = p.Kt / 32; p.PXS = 0; p.CSl = p.CS; p.SPSl = p.SPS; p.ap = 2;
   p.tilesY = p.tilesX = 0; p.G = x_colsum_rows(N, H, W); p.colsum = colsum1;
   p.M = (int64_t)N * H * W;
   const int cp2 = round_up(Cout2, 4);
@@ -3700,23 +3791,26 @@ extern "C" size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo
   return x_plan_wgrad(N, Ho, Wo, Cout, Cin, ks).bytes;
 }
 
-template <int TM>
+template <int TM, int PL = 2>
 static int launch_xwgrad(const XWgradParams& p, hipStream_t stream) {
-  constexpr size_t lds_stage = (size_t)2 * 64 * (xw_stride(TM * 16) + xw_stride(64)) * sizeof(u16);
+  constexpr size_t lds_stage = (size_t)PL * 64 * (xw_stride(TM * 16) + xw_stride(64)) * sizeof(u16);
   constexpr size_t lds_red = (size_t)TM * 16 * (64 + 4) * sizeof(float);
   constexpr size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
   const int per_split = p.ks * p.ks * p.coBlocks * p.ciBlocks;
   const dim3 grid((unsigned)(((p.S + 7) / 8) * 8 * per_split));
-  hipLaunchKernelGGL(conv_wgrad_bf16x3_kernel<TM>, grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<TM, PL>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_wgrad_bf16x3");
 }
 
 extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W, int Cin, const void* dy_split,
                                         int Cout, int ks, int pad, float* dw, float* db, void* workspace,
-                                        size_t workspace_bytes, int phase, const float* dy_colsum_partial, void* stream) {
+                                        size_t workspace_bytes, int phase, const float* dy_colsum_partial, int terms,
+                                        void* stream) {
   WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ks > 0 && pad >= 0 && dw && workspace &&
                    x_split && dy_split,
                WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: bad argument");
+  WCMC_REQUIRE(terms == 3 || terms == 1, WCMC_ERR_BAD_ARG,
+               "conv2d_wgrad_bf16x3: terms must be 3 (hi*hi + hi*lo + lo*hi) or 1 (the hi planes only)");
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   WCMC_REQUIRE(Ho > 0 && Wo > 0, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: empty output");
   WCMC_REQUIRE(aligned16(x_split) && aligned16(dy_split), WCMC_ERR_ALIGNMENT,
@@ -3734,6 +3828,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
   WCMC_REQUIRE(xb < 0x7ff00000u && yb < 0x7ff00000u, WCMC_ERR_BAD_ARG,
                "conv2d_wgrad_bf16x3: operand larger than 2 GiB (split the batch)");
   p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+  p.xps = 4 * p.Cpi; p.yps = 4 * p.Cpo;
   WCMC_REQUIRE(phase >= 0 && phase <= 2, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: phase must be 0, 1 or 2");
   int rc = 0;
   if (phase != 2 && pl.rows) {
@@ -3743,17 +3838,24 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
     { const char* e = getenv("WCMC_WGRAD_ROWS8_PRIO"); q.prio = e ? atoi(e) : 8; if (q.prio < 0 || q.prio > 13) q.prio = 0; }   // (scripts/time_wgrad_rows8.py: 6-8 of 14 best)
     q.pad = pad; q.slabs = p.slabs; q.S = pl.S; q.rps = pl.rps; q.R = pl.R; q.Np = pl.Np; q.Cq = pl.Cq;
     q.coBlocks = pl.coBlocks; q.ciBlocks = pl.ciBlocks; q.x_bytes = p.x_bytes; q.dy_bytes = p.dy_bytes;
-    const int key = ks * 100 + pl.rTM * 10 + pl.rNW;
+    q.xps = p.xps; q.yps = p.yps;
+    const int key = (terms == 1 ? 1000 : 0) + ks * 100 + pl.rTM * 10 + pl.rNW;
     switch (key) {
       case 577: rc = launch_xwgrad_rows<5, 7, 7>(q, st); break;
       case 573: rc = launch_xwgrad_rows<5, 7, 3>(q, st); break;
       case 388: rc = launch_xwgrad_rows<3, 8, 8>(q, st); break;
       case 344: rc = launch_xwgrad_rows<3, 4, 4>(q, st); break;
       case 188: rc = launch_xwgrad_rows<1, 8, 8>(q, st); break;
+      case 1577: rc = launch_xwgrad_rows<5, 7, 7, 1>(q, st); break;
+      case 1573: rc = launch_xwgrad_rows<5, 7, 3, 1>(q, st); break;
+      case 1388: rc = launch_xwgrad_rows<3, 8, 8, 1>(q, st); break;
+      case 1344: rc = launch_xwgrad_rows<3, 4, 4, 1>(q, st); break;
+      case 1188: rc = launch_xwgrad_rows<1, 8, 8, 1>(q, st); break;
       default: WCMC_REQUIRE(false, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: no filter-row instance for the plan");
     }
   } else if (phase != 2) {
-    rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
+    if (terms == 1) rc = pl.TM == 7 ? launch_xwgrad<7, 1>(p, st) : launch_xwgrad<4, 1>(p, st);
+    else rc = pl.TM == 7 ? launch_xwgrad<7>(p, st) : launch_xwgrad<4>(p, st);
   }
   if (rc || phase == 1) return rc;
   // the slab reduction; with the column sums of dy at hand its launch also finishes the bias gradient (extra grid rows)

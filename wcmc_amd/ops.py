@@ -17,16 +17,36 @@ from ._lib import check, lib
 ACT = {"linear": 0, "relu": 1, "leaky_relu": 2}
 LEAKY_SLOPE = 0.01
 
-# Arithmetic of the conv GEMMs: "bf16x3" = split-bf16 operands (hi + lo), 3 bf16 MFMAs per product,
-# fp32 accumulate (conv_bf16x3.hip); "fp32" = exact fp32 MFMA (conv.hip).  Both are HIP paths.
-PRECISION = os.environ.get("WCMC_PRECISION", "bf16x3")
-assert PRECISION in ("bf16x3", "fp32"), PRECISION
+# Arithmetic of the conv GEMMs (all HIP paths; WCMC_PRECISION):
+#   "bf16x321" (default)  split-bf16 operands (hi + lo planes, fp32 accumulate; conv_bf16x3.hip) with the number of bf16 MFMAs
+#                         per product chosen per GEMM role by the measured precision ladder (profiles/r03_precision_ladder.txt):
+#                         forward 3 (hi*hi + hi*lo + lo*hi), data gradient 2 (dy_hi x (W_hi + W_lo)), weight gradient 1
+#                         (dy_hi x x_hi) -- rounding dy and x to bf16 is independent from pixel to pixel and averages out over
+#                         the pixel sums, a rounded W would not; outputs and losses are those of "bf16x3" bit for bit
+#   "bf16x3"              three MFMAs per product in every role (rounds 1-2)
+#   "fp32"                exact fp32 MFMA (conv.hip)
+MODES = ("bf16x321", "bf16x3", "fp32")
+PRECISION = os.environ.get("WCMC_PRECISION", "bf16x321")
+assert PRECISION in MODES, PRECISION
 
 
 def set_precision(mode):
     global PRECISION
-    assert mode in ("bf16x3", "fp32"), mode
+    assert mode in MODES, mode
     PRECISION = mode
+
+
+def split_path():
+    """True when the conv chains run on the split-bf16 GEMMs (either bf16 mode)."""
+    return PRECISION != "fp32"
+
+
+def wgrad_terms():
+    return 1 if PRECISION == "bf16x321" else 3
+
+
+def dgrad_terms():
+    return 2 if PRECISION == "bf16x321" else 3
 
 # Optional per-launch timing (bench.py): HIP events recorded on the launch stream around an op.
 _PROFILER = None
@@ -423,10 +443,16 @@ def unsplit_debug(t, n, c, h, w):
     return (v[:, :, :, 0] + v[:, :, :, 1])[..., :c].permute(0, 3, 1, 2)
 
 
+def _dgrad_mode(terms=None):
+    """Packing mode of the data-gradient weights: 1 = three-term launch, 2 = the K order of a two-term launch (x hi plane only)."""
+    return 2 if (dgrad_terms() if terms is None else terms) == 2 else 1
+
+
 def _pack_x(weight, mode):
+    """mode 0: forward orientation; 1 / 2: the data-gradient orientation for a three- / two-term launch (_dgrad_mode)."""
     cout, cin, ks, _ = weight.shape
     rows, kch = (cout, cin) if mode == 0 else (cin, cout)
-    wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks), device=weight.device, dtype=torch.int16)
+    wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks, mode), device=weight.device, dtype=torch.int16)
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
@@ -453,9 +479,9 @@ def _pack_chain_x(weights, ks):
         keep.append(w)
         cout, cin = w.shape[0], w.shape[1]
         pair = []
-        for mode in (0, 1):
+        for mode in (0, _dgrad_mode()):
             rows, kch = (cout, cin) if mode == 0 else (cin, cout)
-            wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks), device=dev, dtype=torch.int16)
+            wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks, mode), device=dev, dtype=torch.int16)
             ws.append(w.data_ptr()); outs.append(wp.data_ptr()); couts.append(cout); cins.append(cin); modes.append(mode)
             pair.append(wp)
         keep.append(pair)
@@ -496,8 +522,10 @@ def _wgrad_class(n, ho, cin, cout, ks):
 
 
 def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, gate_act="linear", colsum=False,
-                 gate_mask=None, mask_out=False):
+                 gate_mask=None, mask_out=False, terms=3):
     """One split-bf16 implicit-GEMM launch.  xs: split tensor of dims (n,cin,h,w).
+    terms: bf16 MFMAs per product -- 3, or 2 = the hi plane of xs only (wp packed with mode 2: the data gradient of the
+    "bf16x321" mode, whose xs is dy).
     Returns a split tensor when out_split else an fp32 NHWC view; with colsum=True also the per-tile
     column sums of the result (the consumer layer's bias gradient, see colsum_finish_raw); with mask_out=True
     also the (hi plane > 0) bit mask of the result, which a later launch can take as gate_mask instead of
@@ -525,7 +553,7 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     with _Timed(cls, *work):
         check(lib().wcmc_conv2d_igemm_bf16x3(_ptr(xs), n, h, w, cin, _ptr(wp), _ptr(bias), *yv, _ptr(ysp), cout,
                                              ks, pad, ACT[act], LEAKY_SLOPE, _ptr(gate), ACT[gate_act], LEAKY_SLOPE,
-                                             _ptr(part), _ptr(gate_mask), _ptr(mask), _stream()), "conv2d_igemm_bf16x3")
+                                             _ptr(part), _ptr(gate_mask), _ptr(mask), terms, _stream()), "conv2d_igemm_bf16x3")
     out = ysp if out_split else yf
     ret = (out,) + ((part,) if colsum else ()) + ((mask,) if mask_out else ())
     return ret if len(ret) > 1 else out
@@ -558,7 +586,7 @@ def colsum_finish_raw(part, dims):
     return db
 
 
-def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=True, colsum_part=None):
+def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=True, colsum_part=None, terms=None):
     """dw (and db) of one layer.  colsum_part: the per-tile column sums of dys that the launch producing dys left; the bias
     gradient is then finished by the slab-reduction launch itself (no column-sum pass, no finish launch)."""
     n, cin, h, w = xdims
@@ -569,13 +597,14 @@ def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=Tr
     db = torch.empty(cout, device=xs.device, dtype=torch.float32) if (want_bias or colsum_part is not None) else None
     args = (_ptr(xs), n, h, w, cin, _ptr(dys), cout, ks, pad, _ptr(dw), _ptr(db), _ptr(ws), ws.numel() * 4)
     cs = _ptr(colsum_part)
+    terms = wgrad_terms() if terms is None else terms
     if _PROFILER is None:
-        check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 0, cs, _stream()), "conv2d_wgrad_bf16x3")
+        check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 0, cs, terms, _stream()), "conv2d_wgrad_bf16x3")
     else:       # bracket the split-K GEMM launch alone; the slab reduce + bias gradient is its own class
         with _Timed(_wgrad_class(n, ho, cin, cout, ks), 2.0 * n * ho * wo * cout * cin * ks * ks, "flop"):
-            check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, cs, _stream()), "conv2d_wgrad_bf16x3")
+            check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, cs, terms, _stream()), "conv2d_wgrad_bf16x3")
         with _Timed("conv_wgrad_finish", 0.0, "flop"):
-            check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 2, cs, _stream()), "conv2d_wgrad_bf16x3")
+            check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 2, cs, terms, _stream()), "conv2d_wgrad_bf16x3")
     return dw, db
 
 
@@ -605,6 +634,7 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
     pair = (ks == 1 and pad == 0 and nl >= 2 and
             lib().wcmc_conv1x1_pair_supported(params[2 * nl - 4].shape[1], params[2 * nl - 4].shape[0],
                                               params[2 * nl - 2].shape[0]))
+    ctx.terms = (wgrad_terms(), dgrad_terms())     # the backward multiplies as the mode of ITS forward says
     packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks) if PACK_CHAIN and 2 * nl <= 20 else None
     ctx.wp1 = [pk[1] for pk in packs] if packs is not None else None      # the data-gradient orientation, for the backward
     pack0 = (lambda l: packs[l][0]) if packs is not None else (lambda l: _pack_x(params[2 * l], 0))
@@ -675,7 +705,8 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
     side = _side_stream(dys.device)
     keep = []
     wp1 = getattr(ctx, "wp1", None)
-    pack1 = (lambda l: wp1[l]) if wp1 is not None else (lambda l: _pack_x(ws[l], 1))
+    wterms, dterms = ctx.terms
+    pack1 = (lambda l: wp1[l]) if wp1 is not None else (lambda l: _pack_x(ws[l], _dgrad_mode(dterms)))
     for l in range(nl - 1, -1, -1):
         wt = ws[l]
         cout = wt.shape[0]
@@ -683,7 +714,7 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None,
-                                            colsum_part=part if FUSE_BIAS_GRAD else None)
+                                            colsum_part=part if FUSE_BIAS_GRAD else None, terms=wterms)
                 if part is not None and not FUSE_BIAS_GRAD:
                     db = colsum_finish_raw(part, dims[l + 1])
             dw.record_stream(main)
@@ -692,7 +723,7 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
             keep.append(part)
         else:
             dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None,
-                                        colsum_part=part if FUSE_BIAS_GRAD else None)
+                                        colsum_part=part if FUSE_BIAS_GRAD else None, terms=wterms)
             if part is not None and not FUSE_BIAS_GRAD:
                 db = colsum_finish_raw(part, dims[l + 1])
         grads[2 * l], grads[2 * l + 1] = dw, db
@@ -708,11 +739,11 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
             wpt = pack1(l)
             g = dict(gate_mask=masks[l - 1]) if USE_GATE_MASK else dict(gate=xs[l])
             dys, part = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
-                                     out_split=True, gate_act=acts[l - 1], colsum=True, **g)
+                                     out_split=True, gate_act=acts[l - 1], colsum=True, terms=dterms, **g)
         elif need_dx and dx is None:
             wpt = pack1(l)
             dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
-                              out_split=False)
+                              out_split=False, terms=dterms)
     if side is not None:
         main.wait_stream(side)
     del keep
@@ -851,13 +882,13 @@ class _CatUpsampleChainX(torch.autograd.Function):
 
 def cat_upsample_chain(deep, skip, ksize, pad, acts, params):
     """``conv_chain(cat([upsample2(deep), skip], 1), ...)``; one autograd node on the split-bf16 path."""
-    if FUSE_CHAIN_GLUE and PRECISION == "bf16x3" and deep.shape[1] % 8 == 0:
+    if FUSE_CHAIN_GLUE and split_path() and deep.shape[1] % 8 == 0:
         return _CatUpsampleChainX.apply(as_nhwc(deep), as_nhwc(skip), (ksize, pad, tuple(acts)), *params)
     return cat_broadcast_chain(upsample2(deep), skip, 1, ksize, pad, acts, params)
 
 
 def conv_chain(x, ksize, pad, acts, params):
-    fn = _ConvChainX if PRECISION == "bf16x3" else _ConvChain
+    fn = _ConvChainX if split_path() else _ConvChain
     return fn.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
 
 
@@ -867,7 +898,7 @@ FUSE_CHAIN_GLUE = os.environ.get("WCMC_FUSE_CHAIN_GLUE", "1") != "0"
 
 def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
     """``y = conv_chain(x, ...); return y, spp_mean(y, s)``; one autograd node on the split-bf16 path."""
-    if FUSE_CHAIN_GLUE and PRECISION == "bf16x3" and acts[-1] == "linear":
+    if FUSE_CHAIN_GLUE and split_path() and acts[-1] == "linear":
         pre = getattr(x, "_wcmc_split", None)
         if pre is not None and pre[0] == (x._version, None) and not x.requires_grad:
             return _ChainSppMeanX.apply(x, s, (ksize, pad, tuple(acts)), *params)      # channel-first x, split attached
@@ -878,7 +909,7 @@ def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
 
 def cat_broadcast_chain(flat, prop, s, ksize, pad, acts, params):
     """``conv_chain(cat_broadcast(flat, prop, s), ...)``; fused into one autograd node on the split-bf16 path."""
-    if FUSE_CHAIN_GLUE and PRECISION == "bf16x3" and flat.shape[1] % 8 == 0:
+    if FUSE_CHAIN_GLUE and split_path() and flat.shape[1] % 8 == 0:
         return _CatBroadcastChainX.apply(as_nhwc(flat), as_nhwc(prop), s, (ksize, pad, tuple(acts)), *params)
     return conv_chain(cat_broadcast(flat, prop, s), ksize, pad, acts, params)
 
@@ -973,7 +1004,7 @@ FUSE_KERNEL_APPLY = os.environ.get("WCMC_FUSE_KA", "0") != "0"
 
 def chain_kernel_apply(x, data, ksize, pad, acts, params):
     """``kernel_apply(data, conv_chain(x, ...))`` with ``data`` already cropped to the chain's output size."""
-    if (FUSE_CHAIN_GLUE and PRECISION == "bf16x3" and acts[-1] == "linear" and not data.requires_grad
+    if (FUSE_CHAIN_GLUE and split_path() and acts[-1] == "linear" and not data.requires_grad
             and FUSE_KERNEL_APPLY):
         return _ChainKernelApplyX.apply(as_nhwc(x), data, (ksize, pad, tuple(acts)), *params)
     return kernel_apply(data, conv_chain(x, ksize, pad, acts, params))

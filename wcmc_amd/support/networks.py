@@ -40,7 +40,7 @@ class PathNet(nn.Module):
             return cached[1]
         bs, spp, nf, h, w = paths.shape
         flat = paths.reshape(bs * spp, nf, h, w)
-        if (ops.FUSE_CHAIN_GLUE and ops.PRECISION == "bf16x3" and not paths.requires_grad and nf <= 64 and paths.is_cuda
+        if (ops.FUSE_CHAIN_GLUE and ops.split_path() and not paths.requires_grad and nf <= 64 and paths.is_cuda
                 and bs * spp * h <= 65535):
             # the embedding chain is the only reader: transpose + split in one pass, once for both backbones
             flat = ops.presplit_shared(flat.detach())
