@@ -34,6 +34,27 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (not 
 PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
 _ROWS8 = os.environ.get("WCMC_WGRAD_ROWS8", "1")[:1] != "0"     # which filter-row weight-gradient kernel the library launches
 _ROWS8_XE = 0 if os.environ.get("WCMC_WGRAD_ROWS8_XE", "1")[:1] == "0" else 1
+PROFILE_ROUND = "r03"              # profiles/<round>_pmc_summary.json, <round>_bench_kernel_stats.csv: the evidence of THIS binary
+
+
+def rocprof_names(wgrad_terms):
+    """profiler class -> the rocprofv3 name of the ONE kernel its launches run (tests/test_cpu_host.py checks every name
+    against the committed kernel stats).  Template arguments of conv_halo64: <cout tiles, weight stages, pixel tiles per wave,
+    debug, halo stride, planes of x multiplied>; of conv_wgrad_rows8: <debug, dealing of the left-over tiles, planes multiplied>."""
+    return {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 8, 16, 0, 2, 2>",
+            "conv_halo64_pt4": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 2>",
+            "conv_halo64_pt3": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 2>",
+            "conv_halo64_cs32": "wcmc::conv_halo64_bf16x3_kernel<7, 2, 3, 0, 160, 2>",
+            "conv_halo64_pt4_x2": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1>",
+            "conv_halo64_pt3_x2": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1>",
+            "conv_wgrad_rows": ("wcmc::conv_wgrad_rows8_bf16x3_kernel<0, %d, %d>" % (_ROWS8_XE if wgrad_terms == 3 else 1, 1 if wgrad_terms == 1 else 2)) if _ROWS8
+                               else "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, %d>" % (1 if wgrad_terms == 1 else 2),
+            "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}
+
+
+# bf16 MFMAs issued per algorithmic multiply-add, by profiler class (forward 3; "_x2" data gradients 2; weight gradient: the mode's)
+def mfma_terms(cls, wgrad_terms):
+    return 2.0 if cls.endswith("_x2") else float(wgrad_terms) if cls.startswith("conv_wgrad") else 3.0
 B_PER_GPU, SPP, PATCH = 8, 8, 128
 
 
@@ -141,26 +162,27 @@ def kernel_apply_probe(device, iters=24, nsets=4):
 
 
 def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_summary.json):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/<round>_pmc_summary.json):
     (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md section HBM."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_summary.json")
     if not os.path.isfile(path):
         return {}
     with open(path) as f:
         d = json.load(f)
     pick = {}
     for k, v in d.items():
-        for tag, key in (("conv_halo_bf16x3_kernel<7, 8, 16", "conv_halo7"), ("conv_halo64_bf16x3_kernel<7, 3, 4", "conv_halo64_pt4"),
-                         ("conv_halo64_bf16x3_kernel<7, 3, 3", "conv_halo64_pt3"), ("conv_halo64_bf16x3_kernel<7, 2, 3", "conv_halo64_cs32"),
-                         ("conv_wgrad_rows8_bf16x3_kernel<0, " if _ROWS8 else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7", "conv_wgrad_rows"),
+        for tag, key in (("conv_halo_bf16x3_kernel<7, 8, 16", "conv_halo7"), ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 2>", "conv_halo64_pt4"),
+                         ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 2>", "conv_halo64_pt3"), ("conv_halo64_bf16x3_kernel<7, 2, 3", "conv_halo64_cs32"),
+                         ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1>", "conv_halo64_pt4_x2"), ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1>", "conv_halo64_pt3_x2"),
+                         ("conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>" if _ROWS8 else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, 1>", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("kernel_apply_strip_kernel<false", "kernel_apply_fwd"), ("kernel_apply_strip_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
                 shape = ("64x128x128 64->64 1x1 hidden layer (PathNet embedding): 536.9 MB algorithmic" if key == "conv_pw" else
-                         "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles)" if key == "conv_halo64_pt3" else
+                         "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles)" if key.startswith("conv_halo64_pt3") else
                          "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else "logits (8,441,92,92)")
                 pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "shape": shape,
-                             "source": "profiles/r02_pmc_summary.json"}
+                             "source": "profiles/%s_pmc_summary.json" % PROFILE_ROUND}
     return pick
 
 
@@ -266,6 +288,10 @@ def self_launch(n, argv):
     the workers' status.  (Never an exec of a process that touched the GPU; this parent never does.)"""
     import socket
     import subprocess
+    # preflight, before any worker exists (counting devices does not initialise the GPU on this image)
+    have = torch.cuda.device_count()
+    if have < n and "--share-gpu" not in argv:
+        sys.exit("bench.py: --gpus %d but this node shows %d GPU(s) (rocm-smi / HIP_VISIBLE_DEVICES); nothing was launched" % (n, have))
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -293,8 +319,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="smoke test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL refuses two ranks "
                          "on one device); the printed throughput is then meaningless")
-    ap.add_argument("--precision", choices=("bf16x3", "fp32"), default=None,
-                    help="conv GEMM arithmetic: split-bf16 (default) or exact fp32 MFMA (roofline vs the 157.3 TF/s peak)")
+    ap.add_argument("--precision", choices=("bf16x321", "bf16x3", "fp32"), default=None,
+                    help="conv GEMM arithmetic: split-bf16 with 3 / 2 / 1 MFMAs per product in forward / data gradient / weight "
+                         "gradient (default), 3 everywhere (rounds 1-2), or exact fp32 MFMA (roofline vs the 157.3 TF/s peak)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus, sys.argv[1:])
@@ -307,7 +334,14 @@ def main():
     if args.share_gpu:
         assert args.backend == "gloo", "--share-gpu needs --backend gloo"
         os.environ["LOCAL_RANK"] = "0"
-    rank, world, local = wd.init(args.backend)
+    if not args.share_gpu and torch.cuda.device_count() < int(os.environ.get("WORLD_SIZE", "1")):
+        sys.exit("bench.py: WORLD_SIZE=%s but this node shows %d GPU(s); refusing to start (one rank per GPU)" %
+                 (os.environ.get("WORLD_SIZE"), torch.cuda.device_count()))
+    try:
+        rank, world, local = wd.init(args.backend)
+    except Exception as err:            # RCCL / rendezvous failure: a non-zero exit with the reason, never a re-exec or a silent fallback
+        print("bench.py: torch.distributed (%s) failed to initialise: %r" % (args.backend, err), file=sys.stderr, flush=True)
+        sys.exit(3)
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or "
                  "without a launcher: bench.py starts its own workers)" % (args.gpus, world, args.gpus))
@@ -358,7 +392,10 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
-    elapsed = wd.max_over_ranks(time.perf_counter() - t0, device)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = wd.max_over_ranks(my_elapsed, device)
+    rank_ms = wd.gather_floats(my_elapsed / args.steps * 1e3, device)        # every rank's own ms per step (rank 0 reports min / max)
+    comm = wd.time_allreduce(itf.fused_optim, group, device) if world > 1 else None
     last_losses = {k: float(v) for k, v in itf.last_loss_dict.items()}       # of step warmup + steps, this rank
     ops.set_profiler(None)
     prof_elapsed = elapsed
@@ -408,21 +445,18 @@ def main():
                 return None
             rate = d["work"] / (d["ms"] * 1e-3)
             if bound == "mfma":
-                peak = PEAK_BF16_MFMA_TFLOPS if ops.PRECISION == "bf16x3" else PEAK_FP32_MFMA_TFLOPS
+                peak = PEAK_BF16_MFMA_TFLOPS if ops.split_path() else PEAK_FP32_MFMA_TFLOPS
                 ach, unit = rate / 1e12, "TFLOP/s"
             else:
                 ach, peak, unit = rate / 1e9, PEAK_HBM_GBS, "GB/s"
             extra = {}
-            if bound == "mfma" and ops.PRECISION == "bf16x3":
-                # 3 bf16 MFMAs per algorithmic multiply-add (+12 % cout and 5 % k padding): the MFMA pipe does
-                # ~3.5x the counted FLOPs; for scale, the exact-fp32 MFMA peak is 157.3 TFLOP/s
-                extra = {"mfma_flops_per_algorithmic_flop": 3.0, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 3)}
-            rocprof_name = {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 8, 16, 0, 2>",
-                            "conv_halo64_pt4": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80>",
-                            "conv_halo64_pt3": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80>",
-                            "conv_halo64_cs32": "wcmc::conv_halo64_bf16x3_kernel<7, 2, 3, 0, 160>",
-                            "conv_wgrad_rows": "wcmc::conv_wgrad_rows8_bf16x3_kernel<0, %d>" % _ROWS8_XE if _ROWS8 else "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0>",
-                            "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}.get(name, name + " (several kernels)")
+            if bound == "mfma" and ops.split_path():
+                # bf16 MFMAs per algorithmic multiply-add (+12 % cout and 5 % k padding on top): `frac` counts algorithmic
+                # FLOPs once against the dense bf16 peak, so its ceiling is 1 / terms; for scale, the exact-fp32 MFMA peak is 157.3 TFLOP/s
+                t = mfma_terms(name, ops.wgrad_terms())
+                extra = {"mfma_flops_per_algorithmic_flop": t, "frac_of_issued_mfma_flops": round(ach * t / peak, 4),
+                         "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 3)}
+            rocprof_name = rocprof_names(ops.wgrad_terms()).get(name, name + " (several kernels)")
             if ops.PRECISION == "fp32":
                 rocprof_name = ("wcmc::conv_wgrad_kernel" if "wgrad" in name else "wcmc::conv_igemm_kernel") + \
                     " (exact fp32 MFMA; launches of class %s)" % name
@@ -435,12 +469,12 @@ def main():
         # dgrad: 16x16 tiles, 12x16 tiles, 12x16 with 32-channel slabs for the 441-channel data gradient; conv_halo7 = the 8x16
         # kernel they replace, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows8_bf16x3_kernel (WCMC_WGRAD_ROWS8=0: ..._rows_bf16x3_kernel<5,7,7>);
         # conv_igemm / conv_wgrad collect the other GEMM kernels
-        conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_cs32", "conv_halo7", "conv_wgrad_rows", "conv_igemm",
-                                 "conv_wgrad")
+        conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_pt3_x2", "conv_halo64_pt4_x2", "conv_halo64_cs32", "conv_halo7",
+                                 "conv_wgrad_rows", "conv_igemm", "conv_wgrad")
                      if k in summ]
         # the roofline kernel: the single kernel (one rocprof name) with the most time per step; the two catch-all classes
         # collect several kernels and are reported under roofline_other_conv (exact-fp32 mode: one kernel per class anyway)
-        single = ([k for k in conv_keys if k not in ("conv_igemm", "conv_wgrad")] or conv_keys) if ops.PRECISION == "bf16x3" else conv_keys
+        single = ([k for k in conv_keys if k not in ("conv_igemm", "conv_wgrad")] or conv_keys) if ops.split_path() else conv_keys
         dominant = max(single, key=lambda k: summ[k]["ms"]) if conv_keys else None
         ka = kernel_apply_probe(device)
         traffic = pmc_traffic()
@@ -458,9 +492,14 @@ def main():
             "value": round(value, 3), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3" if ops.PRECISION == "bf16x3" else "f32",
-            "data": "synthetic", "rccl_ranks": world if args.backend == "nccl" else 0,
-            "collective_backend": "rccl" if args.backend == "nccl" else args.backend + (" (smoke test, shared GPU)" if args.share_gpu else ""),
+            "dtype": ops.PRECISION if ops.split_path() else "f32",
+            "data": "synthetic",
+            # from the communicator, not from the command line: ranks of the process group whose backend is RCCL ("nccl" on ROCm)
+            "rccl_ranks": (torch.distributed.get_world_size(group) if world > 1 and torch.distributed.get_backend(group) == "nccl"
+                           else 1 if world == 1 and args.backend == "nccl" else 0),
+            "collective_backend": ("rccl" if args.backend == "nccl" else args.backend + (" (smoke test, shared GPU)" if args.share_gpu else "")),
+            "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
+            "allreduce": comm,
             # loss_dict of the last timed step on rank 0 (seeded weights, inputs and pairings: reproducible run to run
             # with the same binary; a stream-ordering race in the captured step would show here)
             "losses_last_step": {k: round(v, 6) for k, v in last_losses.items()},
@@ -470,10 +509,22 @@ def main():
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.eager else "one hipGraph replay per step + eager all-reduce/clip+Adam",
                        "feature_mse_rng": "cpu (reference stream)" if args.cpu_rng else "device",
-                       "precision": ("conv GEMMs: split-bf16 operands (hi+lo), 3 x v_mfma_f32_16x16x32_bf16 per "
-                                     "product, fp32 accumulate (roofline counts algorithmic FLOPs once against "
-                                     "the dense bf16 MFMA peak, so frac <= 1/3); everything else fp32")
-                       if ops.PRECISION == "bf16x3" else "fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate"},
+                       "precision": ("conv GEMMs: split-bf16 operands (hi + lo planes), v_mfma_f32_16x16x32_bf16, fp32 accumulate; per "
+                                     "product 3 MFMAs in the forward (hi*hi + hi*lo + lo*hi), 2 in the data gradients that have a "
+                                     "two-term instance (dy_hi x (W_hi + W_lo): KPCN 5x5, U-Net 3x3; the 1x1 ones still 3), 1 in the "
+                                     "weight gradients (dy_hi x x_hi) -- the rungs of profiles/r03_precision_ladder.txt that hold "
+                                     "every parity bar; outputs and losses are bit-identical to the all-three-term mode "
+                                     "(--precision bf16x3).  roofline counts algorithmic FLOPs once against the dense bf16 MFMA "
+                                     "peak, so frac <= 1 / (MFMAs per product); everything else fp32")
+                       if ops.PRECISION == "bf16x321" else
+                       ("conv GEMMs: split-bf16 operands (hi+lo), 3 x v_mfma_f32_16x16x32_bf16 per product in every GEMM, fp32 "
+                        "accumulate (frac <= 1/3); everything else fp32") if ops.PRECISION == "bf16x3"
+                       else "fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate"},
+            # the whole step against the matrix peak: 549.6 GF algorithmic per patch / step time / dense peak of the mode
+            "whole_step": {"algorithmic_tflop_per_step": round(549.6e9 * B_PER_GPU / 1e12, 3),
+                           "achieved_tflops": round(549.6e9 * global_batch * args.steps / elapsed / 1e12 / world, 1),
+                           "frac_of_mfma_peak": round(549.6e9 * global_batch * args.steps / elapsed / 1e12 / world /
+                                                      (PEAK_BF16_MFMA_TFLOPS if ops.split_path() else PEAK_FP32_MFMA_TFLOPS), 4)},
             "roofline": dict(roof(dominant, "mfma"), traffic=traffic.get(dominant)) if dominant else None,
             "roofline_other_conv": [dict(roof(k, "mfma"), traffic=traffic.get(k)) for k in conv_keys if k != dominant],
             "roofline_pointwise": (dict(roof("conv_pw", "hbm"), traffic=traffic.get("conv_pw")) if roof("conv_pw", "hbm") else None),

@@ -13,7 +13,8 @@ w = torch.randn(100, 100, 5, 5, device=dev) * 0.02
 b = torch.zeros(100, device=dev)
 dy = o.to_nhwc_raw(torch.randn(n, 100, h - 4, h - 4, device=dev))
 xs, dys = o.split_raw(x), o.split_raw(dy)
-wp, wpt = o._pack_x(w, 0), o._pack_x(w, 1)
+wp, wpt, wpt2 = o._pack_x(w, 0), o._pack_x(w, 1), o._pack_x(w, 2)
+dy3s = o.split_raw(o.to_nhwc_raw(torch.randn(n, 100, 104, 104, device=dev)))        # its data gradient: 108x108 outputs (12x16 tiles)
 h3 = 108                                   # 104x104 outputs: the 12x16-tile instance of the 5x5 kernel (116 -> 112: 16x16 tiles)
 x3s = o.split_raw(o.to_nhwc_raw(torch.randn(n, c, h3, h3, device=dev)))
 x1s = o.split_raw(o.to_nhwc_raw(torch.randn(64, 64, 128, 128, device=dev)))
@@ -23,9 +24,12 @@ data = torch.rand(8, 3, 92, 92, device=dev)
 g = torch.randn(8, 3, 92, 92, device=dev)
 def run():
     y = o.conv2d_x_raw(xs, (n, c, h, h), wp, b, 100, 5, 0, "relu", out_split=True)          # bf16x3 fwd
-    o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu")
+    o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu")   # three-term dgrad (bf16x3 mode)
+    o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt2, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu", terms=2)   # two-term dgrad, 16x16 tiles
+    o.conv2d_x_raw(dy3s, (n, 100, 104, 104), wpt2, None, 100, 5, 4, "linear", out_split=True, gate=x3s, gate_act="relu", terms=2)     # ... 12x16 tiles
     o.conv2d_x_raw(x3s, (n, c, h3, h3), wp, b, 100, 5, 0, "relu", out_split=True)
-    o.conv2d_wgrad_x_raw(xs, (n, c, h, h), dys, 100, 5, 0, (100, 100, 5, 5))
+    o.conv2d_wgrad_x_raw(xs, (n, c, h, h), dys, 100, 5, 0, (100, 100, 5, 5), terms=1)     # one-term weight gradient (default mode)
+    o.conv2d_wgrad_x_raw(xs, (n, c, h, h), dys, 100, 5, 0, (100, 100, 5, 5), terms=3)
     o.conv2d_x_raw(x1s, (64, 64, 128, 128), w1p, b1, 64, 1, 0, "relu", out_split=True)       # PathNet 1x1 layer (HBM-bound)
     ld = logits.clone().requires_grad_(True)
     out = o.kernel_apply(data, ld)

@@ -1,12 +1,14 @@
-# Round-2 evidence behind profiles/: the bench line, the two rocprofv3 kernel-stats runs (graphed, eager) and the PMC passes.
-#   gpurun -- 'bash scripts/refresh_profiles.sh r02'      (then copy the summaries from gpurun_out/ into profiles/)
+# Evidence behind profiles/: the bench lines, the two rocprofv3 kernel-stats runs (graphed, eager) and the PMC passes.
+#   gpurun -- 'bash scripts/refresh_profiles.sh r03'      (then copy the summaries from gpurun_out/<tag>/ into profiles/)
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O/pmc
 python3 $R/bench.py --steps 30 --warmup 5 > $O/bench_line.log 2>&1
 tail -1 $O/bench_line.log | cut -c1-200
+python3 $R/bench.py --steps 20 --warmup 5 --precision bf16x3 --no-cpu-baseline > $O/bench_line_bf16x3.log 2>&1
+tail -1 $O/bench_line_bf16x3.log | cut -c1-200
 python3 $R/bench.py --steps 10 --warmup 3 --precision fp32 --no-cpu-baseline > $O/bench_line_fp32.log 2>&1
 tail -1 $O/bench_line_fp32.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
@@ -21,6 +23,7 @@ for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VA
 done
 cd $R
 python3 scripts/pmc_summary.py $O/pmc > $O/pmc_summary.json
+python3 scripts/trace_gaps.py $O/prof_graph > $O/step_trace_gaps.txt 2>&1
 find $O/prof_graph $O/prof_eager -name "*kernel_stats.csv" | head
 # keep the merge under the 64 MiB limit: only the stats / counter CSVs go home
 find $O -name "*kernel_trace.csv" -delete

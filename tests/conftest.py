@@ -35,6 +35,17 @@ def precision(request):
     ops.set_precision(old)
 
 
+@pytest.fixture
+def three_term_mode():
+    """Tests that compare KERNELS with each other (bitwise or at 1e-5) run them on identical arithmetic: three MFMAs per
+    product in every role ("bf16x3"); the reduced-term kernels of the default mode have their own exactness tests."""
+    from wcmc_amd import ops
+    old = ops.PRECISION
+    ops.set_precision("bf16x3")
+    yield
+    ops.set_precision(old)
+
+
 def ptol(precision, fp32_tol, x3_tol):
     return fp32_tol if precision == "fp32" else x3_tol
 

@@ -749,16 +749,15 @@ def test_bench_roofline_names_match_the_committed_profiles():
     import importlib
     bench = importlib.import_module("bench")
     pick = bench.pmc_traffic()
-    for key in ("conv_wgrad_rows", "conv_halo64_pt3", "conv_halo64_pt4", "conv_pw", "kernel_apply_fwd", "kernel_apply_bwd"):
+    for key in ("conv_wgrad_rows", "conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_pt3_x2", "conv_halo64_pt4_x2", "conv_pw",
+                "kernel_apply_fwd", "kernel_apply_bwd"):
         assert key in pick and pick[key]["hbm_bytes_per_launch"] > 0, key
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r02_bench_kernel_stats.csv")) as f:
+    with open(os.path.join(root, "profiles", bench.PROFILE_ROUND + "_bench_kernel_stats.csv")) as f:
         names = [r["Name"] for r in csv.DictReader(f)]
-    src = open(os.path.join(root, "bench.py")).read()
-    printed = re.findall(r'"(wcmc::conv_(?:halo64|wgrad_rows8)_bf16x3_kernel<[^"]*>)"', src)
-    assert len(printed) >= 4
-    for p in printed:
-        p = p.replace("%d", "1")
+    printed = bench.rocprof_names(1)          # the default mode's names (one-term weight gradient)
+    for cls in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_pt3_x2", "conv_halo64_pt4_x2", "conv_wgrad_rows"):
+        p = printed[cls]
         assert any(p.replace("wcmc::", "") in n for n in names), p
 
 

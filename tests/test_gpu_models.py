@@ -359,10 +359,14 @@ def test_sbmc_and_lbmc_interfaces_against_reference_golden(golden_dir, case, pre
     itf.to_eval_mode()
     with torch.no_grad():
         out, pb = itf.validate_batch(batch)
-    assert_close(out, T(d["val/out"]), tol=5e-3, what="validate output")
-    np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=5e-3)
+    # validation runs on the weights AFTER the Adam step, -lr * sign(g) on entries whose gradient is below the gradient noise:
+    # in these 4-channel networks the bf16-rounded backward operands of the default mode turn more of them (one ReLU output
+    # pixel of the P-buffer then differs by a few per cent of the tensor's max)
+    vt = 5e-2 if precision == "bf16x321" else 5e-3
+    assert_close(out, T(d["val/out"]), tol=vt, what="validate output")
+    np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=vt)
     if pb is not None:
-        assert_close(pb, T(d["val/p_buffer"]), tol=5e-3, what="validate p_buffer")
+        assert_close(pb, T(d["val/p_buffer"]), tol=vt, what="validate p_buffer")
 
 
 def test_full_size_step_against_oracle(precision):
@@ -595,7 +599,54 @@ _SWITCHES = [
 ]
 
 
+def test_default_mode_forward_is_the_three_term_forward_and_its_gradients_stay_close():
+    """The default mode ("bf16x321") changes the BACKWARD GEMMs only: loss scalars and denoised patches equal the all-three-term
+    mode's bit for bit; the gradients differ by the bf16 rounding of dy / x (2 x 4 x 64 x 64 patches here: little to average over);
+    and WCMC_DGRAD_AP1=0 (three-term data gradients, one-term weight gradients) lies between the two."""
+    import os
+    from conftest import rel_l2
+    from wcmc_amd import ops
+    runs = {}
+    old = ops.PRECISION
+    try:
+        for mode, env in (("bf16x3", None), ("bf16x321", None), ("bf16x321", "0")):
+            ops.set_precision(mode)
+            if env is not None:
+                os.environ["WCMC_DGRAD_AP1"] = env
+            try:
+                runs[(mode, env)] = _switch_step_body()
+            finally:
+                os.environ.pop("WCMC_DGRAD_AP1", None)
+    finally:
+        ops.set_precision(old)
+    base = runs[("bf16x3", None)]
+    worst = {}
+    for key, got in runs.items():
+        for k, want in base.items():
+            if k.startswith(("loss/", "out/")):
+                assert torch.equal(got[k], want), (key, k)
+            else:
+                worst[key] = max(worst.get(key, 0.0), rel_l2(got[k], want))
+    assert worst[("bf16x3", None)] == 0.0
+    assert 0.0 < worst[("bf16x321", "0")] <= 6e-3 and 0.0 < worst[("bf16x321", None)] <= 6e-3, worst
+
+
 def _switch_step():
+    from wcmc_amd import KPCN
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
+    from wcmc_amd.support.networks import PathNet
+    from wcmc_amd.synthetic import make_batch
+    from wcmc_amd import ops as _o
+    old_mode = _o.PRECISION
+    _o.set_precision("bf16x3")
+    try:
+        return _switch_step_body()
+    finally:
+        _o.set_precision(old_mode)
+
+
+def _switch_step_body():
     from wcmc_amd import KPCN
     from wcmc_amd.support.interfaces import KPCNInterface
     from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
@@ -632,6 +683,8 @@ def switch_baseline():
 
 @pytest.mark.parametrize("kind,name,value,how", _SWITCHES, ids=[s[1] for s in _SWITCHES])
 def test_switch_matrix_against_default_step(switch_baseline, kind, name, value, how, monkeypatch):
+    """(Run on the three-term arithmetic, where a kernel switch changes the kernel and nothing else: in the default mode
+    WCMC_IGEMM_HALO=0 / WCMC_HALO64=0 also take the two-term data-gradient instances away, i.e. change what is computed.)"""
     from wcmc_amd import ops
     if kind == "attr":
         monkeypatch.setattr(ops, name, value)

@@ -366,26 +366,32 @@ def test_one_term_weight_gradient_is_the_three_term_one_on_bf16_operands(case, m
     assert rel_err(dw1, full) < 1.5e-2          # (2^-9 per operand, uncorrelated from pixel to pixel)
 
 
-@pytest.mark.parametrize("case", [(8, 100, 44, 44, 100, 0), (2, 100, 36, 36, 100, 4), (1, 441, 40, 37, 100, 4), (2, 232, 24, 24, 100, 4),
-                                  (2, 100, 30, 29, 39, 4), (2, 120, 24, 24, 100, 4)])
+TWO_TERM_FALLBACKS = ((2, 100, 30, 29, 39, 4, 5), (2, 120, 24, 24, 100, 4, 5), (2, 64, 20, 20, 32, 1, 3))
+
+
+@pytest.mark.parametrize("case", ((8, 100, 44, 44, 100, 0, 5), (2, 100, 36, 36, 100, 4, 5), (1, 441, 40, 37, 100, 4, 5), (2, 232, 24, 24, 100, 4, 5),
+                                  # the U-Net's 3x3 layers (conv_halo_bf16x3_kernel<4 | 7, .., AP = 1>): one 64- / 128-channel slab, two of 96,
+                                  # three of 128, 12 cout tiles (NT = 7), a 40-channel slab, the 16x16 and the 8x16 tiling
+                                  (2, 64, 40, 37, 64, 1, 3), (1, 128, 37, 21, 128, 1, 3), (2, 192, 24, 24, 64, 1, 3), (1, 384, 33, 18, 128, 1, 3),
+                                  (1, 256, 20, 36, 192, 1, 3), (1, 40, 20, 20, 64, 1, 3), (8, 64, 128, 128, 64, 1, 3)) + TWO_TERM_FALLBACKS)
 def test_two_term_data_gradient_against_fp64(case):
     """terms = 2 of wcmc_conv2d_igemm_bf16x3: x (= dy in the data gradient) rounded to its hi plane, W exact to 16 bits,
     weights packed with mode 2 (32-channel slabs in the hi-plane-only halo).  Against fp64 on the rounded x at the kernel's
     usual tolerance, gated and ungated, split and fp32 outputs; and against the three-term launch on bf16 operands.  The last
-    two cases have no two-term instance (39 couts: NT = 4; 120 channels: a 24-channel last slab): packing and launch must fall
-    back to the three-term plan TOGETHER (the result is then the exact data gradient)."""
+    three cases have no two-term instance (5x5 with 39 couts: NT = 4; 120 channels: a 24-channel last slab; 3x3 with two cout
+    tiles): packing and launch must fall back to the three-term plan TOGETHER (the result is then the exact data gradient)."""
     o = ops()
-    n, cin, h, w, cout, pad = case
-    ks = 5
+    n, cin, h, w, cout, pad, ks = case
     ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
     x = gen(n, cin, h, w, seed=290)
-    wt = gen(cin, cout, ks, ks, seed=291, scale=(2.0 / (cin * 25)) ** 0.5 * 1.7)      # layer weight (Cout_l = cin, Cin_l = cout)
+    wt = gen(cin, cout, ks, ks, seed=291, scale=(2.0 / (cin * ks * ks)) ** 0.5 * 1.7)  # layer weight (Cout_l = cin, Cin_l = cout)
     xb = _bf16_round(x)
     xs, xbs = o.split_raw(o.to_nhwc_raw(x.to(DEV))), o.split_raw(o.to_nhwc_raw(xb.to(DEV)))
     wd = wt.to(DEV)
     wp3, wp2 = o._pack_x(wd, 1), o._pack_x(wd, 2)
-    fallback = wp3.numel() == wp2.numel() and torch.equal(wp3, wp2)
-    assert fallback == (case in ((2, 100, 30, 29, 39, 4), (2, 120, 24, 24, 100, 4)))
+    fallback = case in TWO_TERM_FALLBACKS
+    if fallback:          # (the converse does not hold: 448 channels are 14 slabs of 32 in either plan)
+        assert wp3.numel() == wp2.numel() and torch.equal(wp3, wp2)
     # the data-gradient GEMM: conv of x with the flipped, channel-swapped filter
     wf = wt.flip(2, 3).transpose(0, 1).contiguous()
     want = F.conv2d((x if fallback else xb).double(), wf.double(), padding=pad)
@@ -425,7 +431,7 @@ def _pw_chain(o, case, seed):
 
 
 @pytest.mark.parametrize("case", PW_CASES)
-def test_pointwise_chain_matches_fp64_and_the_tiled_kernel_bitwise(case, monkeypatch):
+def test_pointwise_chain_matches_fp64_and_the_tiled_kernel_bitwise(case, monkeypatch, three_term_mode):
     """The persistent 1x1 kernel (LDS-DMA ring, weights in registers) against an fp64 chain, and bit for bit
     against the tiled streaming kernel it replaces (same MFMA sequence per output): outputs, data gradients,
     weight gradients (which consume the hidden activations it wrote) and bias gradients (its column sums are

@@ -350,6 +350,20 @@ static XKPlan x_plan_k(int kchan, int ks, int ap_req = 2, int rows = 0) {
     q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
     return q;
   }
+  if (ap_req == 1 && q.halo && ks == 3 && rows > 0 && x_pick_nt(round_up(rows, 16) / 16) >= 4 && x_env_on("WCMC_DGRAD_AP1")) {
+    // conv_halo_bf16x3_kernel<4 | 7, .., AP = 1> (the U-Net's 3x3 data gradients): hi plane only, so a slab holds up to 128 channels
+    // in the strides the two-plane plan uses for 64 -- half the halo reloads (and a 224-byte halo for the 64-channel layers)
+    q.ap = 1;
+    q.nslabs = (q.Kp + 127) / 128;
+    q.CS = round_up((q.Kp + q.nslabs - 1) / q.nslabs, 8);
+    q.PXS = q.CS <= 112 ? 224 : 288;          // 16 B x (14 or 2 mod 16): conflict-free b128 reads, as below
+    q.Ks = round_up(ks * ks * q.CS, 32);
+    q.CSl = q.Kp - (q.nslabs - 1) * q.CS;
+    if (q.CSl < 32) q.CSl = q.CS;
+    q.Ksl = round_up(ks * ks * q.CSl, 32);
+    q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
+    return q;
+  }
   if (q.halo && ks == 5 && x_env_on("WCMC_HALO64")) {
     // conv_halo64_bf16x3_kernel: slabs of 16 channels (the last one 8 or 16), halo pixel stride 80 B, two taps per stage
     // (5x5 only: on the U-Net's 3x3 layers it wins 4 % at 128^2 and loses 30-70 % on the 64^2 / 32^2 levels, whose 16x16
@@ -898,7 +912,7 @@ __device__ __forceinline__ void pw_barrier() {
 // stage for 256 pixels instead of 30 KB for 128).  512 threads = 8 waves, each 32 pixels (two tile rows)
 // x all NT*16 couts; one workgroup per CU (LDS: halo 90-115 KB + two weight stages).
 // K order: slab-major (pack_weight_split_kernel); stages never straddle slabs (Ks % 32 == 0).
-template <int NT, int TH, int TW, int DBG = 0, int NB = 3>
+template <int NT, int TH, int TW, int DBG = 0, int NB = 3, int AP = 2>       // AP: see conv_halo64_bf16x3_kernel
 __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_halo_bf16x3_kernel(XIgemmParams p) {
   constexpr int BN = NT * 16;
   constexpr int TPX = TH * TW, NTHR = TPX * 2, NWV = NTHR / 64;   // one wave per 32 pixels (two MFMA pixel tiles)
@@ -935,14 +949,14 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
   const int hvecs = HP * VP;
   const float invVP = 1.0f / (float)VP, invHW = 1.0f / (float)HWd;
   auto dma_halo = [&](int slab) {
-    const int V = (slab == p.nslabs - 1 ? p.CSl : p.CS) / 4;      // data vectors per halo pixel (2 planes x cs/8)
+    const int V = (slab == p.nslabs - 1 ? p.CSl : p.CS) / (AP == 1 ? 8 : 4);      // data vectors per halo pixel (AP planes x cs/8)
     for (int ii = wave; ii * 64 < hvecs; ii += NTHR / 64) {
       const int v = ii * 64 + lane;
       if (v < hvecs) {
         const int px = (int)(((float)v + 0.5f) * invVP), part = v - px * VP;     // exact: v < 2^13
         const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
         const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
-        const int plane = part >= (V >> 1), vec = part - plane * (V >> 1);
+        const int plane = AP == 1 ? 0 : part >= (V >> 1), vec = part - plane * (V >> 1);
         const int ch = slab * p.CS + vec * 8;
         unsigned off = XOOB;
         if (part < V && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Cpi)
@@ -1035,7 +1049,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       ah[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
-      al[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
+      if (AP == 2) al[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
     }
     // the following stage's tap / channel of this lane (CS >= 32: at most one wrap); taps past ks*ks (slab
     // padding, zero weights) read the tile's first pixels
@@ -1090,12 +1104,12 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
       for (int i = 0; i < 2; ++i) {
         if (!(DBG & 1)) {
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
+          if (AP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
         }
         if (LATE && j == NT - 1 && !last_of_slab && !(DBG & 8)) {
           ah[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
-          al[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
+          if (AP == 2) al[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
         }
       }
       if (!(DBG & 8)) read_b(b1, j);             // stage g+1, same cout tile, into the registers just consumed
@@ -1103,7 +1117,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           ahn[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff);
-          aln[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
+          if (AP == 2) aln[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + aoff + lo_off);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1112,7 +1126,7 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
     if (!last_of_slab) {
       if (!LATE) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { ah[i] = ahn[i]; al[i] = aln[i]; }
+        for (int i = 0; i < 2; ++i) { ah[i] = ahn[i]; if (AP == 2) al[i] = aln[i]; }
       }
       cl += XKC;
       if (cl >= cs_cur) { cl -= cs_cur; if (++tdx == p.ks) { tdx = 0; ++tdy; } }
@@ -3454,17 +3468,17 @@ static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
   g_xigemm_dbuf = x_env_on("WCMC_IGEMM_DBUF");
   return g_xigemm_dbuf ? launch_xigemm3<NT, PADDED, true>(p, stream) : launch_xigemm3<NT, PADDED, false>(p, stream);
 }
-template <int NT, int NB>
+template <int NT, int NB, int AP = 2>
 static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   constexpr int TH = 16, TW = 16;
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
-  hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB>), grid, dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
 template <int NT, int NB, int PT, int PXST, int AP = 2>
@@ -3623,6 +3637,18 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
     const size_t main8 = halo8 + 2 * bstage;
     const size_t lds8 = main8 > out8 ? main8 : out8;
     const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)((q.Np / 16 + NT - 1) / NT));
+    if constexpr (NT == 4 || NT == 7) {
+      if (p.ap == 1) {                           // (x_plan_k grants ap = 1 to this kernel for ks = 3 and NT = 4 or 7 only)
+        static size_t attr81 = 0;
+        if (lds8 > attr81) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+          attr81 = lds8;
+        }
+        hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2, 1>), grid, dim3(TH8 * TW * 2), lds8, stream, q);
+        return check_launch("conv2d_igemm_bf16x3(halo, 8x16, x hi plane)");
+      }
+    }
     static size_t attr8 = 0;
     if (lds8 > attr8) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>),
@@ -3631,6 +3657,9 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
     }
     hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>), grid, dim3(TH8 * TW * 2), lds8, stream, q);
     return check_launch("conv2d_igemm_bf16x3(halo, 8x16)");
+  }
+  if constexpr (NT == 4 || NT == 7) {
+    if (p.ap == 1) return nb == 3 ? launch_xhalo2<NT, 3, 1>(p, lds, stream) : launch_xhalo2<NT, 2, 1>(p, lds, stream);
   }
   return nb == 3 ? launch_xhalo2<NT, 3>(p, lds, stream) : launch_xhalo2<NT, 2>(p, lds, stream);
 }

@@ -492,10 +492,11 @@ def _pack_chain_x(weights, ks):
     return [keep[2 * i + 1] for i in range(n)]
 
 
-def _igemm_class(cin, cout, ks, dims=None):
+def _igemm_class(cin, cout, ks, dims=None, terms=3):
     """Profiler class of a split-bf16 GEMM launch = the kernel the library's plan picks for it
     (csrc/conv_bf16x3.hip: x_plan_k, x_pick_nt, launch_xhalo64), so that a class average is one kernel's average.
-    dims = (n, ho, wo) of the output selects between the two tile heights of the 5x5 kernel."""
+    dims = (n, ho, wo) of the output selects between the two tile heights of the 5x5 kernel; terms = 2 (the data gradient of
+    the default mode) runs the AP = 1 instances where the plan grants them: classes with the suffix "_x2"."""
     tiles = (cout + 15) // 16
     nt = min((7, 4, 2, 1), key=lambda t: (-(-tiles // t)) * (t + 2))
     halo = 3 <= ks <= 5 and (cin + 7) // 8 * 8 >= 32
@@ -508,12 +509,13 @@ def _igemm_class(cin, cout, ks, dims=None):
         return "conv_halo7"                 # conv_halo_bf16x3_kernel<7, 8, 16, 0, 2> (and the fp32 path's 5x5 class)
     n, ho, wo = dims                        # conv_halo64_bf16x3_kernel<7, NB, PT>: 16x16 tiles (PT = 4) or 12x16 (PT = 3)
     kp = (cin + 7) // 8 * 8
-    if kp >= 256 and kp % 32 == 0 and os.environ.get("WCMC_HALO64_CS32", "1") != "0":
+    x2 = terms == 2 and kp % 32 != 24 and os.environ.get("WCMC_DGRAD_AP1", "1") != "0"     # x_plan_k grants ap = 1 (32-channel slabs, 80 B)
+    if not x2 and kp >= 256 and kp % 32 == 0 and os.environ.get("WCMC_HALO64_CS32", "1") != "0":
         return "conv_halo64_cs32"           # 32-channel slabs: <7, 2, 3> (two weight stages, 12x16 tiles)
     gy = -(-tiles // nt)
     rounds = lambda th: -(-(n * (-(-wo // 16)) * (-(-ho // th)) * gy) // 512) * th
     pt3 = os.environ.get("WCMC_HALO64_PT3", "1") != "0" and rounds(12) < rounds(16)
-    return "conv_halo64_pt3" if pt3 else "conv_halo64_pt4"
+    return ("conv_halo64_pt3" if pt3 else "conv_halo64_pt4") + ("_x2" if x2 else "")
 
 
 def _wgrad_class(n, ho, cin, cout, ks):
@@ -545,7 +547,7 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     mask = None
     if mask_out:
         mask = torch.empty(n * ho * wo * ((cout + 7) // 8), device=dev, dtype=torch.uint8)
-    cls = _igemm_class(cin, cout, ks, (n, ho, wo)) if pad == 0 or ks > 1 else "conv_igemm"
+    cls = _igemm_class(cin, cout, ks, (n, ho, wo), terms) if pad == 0 or ks > 1 else "conv_igemm"
     if cls == "conv_pw":    # algorithmic bytes: the split input and the split / fp32 output, 4 B per channel and pixel
         work = (4.0 * n * pix * ((cin + 7) // 8 * 8 + cout), "byte")
     else:
