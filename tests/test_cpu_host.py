@@ -23,6 +23,14 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (the gloo rendezvous of the world-2 tests)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def test_library_exports_every_declared_symbol():
     import __graft_entry__ as ge
     ge.build()
@@ -489,7 +497,7 @@ def test_two_rank_gloo_gradient_average_and_broadcast():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -603,7 +611,7 @@ def test_two_rank_gloo_fused_clip_adam_reduce_then_scale_then_clip():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_fused_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -618,6 +626,80 @@ def test_two_rank_gloo_fused_clip_adam_reduce_then_scale_then_clip():
         assert log["state_step"] == 2.0
         assert log["global_guard"] == 0.0 and log["skipped"] and log["steps_after_rollback"] == [2, 2, 2], log
         assert log["none_grad_skipped"] and log["weight_moved"] > 1e-4, log
+
+
+def _global_pairing_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from wcmc_amd import distributed as wd
+    from wcmc_amd import ops
+    from wcmc_amd.support.losses import FeatureMSE
+    wd.init("gloo")
+    ops.feature_mse = lambda p, ref, ip, ib: ol.feature_mse(p, ref, ip, ib)      # the HIP op's contract, on the CPU (no GPU here)
+    b, s, c, h, w = 2, 3, 4, 6, 5
+    g = torch.Generator().manual_seed(77)
+    p_all = torch.rand(world * b, s, c, h, w, generator=g)
+    ref_all = torch.rand(world * b, 3, h, w, generator=g) * 2
+    out = {}
+    for mode in ("cpu", "explicit"):
+        fm = FeatureMSE(non_local=True, rng="cpu", pairing="global", process_group=dist.group.WORLD)
+        mine = p_all[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        torch.manual_seed(100 + rank)               # DIFFERENT generators per rank: the pairing must still be one for all (rank 0's)
+        perms = None
+        if mode == "explicit":
+            gp = torch.Generator().manual_seed(5)
+            perms = (torch.randperm(s * h * w, generator=gp), torch.randperm(world * b * s * h * w, generator=gp))
+        loss = fm(mine, ref_all[rank * b:(rank + 1) * b], perms=perms)
+        loss.backward()
+        # what the ranks' gradient MEAN makes of it (FusedClipAdam / average_gradients divide the sum by world)
+        full = torch.zeros_like(p_all)
+        full[rank * b:(rank + 1) * b] = mine.grad
+        dist.all_reduce(full)
+        out[mode] = dict(loss=loss.item(), grad=(full / world).clone(), ip=fm.last_perms[0].clone(), ib=fm.last_perms[1].clone())
+    # local pairing (the default) never communicates and pairs inside the rank's rows
+    fl = FeatureMSE(non_local=True, rng="cpu")
+    torch.manual_seed(9)
+    out["local"] = fl(p_all[rank * b:(rank + 1) * b], ref_all[rank * b:(rank + 1) * b]).item()
+    out["local_rows"] = int(fl.last_perms[1].numel())
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_feature_mse_global_pairing_equals_the_single_process_loss_of_the_gathered_batch():
+    """SURVEY 8e option (b) / VERDICT round 2: ``FeatureMSE(pairing='global')`` evaluates the reference's DataParallel
+    semantics -- the intra-batch permutation spans the GATHERED global batch (``support/losses.py:48-61``;
+    ``train_kpcn.py:266-269``) -- across one process per GPU: loss value = the single-process loss of the concatenated batch
+    with the same permutations, and the rank-mean of the gradients = its gradient, row for row.  One pairing for all ranks
+    (rank 0's draw) although the ranks' generators differ."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_global_pairing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b, s, c, h, w = 2, 3, 4, 6, 5
+    g = torch.Generator().manual_seed(77)
+    p_all = torch.rand(world * b, s, c, h, w, generator=g).requires_grad_(True)
+    ref_all = torch.rand(world * b, 3, h, w, generator=g) * 2
+    for mode in ("cpu", "explicit"):
+        ip, ib = res[0][mode]["ip"], res[0][mode]["ib"]
+        assert torch.equal(ip, res[1][mode]["ip"]) and torch.equal(ib, res[1][mode]["ib"])
+        assert ib.numel() == world * b * s * h * w and torch.equal(torch.sort(ib).values, torch.arange(ib.numel()))
+        p_all.grad = None
+        want = ol.feature_mse(p_all, ref_all, ip, ib)
+        want.backward()
+        for r in range(world):
+            np.testing.assert_allclose(res[r][mode]["loss"], want.item(), rtol=1e-6)
+            np.testing.assert_allclose(res[r][mode]["grad"].numpy(), p_all.grad.numpy(), rtol=1e-5, atol=1e-9)
+    torch.manual_seed(100)                     # rank 0's generator: its draw is the one every rank used
+    assert torch.equal(res[1]["cpu"]["ip"], torch.randperm(s * h * w))
+    assert res[0]["local_rows"] == b * s * h * w and res[0]["local"] != res[1]["local"]
 
 
 def test_launcher_flag_surface_and_argument_errors():

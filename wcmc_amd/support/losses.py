@@ -18,8 +18,18 @@ __all__ = ["GlobalRelativeSimilarityLoss", "FeatureMSE", "RelativeMSE", "SMAPE",
 class FeatureMSE(torch.nn.Module):
     """Feature Mean-Squared Error. Path disentangling loss"""
 
-    def __init__(self, color='rgb', non_local=True, rng='cpu'):
-        """rng: where the pairing permutations are drawn.
+    def __init__(self, color='rgb', non_local=True, rng='cpu', pairing='local', process_group=None):
+        """pairing (one process per GPU; the reference is single-process ``nn.DataParallel``, ``train_kpcn.py:266-269``, whose
+           losses see the GATHERED global batch on one GPU):
+             'local'  -- every rank pairs inside its own patches (default; the same estimator on other sample pairs);
+             'global' -- the reference's semantics: the cropped P-buffers and references of all ranks are all-gathered
+                         (7.3 MB per rank at the benchmark shape) and the loss of the GLOBAL batch is evaluated -- the
+                         intra-batch permutation spans ``world * B * S * H * W`` rows (``losses.py:48-61``) -- with one set
+                         of permutations for all ranks (rank 0's draw, broadcast).  The value returned is the global loss on
+                         every rank; its gradient reaches this rank's rows only and is scaled by ``world`` so that the
+                         gradient MEAN over ranks (``FusedClipAdam``, ``average_gradients``) is the gradient of the global
+                         loss.  Every rank evaluates all ``world * N`` rows (the op is HBM-bound: ~0.1 ms per call and rank).
+        rng: where the pairing permutations are drawn.
              'cpu'    -- torch.randperm on the global CPU generator, patch then batch: bit-identical pairs
                          to the reference under torch.manual_seed (losses.py:35,50); costs ~23 ms of host
                          time per 541,696-row permutation on the MI355X host.
@@ -29,10 +39,12 @@ class FeatureMSE(torch.nn.Module):
         if color != 'rgb':
             raise NotImplementedError("FeatureMSE(color=%r): only 'rgb' is on the KPCN-Manifold path "
                                       "(no caller of the reference uses 'hls')" % (color,))
-        assert rng in ('cpu', 'device')
+        assert rng in ('cpu', 'device') and pairing in ('local', 'global')
         self.color = color
         self.non_local = non_local
         self.rng = rng
+        self.pairing = pairing
+        self.group = process_group
         self.last_perms = None
         self.static_perms = None        # queue of (idx_patch, idx_batch) device tensors (graph replay)
         self.check_finite = True
@@ -46,10 +58,59 @@ class FeatureMSE(torch.nn.Module):
         idx_batch = torch.randperm(b * s * h * w) if self.non_local else None
         return idx_patch, idx_batch
 
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if (self.pairing == 'global' and dist.is_available() and dist.is_initialized()) else 1
+
+    def _forward_global(self, p_buffer, ref, perms, world):
+        """The loss of the gathered global batch (see ``pairing``)."""
+        import torch.distributed as dist
+        b, s, c, h, w = p_buffer.shape
+        dev = p_buffer.device
+        rank = dist.get_rank(self.group)
+        pl, rl = p_buffer.contiguous(), ref.contiguous()
+        with torch.no_grad():
+            pg = [torch.empty_like(pl) for _ in range(world)]
+            rg = [torch.empty_like(rl) for _ in range(world)]
+            dist.all_gather(pg, pl.detach(), group=self.group)
+            dist.all_gather(rg, rl.detach(), group=self.group)
+        pg[rank] = pl                                      # this rank's rows stay in the autograd graph
+        p_all, r_all = torch.cat(pg, 0), torch.cat(rg, 0)
+        if perms is None:                                  # one draw for all ranks: rank 0's
+            if self.rng == 'device':
+                seeds = torch.randint(0, 2 ** 62, (2,), dtype=torch.int64)
+                seeds = seeds.to(dev) if dist.get_backend(self.group) == 'nccl' else seeds
+                dist.broadcast(seeds, 0, group=self.group)
+                sd = seeds.tolist()
+                perms = (ops.random_permutation(s * h * w, dev, seed=sd[0]),
+                         ops.random_permutation(world * b * s * h * w, dev, seed=sd[1]) if self.non_local else None)
+            else:
+                ip = torch.randperm(s * h * w)
+                ib = torch.randperm(world * b * s * h * w) if self.non_local else None
+                on = dev if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
+                ip = ip.to(on)
+                dist.broadcast(ip, 0, group=self.group)
+                if ib is not None:
+                    ib = ib.to(on)
+                    dist.broadcast(ib, 0, group=self.group)
+                perms = (ip, ib)
+        self.last_perms = perms
+        ip = perms[0].to(dev, non_blocking=True)
+        ib = perms[1].to(dev, non_blocking=True) if perms[1] is not None else None
+        loss = ops.feature_mse(p_all, r_all, ip, ib)
+        # value: the global loss; gradient: world x d(global loss)/d(this rank's rows) -- the ranks' gradients are averaged later
+        return loss.detach() + float(world) * (loss - loss.detach())
+
     def forward(self, p_buffer, ref, perms=None):
         """p_buffer (B,S,C,H,W) embedded paths, ref (B,3,H,W) reference radiance -> 0-d loss."""
         b, s, c, h, w = p_buffer.shape
         dev = p_buffer.device
+        world = self._world()
+        if world > 1:
+            loss = self._forward_global(p_buffer, ref, perms, world)
+            if self.check_finite and not torch.isfinite(loss.detach()):
+                raise RuntimeError("Infinite loss at train time.")
+            return loss
         if self.static_perms is not None:                 # pre-drawn device permutations, call order preserved
             idx_patch, idx_batch = self.static_perms[self._static_i % len(self.static_perms)]
             self._static_i += 1

@@ -195,7 +195,8 @@ def init_model(sizes, args, device, group=None):
                       'l_test': RelativeMSE()}
         if args.manif_learn:
             if args.manif_loss == 'FMSE':
-                loss_funcs['l_manif'] = FeatureMSE(non_local=not args.local, rng=args.pairing_rng)
+                loss_funcs['l_manif'] = FeatureMSE(non_local=not args.local, rng=args.pairing_rng, pairing=args.pairing,
+                                                   process_group=group)
                 print('Manifold loss: FeatureMSE')
             else:
                 loss_funcs['l_manif'] = GlobalRelativeSimilarityLoss(rng=args.pairing_rng)
@@ -270,6 +271,9 @@ def build_parser():
     p.add_argument('--graph', action='store_true', help='one hipGraph replay per training step')
     p.add_argument('--pairing_rng', choices=('cpu', 'device'), default='cpu',
                    help="FeatureMSE pairings: the reference's CPU randperm stream, or a keyed permutation on the GPU")
+    p.add_argument('--pairing', choices=('local', 'global'), default='local',
+                   help="FeatureMSE intra-batch pairing under several ranks: inside a rank's patches (default), or over the "
+                        "all-gathered GLOBAL batch as nn.DataParallel's gathered loss does (train_kpcn.py:266-269; not with --graph)")
     return p
 
 
@@ -288,6 +292,8 @@ def check_args(args):
     for s in args.pnet_out_size:
         if args.disentangle != 'm11r11' and s % 2 != 0:
             raise RuntimeError('Argument `pnet_out_size` should be a list of even numbers')
+    if getattr(args, 'pairing', 'local') == 'global' and getattr(args, 'graph', False):
+        raise RuntimeError('`--pairing global` all-gathers inside the loss: not capturable, run it without `--graph`')
     return args
 
 
