@@ -655,7 +655,9 @@ def _global_pairing_worker(rank, world, port, q):
         full = torch.zeros_like(p_all)
         full[rank * b:(rank + 1) * b] = mine.grad
         dist.all_reduce(full)
-        out[mode] = dict(loss=loss.item(), grad=(full / world).clone(), ip=fm.last_perms[0].clone(), ib=fm.last_perms[1].clone())
+        # (numpy: pickled by value -- a torch tensor travels through the queue as a shared-memory handle that dies with this process)
+        out[mode] = dict(loss=loss.item(), grad=(full / world).numpy().copy(), ip=fm.last_perms[0].numpy().copy(),
+                         ib=fm.last_perms[1].numpy().copy())
     # local pairing (the default) never communicates and pairs inside the rank's rows
     fl = FeatureMSE(non_local=True, rng="cpu")
     torch.manual_seed(9)
@@ -688,17 +690,17 @@ def test_two_rank_gloo_feature_mse_global_pairing_equals_the_single_process_loss
     p_all = torch.rand(world * b, s, c, h, w, generator=g).requires_grad_(True)
     ref_all = torch.rand(world * b, 3, h, w, generator=g) * 2
     for mode in ("cpu", "explicit"):
-        ip, ib = res[0][mode]["ip"], res[0][mode]["ib"]
-        assert torch.equal(ip, res[1][mode]["ip"]) and torch.equal(ib, res[1][mode]["ib"])
+        ip, ib = torch.from_numpy(res[0][mode]["ip"]), torch.from_numpy(res[0][mode]["ib"])
+        assert np.array_equal(res[0][mode]["ip"], res[1][mode]["ip"]) and np.array_equal(res[0][mode]["ib"], res[1][mode]["ib"])
         assert ib.numel() == world * b * s * h * w and torch.equal(torch.sort(ib).values, torch.arange(ib.numel()))
         p_all.grad = None
         want = ol.feature_mse(p_all, ref_all, ip, ib)
         want.backward()
         for r in range(world):
             np.testing.assert_allclose(res[r][mode]["loss"], want.item(), rtol=1e-6)
-            np.testing.assert_allclose(res[r][mode]["grad"].numpy(), p_all.grad.numpy(), rtol=1e-5, atol=1e-9)
+            np.testing.assert_allclose(res[r][mode]["grad"], p_all.grad.numpy(), rtol=1e-5, atol=1e-9)
     torch.manual_seed(100)                     # rank 0's generator: its draw is the one every rank used
-    assert torch.equal(res[1]["cpu"]["ip"], torch.randperm(s * h * w))
+    assert np.array_equal(res[1]["cpu"]["ip"], torch.randperm(s * h * w).numpy())
     assert res[0]["local_rows"] == b * s * h * w and res[0]["local"] != res[1]["local"]
 
 
