@@ -387,6 +387,13 @@ int wcmc_random_permutation(int64_t* out, int64_t n, uint64_t seed, void* stream
 int wcmc_clip_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float clip, double lr, double beta1, double beta2, double eps, int step,
                    float grad_scale, const float* guard, void* stream);
+/* The same launch with its per-step scalars read from DEVICE memory, for a launch captured into the step's hipGraph (whose
+ * by-value arguments are frozen at capture): hyper7 = the seven floats wcmc_clip_adam_hyper (host-side, no GPU call)
+ * derives from (lr, betas, eps, step) exactly as wcmc_clip_adam does -- same arithmetic, bit-identical update.  The host
+ * refreshes the buffer before every replay (`optim.param_groups[0]['lr']` may have changed: train_kpcn.py:279-296). */
+void wcmc_clip_adam_hyper(double lr, double beta1, double beta2, double eps, int step, float* out7);
+int wcmc_clip_adam_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float clip,
+                       float grad_scale, const float* hyper7, const float* guard, void* stream);
 
 /* ---------------------------------------------------------------- per-image preprocessing (data step before the path)
  * support/datasets.py: DenoiseDataset._preprocess_llpm :302-361, ._preprocess_kpcn :487-582,

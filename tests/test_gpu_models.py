@@ -417,8 +417,8 @@ def test_full_size_step_against_oracle(precision):
 
 
 def test_graphed_step_equals_eager_step():
-    """GraphedTrainStep (one hipGraph replay + eager optimiser) == preprocess + train_batch, bit for bit
-    in fp32 MFMA mode (deterministic kernels, same CPU-generator pairings)."""
+    """GraphedTrainStep (one hipGraph replay; the optimiser eager behind it, or captured with it) == preprocess + train_batch,
+    bit for bit in fp32 MFMA mode (deterministic kernels, same CPU-generator pairings), including a learning-rate change."""
     from wcmc_amd import KPCN, ops
     from wcmc_amd.graph import GraphedTrainStep
     from wcmc_amd.optim import FusedClipAdam
@@ -430,7 +430,7 @@ def test_graphed_step_equals_eager_step():
     ops.set_precision("fp32")
     try:
         results = []
-        for graphed in (False, True):
+        for graphed in (False, True, "tail"):           # eager | graph + eager optimiser | graph with the optimiser captured
             torch.manual_seed(21)
             kw = dict(ksize=21, depth=3, width=24)
             models = {"dncnn": KPCN(39, **kw), "backbone_diffuse": PathNet(36, intermc=16),
@@ -447,25 +447,70 @@ def test_graphed_step_equals_eager_step():
             itf.to_train_mode()
             batches = [make_batch(2, 4, 48, seed=30 + i, device=DEV) for i in range(3)]
             if graphed:
-                step = GraphedTrainStep(itf, batches[0])
+                step = GraphedTrainStep(itf, batches[0], capture_optimizer=(graphed == "tail"))
+                assert step.tail_captured == (graphed == "tail")
             else:
                 def step(b):
                     itf.preprocess(b)
                     itf.train_batch(b)
             torch.manual_seed(22)
-            for b in batches:
+            for i, b in enumerate(batches):
+                if i == 2:                              # a learning-rate change between steps must reach a captured optimiser
+                    for o in optims.values():
+                        o.param_groups[0]["lr"] = 3e-4
                 step(b)
             results.append(({k: v.item() for k, v in itf.m_losses.items()},
                             torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()]).cpu(),
-                            itf.iters))
-        (l0, p0, i0), (l1, p1, i1) = results
-        assert i0 == i1 == 4
-        assert l0.keys() == l1.keys()
+                            itf.iters, [float(o.state[next(iter(o.state))]["step"]) for o in optims.values()]))
+        (l0, p0, i0, s0), (l1, p1, i1, s1), (l2, p2, i2, s2) = results
+        assert i0 == i1 == i2 == 4 and s0 == s1 == s2 == [3.0, 3.0, 3.0]
+        assert l0.keys() == l1.keys() == l2.keys()
         for k in l0:
             np.testing.assert_allclose(l1[k], l0[k], rtol=1e-6, err_msg=k)
-        assert torch.equal(p0, p1)
+            np.testing.assert_allclose(l2[k], l0[k], rtol=1e-6, err_msg=k)
+        assert torch.equal(p0, p1) and torch.equal(p0, p2)
     finally:
         ops.set_precision(old)
+
+
+def test_captured_optimizer_tail_guard_and_epoch_summary():
+    """The step's tail inside the hipGraph (one rank): a non-finite loss raises the reference's error
+    (``interfaces.py:254-257``) with parameters, moments, step counters and running sums untouched -- the update sits behind a
+    device guard -- and training continues afterwards; ``get_epoch_summary`` (which swaps the running sums for fresh zeros,
+    ``interfaces.py:320-333``) keeps working between replays."""
+    import bench
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.synthetic import make_batch
+    device = torch.device("cuda", 0)
+    itf = bench.build_interface(device, None, rng="device")
+    good = make_batch(2, 4, 64, seed=70, device=device)
+    step = GraphedTrainStep(itf, good)
+    assert step.tail_captured
+    torch.manual_seed(71)
+    step(good)
+    step(good)
+    flat = lambda: torch.cat([fl.flat for fl in itf.fused_optim.flats.values()]).clone()
+    moments = lambda: torch.cat([fl.m for fl in itf.fused_optim.flats.values()]).clone()
+    p_before, m_before = flat(), moments()
+    sums_before = {k: v.item() for k, v in itf.m_losses.items()}
+    steps_before = [fl.steps for fl in itf.fused_optim.flats.values()]
+    assert steps_before == [2, 2, 2]
+    bad = {k: v.clone() for k, v in good.items()}
+    bad["target_diffuse"][0, 0, 30, 30] = float("nan")
+    with pytest.raises(RuntimeError, match="Non-finite loss at train time"):
+        step(bad)
+    assert torch.equal(flat(), p_before) and torch.equal(moments(), m_before)
+    assert [fl.steps for fl in itf.fused_optim.flats.values()] == steps_before
+    assert {k: v.item() for k, v in itf.m_losses.items()} == sums_before
+    step(good)                                          # and on it goes
+    assert [fl.steps for fl in itf.fused_optim.flats.values()] == [3, 3, 3] and not torch.equal(flat(), p_before)
+    three = {k: v.item() for k, v in itf.m_losses.items()}
+    assert all(three[k] > sums_before[k] for k in three if k != "m_val")
+    assert itf.get_epoch_summary(mode="train", norm=3) == -1.0            # prints the means and zeroes the sums
+    assert all(v.item() == 0.0 for k, v in itf.m_losses.items() if k != "m_val")
+    step(good)
+    one = {k: v.item() for k, v in itf.m_losses.items()}
+    assert all(0.0 < one[k] < three[k] for k in one if k != "m_val"), (one, three)
 
 
 def test_graphed_unfused_step_with_grad_sync_equals_eager():

@@ -15,11 +15,19 @@ __device__ __forceinline__ float clamp_nan(float g, float clip) {
   return g != g ? g : fminf(fmaxf(g, -clip), clip);
 }
 
+// hyper (optional, device): {step_size, beta1, beta2, 1 - beta1, 1 - beta2, eps, 1 / sqrt(1 - beta2^t)} -- the same seven
+// floats the host passes by value otherwise.  A launch captured into the step's hipGraph bakes its by-value arguments in;
+// step_size and the bias correction change every step (and lr whenever the caller's schedule says so), so the captured
+// launch reads them from a buffer the host refreshes before each replay.
 __global__ void clip_adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float clip, float step_size, float beta1,
                                  float beta2, float omb1, float omb2, float eps, float inv_bc2_sqrt,
-                                 float grad_scale, const float* __restrict__ guard) {
+                                 float grad_scale, const float* __restrict__ guard, const float* __restrict__ hyper) {
   if (guard && guard[0] == 0.f) return;        // non-finite loss upstream: leave parameters and moments untouched
+  if (hyper) {
+    step_size = hyper[0]; beta1 = hyper[1]; beta2 = hyper[2]; omb1 = hyper[3]; omb2 = hyper[4]; eps = hyper[5];
+    inv_bc2_sqrt = hyper[6];
+  }
   const int64_t n4 = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 g = reinterpret_cast<float4*>(grad)[i];
@@ -73,6 +81,27 @@ extern "C" int wcmc_clip_adam(float* param, float* grad, float* exp_avg, float* 
   const int64_t blocks = ceil_div64(n / 4 > 0 ? n / 4 : 1, 256);
   hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
                      (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, clip, step_size, (float)beta1,
-                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, inv_bc2_sqrt, grad_scale, guard);
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, inv_bc2_sqrt, grad_scale, guard,
+                     (const float*)nullptr);
   return check_launch("clip_adam");
+}
+
+extern "C" void wcmc_clip_adam_hyper(double lr, double beta1, double beta2, double eps, int step, float* out7) {
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  out7[0] = (float)(lr / bc1); out7[1] = (float)beta1; out7[2] = (float)beta2; out7[3] = (float)(1.0 - beta1);
+  out7[4] = (float)(1.0 - beta2); out7[5] = (float)eps; out7[6] = (float)(1.0 / sqrt(bc2));
+}
+
+extern "C" int wcmc_clip_adam_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float clip,
+                                  float grad_scale, const float* hyper7, const float* guard, void* stream) {
+  WCMC_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && hyper7, WCMC_ERR_BAD_ARG,
+               "clip_adam_dev: bad argument (n=%lld)", (long long)n);
+  WCMC_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), WCMC_ERR_ALIGNMENT,
+               "clip_adam_dev: buffers must be 16-byte aligned");
+  const int64_t blocks = ceil_div64(n / 4 > 0 ? n / 4 : 1, 256);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                     (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, clip, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                     grad_scale, guard, hyper7);
+  return check_launch("clip_adam_dev");
 }

@@ -16,7 +16,7 @@ from . import ops
 class GraphedTrainStep:
     """``step = GraphedTrainStep(itf, example_batch); step(batch)`` == ``itf.preprocess(batch); itf.train_batch(batch)``."""
 
-    def __init__(self, itf, batch, warmup=2, side_stream=True):
+    def __init__(self, itf, batch, warmup=2, side_stream=True, capture_optimizer=True):
         self.itf = itf
         self.static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
         self.keys = list(self.static)                     # (PathNet stashes a converted copy of `paths` in the dict)
@@ -30,7 +30,7 @@ class GraphedTrainStep:
         with torch.cuda.stream(s):                        # warm-up off the default stream (torch.cuda.graph rule)
             for _ in range(warmup):
                 self.static.pop('_wcmc_paths_nhwc', None)
-                itf._forward_backward(self.static)
+                warm = itf._forward_backward(self.static)
         cur.wait_stream(s)
         torch.cuda.synchronize()
         if self.fm is not None:
@@ -49,14 +49,34 @@ class GraphedTrainStep:
         # backward passes -- so that the host launches the later segments while the GPU runs the first: hipGraphLaunch of
         # the ~410-node step costs the host 0.94 ms, scripts/diag_step_host.py.  Bit-identical, and no faster: 397.7 vs 400.9
         # patches/s -- the runtime already feeds the GPU while it is still submitting.)
+        # One rank, fused optimiser: the step's tail -- finite check, loss sums, gradient gather, clip + Adam -- is captured too
+        # (a dozen small launches the host used to enqueue behind its sync on the losses: 0.5-0.7 ms per step with an idle
+        # GPU, profiles/r03_step_trace_gaps.txt).  The update sits behind a DEVICE guard (all losses finite); the host reads the
+        # flags after the replay and raises the reference's error (interfaces.py:254-257) -- the update was then skipped.
+        fo = getattr(itf, 'fused_optim', None)
+        self.tail_captured = (capture_optimizer and fo is not None and fo.world == 1 and itf.grad_sync is None)
+        if self.tail_captured:
+            assert warmup >= 1
+            fo.prepare_capture()
+            self.sums = torch.zeros(len(warm), device=dev)            # one slot per loss key (the warm-up's result has them)
+            self._sum_views = [self.sums[i] for i in range(self.sums.numel())]
         self.graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(self.graph):
                 self.losses = itf._forward_backward(self.static)
+                if self.tail_captured:
+                    self.loss_keys = list(self.losses)
+                    vals = torch.stack([self.losses[k].reshape(()) for k in self.loss_keys])
+                    finite = torch.isfinite(vals)
+                    self.guard = finite.all().to(torch.float32).reshape(1)
+                    # the running sums of interfaces.py:263-267, in place on one persistent tensor (itf.m_losses holds views)
+                    self.sums.add_(torch.where(self.guard > 0, vals, torch.zeros_like(vals)))
+                    fo.capture_step(itf.models, itf.optims, self.guard)
+                    self.flags = torch.cat([finite.to(torch.float32), self.guard])
         finally:
             ops.USE_SIDE_STREAM = side
-        if getattr(itf, 'fused_optim', None) is not None:
-            itf.fused_optim.leave_grads = False           # .grad must keep pointing at the captured buffers
+        if fo is not None:
+            fo.leave_grads = False                        # .grad must keep pointing at the captured buffers
 
     def _draw(self):
         """Fresh pairings, in the reference's call order (diffuse: patch, batch; specular: patch, batch)."""
@@ -88,6 +108,25 @@ class GraphedTrainStep:
         if self.fm is not None:
             self._draw()
             self.fm._static_i = 0
+        if not self.tail_captured:
+            self.graph.replay()
+            itf._logging(self.losses)
+            itf._optimization()
+            return
+        fo = itf.fused_optim
+        for i, k in enumerate(self.loss_keys):            # itf.m_losses['m_<key>'] are views of self.sums; get_epoch_summary
+            cur = itf.m_losses.get('m_' + k)              # replaces them with fresh zeros (interfaces.py:320-333): adopt those
+            if cur is not self._sum_views[i]:
+                self.sums[i].copy_(cur) if cur is not None else self.sums[i].zero_()
+                itf.m_losses['m_' + k] = self._sum_views[i]
+        fo.refresh_hyper(itf.optims)
         self.graph.replay()
-        itf._logging(self.losses)
-        itf._optimization()
+        itf.last_loss_dict = self.losses
+        flags = self.flags.tolist()                       # the step's one sync
+        ok = flags[-1] != 0
+        fo.after_replay(ok)
+        fo.last_guard = self.guard
+        if not ok:                                        # (the guard kept the sums, the moments and the parameters as they were)
+            for k, f in zip(self.loss_keys, flags[:-1]):
+                if not f:
+                    raise RuntimeError("%s: Non-finite loss at train time." % (k))

@@ -1351,6 +1351,22 @@ def clip_adam_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.99
           "clip_adam")
 
 
+def clip_adam_hyper(step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """The seven per-step floats of ``clip_adam_dev_`` (host arithmetic of ``wcmc_clip_adam``; no GPU call)."""
+    out = (ctypes.c_float * 7)()
+    lib().wcmc_clip_adam_hyper(float(lr), float(beta1), float(beta2), float(eps), int(step), out)
+    return list(out)
+
+
+def clip_adam_dev_(param, grad, exp_avg, exp_avg_sq, hyper, clip=1.0, grad_scale=1.0, guard=None):
+    """``clip_adam_`` with its per-step scalars read from the device tensor ``hyper`` (7 floats, ``clip_adam_hyper``): the
+    form a hipGraph can replay with other values every step."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq, hyper, guard)
+    assert hyper.numel() >= 7 and hyper.is_contiguous()
+    check(lib().wcmc_clip_adam_dev(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), clip,
+                                   grad_scale, _ptr(hyper), _ptr(guard), _stream()), "clip_adam_dev")
+
+
 # ---------------------------------------------------------------------------------- data step (SURVEY.md 8f rank 3)
 def _need_dense(t, ndim):
     if not t.is_cuda or t.dtype != torch.float32 or t.dim() != ndim or not t.is_contiguous():

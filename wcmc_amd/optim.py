@@ -172,6 +172,56 @@ class FusedClipAdam:
         self.last_guard = gguard
         return gguard
 
+    # ---- the same step as part of a captured hipGraph (one rank: no collective inside the capture)
+    def capture_step(self, models, optims, guard):
+        """Enqueue gather + clip + Adam of every model ONCE, under stream capture (``wcmc_amd.graph.GraphedTrainStep``):
+        the kernels read step size / bias correction from ``self.hyper`` (device), which ``refresh_hyper`` fills before every
+        replay.  The set of parameters that have a gradient is frozen with the capture (as the graph itself is)."""
+        assert self.world == 1, "a collective cannot be captured here: the multi-rank step stays eager"
+        assert getattr(self, "hyper", None) is not None, "prepare_capture() first (no allocation of pinned memory inside a capture)"
+        self._captured = []
+        for i, (name, fl) in enumerate(self.flats.items()):
+            optim = optims["optim_" + name]
+            if not fl.bound(optim):
+                fl._adopt_state(optim)
+            have = [p.grad is not None for p in fl.params]
+            fl.stepped = any(have)
+            self._captured.append((name, fl, fl.stepped))
+            if not fl.stepped:
+                continue
+            gv = fl.grad_views()
+            idx = [j for j, h in enumerate(have) if h]
+            torch._foreach_copy_([gv[j] for j in idx], [fl.params[j].grad for j in idx])
+            for a, b in fl.segments(have):
+                ops.clip_adam_dev_(fl.flat[a:b], fl.g[a:b], fl.m[a:b], fl.v[a:b], self.hyper[i], clip=self.clip,
+                                   grad_scale=1.0, guard=guard)
+
+    def prepare_capture(self):
+        """Buffers of the captured step, allocated BEFORE the capture begins (hipHostMalloc invalidates a stream capture)."""
+        dev = next(iter(self.flats.values())).flat.device
+        self.hyper = torch.zeros(len(self.flats), 8, device=dev, dtype=torch.float32)
+        self._hyper_host = torch.zeros(len(self.flats), 8, dtype=torch.float32).pin_memory()
+        for fl in self.flats.values():
+            fl.grad_views()
+
+    def refresh_hyper(self, optims):
+        """Before a replay: this step's scalars (``optim.param_groups[0]`` is read every step, like the eager path)."""
+        for i, (name, fl, stepped) in enumerate(self._captured):
+            if not stepped:
+                continue
+            g0 = optims["optim_" + name].param_groups[0]
+            h = ops.clip_adam_hyper(fl.steps + 1, float(g0["lr"]), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]))
+            self._hyper_host[i, :7] = torch.tensor(h)
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def after_replay(self, updated):
+        """Host bookkeeping of a replayed step: the counters advance unless the device guard skipped the update."""
+        for name, fl, stepped in self._captured:
+            fl.stepped = stepped and updated
+            if fl.stepped:
+                fl.steps += 1
+                fl.step_t.fill_(float(fl.steps))
+
     def rollback(self):
         """The guard turned the last step into a no-op (non-finite loss): take the step counters back, as the
         reference never reaches ``optim.step()`` in that case (``interfaces.py:254-271``)."""
