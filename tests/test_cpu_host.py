@@ -600,6 +600,27 @@ def _fused_worker(rank, world, port, q):
     log["none_grad_skipped"] = bool(torch.equal(models["dncnn"].bias.detach(), ref_b) and
                                     torch.equal(optims["optim_dncnn"].state[models["dncnn"].bias]["exp_avg"], ref_m))
     log["weight_moved"] = float((models["dncnn"].weight.detach() - ref_models["dncnn"].weight.detach()).abs().max())
+    # ... and keeps its OWN Adam step count: when it rejoins, its bias correction is that of torch.optim.Adam,
+    # which counts per parameter -- checked against a torch Adam fed the same (rank-averaged, clipped) gradients
+    tw = torch.nn.Linear(7, 3)
+    with torch.no_grad():
+        tw.weight.copy_(models["dncnn"].weight); tw.bias.copy_(models["dncnn"].bias)
+    topt = torch.optim.Adam(tw.parameters(), lr=1e-2)
+    st = optims["optim_dncnn"].state
+    for p_t, p_f in ((tw.weight, models["dncnn"].weight), (tw.bias, models["dncnn"].bias)):
+        topt.state[p_t] = {"step": torch.tensor(float(st[p_f]["step"])), "exp_avg": st[p_f]["exp_avg"].clone(),
+                           "exp_avg_sq": st[p_f]["exp_avg_sq"].clone()}
+    log["steps_diverged"] = [float(st[models["dncnn"].weight]["step"]), float(st[models["dncnn"].bias]["step"])]
+    for n, m in models.items():
+        for p in m.parameters():
+            p.grad = torch.full_like(p, 0.125 * (rank + 1))
+    mean = sum(0.125 * (r + 1) for r in range(world)) / world
+    tw.weight.grad = torch.full_like(tw.weight, mean)
+    tw.bias.grad = torch.full_like(tw.bias, mean)
+    fused.step(models, optims, guard=torch.tensor(1.0))
+    topt.step()
+    log["rejoin"] = max(float((tw.weight.detach() - models["dncnn"].weight.detach()).abs().max()),
+                        float((tw.bias.detach() - models["dncnn"].bias.detach()).abs().max()))
     q.put((rank, log))
     dist.destroy_process_group()
 
@@ -626,6 +647,7 @@ def test_two_rank_gloo_fused_clip_adam_reduce_then_scale_then_clip():
         assert log["state_step"] == 2.0
         assert log["global_guard"] == 0.0 and log["skipped"] and log["steps_after_rollback"] == [2, 2, 2], log
         assert log["none_grad_skipped"] and log["weight_moved"] > 1e-4, log
+        assert log["steps_diverged"] == [3.0, 2.0] and log["rejoin"] <= 1e-6, log
 
 
 def _global_pairing_worker(rank, world, port, q):
@@ -788,6 +810,43 @@ def test_training_loop_checkpoints_latest_every_epoch_and_best_on_improvement(tm
     assert ck["start_epoch"] == 6 and ck["best_err"] == 0.2 and ck["description"] == "t"
     with pytest.raises(NotImplementedError):
         tk.train([itf, itf], loaders, params, args)
+
+
+def test_init_model_restores_weight_normalised_pathnets_from_a_checkpoint(tmp_path):
+    """``init_model`` always built ``PathNet(weight_norm=False)``, so a checkpoint trained with upstream sbmc's
+    ConvChain default (``weight_g`` / ``weight_v`` per PathNet layer) could not be resumed.  The parametrisation is now a flag
+    (``--pathnet_weight_norm``) and is detected from the checkpoint on ``--start_epoch != 0``."""
+    from wcmc_amd import KPCN
+    from wcmc_amd import train_kpcn as tk
+    from wcmc_amd.support import checkpoint as ck_mod
+    from wcmc_amd.support.networks import PathNet
+    torch.manual_seed(3)
+    models = {"dncnn": KPCN(39), "backbone_diffuse": PathNet(36, outc=3, weight_norm=True),
+              "backbone_specular": PathNet(36, outc=3, weight_norm=True)}
+    assert any(k.endswith("weight_g") for k in models["backbone_diffuse"].state_dict())
+    itf = types.SimpleNamespace(models=models, best_err=0.25,
+                                optims={"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in models.items()})
+    argv = ["--desc", "d", "--model_name", "wn", "--save", str(tmp_path), "--use_llpm_buf", "--manif_learn", "--manif_loss", "FMSE",
+            "--train_branches", "--start_epoch", "1", "--best_err", "0.25", "--single_gpu"]
+    args = tk.check_args(tk.build_parser().parse_args(argv))
+    ck_mod.save_checkpoint(str(tmp_path / "wn.pth"), itf, 0, args)
+    sizes = {"dncnn_in_size": 34 + 5, "pnet_in_size": 36, "pnet_out_size": 3}
+    itfs, _ = tk.init_model(sizes, args, torch.device("cpu"))
+    got = itfs[0].models
+    for name in models:
+        sd_w, sd_g = models[name].state_dict(), got[name].state_dict()
+        assert list(sd_w) == list(sd_g), name
+        for k in sd_w:
+            assert torch.equal(sd_w[k], sd_g[k].cpu()), (name, k)
+    # a fresh start follows the flag (default: the documented "no norm")
+    fresh = ["--desc", "d", "--save", str(tmp_path), "--use_llpm_buf", "--manif_learn", "--manif_loss", "FMSE", "--train_branches",
+             "--single_gpu"]
+    args0 = tk.check_args(tk.build_parser().parse_args(fresh + ["--model_name", "fresh"]))
+    m0 = tk.init_model(sizes, args0, torch.device("cpu"))[0][0].models["backbone_diffuse"]
+    assert not any(k.endswith("weight_g") for k in m0.state_dict())
+    args1 = tk.check_args(tk.build_parser().parse_args(fresh + ["--model_name", "fresh1", "--pathnet_weight_norm"]))
+    m1 = tk.init_model(sizes, args1, torch.device("cpu"))[0][0].models["backbone_diffuse"]
+    assert any(k.endswith("weight_g") for k in m1.state_dict())
 
 
 def test_frozen_parameter_names_and_state_dict_round_trip():

@@ -62,7 +62,10 @@ class GraphedTrainStep:
             self._sum_views = [self.sums[i] for i in range(self.sums.numel())]
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph):
+            # thread_local: a loader thread (support/loader.py: pinned staging buffers, device allocations, H2D copies on its own
+            # stream) may allocate while this thread captures -- in the default 'global' mode a hipHostMalloc / hipMalloc from
+            # ANY thread invalidates the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.losses = itf._forward_backward(self.static)
                 if self.tail_captured:
                     self.loss_keys = list(self.losses)

@@ -56,8 +56,9 @@ class _Flat:
         self.v = torch.zeros(self.total, device=dev, dtype=torch.float32)
         # gradient bucket: [total gradients | flag slot (number of ranks with a non-finite loss) | 3 x pad]
         self.g = torch.zeros(self.total + _ALIGN, device=dev, dtype=torch.float32)
-        self.steps = 0
-        self.step_t = torch.tensor(0.0)                    # shared by every optim.state[p]['step'] of this model
+        self.steps = 0                                     # updates of this model so far
+        self.psteps = [0] * len(params)                    # Adam's step count PER PARAMETER, as torch.optim.Adam keeps it
+        self.step_t = torch.tensor(0.0)                    # optim.state[p]['step'] of every parameter whose count == steps
         self.stepped = False                               # did the last FusedClipAdam.step() touch this model
         for p, n, o in zip(params, self.sizes, self.offsets):
             self.flat[o:o + n].copy_(p.data.reshape(-1))
@@ -77,32 +78,53 @@ class _Flat:
     def _adopt_state(self, optim):
         """(Re)bind optim.state to views of the flat moments, importing loaded checkpoints."""
         mv, vv = self._views(self.m), self._views(self.v)
-        for p, m, v in zip(self.params, mv, vv):
+        for i, (p, m, v) in enumerate(zip(self.params, mv, vv)):
             st = optim.state[p]
             if "exp_avg" in st and st["exp_avg"].data_ptr() != m.data_ptr():
                 m.copy_(st["exp_avg"])
                 v.copy_(st["exp_avg_sq"])
-                self.steps = int(st["step"]) if "step" in st else self.steps
+                if "step" in st:
+                    self.psteps[i] = int(st["step"])
             st["exp_avg"], st["exp_avg_sq"] = m, v
-            st["step"] = self.step_t
+        self.steps = max(self.psteps) if self.psteps else 0
+        self._publish_steps(optim)
+
+    def _publish_steps(self, optim):
+        """optim.state[p]['step']: the shared tensor for parameters that took part in every update, an own one otherwise."""
         self.step_t.fill_(float(self.steps))
+        uniform = min(self.psteps) == self.steps
+        if uniform and getattr(self, "_uniform_published", False):
+            return                                          # (the usual case: every state already points at step_t)
+        for p, n in zip(self.params, self.psteps):
+            st = optim.state[p]
+            if n == self.steps:
+                st["step"] = self.step_t
+            elif not isinstance(st.get("step"), torch.Tensor) or st["step"] is self.step_t or float(st["step"]) != n:
+                st["step"] = torch.tensor(float(n))
+        self._uniform_published = uniform
 
     def bound(self, optim):
         st = optim.state.get(self.params[0], {})
         return "exp_avg" in st and st["exp_avg"].data_ptr() == self.m.data_ptr()
 
     def segments(self, have):
-        """Runs of consecutive parameters that have a gradient, as (first offset, end offset) of the flat buffers.
-        ``torch.optim.Adam`` skips a parameter whose ``.grad`` is None (no moment decay, no update): so do we."""
-        out, start = [], None
+        """Runs of consecutive parameters that have a gradient AND the same Adam step count, as (first offset, end offset,
+        step count of this update) of the flat buffers.  ``torch.optim.Adam`` skips a parameter whose ``.grad`` is None (no
+        moment decay, no update, no step) and bias-corrects every parameter with ITS OWN count: so do we -- one launch per run,
+        i.e. one per model while all its parameters train together."""
+        out, start, cur = [], None, None
         for i, h in enumerate(have):
+            n = self.psteps[i] + 1
+            if h and start is not None and n != cur:
+                out.append((start, self.offsets[i], cur))
+                start = None
             if h and start is None:
-                start = self.offsets[i]
+                start, cur = self.offsets[i], n
             if not h and start is not None:
-                out.append((start, self.offsets[i]))
+                out.append((start, self.offsets[i], cur))
                 start = None
         if start is not None:
-            out.append((start, self.total))
+            out.append((start, self.total, cur))
         return out
 
 
@@ -130,6 +152,7 @@ class FusedClipAdam:
             if not fl.stepped:                              # e.g. a frozen model: Adam.step() does nothing
                 work.append(None)
                 continue
+            # (several ranks must show the same pattern of gradients: the buckets are collectives, one per stepped model)
             gv = fl.grad_views()
             if all(have):
                 torch._foreach_copy_(gv, [p.grad for p in fl.params])                       # the gather (device copies)
@@ -157,18 +180,20 @@ class FusedClipAdam:
                 gguard = (first_fl.g[first_fl.total] == 0).to(torch.float32)
             optim = optims["optim_" + name]
             g0 = optim.param_groups[0]
-            fl.steps += 1
             have = [p.grad is not None for p in fl.params]
-            for a, b in fl.segments(have):
-                ops.clip_adam_(fl.flat[a:b], fl.g[a:b], fl.m[a:b], fl.v[a:b], fl.steps, float(g0["lr"]),
+            for a, b, nstep in fl.segments(have):
+                ops.clip_adam_(fl.flat[a:b], fl.g[a:b], fl.m[a:b], fl.v[a:b], nstep, float(g0["lr"]),
                                float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), clip=self.clip,
                                grad_scale=1.0 / self.world, guard=gguard)
+            fl.steps += 1
+            fl.psteps = [n + 1 if h else n for n, h in zip(fl.psteps, have)]
+            fl.last_have = have
             # leave the (averaged, clipped) gradients behind as the reference does
             if self.leave_grads:
                 for p, gview, h in zip(fl.params, fl.grad_views(), have):
                     if h:
                         p.grad = gview
-            fl.step_t.fill_(float(fl.steps))
+            fl._publish_steps(optim)
         self.last_guard = gguard
         return gguard
 
@@ -186,13 +211,15 @@ class FusedClipAdam:
                 fl._adopt_state(optim)
             have = [p.grad is not None for p in fl.params]
             fl.stepped = any(have)
-            self._captured.append((name, fl, fl.stepped))
+            self._captured.append((name, fl, fl.stepped, have))
             if not fl.stepped:
                 continue
+            assert len({n for n, h in zip(fl.psteps, have) if h}) == 1, \
+                "a captured optimiser bias-corrects a model's parameters with ONE step count: they must have trained together"
             gv = fl.grad_views()
             idx = [j for j, h in enumerate(have) if h]
             torch._foreach_copy_([gv[j] for j in idx], [fl.params[j].grad for j in idx])
-            for a, b in fl.segments(have):
+            for a, b, _ in fl.segments(have):
                 ops.clip_adam_dev_(fl.flat[a:b], fl.g[a:b], fl.m[a:b], fl.v[a:b], self.hyper[i], clip=self.clip,
                                    grad_scale=1.0, guard=guard)
 
@@ -206,21 +233,24 @@ class FusedClipAdam:
 
     def refresh_hyper(self, optims):
         """Before a replay: this step's scalars (``optim.param_groups[0]`` is read every step, like the eager path)."""
-        for i, (name, fl, stepped) in enumerate(self._captured):
+        for i, (name, fl, stepped, have) in enumerate(self._captured):
             if not stepped:
                 continue
             g0 = optims["optim_" + name].param_groups[0]
-            h = ops.clip_adam_hyper(fl.steps + 1, float(g0["lr"]), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]))
+            nstep = next(n for n, h in zip(fl.psteps, have) if h) + 1
+            h = ops.clip_adam_hyper(nstep, float(g0["lr"]), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]))
             self._hyper_host[i, :7] = torch.tensor(h)
         self.hyper.copy_(self._hyper_host, non_blocking=True)
 
     def after_replay(self, updated):
         """Host bookkeeping of a replayed step: the counters advance unless the device guard skipped the update."""
-        for name, fl, stepped in self._captured:
+        for name, fl, stepped, have in self._captured:
             fl.stepped = stepped and updated
             if fl.stepped:
                 fl.steps += 1
-                fl.step_t.fill_(float(fl.steps))
+                fl.psteps = [n + 1 if h else n for n, h in zip(fl.psteps, have)]
+                fl.last_have = have
+                fl.step_t.fill_(float(fl.steps))          # (parameters outside `have` keep their own 'step' tensors)
 
     def rollback(self):
         """The guard turned the last step into a no-op (non-finite loss): take the step counters back, as the
@@ -228,5 +258,6 @@ class FusedClipAdam:
         for fl in self.flats.values():
             if fl.stepped:
                 fl.steps -= 1
+                fl.psteps = [n - 1 if h else n for n, h in zip(fl.psteps, fl.last_have)]
                 fl.step_t.fill_(float(fl.steps))
                 fl.stepped = False

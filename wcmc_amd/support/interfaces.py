@@ -323,12 +323,24 @@ class KPCNInterface(BaseInterface):
         self.last_loss_dict = loss_dict
         keys = list(loss_dict)
         finite = torch.isfinite(torch.stack([loss_dict[k].reshape(()) for k in keys]))
+        vals = [loss_dict[k] for k in keys]
         if self.fused_optim is not None:
             # Deferred: the fused optimiser is enqueued behind a device-side guard (no update when a
             # loss is non-finite) and the host check -- the only sync of the step -- comes after it.
             self._pending_finite = (keys, finite)
+            ok = finite.all()                            # the reference raises BEFORE it logs (interfaces.py:254-267): a
+            vals = [torch.where(ok, v, torch.zeros_like(v)) for v in vals]      # step that will raise adds nothing to the sums
         else:
-            self._raise_if_nonfinite(keys, finite)
+            if self.grad_sync is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+                # every rank must reach the gradient all-reduce or none: agree on the flag first (a rank that raised alone
+                # would leave the others waiting in the collective)
+                flag = finite.all().to(torch.float32).reshape(1)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                self._raise_if_nonfinite(keys, finite)
+                if flag.item() == 0:
+                    raise RuntimeError("Non-finite loss at train time on another rank.")
+            else:
+                self._raise_if_nonfinite(keys, finite)
 
         if self.grad_sync is not None:
             self.grad_sync(self.models)
@@ -341,7 +353,7 @@ class KPCNInterface(BaseInterface):
         for key in loss_dict:
             if 'm_' + key not in self.m_losses:
                 self.m_losses['m_' + key] = torch.tensor(0.0, device=loss_dict[key].device)
-        sums, vals = [self.m_losses['m_' + k] for k in keys], [loss_dict[k] for k in keys]
+        sums = [self.m_losses['m_' + k] for k in keys]
         if all(a.shape == b.shape and a.device == b.device and a.dtype == b.dtype for a, b in zip(sums, vals)):
             torch._foreach_add_(sums, vals)              # the running sums in one launch (seven tiny ones otherwise)
         else:
@@ -360,6 +372,8 @@ class KPCNInterface(BaseInterface):
             guard = finite.all().to(torch.float32)
             # clip_grad_value_(1.0) + Adam, fused; the guard comes back reduced over the ranks (all skip or none)
             gguard = self.fused_optim.step(self.models, self.optims, guard=guard)
+            if gguard is None:                       # no model had a gradient (all frozen): nothing was reduced or updated
+                gguard = guard
             flags = torch.cat([finite.to(torch.float32), gguard.reshape(1)]).tolist()          # the step's one sync
             if flags[-1] == 0:
                 self.fused_optim.rollback()          # the reference never reaches optim.step() (interfaces.py:254-271)

@@ -48,13 +48,34 @@ class ImageStager:
             slot[key] = buf
         return buf
 
+    @staticmethod
+    def _get(q, stop):
+        """``q.get()`` that gives up when the consumer has gone (``stop``): the producer must never block forever on a queue
+        nobody serves any more -- a daemon thread parked there would keep the pinned ring and the device tensors alive."""
+        while not stop.is_set():
+            try:
+                return q.get(timeout=0.2)
+            except queue.Empty:
+                continue
+        return None
+
+    @staticmethod
+    def _put(q, item, stop):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                continue
+        return False
+
     def _produce(self, out_q, free_q, stop):
         try:
             torch.cuda.set_device(self.device)
             for i in self.indices:
-                if stop.is_set():
+                slot = self._get(free_q, stop)                        # a staging slot whose last copy has completed
+                if slot is None:                                      # (the consumer abandoned the iteration)
                     return
-                slot = free_q.get()                                   # a staging slot whose last copy has completed
                 if slot.get('event') is not None:
                     slot['event'].synchronize()
                 item = self.reader(i)
@@ -72,10 +93,11 @@ class ImageStager:
                     ev.record(self.copy_stream)
                 slot['event'] = ev
                 self.bytes_moved += raw.nbytes + gt.nbytes
-                out_q.put((kpcn, llpm, d_gt, item.get('prob'), ev, slot))
-            out_q.put(None)
+                if not self._put(out_q, (kpcn, llpm, d_gt, item.get('prob'), ev, slot), stop):
+                    return
+            self._put(out_q, None, stop)
         except BaseException as exc:                                  # surface reader / CUDA errors in the consumer
-            out_q.put(exc)
+            self._put(out_q, exc, stop)
 
     def __iter__(self):
         out_q, free_q, stop = queue.Queue(maxsize=self.depth), queue.Queue(), threading.Event()
@@ -99,7 +121,9 @@ class ImageStager:
                 free_q.put(slot)                                      # (its event guards the pinned buffers' reuse)
                 yield kpcn, llpm, gt, prob
         finally:
-            stop.set()
+            stop.set()                                                # the producer's queue waits poll this flag ...
+            free_q.put(None)                                          # ... and a sentinel wakes one that is blocked right now
+            worker.join(timeout=5.0)
 
 
 class PatchLoader:

@@ -161,26 +161,31 @@ def init_model(sizes, args, device, group=None):
     grid = list(itertools.product(args.lr_pnet, args.pnet_out_size, args.w_manif))
     for lr_pnet, pnet_out_size, w_manif in grid:
         models = {}
-        if args.use_llpm_buf:
-            half = args.disentangle in ('m10r01', 'm11r01')
-            n_in = sizes['dncnn_in_size'] - sizes['pnet_out_size'] + (pnet_out_size // 2 if half else pnet_out_size)
-            models['dncnn'] = KPCN(n_in)
-            print('Initialize KPCN for path descriptors (# of input channels: %d).' % (n_in))
-            models['backbone_diffuse'] = PathNet(ic=sizes['pnet_in_size'], outc=pnet_out_size)
-            models['backbone_specular'] = PathNet(ic=sizes['pnet_in_size'], outc=pnet_out_size)
-        else:
-            n_in = sizes['dncnn_in_size'] + (3 if args.kpcn_ref else 0)
-            models['dncnn'] = KPCN(n_in)
-            print('Initialize KPCN for vanilla buffers (# of input channels: %d).' % (n_in))
         if len(grid) == 1:
             model_fn = os.path.join(args.save, args.model_name + '.pth')
         else:
             model_fn = os.path.join(args.save, '%s_lp%f_pos%d_wgt%f.pth' % (args.model_name, lr_pnet, pnet_out_size, w_manif))
         assert args.start_epoch != 0 or not os.path.isfile(model_fn), 'Model %s already exists.' % (model_fn)
         is_pretrained = args.start_epoch != 0 and os.path.isfile(model_fn)
-        ck = None
+        ck = ckpt.load_checkpoint(model_fn) if is_pretrained else None
+        # upstream sbmc's ConvChain is believed to default to weight normalisation (which sbmc.KPCN switches off and PathNet,
+        # support/networks.py:18-24, does not): a checkpoint trained there carries `weight_g` / `weight_v` per PathNet layer
+        wn = bool(getattr(args, 'pathnet_weight_norm', False))
+        if ck is not None and any(k.endswith('weight_g') for k in ck.get('state_dict_backbone_diffuse', {})):
+            wn = True
+            print('The checkpoint holds weight-normalised PathNets (weight_g / weight_v): building them that way.')
+        if args.use_llpm_buf:
+            half = args.disentangle in ('m10r01', 'm11r01')
+            n_in = sizes['dncnn_in_size'] - sizes['pnet_out_size'] + (pnet_out_size // 2 if half else pnet_out_size)
+            models['dncnn'] = KPCN(n_in)
+            print('Initialize KPCN for path descriptors (# of input channels: %d).' % (n_in))
+            models['backbone_diffuse'] = PathNet(ic=sizes['pnet_in_size'], outc=pnet_out_size, weight_norm=wn)
+            models['backbone_specular'] = PathNet(ic=sizes['pnet_in_size'], outc=pnet_out_size, weight_norm=wn)
+        else:
+            n_in = sizes['dncnn_in_size'] + (3 if args.kpcn_ref else 0)
+            models['dncnn'] = KPCN(n_in)
+            print('Initialize KPCN for vanilla buffers (# of input channels: %d).' % (n_in))
         if is_pretrained:
-            ck = ckpt.load_checkpoint(model_fn)
             ckpt.restore_models(ck, models)
             print('Pretraining weights are loaded.')
         else:
@@ -271,6 +276,9 @@ def build_parser():
     p.add_argument('--graph', action='store_true', help='one hipGraph replay per training step')
     p.add_argument('--pairing_rng', choices=('cpu', 'device'), default='cpu',
                    help="FeatureMSE pairings: the reference's CPU randperm stream, or a keyed permutation on the GPU")
+    p.add_argument('--pathnet_weight_norm', action='store_true',
+                   help="weight-normalised PathNet layers (w = g * v / ||v||: upstream sbmc's ConvChain default, which "
+                        "support/networks.py:18-24 does not switch off); detected automatically when a checkpoint is restored")
     p.add_argument('--pairing', choices=('local', 'global'), default='local',
                    help="FeatureMSE intra-batch pairing under several ranks: inside a rank's patches (default), or over the "
                         "all-gathered GLOBAL batch as nn.DataParallel's gathered loss does (train_kpcn.py:266-269; not with --graph)")
