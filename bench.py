@@ -161,6 +161,35 @@ def kernel_apply_probe(device, iters=24, nsets=4):
     return out
 
 
+def measured_peaks(device):
+    """What THIS box sustains on library kernels, printed beside the spec constants the roofline fractions use ("take
+    gfx950 numbers measured on the box ... state which was used"): a 1 GiB device copy and read-only sum (HBM), and an
+    8192^3 bf16 GEMM through torch (hipBLASLt) -- the matrix pipe under a dense load at the clock it settles to."""
+    def timeit(fn, n):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+    n = 256 * 1024 * 1024
+    x = torch.empty(n, device=device).normal_()
+    y = torch.empty_like(x)
+    t_copy, t_read = timeit(lambda: y.copy_(x), 10), timeit(lambda: x.sum(), 10)
+    del y
+    a = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
+    t_mm = timeit(lambda: torch.matmul(a, b), 10)
+    return {"hbm_copy_GBs": round(2 * n * 4 / t_copy / 1e9, 0), "hbm_read_GBs": round(n * 4 / t_read / 1e9, 0),
+            "bf16_gemm_8192_TFLOPs": round(2 * 8192.0 ** 3 / t_mm / 1e12, 0),
+            "used_for_frac": {"hbm_GBs": PEAK_HBM_GBS, "bf16_mfma_TFLOPs": PEAK_BF16_MFMA_TFLOPS, "fp32_mfma_TFLOPs": PEAK_FP32_MFMA_TFLOPS,
+                              "source": "MI355X_MICROARCH.md spec peaks (the fractions are against these, not against the measured values)"}}
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/<round>_pmc_summary.json):
     (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md section HBM."""
@@ -530,6 +559,7 @@ def main():
             "roofline_pointwise": (dict(roof("conv_pw", "hbm"), traffic=traffic.get("conv_pw")) if roof("conv_pw", "hbm") else None),
             "roofline_kernel_apply": ka,
         }
+        line["measured_peaks"] = measured_peaks(device)
         if world == 1 and not args.eager:
             ops.USE_SIDE_STREAM, ops.USE_BRANCH_STREAM = stream_defaults
             line["c2"] = c2_leg(device, args.steps, args.warmup)

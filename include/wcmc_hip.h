@@ -243,16 +243,6 @@ int wcmc_kernel_apply_bwd(const float* logits, int64_t lsn, int64_t lsh, int64_t
                           float* d_logits, int64_t qsn, int64_t qsh, int64_t qsw,
                           float* d_data, int N, int C, int h, int w, int k, void* stream);
 
-/* The same backward with d_logits written directly as the dense split tensor (hi/lo bf16 planes, wcmc_split_bf16's
- * layout with round_up(k*k, 8) channels, pad channels zero) that the kernel-predicting ConvChain's backward consumes:
- * the 119 MB fp32 gradient per branch is neither written nor re-read by a split pass.  No d_data. */
-int wcmc_kernel_apply_bwd_split(const float* logits, int64_t lsn, int64_t lsh, int64_t lsw,
-                                const float* data, int64_t dsn, int64_t dsc, int64_t dsh, int64_t dsw,
-                                const float* out, int64_t osn, int64_t osc, int64_t osh, int64_t osw,
-                                const float* grad_out, int64_t gsn, int64_t gsc, int64_t gsh, int64_t gsw,
-                                const float* lse, void* d_logits_split, int N, int C, int h, int w, int k,
-                                void* stream);
-
 /* Tail of sbmc.KPCN.forward (result keys consumed at support/interfaces.py:207-211):
  *   radiance = albedo * r_diffuse + exp(r_specular) - 1.
  * Inputs (N,C,H,W) with arbitrary element strides; out / grad_out / d_* contiguous (N,C,H,W). */

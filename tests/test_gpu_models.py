@@ -619,9 +619,6 @@ _SWITCHES = [
     ("attr", "USE_GATE_MASK", False, "close"),           # gate from the activation, not the 1-bit mask (and no fused 1x1
                                                          # dgrad pair: the bias sums group per tile, not per workgroup)
     ("attr", "FUSE_CHAIN_GLUE", False, "exact"),         # separate spp-mean / concat / upsample nodes
-    ("attr", "FUSE_KERNEL_APPLY", True, "close"),        # chain + kernel-apply as one node (split d_logits; tile kernel; the head's
-                                                         # bias sums group by colsum_split's blocks)
-    ("attr", "PIPELINE_BRANCHES", True, "exact"),        # the two halves as independent pipelines, specular one phase late
     ("attr", "USE_BRANCH_STREAM", False, "exact"),       # specular half on the main stream
     ("attr", "USE_SIDE_STREAM", False, "exact"),         # weight gradients on the main stream
     ("env", "WCMC_IGEMM_PW", "0", "close"),              # tiled kernel for the 1x1 layers (bias sums group per tile)
@@ -634,7 +631,6 @@ _SWITCHES = [
     ("env", "WCMC_WGRAD_ROWS", "0", "close"),            # one-tap weight-gradient kernel (another split-K order)
     ("env", "WCMC_HALO64", "0", "close"),                # the 8x16 5x5 kernel (32-channel slabs: another K order)
     ("env", "WCMC_HALO64_PT3", "0", "close"),            # 16x16 tiles only (bias sums group per tile)
-    ("env", "WCMC_HALO64_PRIO", "0", "exact"),           # no priority alternation between the workgroups of a CU
     ("env", "WCMC_HALO64_CS32", "0", "close"),           # 16-channel slabs for the 441-channel data gradient too (another K order)
     ("env", "WCMC_WGRAD_ROWS_3X3", "0", "close"),        # filter-row weight gradient only from 256 input channels up
     ("env", "WCMC_WGRAD_ROWS_1X1", "0", "close"),        # one-tap kernel for the 128->128 1x1 weight gradient

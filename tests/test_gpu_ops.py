@@ -266,8 +266,8 @@ def test_conv5x5_kernel_variants_agree_with_fp64(case, monkeypatch):
     mask = torch.from_numpy(np.packbits(bits.numpy().reshape(-1, cp), axis=1, bitorder="little").reshape(-1)).to(DEV)
     outs = {}
     for name, env in (("12x16 where it pays", {}), ("16x16 only", {"WCMC_HALO64_PT3": "0"}),
-                      ("no priority alternation", {"WCMC_HALO64_PRIO": "0"}), ("8x16 kernel", {"WCMC_HALO64": "0"})):
-        for k in ("WCMC_HALO64_PT3", "WCMC_HALO64_PRIO", "WCMC_HALO64"):
+                      ("8x16 kernel", {"WCMC_HALO64": "0"})):
+        for k in ("WCMC_HALO64_PT3", "WCMC_HALO64"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -283,9 +283,8 @@ def test_conv5x5_kernel_variants_agree_with_fp64(case, monkeypatch):
             yd = yd * keep.to(DEV)
         assert_close(yd, ref, tol=2e-5, what=name)
         outs[name] = yd
-    # same kernel, same K order: the tile height and the priority do not change a single bit
+    # same kernel, same K order: the tile height does not change a single bit
     assert torch.equal(outs["12x16 where it pays"], outs["16x16 only"])
-    assert torch.equal(outs["12x16 where it pays"], outs["no priority alternation"])
 
 
 @pytest.mark.parametrize("case", [(16, 36, 64, 64, 64, 1), (12, 128, 48, 40, 128, 1), (16, 128, 64, 64, 3, 1), (4, 128, 40, 37, 128, 3)])
@@ -623,33 +622,6 @@ def test_kernel_apply_strip_equals_tile_kernel(shape, monkeypatch):
     assert torch.equal(res[0][1], res[1][1]), "d_logits differs"
     ref = om.kernel_apply(data.double().cpu(), logits.double().cpu())
     assert_close(res[1][0], ref, what="strip kernel fwd vs oracle")
-
-
-def test_chain_kernel_apply_node_equals_the_separate_ops():
-    """One half of sbmc.KPCN.forward as one autograd node (the apply's backward writes d_logits straight into the
-    chain's split gradient, wcmc_kernel_apply_bwd_split) == conv_chain followed by kernel_apply, bit for bit."""
-    o = ops()
-    n, cin, h = 2, 12, 30
-    x, data = gen(n, cin, h, h, seed=110), gen(n, 3, h - 8, h - 8, seed=111).abs()
-    wt = [gen(16, cin, 5, 5, seed=112, scale=0.1), gen(16, seed=113, scale=0.1),
-          gen(441, 16, 5, 5, seed=114, scale=0.1), gen(441, seed=115, scale=0.1)]
-    g = gen(n, 3, h - 8, h - 8, seed=116)
-    res = []
-    for fused in (True, False):
-        xd = x.to(DEV).requires_grad_(True)
-        ps = [t.to(DEV).requires_grad_(True) for t in wt]
-        d = data.to(DEV)
-        if fused:
-            y = o._ChainKernelApplyX.apply(o.as_nhwc(xd), d, (5, 0, ("relu", "linear")), *ps)
-        else:
-            y = o.kernel_apply(d, o.conv_chain(xd, 5, 0, ["relu", "linear"], ps))
-        y.backward(g.to(DEV))
-        res.append([y.detach().clone(), xd.grad.clone()] + [t.grad.clone() for t in ps])
-    for a, b, nm in zip(res[0], res[1], ["out", "dx", "dw0", "db0", "dw1", "db1"]):
-        if nm == "db1":     # the head's bias gradient: column sums grouped by colsum_split's blocks vs by the split pass's
-            assert_close(a, b, tol=1e-5, what="fused chain + kernel-apply, db1")
-        else:
-            assert torch.equal(a, b), "fused chain + kernel-apply differs in " + nm
 
 
 def test_kernel_apply_known_answers():

@@ -51,7 +51,6 @@ SIGNATURES = {
     "wcmc_kernel_apply_fwd": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, I, I, I, I, I, P]),
     "wcmc_kernel_apply_bwd": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P,
                                   P, L, L, L, P, I, I, I, I, I, P]),
-    "wcmc_kernel_apply_bwd_split": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P, P, I, I, I, I, I, P]),
     "wcmc_recombine_fwd": (I, [P, L, L, L, L, P, L, L, L, L, P, L, L, L, L, P, I, I, I, I, P]),
     "wcmc_image_loss_workspace_bytes": (Z, []),
     "wcmc_image_loss_fwd": (I, [P, L, L, L, L, P, L, L, L, L, F, P, P, P, Z, I, I, I, I, P]),

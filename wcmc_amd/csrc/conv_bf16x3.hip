@@ -385,9 +385,8 @@ static XKPlan x_plan_k(int kchan, int ks, int ap_req = 2, int rows = 0) {
     // 2-way bank conflicts with it (PMC: 23-26 % of the LDS cycles; the four 16-lane groups of a b128 read take k-groups 0
     // and 1 of different pixel columns together and 5 f, 5 f' + 1 meet mod 16); 96 B is conflict-free for the 16-channel
     // slabs and measured 0.7 % SLOWER (3.120 vs 3.097 ms per branch: the LDS pipe is not what the loop waits for, and the
-    // halo grows by a fifth) -- WCMC_HALO64_PXS=96 for the A/B
-    static const int pxs = [] { const char* e = getenv("WCMC_HALO64_PXS"); return e ? atoi(e) : 80; }();
-    q.PXS = pxs;
+    // halo grows by a fifth); the switch for that A/B is gone (round 3)
+    q.PXS = 80;
     q.Ks = round_up(ks * ks * q.CS, 32); q.Ksl = round_up(ks * ks * q.CSl, 32);
     q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
     return q;
@@ -1518,7 +1517,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   for (int j = 0; j < NT; ++j) read_b(0, j);
   int s_in = 0, slab = 0, bcur = 0;
   const int wgpar = (blockIdx.x >> 8) & 1;
-  const bool prio_on = p.SPS & 0x100;          // (A/B switch, set by the launcher: WCMC_HALO64_PRIO)
+  const bool prio_on = p.SPS & 0x100;          // (set by the launcher)
   rstamp(1);
   for (int g = 0; g < nstages; ++g) {
     const int b1 = bcur + 1 == NB ? 0 : bcur + 1;      // buffer of stage g+1; stage g's fragments are in registers
@@ -3507,7 +3506,7 @@ static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream
 template <int NT>
 static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   XIgemmParams p = p0;
-  if (x_env_on("WCMC_HALO64_PRIO")) p.SPS |= 0x100;
+  p.SPS |= 0x100;     // alternate the priority of a CU's two workgroups stage by stage (measured neutral on the launch time, kept: it evens the two workgroups' finish times; its A/B switch is gone)
   // Tile height 16 (four pixel tiles per wave) or 12 (three): 512 workgroups are resident (two per CU), a launch takes
   // ceil(workgroups / 512) rounds of a time proportional to the tile height.  The KPCN layers of 100..108 output rows
   // are 392 tiles of 16x16 (one round, a quarter of the slots empty) but 504 of 12x16 (one round of 3/4 the length).

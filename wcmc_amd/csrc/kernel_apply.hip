@@ -27,7 +27,6 @@ struct KAParams {
   const float* gout; int64_t gsn, gsc, gsh, gsw;          // bwd only
   float* lse;                                             // fwd: written (may be null), bwd: read
   float* dlogits; int64_t qsn, qsh, qsw;                  // bwd only
-  unsigned short* dlsplit; int Cps;                       // bwd only: d_logits as a dense split tensor [pixel][hi Cps][lo Cps] instead
   float* ddata;                                           // bwd only, may be null
   int N, C, h, w, k, r, taps, nvec, halo;
 };
@@ -222,22 +221,7 @@ __global__ __launch_bounds__(128) void kernel_apply_kernel(KAParams p) {
           }
         }
         const int vi = j + 16 * i;
-        if (p.dlsplit) {
-          // straight into the conv chain's split-bf16 gradient layout (hi = bf16(v), lo = bf16(v - hi)); slots past
-          // k*k are exact zeros (their weight is exp2(-1e30)): the pad channels of the split tensor
-          if (valid && 4 * vi < p.Cps) {
-            unsigned short hi[4], lo[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              hi[e] = __builtin_bit_cast(unsigned short, (__bf16)o[e]);
-              const float hf = __builtin_bit_cast(float, (unsigned)hi[e] << 16);
-              lo[e] = __builtin_bit_cast(unsigned short, (__bf16)(o[e] - hf));
-            }
-            unsigned short* q = p.dlsplit + pix * 2 * p.Cps + 4 * vi;
-            *reinterpret_cast<uint2*>(q) = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
-            *reinterpret_cast<uint2*>(q + p.Cps) = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
-          }
-        } else if (valid && vi < nvec) {
+        if (valid && vi < nvec) {
           *reinterpret_cast<float4*>(qrow + 4 * vi) = make_float4(o[0], o[1], o[2], o[3]);
         }
       }
@@ -678,27 +662,6 @@ static int ka_bwd_launch(KAParams& p, int N, int C, int h, int w, int k, void* s
   if (k == 21 && C <= 3) hipLaunchKernelGGL((kernel_apply_kernel<true, 21, false>), grid, dim3(128), lds, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((kernel_apply_kernel<true, 0, true>), grid, dim3(128), lds, (hipStream_t)stream, p);
   return check_launch("kernel_apply_bwd");
-}
-
-extern "C" int wcmc_kernel_apply_bwd_split(const float* logits, int64_t lsn, int64_t lsh, int64_t lsw, const float* data,
-                                           int64_t dsn, int64_t dsc, int64_t dsh, int64_t dsw, const float* out,
-                                           int64_t osn, int64_t osc, int64_t osh, int64_t osw, const float* grad_out,
-                                           int64_t gsn, int64_t gsc, int64_t gsh, int64_t gsw, const float* lse,
-                                           void* d_logits_split, int N, int C, int h, int w, int k, void* stream) {
-  KAParams p = {};
-  if (int rc = ka_fill(p, N, C, h, w, k)) return rc;
-  WCMC_REQUIRE(data && out && grad_out && lse && d_logits_split, WCMC_ERR_BAD_ARG, "kernel_apply_bwd_split: null pointer");
-  WCMC_REQUIRE(nhwc_view_ok(logits, lsn, lsh, lsw, k * k) && aligned16(d_logits_split), WCMC_ERR_ALIGNMENT,
-               "kernel_apply_bwd_split: logits violate the NHWC-view contract (or the split output is unaligned)");
-  WCMC_REQUIRE(round_up(k * k, 8) <= 64 * KA_MAXV, WCMC_ERR_BAD_ARG, "kernel_apply_bwd_split: k*k too large");
-  p.logits = logits; p.lsn = lsn; p.lsh = lsh; p.lsw = lsw;
-  p.data = data; p.dsn = dsn; p.dsc = dsc; p.dsh = dsh; p.dsw = dsw;
-  p.out = out; p.osn = osn; p.osc = osc; p.osh = osh; p.osw = osw;
-  p.gout = grad_out; p.gsn = gsn; p.gsc = gsc; p.gsh = gsh; p.gsw = gsw;
-  p.lse = const_cast<float*>(lse);
-  p.dlogits = nullptr; p.ddata = nullptr;
-  p.dlsplit = (unsigned short*)d_logits_split; p.Cps = round_up(k * k, 8);
-  return ka_bwd_launch(p, N, C, h, w, k, stream);
 }
 
 extern "C" int wcmc_kernel_apply_bwd(const float* logits, int64_t lsn, int64_t lsh, int64_t lsw, const float* data,

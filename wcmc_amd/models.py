@@ -27,11 +27,6 @@ class KPCN(nn.Module):
         k_like = types.SimpleNamespace(shape=tuple(x.shape[:2]) + (x.shape[2] - shrink, x.shape[3] - shrink))
         return chain.forward_kernel_apply(x, crop_like(buffer, k_like))
 
-    def forward_branch(self, name, x, buffer):
-        """One half of ``forward`` (``name``: 'diffuse' | 'specular'): the kernel-predicting chain on ``x`` and the
-        kernel-apply on the cropped noisy ``buffer``.  Lets a caller run the two halves as two independent pipelines."""
-        return self._branch(self.diffuse if name == "diffuse" else self.specular, x, buffer)
-
     def forward(self, data):
         with ops.on_branch(data["kpcn_specular_in"].device) as br:      # specular half on the branch stream
             r_specular = self._branch(self.specular, data["kpcn_specular_in"], data["kpcn_specular_buffer"])

@@ -237,15 +237,6 @@ USE_BRANCH_STREAM = os.environ.get("WCMC_BRANCH_STREAM", "1") != "0"   # +1.8 % 
 _BRANCH_STREAMS = {}
 
 
-# The two halves of a KPCN-Manifold step (PathNet -> input assembly -> KPCN chain -> kernel-apply -> losses -> backward) as
-# two INDEPENDENT pipelines, the specular one started one phase late so that its HBM-bound PathNet work would run beside the
-# MFMA-bound KPCN GEMMs of the diffuse half (interfaces.KPCNInterface._forward_backward_pipelined).  Bit-identical, and
-# measured 2.5 % SLOWER than the joined structure (360 against 369 patches/s, three alternations on one box, with or
-# without the lag): the MFMA kernels of both halves time-share the chip either way, and the pipelines lose the shared
-# round-2 filling of the joined launches.  Off; WCMC_PIPELINE_BRANCHES=1 for the A/B.
-PIPELINE_BRANCHES = os.environ.get("WCMC_PIPELINE_BRANCHES", "0") != "0"
-
-
 def branch_stream(device):
     key = (device.type, device.index)
     if key not in _BRANCH_STREAMS:
@@ -956,59 +947,10 @@ def kernel_apply(data, logits):
     return _KernelApply.apply(data, as_nhwc(logits))
 
 
-class _ChainKernelApplyX(torch.autograd.Function):
-    """``kernel_apply(crop(data), chain(x))`` -- one half of ``sbmc.KPCN.forward`` -- as one node: the backward's
-    kernel-apply writes d_logits directly as the split gradient of the chain's backward
-    (``wcmc_kernel_apply_bwd_split``) instead of an fp32 tensor that a split pass would re-read."""
-
-    @staticmethod
-    def forward(ctx, x, data, spec, *params):
-        _need_cuda(x, data, *params)
-        assert spec[2][-1] == "linear" and not data.requires_grad
-        out_box = []
-
-        def apply(logits):
-            n, k2, h, w = logits.shape
-            k = int(round(k2 ** 0.5))
-            c = data.shape[1]
-            assert k * k == k2 and data.shape[0] == n and data.shape[2:] == logits.shape[2:]
-            out = torch.empty((n, c, h, w), device=logits.device, dtype=torch.float32)
-            lse = torch.empty(n * h * w, device=logits.device, dtype=torch.float32)
-            with _Timed("kernel_apply_fwd", 4.0 * n * h * w * (k2 + 2 * c), "byte"):
-                check(lib().wcmc_kernel_apply_fwd(*_v(logits), _ptr(data), *data.stride(), _ptr(out), *out.stride(),
-                                                  _ptr(lse), n, c, h, w, k, _stream()), "kernel_apply_fwd")
-            ctx.k = k
-            out_box.append(out)
-            return data, logits, out, lse
-
-        _chainx_forward(ctx, split_raw(x), tuple(x.shape), spec, params, extra_saved=apply)
-        return out_box[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        data, logits, out, lse = ctx.saved_tensors[-4:]
-        n, k2, h, w = logits.shape
-        c = data.shape[1]
-        g = g.contiguous()
-        dys = _split_empty(n, k2, h, w, logits.device)
-        with _Timed("kernel_apply_bwd", 4.0 * n * h * w * (2 * k2 + 3 * c), "byte"):
-            check(lib().wcmc_kernel_apply_bwd_split(*_v(logits), _ptr(data), *data.stride(), _ptr(out), *out.stride(),
-                                                    _ptr(g), *g.stride(), _ptr(lse), _ptr(dys), n, c, h, w, ctx.k,
-                                                    _stream()), "kernel_apply_bwd_split")
-        dx, grads = _chainx_backward(ctx, None, ctx.needs_input_grad[0], dys=dys)
-        return (dx, None, None, *grads)
-
-
-# Measured neutral at the benchmark shapes (369-371 patches/s either way, three alternations on one box: the 8-byte
-# split stores of the apply's backward cost what the saved fp32 round trip gains) -- off unless WCMC_FUSE_KA=1.
-FUSE_KERNEL_APPLY = os.environ.get("WCMC_FUSE_KA", "0") != "0"
-
-
 def chain_kernel_apply(x, data, ksize, pad, acts, params):
-    """``kernel_apply(data, conv_chain(x, ...))`` with ``data`` already cropped to the chain's output size."""
-    if (FUSE_CHAIN_GLUE and split_path() and acts[-1] == "linear" and not data.requires_grad
-            and FUSE_KERNEL_APPLY):
-        return _ChainKernelApplyX.apply(as_nhwc(x), data, (ksize, pad, tuple(acts)), *params)
+    """``kernel_apply(data, conv_chain(x, ...))`` with ``data`` already cropped to the chain's output size.  (Round 2 also had
+    the two as ONE autograd node whose backward wrote d_logits straight into the chain's split gradient; it measured neutral
+    -- 369-371 patches/s either way -- and was removed in round 3.)"""
     return kernel_apply(data, conv_chain(x, ksize, pad, acts, params))
 
 

@@ -143,77 +143,9 @@ class KPCNInterface(BaseInterface):
             pimg = np.mean(np.transpose(p_buffers[br].detach().cpu().numpy()[0, :, :3, ...], (2, 3, 0, 1)), 2)
             plt.imsave('../LLPM_results/pbuf_%s_%s.png' % (self.args.model_name, br), np.clip(pimg, 0.0, 1.0))
 
-    def _pipelined(self, batch):
-        return (self.use_llpm_buf and self.train_branches and batch['kpcn_diffuse_in'].is_cuda
-                and getattr(_ops, 'PIPELINE_BRANCHES', False) and _ops.USE_BRANCH_STREAM and hasattr(self.models['dncnn'], 'forward_branch')
-                and not (self.iters % 1000 == 1 and os.path.isdir('../LLPM_results')))
-
-    def _forward_backward_pipelined(self, batch):
-        """``_forward_backward`` for the manifold / train-branches configuration with the diffuse and the specular half as
-        two independent pipelines (``interfaces.py:122-251``: the halves share nothing but the inputs until the logged
-        ``l_total`` / ``rmse``): diffuse on the current stream, specular on the branch stream and ONE PHASE LATE -- it starts
-        when the diffuse PathNet forward is done, so that the HBM-bound PathNet work of one half overlaps the MFMA-bound KPCN
-        GEMMs of the other instead of the two PathNets (and then the two KPCN halves) contending for the same resource.
-        Same kernels, same arithmetic, same order of FeatureMSE draws: bit-identical to the un-pipelined step."""
-        dev = batch['kpcn_diffuse_in'].device
-        _ops.fork_all_streams(dev)
-        for name in ('backbone_diffuse', 'backbone_specular', 'dncnn'):
-            self.models[name].zero_grad()
-        pre = getattr(self.models['backbone_diffuse'], '_paths_nhwc', None)
-        if pre is not None:
-            pre(batch)                       # shared converted copy of `paths`, made before the streams fork
-        kp = self.models['dncnn']
-        main = torch.cuda.current_stream(dev)
-        loss_dict, halves = {}, {}
-
-        def half(name, after=None):
-            p = self.models['backbone_' + name](batch)
-            if after is not None:
-                after.record(main)           # (diffuse PathNet forward enqueued: the specular half may start)
-            out_manif, p_regress = self._split({name: p}, train=True)
-            x_in = _ops.pbuffer_cat(batch['kpcn_%s_in' % name], p_regress[name])
-            r = kp.forward_branch(name, x_in, batch['kpcn_%s_buffer' % name])
-            tgt = crop_like(batch['target_' + name], r)
-            L = _l1(self.loss_funcs['l_' + name], r, tgt)
-            lm = None
-            if self.manif_learn:
-                lm = self.loss_funcs['l_manif'](crop_like(out_manif[name], r), tgt)
-                L = L + lm * self.w_manif
-            halves[name] = (r, L, lm)
-
-        ev = torch.cuda.Event()
-        half('diffuse', after=ev)
-        br = _ops.on_branch(dev)
-        with br:
-            torch.cuda.current_stream(dev).wait_event(ev)
-            half('specular')
-        if self.manif_learn:
-            loss_dict['l_manif_diffuse'] = halves['diffuse'][2].detach()
-            loss_dict['l_manif_specular'] = halves['specular'][2].detach()
-        loss_dict['l_diffuse'] = halves['diffuse'][1].detach()          # (L1 + w * manifold: the reference's aliasing quirk)
-        loss_dict['l_specular'] = halves['specular'][1].detach()
-        halves['diffuse'][1].backward()
-        with br:
-            halves['specular'][1].backward()
-        r_d, r_s = halves['diffuse'][0], halves['specular'][0]
-        br.join(r_s)
-        with torch.no_grad():
-            total = _ops.recombine(crop_like(batch['kpcn_albedo'], r_d), r_d.detach(), r_s.detach())
-            tgt_total = crop_like(batch['target_total'], total)
-            self.last_out = {'radiance': total, 'diffuse': r_d.detach(), 'specular': r_s.detach()}
-            if self._fused_metrics(total, tgt_total):
-                loss_dict['l_total'], loss_dict['rmse'] = _ops.image_metrics(total, tgt_total, self.loss_funcs['l_test'].eps)
-            else:
-                loss_dict['l_total'] = self.loss_funcs['l_recon'](total, tgt_total).detach()
-                loss_dict['rmse'] = self.loss_funcs['l_test'](total, tgt_total).detach()
-        _ops.join_all_streams(dev)
-        return loss_dict
-
     def _forward_backward(self, batch):
         """Everything of ``train_batch`` up to (not including) ``_logging``: no host sync inside, so
         ``wcmc_amd.graph.GraphedTrainStep`` can capture it into one hipGraph."""
-        if self._pipelined(batch):
-            return self._forward_backward_pipelined(batch)
         out_manif = None
         dev = batch['kpcn_diffuse_in'].device
         _ops.fork_all_streams(dev)
