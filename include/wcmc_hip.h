@@ -197,6 +197,25 @@ int wcmc_conv1x1_pair_bf16x3(const void* x_split, int N, int H, int W, int Cin, 
                              int gate_act1, float gate_slope1, float* colsum1, const void* wp2, const float* bias2,
                              int Cout2, int act2, float slope2, float* y2, int64_t y2sn, int64_t y2sh, int64_t y2sw,
                              void* stream);
+/* ---------------------------------------------------------------- PathNet.embedding, fused (support/networks.py:33-36)
+ * y = ConvChain(Cin -> 64 -> 64 -> 64, ksize 1, ReLU, ReLU, linear)(x) over M = B*S*H*W pixels as ONE launch per direction:
+ * the hidden activations never leave the chip (forward) and are recomputed from x (backward).
+ *   x_split   split tensor [M][2][round_up(Cin, 8)] (wcmc_split_from_nchw / wcmc_split_bf16)
+ *   wp0..wp2  forward packs (wcmc_conv2d_pack_weight_bf16x3, mode 0), wt1 / wt2 data-gradient packs (mode 1) of layers 1, 2
+ *   y         fp32 [M][64] (an NHWC tensor of 64 channels); bit-identical to three wcmc_conv2d_igemm_bf16x3 launches
+ *   backward  dy = gy (fp32, pixel stride gy_pixel_stride floats; may be null) + repeat_S(gm) * gm_scale (gm: fp32 over
+ *             M / S pixels, B images of HW pixels; may be null) -- the gradient of `y` and of its spp mean
+ *             (support/networks.py:35-36) -- and dw / db of the three layers (OIHW, ks = 1) in the default mode's arithmetic
+ *             (data gradients dy_hi x (W_hi + W_lo), weight gradients hi x hi); no gradient for x.  Fixed summation order:
+ *             bitwise reproducible. */
+int wcmc_embed3_supported(int Cin, int C1, int C2, int C3);
+size_t wcmc_embed3_bwd_workspace_bytes(void);
+int wcmc_embed3_fwd(const void* x_split, int64_t M, int Cin, const void* wp0, const float* b0, const void* wp1,
+                    const float* b1, const void* wp2, const float* b2, float* y, void* stream);
+int wcmc_embed3_bwd(const void* x_split, int64_t M, int Cin, const void* wp0, const float* b0, const void* wp1,
+                    const float* b1, const void* wt1, const void* wt2, const float* gy, int gy_pixel_stride,
+                    const float* gm, int gm_pixel_stride, int S, int64_t HW, float gm_scale, float* dw0, float* db0,
+                    float* dw1, float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
 size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout);
 int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, int Cout, float* db, void* stream);
 size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks);

@@ -624,6 +624,78 @@ def test_kernel_apply_strip_equals_tile_kernel(shape, monkeypatch):
     assert_close(res[1][0], ref, what="strip kernel fwd vs oracle")
 
 
+EMBED_CASES = [(6, 3, 36, 20, 23), (8, 4, 36, 32, 32), (4, 2, 64, 16, 24), (2, 1, 8, 9, 7), (16, 8, 36, 64, 64)]
+
+
+def _embed_params(cin, seed):
+    ws = [gen(64, cin, 1, 1, seed=seed, scale=(2.0 / cin) ** 0.5 * 1.7), gen(64, 64, 1, 1, seed=seed + 1, scale=(2.0 / 64) ** 0.5 * 1.7),
+          gen(64, 64, 1, 1, seed=seed + 2, scale=(2.0 / 64) ** 0.5 * 1.7)]
+    bs = [gen(64, seed=seed + 3 + i, scale=0.2) for i in range(3)]
+    return [t for pair in zip(ws, bs) for t in pair]
+
+
+@pytest.mark.parametrize("case", EMBED_CASES)
+def test_fused_embedding_chain_forward_is_bit_identical_and_backward_matches_its_fp64_emulation(case, monkeypatch):
+    """``wcmc_embed3_fwd`` / ``_bwd`` (PathNet.embedding + spp mean as one launch per direction, hidden activations on chip /
+    recomputed) against the layer-by-layer path: the forward output and its spp mean BIT FOR BIT (same MFMA sequence per
+    output); the backward against an fp64 evaluation that rounds where the kernel rounds -- dy, dh1, dh0, x, h0, h1 to bf16
+    as MFMA operands of the two-term data gradients and one-term weight gradients, exact sums for the bias gradients --
+    and against the unfused backward of the same mode within the mode's gradient tolerance.  Ragged last tile, S = 1, 8
+    input channels, a gradient that is a channel slice of a wider tensor, a missing gradient of the mean."""
+    from conftest import rel_l2
+    o = ops()
+    assert o.PRECISION == "bf16x321"
+    n, s, cin, h, w = case
+    x = gen(n, cin, h, w, seed=300)
+    params = _embed_params(cin, 310)
+    gwide = gen(n, 128, h, w, seed=320)                    # g_y arrives as the first 64 channels of the concatenation's gradient
+    gm = gen(n // s, 64, h, w, seed=321)
+    res = {}
+    acts = []
+    for fused in (True, False):
+        monkeypatch.setattr(o, "FUSE_EMBED", fused)
+        monkeypatch.setattr(o, "DEBUG_ACTS", None if fused else acts)      # the layer-by-layer path hands out its hidden activations
+        xd = o.presplit_shared(x.to(DEV)) if cin <= 64 and n * h <= 65535 else o.as_nhwc(x.to(DEV))
+        ps = [t.to(DEV).requires_grad_(True) for t in params]
+        y, m = o.conv_chain_spp_mean(xd, s, 1, 0, ["relu", "relu", "linear"], ps)
+        gw = o.to_nhwc_raw(gwide.to(DEV))
+        torch.autograd.backward([y, m], [gw[:, :64], gm.to(DEV)])
+        res[fused] = (y.detach().clone(), m.detach().clone(), [t.grad.clone() for t in ps])
+    monkeypatch.setattr(o, "DEBUG_ACTS", None)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    # fp64 emulation of the fused backward ON THE PRODUCT'S OWN hidden activations (the fused forward is bit-identical, so
+    # these are the h0 / h1 it recomputes): a hidden unit within rounding of zero may sit on the other side in an fp64
+    # forward, and in these small cases ONE such unit moves a layer-0 gradient by ~1e-2 (measured; DESIGN.md section 2)
+    bf = lambda t: t.float().bfloat16().double()
+    W0, b0, W1, b1, W2, b2 = [t.double() for t in params]
+    X = x.double().permute(0, 2, 3, 1).reshape(-1, cin)
+    assert len(acts) == 2
+    h0, h1 = (a.detach().cpu().double().permute(0, 2, 3, 1).reshape(-1, 64) for a in acts)
+    dy = gwide[:, :64].double().permute(0, 2, 3, 1).reshape(-1, 64) + \
+        (gm.double() / s).unsqueeze(1).expand(n // s, s, 64, h, w).reshape(n, 64, h, w).permute(0, 2, 3, 1).reshape(-1, 64)
+    dyh = bf(dy)
+    dh1 = (dyh @ W2.view(64, 64)) * (bf(h1) > 0)
+    dh1h = bf(dh1)
+    dh0 = (dh1h @ W1.view(64, 64)) * (bf(h0) > 0)
+    want = [bf(dh0).t() @ bf(X), dh0.sum(0), dh1h.t() @ bf(h0), dh1.sum(0), dyh.t() @ bf(h1), dy.sum(0)]
+    for got, wnt, unf, name in zip(res[True][2], want, res[False][2], ("dw0", "db0", "dw1", "db1", "dw2", "db2")):
+        e = rel_l2(got.reshape(wnt.shape), wnt)
+        # (5e-4: a value the kernel forms in fp32 and the emulation in fp64 now and then rounds to the other bf16 neighbour,
+        # 2^-8 of that element; measured 1e-7 .. 2.1e-4)
+        assert e <= 5e-4, "%s: relative L2 %.3e against the fp64 emulation" % (name, e)
+        assert rel_l2(got, unf) <= 8e-3, name                # the unfused backward of the same mode (three-term 1x1 data gradients)
+    # the gradient of the mean alone / of y alone
+    monkeypatch.setattr(o, "FUSE_EMBED", True)
+    for which in ("y", "m"):
+        ps = [t.to(DEV).requires_grad_(True) for t in params]
+        xd = o.presplit_shared(x.to(DEV))
+        y, m = o.conv_chain_spp_mean(xd, s, 1, 0, ["relu", "relu", "linear"], ps)
+        (y * gen(n, 64, h, w, seed=330).to(DEV)).sum().backward() if which == "y" else (m * gm.to(DEV)).sum().backward()
+        assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in ps)
+        if which == "m":
+            np.testing.assert_allclose(ps[5].grad.cpu().numpy(), gm.double().sum(dim=(0, 2, 3)).numpy(), rtol=2e-5, atol=1e-5)
+
+
 def test_kernel_apply_known_answers():
     o = ops()
     n, h, w, k = 1, 26, 29, 21

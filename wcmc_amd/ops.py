@@ -809,6 +809,70 @@ class _ChainSppMeanX(torch.autograd.Function):
         return (dx, None, None, *grads)
 
 
+# PathNet.embedding as one launch per direction (csrc/pathnet_fused.hip): hidden activations stay on chip in the forward and
+# are recomputed in the backward.  Default mode only (its backward arithmetic is built in); WCMC_FUSE_EMBED=0: A/B switch.
+FUSE_EMBED = os.environ.get("WCMC_FUSE_EMBED", "1") != "0"
+
+
+def _dense_pixel_stride(g):
+    """Pixel stride (floats) of an NHWC view whose pixels form one dense run (rows and images back to back), else None."""
+    n, c, h, w = g.shape
+    sn, sc, sh, sw = g.stride()
+    if sc == 1 and sw >= c and sw % 4 == 0 and sh == w * sw and (n == 1 or sn == h * sh) and g.data_ptr() % 16 == 0:
+        return sw
+    return None
+
+
+class _EmbedSppMeanFusedX(torch.autograd.Function):
+    """``y = chain3(x); m = y.view(B,S,...).mean(1)`` (networks.py:33-36) with the three 1x1 layers in ONE launch
+    (``wcmc_embed3_fwd``) and a backward that recomputes the hidden activations (``wcmc_embed3_bwd``): nothing but x, y and
+    the two gradients of y ever touches HBM."""
+
+    @staticmethod
+    def forward(ctx, x, s, *params):
+        _need_cuda(x, *params)
+        xs = _split_shared(x)
+        n, cin, h, w = x.shape
+        ws_ = [params[0], params[2], params[4]]
+        packs = _pack_chain_x(ws_, 1)                        # [(forward, data-gradient orientation)] per layer
+        y = torch.empty((n, h, w, 64), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        with _Timed("embed3", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64), "byte"):
+            check(lib().wcmc_embed3_fwd(_ptr(xs), n * h * w, cin, _ptr(packs[0][0]), _ptr(params[1].detach()),
+                                        _ptr(packs[1][0]), _ptr(params[3].detach()), _ptr(packs[2][0]), _ptr(params[5].detach()),
+                                        _ptr(y), _stream()), "embed3_fwd")
+        m = nhwc_empty(n // s, 64, h, w, y.device)
+        check(lib().wcmc_spp_reduce(*_v(y), *_v(m), n // s, s, h, w, 64, 1.0 / s, _stream()), "spp_reduce")
+        ctx.s, ctx.dims = s, (n, cin, h, w)
+        ctx.packs = packs
+        ctx.save_for_backward(xs, *params)
+        return y, m
+
+    @staticmethod
+    def backward(ctx, gy, gm):
+        s = ctx.s
+        n, cin, h, w = ctx.dims
+        xs, w0, b0, w1, b1, w2, b2 = ctx.saved_tensors
+        gy = _as_nhwc_nograd(gy) if gy is not None else None
+        gm = _as_nhwc_nograd(gm) if gm is not None else None
+        if gy is not None and _dense_pixel_stride(gy) is None:
+            gy = to_nhwc_raw(gy)
+        if gm is not None and _dense_pixel_stride(gm) is None:
+            gm = to_nhwc_raw(gm)
+        dev = xs.device
+        dw0, dw1, dw2 = torch.empty_like(w0), torch.empty_like(w1), torch.empty_like(w2)
+        db0, db1, db2 = torch.empty_like(b0), torch.empty_like(b1), torch.empty_like(b2)
+        nb = lib().wcmc_embed3_bwd_workspace_bytes()
+        ws = torch.empty(nb // 4, device=dev, dtype=torch.float32)
+        packs = ctx.packs
+        with _Timed("embed3", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64 + (64 // s if gm is not None else 0)), "byte"):
+            check(lib().wcmc_embed3_bwd(_ptr(xs), n * h * w, cin, _ptr(packs[0][0]), _ptr(b0), _ptr(packs[1][0]), _ptr(b1),
+                                        _ptr(packs[1][1]), _ptr(packs[2][1]), _ptr(gy), _dense_pixel_stride(gy) if gy is not None else 0,
+                                        _ptr(gm), _dense_pixel_stride(gm) if gm is not None else 0, s, h * w, 1.0 / s,
+                                        _ptr(dw0), _ptr(db0), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(ws), nb, _stream()),
+                  "embed3_bwd")
+        return (None, None, dw0, db0, dw1, db1, dw2, db2)
+
+
 class _CatBroadcastChainX(torch.autograd.Function):
     """``chain(cat([flat, repeat_S(prop)], 1))`` (networks.py:39-42) with the concatenation written once,
     directly as the chain's split input (``wcmc_cat_broadcast_split``); the backward splits the chain's
@@ -891,6 +955,12 @@ FUSE_CHAIN_GLUE = os.environ.get("WCMC_FUSE_CHAIN_GLUE", "1") != "0"
 
 def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
     """``y = conv_chain(x, ...); return y, spp_mean(y, s)``; one autograd node on the split-bf16 path."""
+    # (DEBUG_ACTS: the parity tests' hook wants the hidden activations, which the fused chain never materialises)
+    if (FUSE_EMBED and DEBUG_ACTS is None and FUSE_CHAIN_GLUE and PRECISION == "bf16x321" and ksize == 1 and pad == 0 and len(acts) == 3 and
+            tuple(acts) == ("relu", "relu", "linear") and not x.requires_grad and
+            lib().wcmc_embed3_supported(params[0].shape[1], params[0].shape[0], params[2].shape[0], params[4].shape[0]) and
+            (getattr(x, "_wcmc_split", None) is not None or is_nhwc_view(x))):
+        return _EmbedSppMeanFusedX.apply(x, s, *params)
     if FUSE_CHAIN_GLUE and split_path() and acts[-1] == "linear":
         pre = getattr(x, "_wcmc_split", None)
         if pre is not None and pre[0] == (x._version, None) and not x.requires_grad:
