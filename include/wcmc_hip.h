@@ -216,6 +216,21 @@ int wcmc_embed3_bwd(const void* x_split, int64_t M, int Cin, const void* wp0, co
                     const float* b1, const void* wt1, const void* wt2, const float* gy, int gy_pixel_stride,
                     const float* gm, int gm_pixel_stride, int S, int64_t HW, float gm_scale, float* dw0, float* db0,
                     float* dw1, float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
+/* ---------------------------------------------------------------- PathNet.final, fused (support/networks.py:39-42)
+ * out = ConvChain(128 -> 128 -> outc <= 4, ksize 1, ReLU, ReLU)(cat([y, repeat_S(prop)], 1)): y fp32 over M = B*S*HW pixels
+ * (64 channels, pixel stride y_pixel_stride floats), prop fp32 over B*HW pixels (64 channels), out fp32 [M][4] (an NHWC view of
+ * outc channels); HW % 64 == 0.  Neither the concatenation nor the hidden activation is written: the backward recomputes
+ * them, writes dy [M][64] and dprop [B*HW][64] (the sum over the S samples) and the weight / bias gradients (OIHW, ks = 1) in the
+ * default mode's arithmetic.  Forward bit-identical to wcmc_cat_broadcast_split + wcmc_conv1x1_pair_bf16x3.
+ *   wp0 / wp1  forward packs (mode 0) of the two layers, wt0 / wt1 their data-gradient packs (mode 1). */
+int wcmc_final2_supported(int C1, int C2, int Chid, int outc, int64_t HW);
+size_t wcmc_final2_bwd_workspace_bytes(void);
+int wcmc_final2_fwd(const float* y, int y_pixel_stride, const float* prop, int prop_pixel_stride, int B, int S, int64_t HW,
+                    const void* wp0, const float* b0, const void* wp1, const float* b1, int outc, float* out, void* stream);
+int wcmc_final2_bwd(const float* y, int y_pixel_stride, const float* prop, int prop_pixel_stride, int B, int S, int64_t HW,
+                    const void* wp0, const float* b0, const void* wp1, const float* b1, int outc, const void* wt0,
+                    const void* wt1, const float* gout, float* dy, float* dprop, float* dw0, float* db0, float* dw1,
+                    float* db1, void* workspace, size_t workspace_bytes, void* stream);
 size_t wcmc_conv2d_igemm_colsum_elems(int N, int Ho, int Wo, int Cout);
 int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, int Cout, float* db, void* stream);
 size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks);

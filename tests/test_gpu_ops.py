@@ -696,6 +696,56 @@ def test_fused_embedding_chain_forward_is_bit_identical_and_backward_matches_its
             np.testing.assert_allclose(ps[5].grad.cpu().numpy(), gm.double().sum(dim=(0, 2, 3)).numpy(), rtol=2e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 8, 8, 3), (1, 1, 16, 12, 4), (2, 8, 16, 16, 3), (8, 8, 64, 64, 3), (3, 2, 8, 24, 1)])
+def test_fused_final_chain_forward_is_bit_identical_and_backward_matches_its_fp64_emulation(case, monkeypatch):
+    """``wcmc_final2_fwd`` / ``_bwd`` (PathNet.final with the broadcast concatenation, one launch per direction: concatenation
+    and hidden activation on chip / recomputed, d_prop summed over the samples in registers) against the layer-by-layer path
+    (``wcmc_cat_broadcast_split`` + the fused layer pair): output BIT FOR BIT; backward against an fp64 evaluation on the
+    product's own hidden activation and output that rounds where the kernel rounds (d_out, dh, c, h to bf16 as operands of
+    the two-term data gradients / one-term weight gradients; exact sums for the bias gradients), and against the unfused
+    backward of the same mode."""
+    from conftest import rel_l2
+    o = ops()
+    assert o.PRECISION == "bf16x321"
+    b, s, h, w, outc = case
+    flat = gen(b * s, 64, h, w, seed=400)
+    prop = gen(b, 64, h, w, seed=401)
+    params = [gen(128, 128, 1, 1, seed=402, scale=(2.0 / 128) ** 0.5 * 1.7), gen(128, seed=403, scale=0.2),
+              gen(outc, 128, 1, 1, seed=404, scale=(2.0 / 128) ** 0.5 * 1.7), gen(outc, seed=405, scale=0.2)]
+    g = gen(b * s, outc, h, w, seed=406)
+    res, acts = {}, []
+    for fused in (True, False):
+        monkeypatch.setattr(o, "FUSE_FINAL", fused)
+        monkeypatch.setattr(o, "DEBUG_ACTS", None if fused else acts)
+        fd = o.to_nhwc_raw(flat.to(DEV)).requires_grad_(True)
+        pd = o.to_nhwc_raw(prop.to(DEV)).requires_grad_(True)
+        ps = [t.to(DEV).requires_grad_(True) for t in params]
+        out = o.cat_broadcast_chain(fd, pd, s, 1, 0, ["relu", "relu"], ps)
+        out.backward(g.to(DEV))
+        res[fused] = (out.detach().clone(), [fd.grad.clone(), pd.grad.clone()] + [t.grad.clone() for t in ps])
+    monkeypatch.setattr(o, "DEBUG_ACTS", None)
+    assert torch.equal(res[True][0], res[False][0])
+    bf = lambda t: t.float().bfloat16().double()
+    W0, b0, W1, b1 = [t.double() for t in params]
+    M = b * s * h * w
+    rows = lambda t, c: t.double().permute(0, 2, 3, 1).reshape(-1, c)
+    C = torch.cat([rows(flat, 64), rows(prop.unsqueeze(1).expand(b, s, 64, h, w).reshape(b * s, 64, h, w), 64)], 1)
+    assert len(acts) == 2
+    H, O = rows(acts[0].detach().cpu(), 128), rows(acts[1].detach().cpu(), outc)
+    do = rows(g, outc) * (O > 0)
+    doh = bf(do)
+    dh = (doh @ W1.view(outc, 128)) * (bf(H) > 0)
+    dhh = bf(dh)
+    dc = dhh @ W0.view(128, 128)
+    dflat = dc[:, :64].reshape(b * s, h, w, 64).permute(0, 3, 1, 2)
+    dprop = dc[:, 64:].reshape(b, s, h, w, 64).sum(1).permute(0, 3, 1, 2)
+    want = [dflat, dprop, dhh.t() @ bf(C), dh.sum(0), doh.t() @ bf(H), do.sum(0)]
+    for got, wnt, unf, name in zip(res[True][1], want, res[False][1], ("dflat", "dprop", "dw0", "db0", "dw1", "db1")):
+        e = rel_l2(got.reshape(wnt.shape), wnt)
+        assert e <= 5e-4, "%s: relative L2 %.3e against the fp64 emulation" % (name, e)
+        assert rel_l2(got, unf) <= 8e-3, name
+
+
 def test_kernel_apply_known_answers():
     o = ops()
     n, h, w, k = 1, 26, 29, 21

@@ -41,6 +41,7 @@ __device__ __forceinline__ u16 e3_bf(float x) { return __builtin_bit_cast(u16, (
 __device__ __forceinline__ float e3_f(u16 h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 // (by-value helper on purpose: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0 -- ROCm 7.2)
 __device__ __forceinline__ float e3_u2f(unsigned v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ unsigned e3_f2u(float v) { return __builtin_bit_cast(unsigned, v); }
 
 struct E3Params {
   const u16* x; int64_t M; int Cp0, Kt0;              // split input [M][2][Cp0]; k extent of layer 0's pack (32 or 64)
@@ -377,6 +378,337 @@ __global__ __launch_bounds__(256) void embed3_bwd_finish_kernel(const float* __r
   }
 }
 
+// ================================================================== PathNet.final, fused
+//   support/networks.py:39-42:  out = ConvChain(128 -> 128 -> outc <= 4, ksize 1, ReLU, ReLU)(cat([y, repeat_S(prop)], 1))
+// The layer-by-layer path writes the 128-channel concatenation (537 MB, split) and the 128-channel hidden activation
+// (537 MB + mask) per backbone and direction, re-reads both in the backward, and materialises the 128-channel input
+// gradient (537 MB fp32) only to slice it into d_y and sum the other half over the samples.  Here a workgroup (eight
+// waves, one cout tile of the 128 each) owns "super-tiles": 64 pixels of one image x its S samples.  prop's 64 pixels
+// are split into the tile once per super-tile; per sample the y tile arrives, the concatenation and the hidden
+// activation live in LDS only; the backward recomputes them, gates with them, writes d_y, keeps d_prop in registers over
+// the S samples (written once) and accumulates all weight / bias gradients in registers across the workgroup's tiles.
+constexpr int F2_C = 128;                  // concatenation and hidden width
+constexpr int F2_RS = 144;                 // LDS row stride in bf16: 288 B = 9 x 32 (conflict-free transposing reads)
+constexpr int F2_TILE = E3_TP * F2_RS;
+constexpr int F2_ORS = 48;                 // row stride of the d_out tile (32 channels + pad: 96 B = 3 x 32)
+
+struct F2Params {
+  const float* y; int y_ps;                // fp32, pixel stride y_ps floats, M = B*S*HW pixels
+  const float* prop; int p_ps;             // fp32, B*HW pixels
+  int B, S; int64_t HW;
+  const u16* wp0; const u16* wp1;          // forward packs: [128][2][128], [16][2][128]
+  const float* b0; const float* b1; int outc;
+  float* out;                              // fp32 [M][4]
+  // backward
+  const u16* wt0; const u16* wt1;          // data-gradient packs: [128][2][128] (rows = concat channels), [128][2][32] (rows = hidden channels)
+  const float* gout;                       // fp32 [M][4]
+  float* dy; float* dprop;                 // fp32 [M][64], [B*HW][64]
+  float* ws;
+  unsigned y_bytes, p_bytes, o_bytes, dy_bytes, dp_bytes;
+};
+constexpr int F2_WS_PER_BLOCK = F2_C * F2_C + 16 * F2_C + F2_C + 16;      // dW0, dW1 (16 rows), db0, db1 (16)
+
+struct F2W { bf16x8 h[4], l[4]; };
+__device__ __forceinline__ F2W f2_load_w(const u16* wp, int row, int q) {
+  F2W w;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const u16* a = wp + (int64_t)(row * 2) * F2_C + c * 32 + q * 8;
+    w.h[c] = *reinterpret_cast<const bf16x8*>(a);
+    w.l[c] = *reinterpret_cast<const bf16x8*>(a + F2_C);
+  }
+  return w;
+}
+template <int TERMS, int NPT>
+__device__ __forceinline__ void f2_gemm(f32x4 (&acc)[NPT], const F2W& w, const u16* th, const u16* tl, int pt0, int fr, int q) {
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int o = (16 * (pt0 + i) + fr) * F2_RS + c * 32 + q * 8;
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(th + o);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[c], ah, acc[i], 0, 0, 0);
+      if (TERMS == 3) {
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(tl + o);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[c], al, acc[i], 0, 0, 0);
+      }
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[c], ah, acc[i], 0, 0, 0);
+    }
+  }
+}
+__device__ __forceinline__ bf16x8 f2_tr(const u16* tile, int rs, int kk, int ct, int lane) {
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const u16* a0 = tile + (kk * 32 + 4 * g + tq) * rs + ct * 16 + 4 * tp;
+  const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+  const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 16 * rs));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 cat = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  return __builtin_bit_cast(bf16x8, cat);
+}
+// 64 pixels x 64 fp32 channels (two float4 per thread of 512) -> hi / lo planes of channels [c0, c0 + 64) of a concat tile
+struct F2Pre { u32x4 v[2]; };
+__device__ __forceinline__ F2Pre f2_load64(const __amdgpu_buffer_rsrc_t r, int64_t m0, int ps, int tid) {
+  F2Pre o;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = tid + 512 * k, px = v >> 4, c4 = (v & 15) * 4;
+    o.v[k] = __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(((m0 + px) * ps + c4) * 4), 0, 0);
+  }
+  return o;
+}
+__device__ __forceinline__ void f2_store64_split(const F2Pre& o, u16* th, u16* tl, int c0, int tid) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = tid + 512 * k, px = v >> 4, c4 = (v & 15) * 4;
+    u16 hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float f = e3_u2f(o.v[k][e]);
+      hi[e] = e3_bf(f);
+      lo[e] = e3_bf(f - e3_f(hi[e]));
+    }
+    const int a = px * F2_RS + c0 + c4;
+    *reinterpret_cast<u32x2*>(th + a) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+    *reinterpret_cast<u32x2*>(tl + a) = u32x2{(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
+  }
+}
+// h = relu(acc + bias): split planes of this lane's (pixel 16 i + fr, couts 16 wave + 4 q ..) into th / tl
+__device__ __forceinline__ void f2_store_relu_split(const f32x4 (&acc)[4], const float (&b)[4], u16* th, u16* tl, int wave, int fr, int q) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u16 hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = acc[i][e] + b[e];
+      const float v = t > 0.f ? t : 0.f;
+      hi[e] = e3_bf(v);
+      lo[e] = e3_bf(v - e3_f(hi[e]));
+    }
+    const int o = (16 * i + fr) * F2_RS + 16 * wave + 4 * q;
+    *reinterpret_cast<u32x2*>(th + o) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+    *reinterpret_cast<u32x2*>(tl + o) = u32x2{(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
+  extern __shared__ __attribute__((aligned(16))) u16 lds[];
+  u16* const CH = lds; u16* const CL = lds + F2_TILE; u16* const HH = lds + 2 * F2_TILE; u16* const HL = lds + 3 * F2_TILE;
+  u16* const DHH = lds + 4 * F2_TILE;                            // (backward) dh, hi plane
+  u16* const DOH = lds + 5 * F2_TILE;                            // (backward) gated d_out, hi plane, [64][F2_ORS]
+  float* const stg = reinterpret_cast<float*>(HL);               // (backward) d_y tile [64][68] over h's lo plane
+  float* const red = reinterpret_cast<float*>(lds + 5 * F2_TILE + E3_TP * F2_ORS);    // (backward) bias sums [16][128] + [64][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, q = lane >> 4;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)p.prop, 0, (int)p.p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)(BWD ? (void*)p.gout : (void*)p.out), 0, (int)p.o_bytes, 0x00020000);
+  const F2W w0 = f2_load_w(p.wp0, 16 * wave + fr, q);
+  const F2W w1 = f2_load_w(p.wp1, fr, q);                        // the output layer's one cout tile (rows >= outc are zero)
+  float b0[4], b1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { b0[e] = p.b0[16 * wave + 4 * q + e]; b1[e] = (q == 0 && e < p.outc) ? p.b1[e] : 0.f; }
+  const int64_t tpi = p.HW / E3_TP;                              // 64-pixel tiles per image (HW % 64 == 0: checked by the host)
+  const int64_t nsuper = (int64_t)p.B * tpi;
+
+  // backward state
+  F2W t0;                                                        // W0^T rows of this wave's concat-channel tile
+  bf16x8 t1h, t1l;                                               // W1^T rows of this wave's hidden-channel tile (k = 32: one step)
+  f32x4 gw0[8], gw1;                                             // dW0[co tile = wave][8 ci tiles], dW1[16][ci tile = wave]
+  float sb0[4] = {0.f, 0.f, 0.f, 0.f}, sb1[4] = {0.f, 0.f, 0.f, 0.f};
+  __amdgpu_buffer_rsrc_t dyr = yr, dpr = yr;
+  if (BWD) {
+    t0 = f2_load_w(p.wt0, 16 * wave + fr, q);
+    const u16* a = p.wt1 + (int64_t)((16 * wave + fr) * 2) * 32 + q * 8;
+    t1h = *reinterpret_cast<const bf16x8*>(a); t1l = *reinterpret_cast<const bf16x8*>(a + 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gw0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gw1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    dyr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+    dpr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dprop, 0, (int)p.dp_bytes, 0x00020000);
+    for (int i = tid; i < E3_TP * F2_ORS / 2; i += 512) reinterpret_cast<unsigned*>(DOH)[i] = 0u;     // channels >= 4 stay zero
+  }
+
+  for (int64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
+    const int64_t b = st / tpi, hw0 = (st - b * tpi) * E3_TP;
+    // the spp-broadcast half of the concatenation: once per super-tile
+    F2Pre pp = f2_load64(pr, b * p.HW + hw0, p.p_ps, tid);
+    F2Pre yp = f2_load64(yr, (b * p.S) * p.HW + hw0, p.y_ps, tid);
+    __syncthreads();                                             // (the previous super-tile's last readers of the tiles are done)
+    f2_store64_split(pp, CH, CL, 64, tid);
+    f32x4 dpacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dpacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.S; ++s) {
+      const int64_t m0 = (b * p.S + s) * p.HW + hw0;
+      f2_store64_split(yp, CH, CL, 0, tid);
+      u32x4 go = {0u, 0u, 0u, 0u};
+      if (BWD && tid < 64) go = __builtin_amdgcn_raw_buffer_load_b128(orr, (unsigned)((m0 + tid) * 16), 0, 0);
+      if (s + 1 < p.S) yp = f2_load64(yr, (b * p.S + s + 1) * p.HW + hw0, p.y_ps, tid);      // next sample's tile flies under the GEMMs
+      __syncthreads();
+      // ---- h = relu(W0 c + b0)
+      f32x4 acc[4];
+      f2_gemm<3, 4>(acc, w0, CH, CL, 0, fr, q);
+      f2_store_relu_split(acc, b0, HH, HL, wave, fr, q);
+      __syncthreads();
+      // ---- out = relu(W1 h + b1): wave w < 4 multiplies pixel tile w; lanes q == 0 hold couts 0..3 of pixel 16 w + fr
+      float ov[4] = {0.f, 0.f, 0.f, 0.f};
+      if (wave < 4) {
+        f32x4 a2[1];
+        f2_gemm<3, 1>(a2, w1, HH, HL, wave, fr, q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = a2[0][e] + b1[e]; ov[e] = (e < p.outc && t > 0.f) ? t : 0.f; }
+      }
+      if (!BWD) {
+        if (wave < 4 && q == 0) {
+          const u32x4 o4 = {__builtin_bit_cast(unsigned, ov[0]), __builtin_bit_cast(unsigned, ov[1]), __builtin_bit_cast(unsigned, ov[2]),
+                            __builtin_bit_cast(unsigned, ov[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o4, orr, (unsigned)((m0 + 16 * wave + fr) * 16), 0, 0);
+        }
+        __syncthreads();                                         // h is consumed: the next sample may overwrite the tiles
+        continue;
+      }
+      // ---- backward.  d_o = d_out . [out > 0] (hi plane into its tile; exact sums = the output layer's bias gradient)
+      {
+        // the loader thread `tid` (pixel tid) needs the sign of out at pixel tid, which lane (wave = tid >> 4, q = 0, fr = tid & 15)
+        // holds: passed through the pad of the d_out tile's row (channels 32..35: beyond the 32-wide k step the GEMMs read)
+        if (wave < 4 && q == 0) {
+          const int px = 16 * wave + fr;
+          *reinterpret_cast<u32x2*>(DOH + px * F2_ORS + 32) = u32x2{(ov[0] > 0.f ? 1u : 0u) | (ov[1] > 0.f ? 0x10000u : 0u),
+                                                                    (ov[2] > 0.f ? 1u : 0u) | (ov[3] > 0.f ? 0x10000u : 0u)};
+        }
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const u32x2 gt = *reinterpret_cast<const u32x2*>(DOH + tid * F2_ORS + 32);
+        u16 hi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool on = ((e < 2 ? gt[0] : gt[1]) >> (16 * (e & 1))) & 1u;
+          const float d = on ? e3_u2f(go[e]) : 0.f;
+          sb1[e] += d;
+          hi[e] = e3_bf(d);
+        }
+        *reinterpret_cast<u32x2*>(DOH + tid * F2_ORS) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+      }
+      __syncthreads();
+      // ---- dh = (W1^T d_o) . [h > 0]: this wave's hidden-channel tile, k = the 32-wide step whose channels >= 4 are zero
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 dof = *reinterpret_cast<const bf16x8*>(DOH + (16 * i + fr) * F2_ORS + q * 8);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1l, dof, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1h, dof, a, 0, 0, 0);
+        const int o = (16 * i + fr) * F2_RS + 16 * wave + 4 * q;
+        const u32x2 hm = *reinterpret_cast<const u32x2*>(HH + o);
+        u16 hi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const u16 hv = (u16)((e < 2 ? hm[0] : hm[1]) >> (16 * (e & 1)));
+          const float d = e3_f(hv) > 0.f ? a[e] : 0.f;
+          sb0[e] += d;
+          hi[e] = e3_bf(d);
+        }
+        *reinterpret_cast<u32x2*>(DHH + o) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+      }
+      __syncthreads();
+      // ---- dc = W0^T dh: waves 0..3 hold d_y (concat channels 0..63), waves 4..7 the d_prop contribution of this sample
+      f2_gemm<2, 4>(acc, t0, DHH, nullptr, 0, fr, q);
+      if (wave < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<float4*>(stg + (16 * i + fr) * 68 + 16 * wave + 4 * q) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dpacc[i] += acc[i];
+      }
+      // ---- weight gradients (hi x hi, pixels on k): dW0[co tile = wave][ci tile j] += dh^T c;  dW1[16][ci tile = wave] += d_o^T h
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 a0 = f2_tr(DHH, F2_RS, kk, wave, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gw0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, f2_tr(CH, F2_RS, kk, j, lane), gw0[j], 0, 0, 0);
+        gw1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2_tr(DOH, F2_ORS, kk, 0, lane), f2_tr(HH, F2_RS, kk, wave, lane), gw1, 0, 0, 0);
+      }
+      __syncthreads();
+      // d_y tile: whole 256-byte rows
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int v = tid + 512 * k, px = v >> 4, c4 = (v & 15) * 4;
+        const float4 o = *reinterpret_cast<const float4*>(stg + px * 68 + c4);
+        const u32x4 o4 = {__builtin_bit_cast(unsigned, o.x), __builtin_bit_cast(unsigned, o.y), __builtin_bit_cast(unsigned, o.z),
+                          __builtin_bit_cast(unsigned, o.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(o4, dyr, (unsigned)((m0 + px) * 256 + c4 * 4), 0, 0);
+      }
+      __syncthreads();                                           // the staging tile (h's lo plane) and c / h / dh are free again
+    }
+    if (BWD && wave >= 4) {                                      // d_prop of the super-tile: the sum over its S samples
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 o4 = {e3_f2u(dpacc[i][0]), e3_f2u(dpacc[i][1]), e3_f2u(dpacc[i][2]), e3_f2u(dpacc[i][3])};
+        __builtin_amdgcn_raw_buffer_store_b128(o4, dpr, (unsigned)((b * p.HW + hw0 + 16 * i + fr) * 256 + (16 * (wave - 4) + 4 * q) * 4), 0, 0);
+      }
+    }
+  }
+  if (!BWD) return;
+  // ---- per-workgroup partials: dW0 [128][128] | dW1 [16][128] | db0 [128] | db1 [16]
+  float* ws = p.ws + (int64_t)blockIdx.x * F2_WS_PER_BLOCK;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ws[(16 * wave + 4 * q + e) * F2_C + 16 * j + fr] = gw0[j][e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ws[F2_C * F2_C + (4 * q + e) * F2_C + 16 * wave + fr] = gw1[e];
+  __syncthreads();
+  float* redb = red;                                             // [16 pixel columns][128 channels], then [64 threads][4]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) redb[fr * F2_C + 16 * wave + 4 * q + e] = sb0[e];
+  if (tid < 64) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) redb[16 * F2_C + tid * 4 + e] = sb1[e];
+  }
+  __syncthreads();
+  if (tid < F2_C) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc += redb[r * F2_C + tid];
+    ws[F2_C * F2_C + 16 * F2_C + tid] = sacc;
+  } else if (tid < F2_C + 16) {
+    const int c = tid - F2_C;
+    float sacc = 0.f;
+    if (c < 4)
+      for (int r = 0; r < 64; ++r) sacc += redb[16 * F2_C + r * 4 + c];
+    ws[F2_C * F2_C + 16 * F2_C + F2_C + c] = sacc;
+  }
+}
+
+__global__ __launch_bounds__(256) void final2_bwd_finish_kernel(const float* __restrict__ ws, int nblk, int outc, float* __restrict__ dw0,
+                                                                float* __restrict__ db0, float* __restrict__ dw1, float* __restrict__ db1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F2_WS_PER_BLOCK) return;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = 0;
+  for (; b + 8 <= nblk; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += ws[(int64_t)(b + u) * F2_WS_PER_BLOCK + i];
+  }
+  for (; b < nblk; ++b) a[0] += ws[(int64_t)b * F2_WS_PER_BLOCK + i];
+  const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  if (i < F2_C * F2_C) dw0[i] = s;
+  else if (i < F2_C * F2_C + 16 * F2_C) {
+    const int r = i - F2_C * F2_C, co = r / F2_C, ci = r - co * F2_C;
+    if (co < outc) dw1[co * F2_C + ci] = s;
+  } else if (i < F2_C * F2_C + 16 * F2_C + F2_C) db0[i - F2_C * F2_C - 16 * F2_C] = s;
+  else {
+    const int c = i - F2_C * F2_C - 16 * F2_C - F2_C;
+    if (c < outc) db1[c] = s;
+  }
+}
+
+static int f2_grid() { return 256; }
+constexpr size_t F2_LDS_FWD = (size_t)4 * F2_TILE * sizeof(u16);
+constexpr size_t F2_LDS_BWD = (size_t)5 * F2_TILE * sizeof(u16) + (size_t)E3_TP * F2_ORS * sizeof(u16) + (size_t)(16 * F2_C + 64 * 4) * sizeof(float);
+
 static int e3_grid_bwd() { return 512; }
 
 }  // namespace wcmc
@@ -439,4 +771,68 @@ extern "C" int wcmc_embed3_bwd(const void* x_split, int64_t M, int Cin, const vo
   hipLaunchKernelGGL(embed3_bwd_finish_kernel, dim3((unsigned)((E3_WS_PER_BLOCK + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, nblk, Cin, dw0, db0, dw1, db1, dw2, db2);
   return check_launch("embed3_bwd_finish");
+}
+
+
+// ---------------------------------------------------------------- PathNet.final, fused
+extern "C" int wcmc_final2_supported(int C1, int C2, int Chid, int outc, int64_t HW) {
+  return C1 == 64 && C2 == 64 && Chid == 128 && outc >= 1 && outc <= 4 && HW > 0 && HW % 64 == 0;
+}
+extern "C" size_t wcmc_final2_bwd_workspace_bytes(void) { return (size_t)f2_grid() * F2_WS_PER_BLOCK * sizeof(float); }
+
+static int f2_fill(F2Params& p, const float* y, int y_ps, const float* prop, int p_ps, int B, int S, int64_t HW, const void* wp0,
+                   const float* b0, const void* wp1, const float* b1, int outc) {
+  WCMC_REQUIRE(y && prop && wp0 && wp1 && b0 && b1 && B > 0 && S > 0 && wcmc_final2_supported(64, 64, 128, outc, HW), WCMC_ERR_BAD_ARG,
+               "final2: bad argument (64 + 64 -> 128 -> <= 4 channels, H*W a multiple of 64)");
+  WCMC_REQUIRE(aligned16(y) && aligned16(prop) && aligned16(wp0) && aligned16(wp1) && y_ps >= 64 && y_ps % 4 == 0 && p_ps >= 64 && p_ps % 4 == 0,
+               WCMC_ERR_ALIGNMENT, "final2: views must be 16-byte aligned with pixel strides that are multiples of 4 floats");
+  p.y = y; p.y_ps = y_ps; p.prop = prop; p.p_ps = p_ps; p.B = B; p.S = S; p.HW = HW;
+  p.wp0 = (const u16*)wp0; p.wp1 = (const u16*)wp1; p.b0 = b0; p.b1 = b1; p.outc = outc;
+  const int64_t M = (int64_t)B * S * HW;
+  const int64_t yb = ((M - 1) * y_ps + 64) * 4, pb = (((int64_t)B * HW - 1) * p_ps + 64) * 4, ob = M * 16;
+  WCMC_REQUIRE(yb < 0x7ff00000ll && pb < 0x7ff00000ll && M * 256 < 0x7ff00000ll, WCMC_ERR_BAD_ARG, "final2: more than 2 GiB per tensor");
+  p.y_bytes = (unsigned)yb; p.p_bytes = (unsigned)pb; p.o_bytes = (unsigned)ob;
+  return 0;
+}
+
+extern "C" int wcmc_final2_fwd(const float* y, int y_pixel_stride, const float* prop, int prop_pixel_stride, int B, int S, int64_t HW,
+                               const void* wp0, const float* b0, const void* wp1, const float* b1, int outc, float* out, void* stream) {
+  F2Params p = {};
+  if (int rc = f2_fill(p, y, y_pixel_stride, prop, prop_pixel_stride, B, S, HW, wp0, b0, wp1, b1, outc)) return rc;
+  WCMC_REQUIRE(out && aligned16(out), WCMC_ERR_BAD_ARG, "final2_fwd: bad output");
+  p.out = out;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&final2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2_LDS_FWD);
+    attr = true;
+  }
+  const int64_t nsuper = (int64_t)B * (HW / 64);
+  hipLaunchKernelGGL(final2_kernel<false>, dim3((unsigned)(nsuper < f2_grid() ? nsuper : f2_grid())), dim3(512), F2_LDS_FWD, (hipStream_t)stream, p);
+  return check_launch("final2_fwd");
+}
+
+extern "C" int wcmc_final2_bwd(const float* y, int y_pixel_stride, const float* prop, int prop_pixel_stride, int B, int S, int64_t HW,
+                               const void* wp0, const float* b0, const void* wp1, const float* b1, int outc, const void* wt0,
+                               const void* wt1, const float* gout, float* dy, float* dprop, float* dw0, float* db0, float* dw1,
+                               float* db1, void* workspace, size_t workspace_bytes, void* stream) {
+  F2Params p = {};
+  if (int rc = f2_fill(p, y, y_pixel_stride, prop, prop_pixel_stride, B, S, HW, wp0, b0, wp1, b1, outc)) return rc;
+  WCMC_REQUIRE(wt0 && wt1 && gout && dy && dprop && dw0 && db0 && dw1 && db1 && workspace && aligned16(wt0) && aligned16(wt1) &&
+                   aligned16(gout) && aligned16(dy) && aligned16(dprop) && aligned16(workspace),
+               WCMC_ERR_BAD_ARG, "final2_bwd: bad argument");
+  WCMC_REQUIRE(workspace_bytes >= wcmc_final2_bwd_workspace_bytes(), WCMC_ERR_WORKSPACE, "final2_bwd: workspace too small");
+  p.wt0 = (const u16*)wt0; p.wt1 = (const u16*)wt1; p.gout = gout; p.dy = dy; p.dprop = dprop; p.ws = (float*)workspace;
+  const int64_t M = (int64_t)B * S * HW;
+  p.dy_bytes = (unsigned)(M * 256); p.dp_bytes = (unsigned)((int64_t)B * HW * 256);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&final2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2_LDS_BWD);
+    attr = true;
+  }
+  const int nblk = f2_grid();
+  hipLaunchKernelGGL(final2_kernel<true>, dim3((unsigned)nblk), dim3(512), F2_LDS_BWD, (hipStream_t)stream, p);
+  if (int rc = check_launch("final2_bwd")) return rc;
+  hipLaunchKernelGGL(final2_bwd_finish_kernel, dim3((unsigned)((F2_WS_PER_BLOCK + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, nblk, outc, dw0, db0, dw1, db1);
+  return check_launch("final2_bwd_finish");
 }

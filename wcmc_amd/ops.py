@@ -873,6 +873,52 @@ class _EmbedSppMeanFusedX(torch.autograd.Function):
         return (None, None, dw0, db0, dw1, db1, dw2, db2)
 
 
+class _FinalFusedX(torch.autograd.Function):
+    """``chain2(cat([flat, repeat_S(prop)], 1))`` (networks.py:39-42) as one launch per direction (``wcmc_final2_*``): neither
+    the 128-channel concatenation nor the hidden activation is written; the backward recomputes them."""
+
+    @staticmethod
+    def forward(ctx, flat, prop, s, *params):
+        _need_cuda(flat, prop, *params)
+        bs, c1, h, w = flat.shape
+        b = prop.shape[0]
+        outc = params[2].shape[0]
+        packs = _pack_chain_x([params[0], params[2]], 1)
+        buf = torch.empty((bs, h, w, 4), device=flat.device, dtype=torch.float32)
+        with _Timed("final2", 4.0 * bs * h * w * (64 + 64 // s + 4), "byte"):
+            check(lib().wcmc_final2_fwd(_ptr(flat), _dense_pixel_stride(flat), _ptr(prop), _dense_pixel_stride(prop), b, s, h * w,
+                                        _ptr(packs[0][0]), _ptr(params[1].detach()), _ptr(packs[1][0]), _ptr(params[3].detach()), outc,
+                                        _ptr(buf), _stream()), "final2_fwd")
+        ctx.geom, ctx.packs = (b, s, h, w, outc), packs
+        ctx.save_for_backward(flat, prop, *params)
+        return buf.permute(0, 3, 1, 2)[:, :outc]
+
+    @staticmethod
+    def backward(ctx, g):
+        b, s, h, w, outc = ctx.geom
+        flat, prop, w0, b0, w1, b1 = ctx.saved_tensors
+        g = _as_nhwc_nograd(g)
+        if not (_dense_pixel_stride(g) == 4):
+            g = to_nhwc_raw(g)
+        dev = flat.device
+        dy = torch.empty((b * s, h, w, 64), device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
+        dprop = nhwc_empty(b, 64, h, w, dev)
+        dw0, dw1, db0, db1 = torch.empty_like(w0), torch.empty_like(w1), torch.empty_like(b0), torch.empty_like(b1)
+        nb = lib().wcmc_final2_bwd_workspace_bytes()
+        ws = torch.empty(nb // 4, device=dev, dtype=torch.float32)
+        packs = ctx.packs
+        with _Timed("final2", 4.0 * b * s * h * w * (64 + 64 // s + 4 + 64 + 64 // s), "byte"):
+            check(lib().wcmc_final2_bwd(_ptr(flat), _dense_pixel_stride(flat), _ptr(prop), _dense_pixel_stride(prop), b, s, h * w,
+                                        _ptr(packs[0][0]), _ptr(b0), _ptr(packs[1][0]), _ptr(b1), outc, _ptr(packs[0][1]), _ptr(packs[1][1]),
+                                        _ptr(g), _ptr(dy), _ptr(dprop), _ptr(dw0), _ptr(db0), _ptr(dw1), _ptr(db1), _ptr(ws), nb,
+                                        _stream()), "final2_bwd")
+        return (dy if ctx.needs_input_grad[0] else None, dprop if ctx.needs_input_grad[1] else None, None, dw0, db0, dw1, db1)
+
+
+# WCMC_FUSE_FINAL=0: A/B switch back to concatenation + fused layer pair (csrc/pathnet_fused.hip; default mode only)
+FUSE_FINAL = os.environ.get("WCMC_FUSE_FINAL", "1") != "0"
+
+
 class _CatBroadcastChainX(torch.autograd.Function):
     """``chain(cat([flat, repeat_S(prop)], 1))`` (networks.py:39-42) with the concatenation written once,
     directly as the chain's split input (``wcmc_cat_broadcast_split``); the backward splits the chain's
@@ -972,6 +1018,13 @@ def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
 
 def cat_broadcast_chain(flat, prop, s, ksize, pad, acts, params):
     """``conv_chain(cat_broadcast(flat, prop, s), ...)``; fused into one autograd node on the split-bf16 path."""
+    if (FUSE_FINAL and DEBUG_ACTS is None and FUSE_CHAIN_GLUE and PRECISION == "bf16x321" and ksize == 1 and pad == 0 and
+            tuple(acts) == ("relu", "relu") and flat.is_cuda and prop.shape[0] * s == flat.shape[0] and
+            lib().wcmc_final2_supported(flat.shape[1], prop.shape[1], params[0].shape[0], params[2].shape[0], flat.shape[2] * flat.shape[3])
+            and params[0].shape[1] == 128):
+        fl, pr = as_nhwc(flat), as_nhwc(prop)
+        if _dense_pixel_stride(fl) is not None and _dense_pixel_stride(pr) is not None:
+            return _FinalFusedX.apply(fl, pr, s, *params)
     if FUSE_CHAIN_GLUE and split_path() and flat.shape[1] % 8 == 0:
         return _CatBroadcastChainX.apply(as_nhwc(flat), as_nhwc(prop), s, (ksize, pad, tuple(acts)), *params)
     return conv_chain(cat_broadcast(flat, prop, s), ksize, pad, acts, params)
