@@ -73,15 +73,15 @@ __device__ __forceinline__ E3W e3_load_w(const u16* wp, int row, int q, int Kt =
   return w;
 }
 
-// acc[i] (pixel tile i) += W x T over the 64 channels of tile T; TERMS = 3: W_lo*T_hi + W_hi*T_lo + W_hi*T_hi, 2: no T_lo term
-template <int TERMS>
-__device__ __forceinline__ void e3_gemm(f32x4 (&acc)[4], const E3W& w, const u16* th, const u16* tl, int fr, int q) {
+// acc[i] (pixel tile pt0 + i) += W x T over the 64 channels of tile T; TERMS = 3: W_lo*T_hi + W_hi*T_lo + W_hi*T_hi, 2: no T_lo term
+template <int TERMS, int NPT>
+__device__ __forceinline__ void e3_gemm(f32x4 (&acc)[NPT], const E3W& w, const u16* th, const u16* tl, int pt0, int fr, int q) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NPT; ++i) {
     acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int o = (16 * i + fr) * E3_RS + c * 32 + q * 8;
+      const int o = (16 * (pt0 + i) + fr) * E3_RS + c * 32 + q * 8;
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(th + o);
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[c], ah, acc[i], 0, 0, 0);      // small terms first
       if (TERMS == 3) {
@@ -93,11 +93,12 @@ __device__ __forceinline__ void e3_gemm(f32x4 (&acc)[4], const E3W& w, const u16
   }
 }
 
-// relu(acc + bias) of this lane's (pixel 16 i + fr, couts 16 wave + 4 q ..) as split planes into th / tl (tl may be null)
-__device__ __forceinline__ void e3_store_relu_split(const f32x4 (&acc)[4], const float (&b)[4], u16* th, u16* tl, int wave,
+// relu(acc + bias) of this lane's (pixel 16 (pt0 + i) + fr, couts 16 ct + 4 q ..) as split planes into th / tl (tl may be null)
+template <int NPT>
+__device__ __forceinline__ void e3_store_relu_split(const f32x4 (&acc)[NPT], const float (&b)[4], u16* th, u16* tl, int ct, int pt0,
                                                     int fr, int q) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NPT; ++i) {
     u16 hi[4], lo[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -106,30 +107,36 @@ __device__ __forceinline__ void e3_store_relu_split(const f32x4 (&acc)[4], const
       hi[e] = e3_bf(v);
       lo[e] = e3_bf(v - e3_f(hi[e]));
     }
-    const int o = (16 * i + fr) * E3_RS + 16 * wave + 4 * q;
+    const int o = (16 * (pt0 + i) + fr) * E3_RS + 16 * ct + 4 * q;
     *reinterpret_cast<u32x2*>(th + o) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
     if (tl) *reinterpret_cast<u32x2*>(tl + o) = u32x2{(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
   }
 }
 
-// the x tile: 16 16-byte units per pixel in LDS (8 per plane: Cp0 / 8 of data, zeros behind them); thread -> units tid + 256 k
-struct E3XPre { u32x4 v[4]; };
-__device__ __forceinline__ E3XPre e3_load_x(const __amdgpu_buffer_rsrc_t xr, int64_t m0, int64_t M, int Cp0, int tid) {
-  E3XPre r;
+// the x tile: 16 16-byte units per pixel in LDS (8 per plane: Cp0 / 8 of data, zeros behind them); thread -> units tid + NT k
+template <int NT>
+struct E3XPre { u32x4 v[1024 / NT]; };
+// (m0 is wave-uniform: the 64-bit products stay scalar; per thread everything is 32-bit -- these kernels run ~100 MFMAs per
+// tile and wave, a 64-bit multiply or divide per thread and vector would cost as much as the GEMMs)
+template <int NT>
+__device__ __forceinline__ E3XPre<NT> e3_load_x(const __amdgpu_buffer_rsrc_t xr, int64_t m0, int64_t M, int Cp0, int tid) {
+  E3XPre<NT> r;
   const int dv = Cp0 >> 3;                                    // data units per plane
+  const unsigned base = (unsigned)(m0 * (4 * Cp0));
+  const int left = (int)(M - m0 < E3_TP ? M - m0 : E3_TP);    // pixels of this tile that exist
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int v = tid + 256 * k, px = v >> 4, u = v & 15, plane = u >> 3, vec = u & 7;
-    const int64_t m = m0 + px;
-    const unsigned off = (vec < dv && m < M) ? (unsigned)(m * (4 * Cp0) + plane * 2 * Cp0 + vec * 16) : E3_OOB;
+  for (int k = 0; k < 1024 / NT; ++k) {
+    const int v = tid + NT * k, px = v >> 4, u = v & 15, plane = u >> 3, vec = u & 7;
+    const unsigned off = (vec < dv && px < left) ? base + (unsigned)(px * (4 * Cp0) + plane * 2 * Cp0 + vec * 16) : E3_OOB;
     r.v[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
   }
   return r;
 }
-__device__ __forceinline__ void e3_store_x(const E3XPre& r, u16* xh, u16* xl, int tid) {
+template <int NT>
+__device__ __forceinline__ void e3_store_x(const E3XPre<NT>& r, u16* xh, u16* xl, int tid) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int v = tid + 256 * k, px = v >> 4, u = v & 15, plane = u >> 3, vec = u & 7;
+  for (int k = 0; k < 1024 / NT; ++k) {
+    const int v = tid + NT * k, px = v >> 4, u = v & 15, plane = u >> 3, vec = u & 7;
     *reinterpret_cast<u32x4*>((plane ? xl : xh) + px * E3_RS + vec * 8) = r.v[k];
   }
 }
@@ -147,21 +154,21 @@ __global__ __launch_bounds__(256, 3) void embed3_fwd_kernel(E3Params p) {
   for (int e = 0; e < 4; ++e) { const int co = 16 * wave + 4 * q + e; b0[e] = p.b0[co]; b1[e] = p.b1[co]; b2[e] = p.b2[co]; }
   const int64_t ntiles = (p.M + E3_TP - 1) / E3_TP;
   int64_t t = blockIdx.x;
-  E3XPre pre;
-  if (t < ntiles) pre = e3_load_x(xr, t * E3_TP, p.M, p.Cp0, tid);
+  E3XPre<256> pre;
+  if (t < ntiles) pre = e3_load_x<256>(xr, t * E3_TP, p.M, p.Cp0, tid);
   for (; t < ntiles; t += gridDim.x) {
-    e3_store_x(pre, XH, XL, tid);
+    e3_store_x<256>(pre, XH, XL, tid);
     const int64_t tn = t + gridDim.x;
-    if (tn < ntiles) pre = e3_load_x(xr, tn * E3_TP, p.M, p.Cp0, tid);       // next tile's loads fly under this tile's GEMMs
+    if (tn < ntiles) pre = e3_load_x<256>(xr, tn * E3_TP, p.M, p.Cp0, tid);       // next tile's loads fly under this tile's GEMMs
     __syncthreads();
     f32x4 acc[4];
-    e3_gemm<3>(acc, w0, XH, XL, fr, q);
-    e3_store_relu_split(acc, b0, AH, AL, wave, fr, q);
+    e3_gemm<3, 4>(acc, w0, XH, XL, 0, fr, q);
+    e3_store_relu_split<4>(acc, b0, AH, AL, wave, 0, fr, q);
     __syncthreads();
-    e3_gemm<3>(acc, w1, AH, AL, fr, q);
-    e3_store_relu_split(acc, b1, XH, XL, wave, fr, q);                         // h1 takes the x tile's place
+    e3_gemm<3, 4>(acc, w1, AH, AL, 0, fr, q);
+    e3_store_relu_split<4>(acc, b1, XH, XL, wave, 0, fr, q);                         // h1 takes the x tile's place
     __syncthreads();
-    e3_gemm<3>(acc, w2, XH, XL, fr, q);
+    e3_gemm<3, 4>(acc, w2, XH, XL, 0, fr, q);
     // y tile through LDS (fp32 [64][68] over the h0 tiles) so that it leaves as whole 256-byte rows
     float* stg = reinterpret_cast<float*>(AH);
 #pragma unroll
@@ -170,13 +177,15 @@ __global__ __launch_bounds__(256, 3) void embed3_fwd_kernel(E3Params p) {
           make_float4(acc[i][0] + b2[0], acc[i][1] + b2[1], acc[i][2] + b2[2], acc[i][3] + b2[3]);
     __syncthreads();
     const int64_t m0 = t * E3_TP;
+    const unsigned ybase = (unsigned)(m0 * 256);
+    const int left = (int)(p.M - m0 < E3_TP ? p.M - m0 : E3_TP);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int v = tid + 256 * k, px = v >> 4, c4 = (v & 15) * 4;
       const float4 o = *reinterpret_cast<const float4*>(stg + px * 68 + c4);
       const u32x4 ov = {__builtin_bit_cast(unsigned, o.x), __builtin_bit_cast(unsigned, o.y), __builtin_bit_cast(unsigned, o.z),
                         __builtin_bit_cast(unsigned, o.w)};
-      __builtin_amdgcn_raw_buffer_store_b128(ov, yr, m0 + px < p.M ? (unsigned)((m0 + px) * 256 + c4 * 4) : E3_OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ov, yr, px < left ? ybase + (unsigned)(px * 256 + c4 * 4) : E3_OOB, 0, 0);
     }
     // (the next iteration's x stores touch XH / XL only, which every wave finished reading before the barrier above;
     // the staging tile is read here and first written again behind the next tile's first barrier)
@@ -197,62 +206,92 @@ __device__ __forceinline__ bf16x8 e3_tr(const u16* tile, int kk, int ct, int lan
   return __builtin_bit_cast(bf16x8, cat);
 }
 
-__global__ __launch_bounds__(256, 2) void embed3_bwd_kernel(E3Params p) {
+// One workgroup of eight waves per CU: wave (ct = wave & 3, ph = wave >> 2) owns cout tile ct of every GEMM for the pixel tiles
+// 2 ph, 2 ph + 1, and the weight-gradient tiles (cout tile ct) x (cin tiles 2 ph, 2 ph + 1) of the three layers -- half the
+// accumulators and half the prefetch registers of a four-wave layout, which spilled (40 VGPRs to scratch inside the loop: the
+// kernel ran at 1.2 TB/s).
+__global__ __launch_bounds__(512, 1) void embed3_bwd_kernel(E3Params p) {
   __shared__ __attribute__((aligned(16))) u16 lds[6 * E3_TILE];
-  __shared__ float red[3][16][64];
+  __shared__ float red[3][32][64];
   u16* const XH = lds; u16* const XL = lds + E3_TILE; u16* const H0H = lds + 2 * E3_TILE; u16* const H0L = lds + 3 * E3_TILE;
   u16* const H1H = lds + 4 * E3_TILE; u16* const DYH = lds + 5 * E3_TILE;
   u16* const DH1H = H0L;                   // h0's lo plane is dead once h1 is recomputed
   u16* const DH0H = XL;                    // x's lo plane is dead once h0 is recomputed
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, q = lane >> 4;
+  const int ct = wave & 3, ph = wave >> 2, pt0 = 2 * ph;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t gyr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gy ? (const void*)p.gy : (const void*)p.x), 0,
                                                                        p.gy ? (int)p.gy_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t gmr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gm ? (const void*)p.gm : (const void*)p.x), 0,
                                                                        p.gm ? (int)p.gm_bytes : 0, 0x00020000);
-  const E3W w0 = e3_load_w(p.wp0, 16 * wave + fr, q, p.Kt0), w1 = e3_load_w(p.wp1, 16 * wave + fr, q);
-  const E3W t2 = e3_load_w(p.wt2, 16 * wave + fr, q), t1 = e3_load_w(p.wt1, 16 * wave + fr, q);
+  const E3W w0 = e3_load_w(p.wp0, 16 * ct + fr, q, p.Kt0), w1 = e3_load_w(p.wp1, 16 * ct + fr, q);
+  const E3W t2 = e3_load_w(p.wt2, 16 * ct + fr, q), t1 = e3_load_w(p.wt1, 16 * ct + fr, q);
   float b0[4], b1[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { const int co = 16 * wave + 4 * q + e; b0[e] = p.b0[co]; b1[e] = p.b1[co]; }
-  // weight-gradient accumulators of this wave: cout tile `wave` x the cin tiles of dW2 (4), dW1 (4), dW0 (<= 4)
-  f32x4 g2[4], g1[4], g0[4];
+  for (int e = 0; e < 4; ++e) { const int co = 16 * ct + 4 * q + e; b0[e] = p.b0[co]; b1[e] = p.b1[co]; }
+  // weight-gradient accumulators of this wave: cout tile ct x the cin tiles 2 ph, 2 ph + 1 of dW2, dW1, dW0
+  f32x4 g2[2], g1[2], g0[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { g2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; g1[j] = g2[j]; g0[j] = g2[j]; }
+  for (int j = 0; j < 2; ++j) { g2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; g1[j] = g2[j]; g0[j] = g2[j]; }
   const int nci0 = (p.Cp0 + 15) >> 4;       // cin tiles of layer 0
   float sb2[4] = {0.f, 0.f, 0.f, 0.f}, sb1[4] = {0.f, 0.f, 0.f, 0.f}, sb0[4] = {0.f, 0.f, 0.f, 0.f};
   const int64_t ntiles = (p.M + E3_TP - 1) / E3_TP;
   const int64_t SHW = (int64_t)p.S * p.HW;
 
-  struct DyPre { u32x4 g[4], m[4]; };
+  struct DyPre { u32x4 g[2], m[2]; };
+  // (HW % 64 == 0: a tile lies inside one image, its (image, pixel) of the mean is wave-uniform; otherwise per thread, in 32
+  // bits -- M < 2^23 pixels, checked by the host)
+  const bool mean_uniform = p.HW % E3_TP == 0;
   auto load_dy = [&](int64_t m0) {
     DyPre r;
+    const unsigned gbase = (unsigned)(m0 * p.gy_ps * 4);
+    const int left = (int)(p.M - m0 < E3_TP ? p.M - m0 : E3_TP);
+    const int64_t b = m0 / SHW, hw0 = m0 % p.HW;
+    const unsigned mbase = (unsigned)((b * p.HW + hw0) * p.gm_ps * 4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int v = tid + 256 * k, px = v >> 4, c4 = (v & 15) * 4;
-      const int64_t m = m0 + px;
-      const bool ok = m < p.M;
-      r.g[k] = __builtin_amdgcn_raw_buffer_load_b128(gyr, ok ? (unsigned)((m * p.gy_ps + c4) * 4) : E3_OOB, 0, 0);
-      unsigned moff = E3_OOB;
-      if (ok && p.gm) {
-        const int64_t b = m / SHW, hw = m % p.HW;
-        moff = (unsigned)(((b * p.HW + hw) * p.gm_ps + c4) * 4);
+    for (int k = 0; k < 2; ++k) {
+      const int v = tid + 512 * k, px = v >> 4, c4 = (v & 15) * 4;
+      const bool ok = px < left;
+      r.g[k] = __builtin_amdgcn_raw_buffer_load_b128(gyr, ok ? gbase + (unsigned)((px * p.gy_ps + c4) * 4) : E3_OOB, 0, 0);
+      unsigned moff;
+      if (mean_uniform) {
+        moff = mbase + (unsigned)((px * p.gm_ps + c4) * 4);
+      } else {
+        const unsigned m = (unsigned)m0 + (unsigned)px, bi = m / (unsigned)SHW, hw = m % (unsigned)p.HW;
+        moff = (bi * (unsigned)p.HW + hw) * (unsigned)(p.gm_ps * 4) + (unsigned)(c4 * 4);
       }
-      r.m[k] = __builtin_amdgcn_raw_buffer_load_b128(gmr, moff, 0, 0);
+      r.m[k] = __builtin_amdgcn_raw_buffer_load_b128(gmr, (ok && p.gm) ? moff : E3_OOB, 0, 0);
     }
     return r;
   };
+  // (acc . [h > 0]) of this lane's pixels / channels: bf16 hi plane into `dst`, exact column sums into sb
+  auto gate_store = [&](const f32x4 (&acc)[2], const u16* hplane, u16* dst, float (&sb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (16 * (pt0 + i) + fr) * E3_RS + 16 * ct + 4 * q;
+      const u32x2 hm = *reinterpret_cast<const u32x2*>(hplane + o);
+      u16 hi[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const u16 h = (u16)((e < 2 ? hm[0] : hm[1]) >> (16 * (e & 1)));
+        const float d = e3_f(h) > 0.f ? acc[i][e] : 0.f;
+        sb[e] += d;
+        hi[e] = e3_bf(d);
+      }
+      *reinterpret_cast<u32x2*>(dst + o) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+    }
+  };
 
   int64_t t = blockIdx.x;
-  E3XPre pre;
+  E3XPre<512> pre;
   DyPre dpre;
-  if (t < ntiles) { pre = e3_load_x(xr, t * E3_TP, p.M, p.Cp0, tid); dpre = load_dy(t * E3_TP); }
+  if (t < ntiles) { pre = e3_load_x<512>(xr, t * E3_TP, p.M, p.Cp0, tid); dpre = load_dy(t * E3_TP); }
   for (; t < ntiles; t += gridDim.x) {
-    e3_store_x(pre, XH, XL, tid);
+    e3_store_x<512>(pre, XH, XL, tid);
     // dy = g_y + g_mean / S: hi plane into its tile, exact column sums (the last layer's bias gradient) on the side
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int v = tid + 256 * k, px = v >> 4, c4 = (v & 15) * 4;
+    for (int k = 0; k < 2; ++k) {
+      const int v = tid + 512 * k, px = v >> 4, c4 = (v & 15) * 4;
       u16 hi[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -263,62 +302,37 @@ __global__ __launch_bounds__(256, 2) void embed3_bwd_kernel(E3Params p) {
       *reinterpret_cast<u32x2*>(DYH + px * E3_RS + c4) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
     }
     const int64_t tn = t + gridDim.x;
-    if (tn < ntiles) { pre = e3_load_x(xr, tn * E3_TP, p.M, p.Cp0, tid); dpre = load_dy(tn * E3_TP); }
+    if (tn < ntiles) { pre = e3_load_x<512>(xr, tn * E3_TP, p.M, p.Cp0, tid); dpre = load_dy(tn * E3_TP); }
     __syncthreads();
-    f32x4 acc[4];
+    f32x4 acc[2];
     // ---- recompute h0, h1 (the forward's arithmetic)
-    e3_gemm<3>(acc, w0, XH, XL, fr, q);
-    e3_store_relu_split(acc, b0, H0H, H0L, wave, fr, q);
+    e3_gemm<3, 2>(acc, w0, XH, XL, pt0, fr, q);
+    e3_store_relu_split<2>(acc, b0, H0H, H0L, ct, pt0, fr, q);
     __syncthreads();
-    e3_gemm<3>(acc, w1, H0H, H0L, fr, q);
-    e3_store_relu_split(acc, b1, H1H, nullptr, wave, fr, q);
+    e3_gemm<3, 2>(acc, w1, H0H, H0L, pt0, fr, q);
+    e3_store_relu_split<2>(acc, b1, H1H, nullptr, ct, pt0, fr, q);
     __syncthreads();
-    // ---- dh1 = (W2^T dy) . [h1 > 0]   (this lane: channels 16 wave + 4 q .. of pixel 16 i + fr)
-    e3_gemm<2>(acc, t2, DYH, nullptr, fr, q);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = (16 * i + fr) * E3_RS + 16 * wave + 4 * q;
-      const u32x2 hm = *reinterpret_cast<const u32x2*>(H1H + o);
-      u16 hi[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const u16 h = (u16)((e < 2 ? hm[0] : hm[1]) >> (16 * (e & 1)));
-        const float d = e3_f(h) > 0.f ? acc[i][e] : 0.f;
-        sb1[e] += d;
-        hi[e] = e3_bf(d);
-      }
-      *reinterpret_cast<u32x2*>(DH1H + o) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
-    }
+    // ---- dh1 = (W2^T dy) . [h1 > 0]   (this lane: channels 16 ct + 4 q .. of pixel 16 (pt0 + i) + fr)
+    e3_gemm<2, 2>(acc, t2, DYH, nullptr, pt0, fr, q);
+    gate_store(acc, H1H, DH1H, sb1);
     __syncthreads();
     // ---- dh0 = (W1^T dh1) . [h0 > 0]
-    e3_gemm<2>(acc, t1, DH1H, nullptr, fr, q);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = (16 * i + fr) * E3_RS + 16 * wave + 4 * q;
-      const u32x2 hm = *reinterpret_cast<const u32x2*>(H0H + o);
-      u16 hi[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const u16 h = (u16)((e < 2 ? hm[0] : hm[1]) >> (16 * (e & 1)));
-        const float d = e3_f(h) > 0.f ? acc[i][e] : 0.f;
-        sb0[e] += d;
-        hi[e] = e3_bf(d);
-      }
-      *reinterpret_cast<u32x2*>(DH0H + o) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
-    }
+    e3_gemm<2, 2>(acc, t1, DH1H, nullptr, pt0, fr, q);
+    gate_store(acc, H0H, DH0H, sb0);
     __syncthreads();
-    // ---- weight gradients: D[co][ci] += sum over the tile's pixels; cout tile = wave, one MFMA per product (hi x hi)
+    // ---- weight gradients: D[co][ci] += sum over the tile's pixels; one MFMA per product (hi x hi)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 a2 = e3_tr(DYH, kk, wave, lane), a1 = e3_tr(DH1H, kk, wave, lane), a0 = e3_tr(DH0H, kk, wave, lane);
+      const bf16x8 a2 = e3_tr(DYH, kk, ct, lane), a1 = e3_tr(DH1H, kk, ct, lane), a0 = e3_tr(DH0H, kk, ct, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = pt0 + jj;
         const bf16x8 bh1 = e3_tr(H1H, kk, j, lane), bh0 = e3_tr(H0H, kk, j, lane);
-        g2[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bh1, g2[j], 0, 0, 0);
-        g1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bh0, g1[j], 0, 0, 0);
+        g2[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bh1, g2[jj], 0, 0, 0);
+        g1[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bh0, g1[jj], 0, 0, 0);
         if (j < nci0) {
           const bf16x8 bx = e3_tr(XH, kk, j, lane);
-          g0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bx, g0[j], 0, 0, 0);
+          g0[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bx, g0[jj], 0, 0, 0);
         }
       }
     }
@@ -327,28 +341,28 @@ __global__ __launch_bounds__(256, 2) void embed3_bwd_kernel(E3Params p) {
   // ---- per-workgroup partials: [layer 2 | 1 | 0][co][ci], then the bias sums [2 | 1 | 0][64]
   float* ws = p.ws + (int64_t)blockIdx.x * E3_WS_PER_BLOCK;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int co = 16 * wave + 4 * q + e, ci = 16 * j + fr;
-      ws[(0 * E3_C + co) * E3_C + ci] = g2[j][e];
-      ws[(1 * E3_C + co) * E3_C + ci] = g1[j][e];
-      ws[(2 * E3_C + co) * E3_C + ci] = j < nci0 ? g0[j][e] : 0.f;
+      const int co = 16 * ct + 4 * q + e, j = pt0 + jj, ci = 16 * j + fr;
+      ws[(0 * E3_C + co) * E3_C + ci] = g2[jj][e];
+      ws[(1 * E3_C + co) * E3_C + ci] = g1[jj][e];
+      ws[(2 * E3_C + co) * E3_C + ci] = j < nci0 ? g0[jj][e] : 0.f;
     }
-  // bias sums: sb2 per (thread: channels 4 (tid & 15) .., pixels of its rows) -> 16 threads share a channel quad;
-  // sb1 / sb0 per lane (channels 16 wave + 4 q .., pixel column fr) -> the 16 lanes of a q-group share them
+  // bias sums: sb2 per (thread: channels 4 (tid & 15) .., pixels of its rows) -> 32 threads share a channel quad;
+  // sb1 / sb0 per lane (channels 16 ct + 4 q .., pixel columns fr of its two pixel tiles) -> 32 lanes share them
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     red[0][tid >> 4][(tid & 15) * 4 + e] = sb2[e];
-    red[1][fr][16 * wave + 4 * q + e] = sb1[e];
-    red[2][fr][16 * wave + 4 * q + e] = sb0[e];
+    red[1][16 * ph + fr][16 * ct + 4 * q + e] = sb1[e];
+    red[2][16 * ph + fr][16 * ct + 4 * q + e] = sb0[e];
   }
   __syncthreads();
   if (tid < 3 * E3_C) {
     const int l = tid / E3_C, c = tid - l * E3_C;
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += red[l][r][c];
+    for (int r = 0; r < 32; ++r) s += red[l][r][c];
     ws[3 * E3_C * E3_C + l * E3_C + c] = s;
   }
 }
@@ -391,6 +405,7 @@ constexpr int F2_C = 128;                  // concatenation and hidden width
 constexpr int F2_RS = 144;                 // LDS row stride in bf16: 288 B = 9 x 32 (conflict-free transposing reads)
 constexpr int F2_TILE = E3_TP * F2_RS;
 constexpr int F2_ORS = 48;                 // row stride of the d_out tile (32 channels + pad: 96 B = 3 x 32)
+constexpr int F2_W1RS = 2 * 128 + 8;       // row stride of the output layer's pack in LDS (hi | lo | pad: 16 rows spread over the banks)
 
 struct F2Params {
   const float* y; int y_ps;                // fp32, pixel stride y_ps floats, M = B*S*HW pixels
@@ -450,10 +465,11 @@ __device__ __forceinline__ bf16x8 f2_tr(const u16* tile, int rs, int kk, int ct,
 struct F2Pre { u32x4 v[2]; };
 __device__ __forceinline__ F2Pre f2_load64(const __amdgpu_buffer_rsrc_t r, int64_t m0, int ps, int tid) {
   F2Pre o;
+  const unsigned base = (unsigned)(m0 * ps * 4);               // (m0 is wave-uniform: scalar arithmetic)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int v = tid + 512 * k, px = v >> 4, c4 = (v & 15) * 4;
-    o.v[k] = __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(((m0 + px) * ps + c4) * 4), 0, 0);
+    o.v[k] = __builtin_amdgcn_raw_buffer_load_b128(r, base + (unsigned)((px * ps + c4) * 4), 0, 0);
   }
   return o;
 }
@@ -503,8 +519,12 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)p.prop, 0, (int)p.p_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)(BWD ? (void*)p.gout : (void*)p.out), 0, (int)p.o_bytes, 0x00020000);
+  u16* const W1S = reinterpret_cast<u16*>(red + 16 * F2_C + 64 * 4);                  // (backward) the output layer's pack, [16][F2_W1RS]
   const F2W w0 = f2_load_w(p.wp0, 16 * wave + fr, q);
-  const F2W w1 = f2_load_w(p.wp1, fr, q);                        // the output layer's one cout tile (rows >= outc are zero)
+  // the output layer's one cout tile (rows >= outc are zero): registers in the forward; the backward, which has none to spare
+  // (it spilled with them), keeps the 8 KB pack in LDS and reads the fragments where waves 0..3 multiply
+  F2W w1;
+  if (!BWD) w1 = f2_load_w(p.wp1, fr, q);
   float b0[4], b1[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { b0[e] = p.b0[16 * wave + 4 * q + e]; b1[e] = (q == 0 && e < p.outc) ? p.b1[e] : 0.f; }
@@ -527,6 +547,7 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
     dyr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
     dpr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dprop, 0, (int)p.dp_bytes, 0x00020000);
     for (int i = tid; i < E3_TP * F2_ORS / 2; i += 512) reinterpret_cast<unsigned*>(DOH)[i] = 0u;     // channels >= 4 stay zero
+    *reinterpret_cast<u32x4*>(W1S + (tid >> 5) * F2_W1RS + (tid & 31) * 8) = *reinterpret_cast<const u32x4*>(p.wp1 + tid * 8);
   }
 
   for (int64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
@@ -543,7 +564,7 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
       const int64_t m0 = (b * p.S + s) * p.HW + hw0;
       f2_store64_split(yp, CH, CL, 0, tid);
       u32x4 go = {0u, 0u, 0u, 0u};
-      if (BWD && tid < 64) go = __builtin_amdgcn_raw_buffer_load_b128(orr, (unsigned)((m0 + tid) * 16), 0, 0);
+      if (BWD && tid < 64) go = __builtin_amdgcn_raw_buffer_load_b128(orr, (unsigned)(m0 * 16) + (unsigned)(tid * 16), 0, 0);
       if (s + 1 < p.S) yp = f2_load64(yr, (b * p.S + s + 1) * p.HW + hw0, p.y_ps, tid);      // next sample's tile flies under the GEMMs
       __syncthreads();
       // ---- h = relu(W0 c + b0)
@@ -555,7 +576,21 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
       float ov[4] = {0.f, 0.f, 0.f, 0.f};
       if (wave < 4) {
         f32x4 a2[1];
-        f2_gemm<3, 1>(a2, w1, HH, HL, wave, fr, q);
+        if (BWD) {
+          a2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int o = (16 * wave + fr) * F2_RS + c * 32 + q * 8;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(HH + o), al = *reinterpret_cast<const bf16x8*>(HL + o);
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(W1S + fr * F2_W1RS + c * 32 + q * 8);
+            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(W1S + fr * F2_W1RS + F2_C + c * 32 + q * 8);
+            a2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, a2[0], 0, 0, 0);
+            a2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, a2[0], 0, 0, 0);
+            a2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, a2[0], 0, 0, 0);
+          }
+        } else {
+          f2_gemm<3, 1>(a2, w1, HH, HL, wave, fr, q);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float t = a2[0][e] + b1[e]; ov[e] = (e < p.outc && t > 0.f) ? t : 0.f; }
       }
@@ -563,7 +598,7 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
         if (wave < 4 && q == 0) {
           const u32x4 o4 = {__builtin_bit_cast(unsigned, ov[0]), __builtin_bit_cast(unsigned, ov[1]), __builtin_bit_cast(unsigned, ov[2]),
                             __builtin_bit_cast(unsigned, ov[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(o4, orr, (unsigned)((m0 + 16 * wave + fr) * 16), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o4, orr, (unsigned)(m0 * 16) + (unsigned)((16 * wave + fr) * 16), 0, 0);
         }
         __syncthreads();                                         // h is consumed: the next sample may overwrite the tiles
         continue;
@@ -638,7 +673,7 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
         const float4 o = *reinterpret_cast<const float4*>(stg + px * 68 + c4);
         const u32x4 o4 = {__builtin_bit_cast(unsigned, o.x), __builtin_bit_cast(unsigned, o.y), __builtin_bit_cast(unsigned, o.z),
                           __builtin_bit_cast(unsigned, o.w)};
-        __builtin_amdgcn_raw_buffer_store_b128(o4, dyr, (unsigned)((m0 + px) * 256 + c4 * 4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o4, dyr, (unsigned)(m0 * 256) + (unsigned)(px * 256 + c4 * 4), 0, 0);
       }
       __syncthreads();                                           // the staging tile (h's lo plane) and c / h / dh are free again
     }
@@ -646,7 +681,7 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const u32x4 o4 = {e3_f2u(dpacc[i][0]), e3_f2u(dpacc[i][1]), e3_f2u(dpacc[i][2]), e3_f2u(dpacc[i][3])};
-        __builtin_amdgcn_raw_buffer_store_b128(o4, dpr, (unsigned)((b * p.HW + hw0 + 16 * i + fr) * 256 + (16 * (wave - 4) + 4 * q) * 4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o4, dpr, (unsigned)((b * p.HW + hw0) * 256) + (unsigned)((16 * i + fr) * 256 + (16 * (wave - 4) + 4 * q) * 4), 0, 0);
       }
     }
   }
@@ -707,9 +742,10 @@ __global__ __launch_bounds__(256) void final2_bwd_finish_kernel(const float* __r
 
 static int f2_grid() { return 256; }
 constexpr size_t F2_LDS_FWD = (size_t)4 * F2_TILE * sizeof(u16);
-constexpr size_t F2_LDS_BWD = (size_t)5 * F2_TILE * sizeof(u16) + (size_t)E3_TP * F2_ORS * sizeof(u16) + (size_t)(16 * F2_C + 64 * 4) * sizeof(float);
+constexpr size_t F2_LDS_BWD = (size_t)5 * F2_TILE * sizeof(u16) + (size_t)E3_TP * F2_ORS * sizeof(u16) + (size_t)(16 * F2_C + 64 * 4) * sizeof(float) +
+                              (size_t)16 * F2_W1RS * sizeof(u16);
 
-static int e3_grid_bwd() { return 512; }
+static int e3_grid_bwd() { return 256; }
 
 }  // namespace wcmc
 
@@ -756,7 +792,7 @@ extern "C" int wcmc_embed3_bwd(const void* x_split, int64_t M, int Cin, const vo
                WCMC_ERR_BAD_ARG, "embed3_bwd: bad argument");
   WCMC_REQUIRE(workspace_bytes >= wcmc_embed3_bwd_workspace_bytes(), WCMC_ERR_WORKSPACE, "embed3_bwd: workspace too small");
   WCMC_REQUIRE(!gm || (S >= 1 && HW >= 1 && M % ((int64_t)S * HW) == 0), WCMC_ERR_BAD_ARG,
-               "embed3_bwd: M must be B * S * HW when the gradient of the spp mean is given");
+               "embed3_bwd: with the gradient of the spp mean M must be B * S * HW");
   p.wt1 = (const u16*)wt1; p.wt2 = (const u16*)wt2; p.gy = gy; p.gm = gm; p.S = S > 0 ? S : 1; p.HW = HW > 0 ? HW : M;
   p.gm_scale = gm_scale; p.ws = (float*)workspace;
   WCMC_REQUIRE((!gy || (gy_pixel_stride >= 64 && gy_pixel_stride % 4 == 0)) && (!gm || (gm_pixel_stride >= 64 && gm_pixel_stride % 4 == 0)),
@@ -766,7 +802,7 @@ extern "C" int wcmc_embed3_bwd(const void* x_split, int64_t M, int Cin, const vo
   WCMC_REQUIRE(gyb < 0x7ff00000ll && gmb < 0x7ff00000ll, WCMC_ERR_BAD_ARG, "embed3_bwd: gradient view spans more than 2 GiB");
   p.gy_bytes = (unsigned)gyb; p.gm_bytes = (unsigned)gmb;
   const int nblk = e3_grid_bwd();
-  hipLaunchKernelGGL(embed3_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(embed3_bwd_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, p);
   if (int rc = check_launch("embed3_bwd")) return rc;
   hipLaunchKernelGGL(embed3_bwd_finish_kernel, dim3((unsigned)((E3_WS_PER_BLOCK + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, nblk, Cin, dw0, db0, dw1, db1, dw2, db2);
