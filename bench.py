@@ -49,7 +49,10 @@ def rocprof_names(wgrad_terms):
             "conv_halo64_pt3_x2": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1>",
             "conv_wgrad_rows": ("wcmc::conv_wgrad_rows8_bf16x3_kernel<0, %d, %d>" % (_ROWS8_XE if wgrad_terms == 3 else 1, 1 if wgrad_terms == 1 else 2)) if _ROWS8
                                else "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, %d>" % (1 if wgrad_terms == 1 else 2),
-            "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)"}
+            "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)",
+            # the fused PathNet chains (csrc/pathnet_fused.hip); the backward brackets include their small finish kernels
+            "embed3_fwd": "wcmc::embed3_fwd_kernel", "embed3_bwd": "wcmc::embed3_bwd_kernel",
+            "final2_fwd": "wcmc::final2_kernel<false>", "final2_bwd": "wcmc::final2_kernel<true>"}
 
 
 # bf16 MFMAs issued per algorithmic multiply-add, by profiler class (forward 3; "_x2" data gradients 2; weight gradient: the mode's)
@@ -205,9 +208,13 @@ def pmc_traffic():
                          ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1>", "conv_halo64_pt4_x2"), ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1>", "conv_halo64_pt3_x2"),
                          ("conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>" if _ROWS8 else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, 1>", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
+                         ("embed3_fwd_kernel", "embed3_fwd"), ("embed3_bwd_kernel", "embed3_bwd"),
+                         ("final2_kernel<false>", "final2_fwd"), ("final2_kernel<true>", "final2_bwd"),
                          ("kernel_apply_strip_kernel<false", "kernel_apply_fwd"), ("kernel_apply_strip_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
                 shape = ("64x128x128 64->64 1x1 hidden layer (PathNet embedding): 536.9 MB algorithmic" if key == "conv_pw" else
+                         "64x128x128: PathNet.embedding 36->64->64->64 (+ spp mean) / PathNet.final 64+64->128->3, the benchmark's shape"
+                         if key.startswith(("embed3", "final2")) else
                          "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles)" if key.startswith("conv_halo64_pt3") else
                          "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else "logits (8,441,92,92)")
                 pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "shape": shape,
@@ -557,6 +564,10 @@ def main():
             "roofline": dict(roof(dominant, "mfma"), traffic=traffic.get(dominant)) if dominant else None,
             "roofline_other_conv": [dict(roof(k, "mfma"), traffic=traffic.get(k)) for k in conv_keys if k != dominant],
             "roofline_pointwise": (dict(roof("conv_pw", "hbm"), traffic=traffic.get("conv_pw")) if roof("conv_pw", "hbm") else None),
+            # PathNet.embedding / PathNet.final as one launch per direction (hidden activations never leave the CU): HBM-bound by
+            # construction, algorithmic bytes = input + output (+ gradients) once
+            "roofline_pathnet_fused": [dict(roof(k, "hbm"), traffic=traffic.get(k))
+                                       for k in ("embed3_fwd", "embed3_bwd", "final2_fwd", "final2_bwd") if roof(k, "hbm")],
             "roofline_kernel_apply": ka,
         }
         line["measured_peaks"] = measured_peaks(device)

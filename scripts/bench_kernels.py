@@ -22,7 +22,20 @@ w1p, b1 = o._pack_x(torch.randn(64, 64, 1, 1, device=dev) * 0.1, 0), torch.zeros
 logits = o.to_nhwc_raw(torch.randn(8, 441, 92, 92, device=dev))
 data = torch.rand(8, 3, 92, 92, device=dev)
 g = torch.randn(8, 3, 92, 92, device=dev)
+# the fused PathNet chains at the benchmark shape (B*S = 64 images of 128x128)
+xe = o.presplit_shared(torch.randn(64, 36, 128, 128, device=dev))
+pe = [torch.randn(64, 36, 1, 1, device=dev) * 0.3, torch.zeros(64, device=dev), torch.randn(64, 64, 1, 1, device=dev) * 0.2, torch.zeros(64, device=dev),
+      torch.randn(64, 64, 1, 1, device=dev) * 0.2, torch.zeros(64, device=dev)]
+pf = [torch.randn(128, 128, 1, 1, device=dev) * 0.15, torch.zeros(128, device=dev), torch.randn(3, 128, 1, 1, device=dev) * 0.15, torch.zeros(3, device=dev)]
+for t in pe + pf: t.requires_grad_(True)
+gy = o.to_nhwc_raw(torch.randn(64, 64, 128, 128, device=dev)); gm = o.to_nhwc_raw(torch.randn(8, 64, 128, 128, device=dev))
+prop = o.to_nhwc_raw(torch.randn(8, 64, 128, 128, device=dev)).requires_grad_(True)
+gout = o.to_nhwc_raw(torch.randn(64, 3, 128, 128, device=dev))
 def run():
+    ye, me = o.conv_chain_spp_mean(xe, 8, 1, 0, ["relu", "relu", "linear"], pe)              # embed3_fwd / embed3_bwd
+    torch.autograd.backward([ye, me], [gy, gm])
+    yl = ye.detach().requires_grad_(True)
+    o.cat_broadcast_chain(yl, prop, 8, 1, 0, ["relu", "relu"], pf).backward(gout)             # final2_kernel<false> / <true>
     y = o.conv2d_x_raw(xs, (n, c, h, h), wp, b, 100, 5, 0, "relu", out_split=True)          # bf16x3 fwd
     o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu")   # three-term dgrad (bf16x3 mode)
     o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt2, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu", terms=2)   # two-term dgrad, 16x16 tiles

@@ -836,7 +836,7 @@ class _EmbedSppMeanFusedX(torch.autograd.Function):
         ws_ = [params[0], params[2], params[4]]
         packs = _pack_chain_x(ws_, 1)                        # [(forward, data-gradient orientation)] per layer
         y = torch.empty((n, h, w, 64), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
-        with _Timed("embed3", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64), "byte"):
+        with _Timed("embed3_fwd", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64), "byte"):
             check(lib().wcmc_embed3_fwd(_ptr(xs), n * h * w, cin, _ptr(packs[0][0]), _ptr(params[1].detach()),
                                         _ptr(packs[1][0]), _ptr(params[3].detach()), _ptr(packs[2][0]), _ptr(params[5].detach()),
                                         _ptr(y), _stream()), "embed3_fwd")
@@ -864,7 +864,7 @@ class _EmbedSppMeanFusedX(torch.autograd.Function):
         nb = lib().wcmc_embed3_bwd_workspace_bytes()
         ws = torch.empty(nb // 4, device=dev, dtype=torch.float32)
         packs = ctx.packs
-        with _Timed("embed3", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64 + (64 // s if gm is not None else 0)), "byte"):
+        with _Timed("embed3_bwd", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64 + (64 // s if gm is not None else 0)), "byte"):
             check(lib().wcmc_embed3_bwd(_ptr(xs), n * h * w, cin, _ptr(packs[0][0]), _ptr(b0), _ptr(packs[1][0]), _ptr(b1),
                                         _ptr(packs[1][1]), _ptr(packs[2][1]), _ptr(gy), _dense_pixel_stride(gy) if gy is not None else 0,
                                         _ptr(gm), _dense_pixel_stride(gm) if gm is not None else 0, s, h * w, 1.0 / s,
@@ -885,7 +885,7 @@ class _FinalFusedX(torch.autograd.Function):
         outc = params[2].shape[0]
         packs = _pack_chain_x([params[0], params[2]], 1)
         buf = torch.empty((bs, h, w, 4), device=flat.device, dtype=torch.float32)
-        with _Timed("final2", 4.0 * bs * h * w * (64 + 64 // s + 4), "byte"):
+        with _Timed("final2_fwd", 4.0 * bs * h * w * (64 + 64 // s + 4), "byte"):
             check(lib().wcmc_final2_fwd(_ptr(flat), _dense_pixel_stride(flat), _ptr(prop), _dense_pixel_stride(prop), b, s, h * w,
                                         _ptr(packs[0][0]), _ptr(params[1].detach()), _ptr(packs[1][0]), _ptr(params[3].detach()), outc,
                                         _ptr(buf), _stream()), "final2_fwd")
@@ -907,7 +907,7 @@ class _FinalFusedX(torch.autograd.Function):
         nb = lib().wcmc_final2_bwd_workspace_bytes()
         ws = torch.empty(nb // 4, device=dev, dtype=torch.float32)
         packs = ctx.packs
-        with _Timed("final2", 4.0 * b * s * h * w * (64 + 64 // s + 4 + 64 + 64 // s), "byte"):
+        with _Timed("final2_bwd", 4.0 * b * s * h * w * (64 + 64 // s + 4 + 64 + 64 // s), "byte"):
             check(lib().wcmc_final2_bwd(_ptr(flat), _dense_pixel_stride(flat), _ptr(prop), _dense_pixel_stride(prop), b, s, h * w,
                                         _ptr(packs[0][0]), _ptr(b0), _ptr(packs[1][0]), _ptr(b1), outc, _ptr(packs[0][1]), _ptr(packs[1][1]),
                                         _ptr(g), _ptr(dy), _ptr(dprop), _ptr(dw0), _ptr(db0), _ptr(dw1), _ptr(db1), _ptr(ws), nb,
