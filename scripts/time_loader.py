@@ -25,6 +25,16 @@ from wcmc_amd.graph import GraphedTrainStep
 first = next(iter(loader))
 step = GraphedTrainStep(itf, first)
 for b in loader: step(b)                                # warm-up
+# where the difference to resident inputs goes: (a) the same step on one resident batch, (b) on that batch while the loader
+# runs beside it (its batches are drawn and dropped), (c) fed by the loader
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(96): step(first)
+torch.cuda.synchronize(); ta = (time.perf_counter() - t0) / 96
+torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
+for b in loader:
+    step(first); nb += 1
+torch.cuda.synchronize(); tb = (time.perf_counter() - t0) / nb
+print("graphed step on a resident batch: %.2f ms; the same with the loader running beside it: %.2f ms" % (ta * 1e3, tb * 1e3))
 torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
 for b in loader:
     step(b); nb += 1

@@ -58,11 +58,17 @@ class PatchBatcher:
             roi = np.random.choice(h * w, size=n)
         return np.stack([roi // w, roi % w], axis=1).astype(np.int32)
 
-    def batch(self, kpcn, llpm, gt, origins):
-        """kpcn (H,W,44), llpm (H,W,S,37) or None, gt (H,W,9): device tensors; origins: (B,2) rows/columns (numpy or
-        tensor).  Windows must lie inside the image (the reference would silently return a smaller patch)."""
-        o = torch.as_tensor(np.asarray(origins), dtype=torch.int32) if not isinstance(origins, torch.Tensor) else origins
-        h, w = kpcn.shape[:2]
-        if int(o[:, 0].max()) + self.patch_size > h or int(o[:, 1].max()) + self.patch_size > w or int(o.min()) < 0:
+    def check_origins(self, origins, h, w):
+        """Windows must lie inside the image (the reference would silently return a smaller patch)."""
+        o = origins.cpu().numpy() if isinstance(origins, torch.Tensor) else np.asarray(origins)
+        if o.size and (int(o[:, 0].max()) + self.patch_size > h or int(o[:, 1].max()) + self.patch_size > w or int(o.min()) < 0):
             raise ValueError("PatchBatcher: a %d-pixel patch origin lies outside the %dx%d image" % (self.patch_size, h, w))
+
+    def batch(self, kpcn, llpm, gt, origins, check=True):
+        """kpcn (H,W,44), llpm (H,W,S,37) or None, gt (H,W,9): device tensors; origins: (B,2) rows/columns (numpy or
+        tensor).  ``check=False``: the caller has run ``check_origins`` on them (``PatchLoader`` does, once per image, on the
+        host copy -- checking a device tensor here would synchronise every batch)."""
+        if check:
+            self.check_origins(origins, *kpcn.shape[:2])
+        o = torch.as_tensor(np.asarray(origins), dtype=torch.int32) if not isinstance(origins, torch.Tensor) else origins
         return _ops.assemble_kpcn_patches(kpcn, llpm, gt, o.to(kpcn.device, torch.int32).contiguous(), self.patch_size)

@@ -13,10 +13,13 @@ PCIe without stalling the training stream:
     is still drawing patches from image i;
   * ``PatchLoader``: the iterable the epoch loop consumes (``dataloaders['train']`` of ``wcmc_amd.train_kpcn``):
     ``patches_per_image`` patches per image in batches of ``batch_size``, origins importance-sampled with the reference's
-    ``np.random.choice`` call (``datasets.py:795-810``), one ``wcmc_assemble_kpcn_patches`` launch per batch.
+    ``np.random.choice`` call (``datasets.py:795-810``), one ``wcmc_assemble_kpcn_patches`` launch per batch -- enqueued on a
+    side stream by a producer thread ``prefetch`` batches ahead of the consumer, which only makes its stream wait for the
+    batch's event.
 
 ``scripts/time_loader.py`` measures it (patches/s and PCIe GB/s) next to the train step's consumption rate.
 """
+import ctypes
 import queue
 import threading
 
@@ -79,11 +82,14 @@ class ImageStager:
                 if slot.get('event') is not None:
                     slot['event'].synchronize()
                 item = self.reader(i)
-                raw = np.asarray(item['raw'], dtype=np.float32)
-                gt = np.asarray(item['gt'], dtype=np.float32)
+                raw = np.ascontiguousarray(item['raw'], dtype=np.float32)
+                gt = np.ascontiguousarray(item['gt'], dtype=np.float32)
                 p_raw, p_gt = self._pinned_like(slot, 'raw', raw), self._pinned_like(slot, 'gt', gt)
-                p_raw.copy_(torch.from_numpy(raw))                    # pageable -> pinned (host memcpy on this thread)
-                p_gt.copy_(torch.from_numpy(gt))
+                # pageable -> pinned on this thread, through ctypes: the foreign call runs WITHOUT the interpreter lock.
+                # ``Tensor.copy_`` held it for the whole 0.9 GB memcpy of a 512x512x8-spp image -- the training thread
+                # could not enqueue a step meanwhile: +1.4 ms per step (scripts/time_loader.py)
+                ctypes.memmove(p_raw.data_ptr(), raw.ctypes.data, raw.nbytes)
+                ctypes.memmove(p_gt.data_ptr(), gt.ctypes.data, gt.nbytes)
                 with torch.cuda.stream(self.copy_stream):
                     d_raw = p_raw.to(self.device, non_blocking=True)
                     d_gt = p_gt.to(self.device, non_blocking=True)
@@ -130,31 +136,92 @@ class PatchLoader:
     """Batches of the KPCN base model over the staged images; ``len()`` = batches per epoch."""
 
     def __init__(self, reader, indices, device, batch_size=8, patch_size=PatchBatcher.PATCH_SIZE, use_llpm=True, depth=2,
-                 patches_per_image=None):
+                 patches_per_image=None, prefetch=2):
         self.stager = ImageStager(reader, indices, device, depth=depth, use_llpm=use_llpm)
         self.batcher = PatchBatcher(patch_size, batch_size)
         if patches_per_image is not None:
             self.batcher.patches_per_image = (patches_per_image // batch_size) * batch_size
         self.batch_size = batch_size
+        self.assemble_stream = torch.cuda.Stream(device=self.stager.device)
+        self.prefetch = max(1, int(prefetch))                         # batches assembled ahead of the consumer
 
     def __len__(self):
         return len(self.stager.indices) * (self.batcher.patches_per_image // self.batch_size)
 
-    def __iter__(self):
+    def _produce(self, out_q, stop):
+        """Producer thread: walks the staged images, draws an image's origins and enqueues the assembly of its batches on
+        the side stream; hands ``(batch, event)`` to the consumer through a bounded queue."""
         p = self.batcher.patch_size
-        for kpcn, llpm, gt, prob in self.stager:
-            h, w = kpcn.shape[:2]
-            if prob is None:
-                prob = np.zeros((h, w), dtype=np.float64)             # (not a distribution: uniform, as the reference falls back)
-            # origins must keep the window inside the image: the reference crops what it gets, which silently shrinks a
-            # patch at the border; its probability maps are zero there (datasets.py:795-810)
-            valid = np.zeros((h, w), dtype=np.float64)
-            valid[:h - p + 1, :w - p + 1] = np.asarray(prob, dtype=np.float64)[:h - p + 1, :w - p + 1]
-            s = valid.sum()
-            if s > 0:
-                valid /= s
-            else:
-                valid[:h - p + 1, :w - p + 1] = 1.0 / ((h - p + 1) * (w - p + 1))
-            origins = self.batcher.sample_origins(valid)
-            for k in range(0, len(origins), self.batch_size):
-                yield self.batcher.batch(kpcn, llpm, gt, origins[k:k + self.batch_size])
+        dev = self.stager.device
+        side = self.assemble_stream
+        images = None
+        try:
+            torch.cuda.set_device(dev)
+            images = iter(self.stager)
+            while not stop.is_set():
+                with torch.cuda.stream(side):                     # (the stager hands its buffers to the CURRENT stream)
+                    got = next(images, None)
+                if got is None:
+                    break
+                kpcn, llpm, gt, prob = got
+                h, w = kpcn.shape[:2]
+                if prob is None:
+                    prob = np.zeros((h, w), dtype=np.float64)         # (not a distribution: uniform, as the reference falls back)
+                # origins must keep the window inside the image: the reference crops what it gets, which silently shrinks a
+                # patch at the border; its probability maps are zero there (datasets.py:795-810)
+                valid = np.zeros((h, w), dtype=np.float64)
+                valid[:h - p + 1, :w - p + 1] = np.asarray(prob, dtype=np.float64)[:h - p + 1, :w - p + 1]
+                s = valid.sum()
+                if s > 0:
+                    valid /= s
+                else:
+                    valid[:h - p + 1, :w - p + 1] = 1.0 / ((h - p + 1) * (w - p + 1))
+                origins = self.batcher.sample_origins(valid)
+                self.batcher.check_origins(origins, h, w)
+                with torch.cuda.stream(side):
+                    origins_dev = torch.as_tensor(origins, dtype=torch.int32).to(dev)      # one copy per image
+                    for k in range(0, len(origins), self.batch_size):
+                        batch = self.batcher.batch(kpcn, llpm, gt, origins_dev[k:k + self.batch_size], check=False)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        if not ImageStager._put(out_q, (batch, ev), stop):
+                            return
+            ImageStager._put(out_q, None, stop)
+        except BaseException as exc:                              # surface reader / CUDA errors in the consumer
+            ImageStager._put(out_q, exc, stop)
+        finally:
+            if images is not None:
+                images.close()
+
+    def __iter__(self):
+        """Batches are assembled AHEAD of the consumer, on a side stream, by a producer thread: while the training thread
+        waits for its step (the wait releases the interpreter lock) the next batches' origins are drawn and their assembly
+        kernels enqueued, so between two steps the consumer only pops a queue and makes its stream wait for an event
+        (the assembly kernel, 150 us, and ~0.3 ms of host work per batch used to sit in the gap between two graph replays:
+        ``scripts/time_loader.py``).  ``numpy.random`` is drawn from on the producer thread, in image order."""
+        dev = self.stager.device
+        out_q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
+        worker = threading.Thread(target=self._produce, args=(out_q, stop), daemon=True)
+        worker.start()
+        try:
+            while True:
+                got = out_q.get()
+                if got is None:
+                    return
+                if isinstance(got, BaseException):
+                    raise got
+                batch, ev = got
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(ev)
+                for t in batch.values():
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(cur)
+                yield batch
+        finally:
+            stop.set()
+            try:                                                  # wake a producer blocked on a full queue
+                while True:
+                    out_q.get_nowait()
+            except queue.Empty:
+                pass
+            worker.join(timeout=10.0)
