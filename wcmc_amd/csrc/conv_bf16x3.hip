@@ -3061,8 +3061,8 @@ static constexpr size_t xwr_lds_bytes() {
   constexpr size_t red = (size_t)TM * 16 * (NW * 16 + 4) * sizeof(float);
   return stage > red ? stage : red;
 }
-static size_t xwr_lds_bytes_rt(int ks, int tm, int nw) {
-  const int nvec = 2 * 64 * (xwr_stride(tm * 16) / 8) + 2 * (64 + ks - 1) * (xwr_stride(nw * 16) / 8);
+static size_t xwr_lds_bytes_rt(int ks, int tm, int nw, int pl = 2) {
+  const int nvec = pl * 64 * (xwr_stride(tm * 16) / 8) + pl * (64 + ks - 1) * (xwr_stride(nw * 16) / 8);
   const int ni = (nvec + nw * 64 - 1) / (nw * 64);
   const size_t stage = (size_t)2 * ni * nw * 64 * 16, red = (size_t)tm * 16 * (nw * 16 + 4) * sizeof(float);
   return stage > red ? stage : red;
@@ -3180,7 +3180,11 @@ static int x_pick_nt(int tiles) {
 }
 
 struct XWgradPlan { int rows, rps, R, rTM, rNW; int TM, coBlocks, ciBlocks, S, Np, Cq, G; int64_t pix_per_split, per_block; size_t slab_elems, bytes; };
-static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks) {
+// terms: bf16 MFMAs per product of the launch (3 | 1).  The one-plane instances need half the LDS per stage, so two of the
+// four-wave filter-row blocks share a CU where the two-plane ones run alone: twice the splits for those layers (the
+// U-Net's 64-channel levels: 28 -> 23 us, 192 -> 64: 72 -> 47 us; scripts/time_wgrad_unet.py) -- one wave per SIMD cannot hide
+// its own DMA issue and barriers.  The slab layout follows the plan: the launch and its reduction ask with the same `terms`.
+static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks, int terms = 3) {
   XWgradPlan pl;
   pl.Np = round_up(Cout, 16); pl.Cq = round_up(Cin, 16);
   const int coT = pl.Np / 16, ciT = pl.Cq / 16;
@@ -3217,7 +3221,7 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks)
       pl.coBlocks = coT / tm; pl.ciBlocks = ciT / nw;
       // one block per (unit, filter row); the ks blocks of a unit share an XCD (32 CUs x resident blocks
       // per CU): at most that many per XCD keeps the launch to one round
-      const size_t lds = xwr_lds_bytes_rt(ks, tm, nw);
+      const size_t lds = xwr_lds_bytes_rt(ks, tm, nw, terms == 1 ? 1 : 2);
       int wpc = (int)((160 * 1024) / lds);
       const int wcap = nw <= 4 ? 2 : 1;               // as the kernel's __launch_bounds__
       if (wpc > wcap) wpc = wcap;
@@ -3816,7 +3820,8 @@ extern "C" int wcmc_colsum_finish(const float* partial, int N, int Ho, int Wo, i
 
 extern "C" size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int ks) {
   if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin <= 0 || ks <= 0) return 0;
-  return x_plan_wgrad(N, Ho, Wo, Cout, Cin, ks).bytes;
+  const size_t b3 = x_plan_wgrad(N, Ho, Wo, Cout, Cin, ks, 3).bytes, b1 = x_plan_wgrad(N, Ho, Wo, Cout, Cin, ks, 1).bytes;
+  return b3 > b1 ? b3 : b1;                              // (enough for either number of terms)
 }
 
 template <int TM, int PL = 2>
@@ -3843,7 +3848,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
   WCMC_REQUIRE(Ho > 0 && Wo > 0, WCMC_ERR_BAD_ARG, "conv2d_wgrad_bf16x3: empty output");
   WCMC_REQUIRE(aligned16(x_split) && aligned16(dy_split), WCMC_ERR_ALIGNMENT,
                "conv2d_wgrad_bf16x3: split buffers must be 16-byte aligned");
-  const XWgradPlan pl = x_plan_wgrad(N, Ho, Wo, Cout, Cin, ks);
+  const XWgradPlan pl = x_plan_wgrad(N, Ho, Wo, Cout, Cin, ks, terms);
   WCMC_REQUIRE(workspace_bytes >= pl.bytes && aligned16(workspace), WCMC_ERR_WORKSPACE,
                "conv2d_wgrad_bf16x3: workspace %zu < %zu bytes (or unaligned)", workspace_bytes, pl.bytes);
   hipStream_t st = (hipStream_t)stream;
