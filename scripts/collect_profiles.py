@@ -18,9 +18,9 @@ for log, out in (("bench_line.log", "bench_line.json"), ("bench_line_bf16x3.log"
         json.dump(last_json_line(os.path.join(src, log)), f, indent=1)
         f.write("\n")
 for sub, out in (("prof_graph", "bench_kernel_stats.csv"), ("prof_eager", "bench_eager_kernel_stats.csv")):
-    got = glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv"))
-    assert len(got) == 1, got
-    shutil.copy(got[0], os.path.join(dst, "%s_%s" % (tag, out)))
+    got = sorted(glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv")), key=os.path.getmtime)
+    assert got, sub                                       # (gpurun merges into gpurun_out/: an earlier call's file may still be there)
+    shutil.copy(got[-1], os.path.join(dst, "%s_%s" % (tag, out)))
 for name in ("pmc_summary.json", "step_trace_gaps.txt"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
 line = last_json_line(os.path.join(src, "bench_line.log"))
