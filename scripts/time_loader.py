@@ -41,3 +41,12 @@ for b in loader:
 torch.cuda.synchronize(); t = time.perf_counter() - t0
 print("loader feeding the graphed KPCN-Manifold step: %d steps in %.3f s = %.1f patches/s (bench.py on resident inputs: see its line)"
       % (nb, t, nb * 8 / t))
+step2 = GraphedTrainStep(itf, first, defer_check=True)
+for b in loader: step2(b)
+step2.flush()
+torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
+for b in loader:
+    step2(b); nb += 1
+step2.flush()
+torch.cuda.synchronize(); t = time.perf_counter() - t0
+print("the same with defer_check=True (non-finite check of step t after step t + 1 is enqueued): %.1f patches/s" % (nb * 8 / t))

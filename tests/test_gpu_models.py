@@ -430,7 +430,8 @@ def test_graphed_step_equals_eager_step():
     ops.set_precision("fp32")
     try:
         results = []
-        for graphed in (False, True, "tail"):           # eager | graph + eager optimiser | graph with the optimiser captured
+        # eager | graph + eager optimiser | graph with the optimiser captured | the same with the deferred non-finite check
+        for graphed in (False, True, "tail", "deferred"):
             torch.manual_seed(21)
             kw = dict(ksize=21, depth=3, width=24)
             models = {"dncnn": KPCN(39, **kw), "backbone_diffuse": PathNet(36, intermc=16),
@@ -447,8 +448,9 @@ def test_graphed_step_equals_eager_step():
             itf.to_train_mode()
             batches = [make_batch(2, 4, 48, seed=30 + i, device=DEV) for i in range(3)]
             if graphed:
-                step = GraphedTrainStep(itf, batches[0], capture_optimizer=(graphed == "tail"))
-                assert step.tail_captured == (graphed == "tail")
+                step = GraphedTrainStep(itf, batches[0], capture_optimizer=(graphed in ("tail", "deferred")),
+                                        defer_check=(graphed == "deferred"))
+                assert step.tail_captured == (graphed in ("tail", "deferred"))
             else:
                 def step(b):
                     itf.preprocess(b)
@@ -459,16 +461,18 @@ def test_graphed_step_equals_eager_step():
                     for o in optims.values():
                         o.param_groups[0]["lr"] = 3e-4
                 step(b)
+            if graphed:
+                step.flush()
             results.append(({k: v.item() for k, v in itf.m_losses.items()},
                             torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()]).cpu(),
                             itf.iters, [float(o.state[next(iter(o.state))]["step"]) for o in optims.values()]))
-        (l0, p0, i0, s0), (l1, p1, i1, s1), (l2, p2, i2, s2) = results
-        assert i0 == i1 == i2 == 4 and s0 == s1 == s2 == [3.0, 3.0, 3.0]
-        assert l0.keys() == l1.keys() == l2.keys()
-        for k in l0:
-            np.testing.assert_allclose(l1[k], l0[k], rtol=1e-6, err_msg=k)
-            np.testing.assert_allclose(l2[k], l0[k], rtol=1e-6, err_msg=k)
-        assert torch.equal(p0, p1) and torch.equal(p0, p2)
+        l0, p0, i0, s0 = results[0]
+        for l1, p1, i1, s1 in results[1:]:
+            assert i0 == i1 == 4 and s0 == s1 == [3.0, 3.0, 3.0]
+            assert l0.keys() == l1.keys()
+            for k in l0:
+                np.testing.assert_allclose(l1[k], l0[k], rtol=1e-6, err_msg=k)
+            assert torch.equal(p0, p1)
     finally:
         ops.set_precision(old)
 
@@ -511,6 +515,38 @@ def test_captured_optimizer_tail_guard_and_epoch_summary():
     step(good)
     one = {k: v.item() for k, v in itf.m_losses.items()}
     assert all(0.0 < one[k] < three[k] for k in one if k != "m_val"), (one, three)
+
+
+def test_deferred_check_raises_one_call_later_with_the_update_skipped():
+    """``GraphedTrainStep(defer_check=True)``: the host does not wait for a step before it enqueues the next one.  A non-finite
+    loss still leaves parameters and moments untouched AT ONCE (device guard); the reference's error surfaces at the next
+    call -- or at ``flush()`` when there is none -- and the step counters are taken back."""
+    import bench
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.synthetic import make_batch
+    device = torch.device("cuda", 0)
+    itf = bench.build_interface(device, None, rng="device")
+    good = make_batch(2, 4, 64, seed=70, device=device)
+    step = GraphedTrainStep(itf, good, defer_check=True)
+    assert step.tail_captured and step.defer_check
+    torch.manual_seed(71)
+    step(good)
+    step(good)
+    step.flush()
+    flat = lambda: torch.cat([fl.flat for fl in itf.fused_optim.flats.values()]).clone()
+    p_before = flat()
+    bad = {k: v.clone() for k, v in good.items()}
+    bad["target_diffuse"][0, 0, 30, 30] = float("nan")
+    step(bad)                                           # returns: its check is pending
+    torch.cuda.synchronize()
+    assert torch.equal(flat(), p_before)                # ... but the device guard has already skipped the update
+    with pytest.raises(RuntimeError, match="Non-finite loss at train time"):
+        step.flush()
+    assert [fl.steps for fl in itf.fused_optim.flats.values()] == [2, 2, 2]
+    step(bad)
+    with pytest.raises(RuntimeError, match="Non-finite loss at train time"):
+        step(good)                                      # raised by the NEXT call when there is one
+    step.flush() if step._pending is None else None
 
 
 def test_graphed_unfused_step_with_grad_sync_equals_eager():

@@ -16,7 +16,12 @@ from . import ops
 class GraphedTrainStep:
     """``step = GraphedTrainStep(itf, example_batch); step(batch)`` == ``itf.preprocess(batch); itf.train_batch(batch)``."""
 
-    def __init__(self, itf, batch, warmup=2, side_stream=True, capture_optimizer=True):
+    def __init__(self, itf, batch, warmup=2, side_stream=True, capture_optimizer=True, defer_check=False):
+        """``defer_check`` (captured optimiser only): the non-finite-loss check of step t -- the step's one host sync -- is made
+        after step t + 1 has been enqueued, so the host prepares the next batch while the GPU runs (a loader-fed loop gains
+        what the sync-then-prepare gap cost).  The device guard still skips the update of a non-finite step at once; the
+        reference's error (``interfaces.py:254-257``) is raised one call later, or by ``flush()``, which the epoch loop calls
+        after its last step."""
         self.itf = itf
         self.static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
         self.keys = list(self.static)                     # (PathNet stashes a converted copy of `paths` in the dict)
@@ -55,6 +60,8 @@ class GraphedTrainStep:
         # flags after the replay and raises the reference's error (interfaces.py:254-257) -- the update was then skipped.
         fo = getattr(itf, 'fused_optim', None)
         self.tail_captured = (capture_optimizer and fo is not None and fo.world == 1 and itf.grad_sync is None)
+        self.defer_check = bool(defer_check) and self.tail_captured
+        self._pending, self._flag_bufs, self._n_calls = None, None, 0
         if self.tail_captured:
             assert warmup >= 1
             fo.prepare_capture()
@@ -125,11 +132,43 @@ class GraphedTrainStep:
         fo.refresh_hyper(itf.optims)
         self.graph.replay()
         itf.last_loss_dict = self.losses
-        flags = self.flags.tolist()                       # the step's one sync
+        if self.defer_check:
+            if self._flag_bufs is None:
+                self._flag_bufs = [(torch.empty(self.flags.numel(), dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            slot = self._n_calls & 1
+            self._n_calls += 1
+            host, ev = self._flag_bufs[slot]
+            host.copy_(self.flags, non_blocking=True)
+            ev.record()
+            fo.after_replay(True)                         # optimistic: taken back by _check if the guard skipped the update
+            fo.last_guard = self.guard
+            prev, self._pending = self._pending, slot
+            if prev is not None:
+                self._check(prev)
+            return
+        self._raise_unless_finite(self.flags.tolist())    # the step's one sync
+
+    def _raise_unless_finite(self, flags, rollback=False):
+        fo = self.itf.fused_optim
         ok = flags[-1] != 0
-        fo.after_replay(ok)
-        fo.last_guard = self.guard
+        if rollback:
+            if not ok:
+                fo.rollback()
+        else:
+            fo.after_replay(ok)
+            fo.last_guard = self.guard
         if not ok:                                        # (the guard kept the sums, the moments and the parameters as they were)
             for k, f in zip(self.loss_keys, flags[:-1]):
                 if not f:
                     raise RuntimeError("%s: Non-finite loss at train time." % (k))
+
+    def _check(self, slot):
+        host, ev = self._flag_bufs[slot]
+        ev.synchronize()
+        self._raise_unless_finite(host.tolist(), rollback=True)
+
+    def flush(self):
+        """The deferred check of the last step (``defer_check=True``); a no-op otherwise."""
+        prev, self._pending = self._pending, None
+        if prev is not None:
+            self._check(prev)

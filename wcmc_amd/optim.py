@@ -227,20 +227,24 @@ class FusedClipAdam:
         """Buffers of the captured step, allocated BEFORE the capture begins (hipHostMalloc invalidates a stream capture)."""
         dev = next(iter(self.flats.values())).flat.device
         self.hyper = torch.zeros(len(self.flats), 8, device=dev, dtype=torch.float32)
-        self._hyper_host = torch.zeros(len(self.flats), 8, dtype=torch.float32).pin_memory()
+        # (a ring: with GraphedTrainStep(defer_check=True) the host prepares step t + 1 while step t's copy may still be queued)
+        self._hyper_host = [torch.zeros(len(self.flats), 8, dtype=torch.float32).pin_memory() for _ in range(3)]
+        self._hyper_slot = 0
         for fl in self.flats.values():
             fl.grad_views()
 
     def refresh_hyper(self, optims):
         """Before a replay: this step's scalars (``optim.param_groups[0]`` is read every step, like the eager path)."""
+        self._hyper_slot = (self._hyper_slot + 1) % len(self._hyper_host)
+        host = self._hyper_host[self._hyper_slot]
         for i, (name, fl, stepped, have) in enumerate(self._captured):
             if not stepped:
                 continue
             g0 = optims["optim_" + name].param_groups[0]
             nstep = next(n for n, h in zip(fl.psteps, have) if h) + 1
             h = ops.clip_adam_hyper(nstep, float(g0["lr"]), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]))
-            self._hyper_host[i, :7] = torch.tensor(h)
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+            host[i, :7] = torch.tensor(h)
+        self.hyper.copy_(host, non_blocking=True)
 
     def after_replay(self, updated):
         """Host bookkeeping of a replayed step: the counters advance unless the device guard skipped the update."""

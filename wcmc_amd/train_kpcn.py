@@ -65,12 +65,14 @@ def train_epoch_kpcn(epoch, interfaces, dataloaders, params, args):
             if getattr(args, 'graph', False):
                 if i not in steps:
                     from .graph import GraphedTrainStep
-                    steps[i] = GraphedTrainStep(itf, batch)
+                    steps[i] = GraphedTrainStep(itf, batch, defer_check=getattr(args, 'defer_check', False))
                 steps[i](batch)
             else:
                 itf.preprocess(batch)
                 itf.train_batch(batch)
         n += 1
+    for step in steps.values():
+        step.flush()                                      # (--defer_check: the last step's non-finite check)
     if not args.visual:
         for itf in interfaces:
             itf.get_epoch_summary(mode='train', norm=n)
@@ -274,6 +276,10 @@ def build_parser():
     p.add_argument('--synthetic', type=int, default=16, help='synthetic batches per epoch (the dataset reader is out of scope)')
     p.add_argument('--patch_size', type=int, default=128)
     p.add_argument('--graph', action='store_true', help='one hipGraph replay per training step')
+    p.add_argument('--defer_check', action='store_true',
+                   help="with --graph: check a step's losses for non-finite values after the NEXT step has been enqueued (the "
+                        "device guard still skips the update at once; the error is raised one step later) -- the host prepares "
+                        "the next batch while the GPU runs")
     p.add_argument('--pairing_rng', choices=('cpu', 'device'), default='cpu',
                    help="FeatureMSE pairings: the reference's CPU randperm stream, or a keyed permutation on the GPU")
     p.add_argument('--pathnet_weight_norm', action='store_true',
