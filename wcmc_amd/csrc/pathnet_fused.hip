@@ -211,11 +211,11 @@ __device__ __forceinline__ bf16x8 e3_tr(const u16* tile, int kk, int ct, int lan
 // accumulators and half the prefetch registers of a four-wave layout, which spilled (40 VGPRs to scratch inside the loop: the
 // kernel ran at 1.2 TB/s).
 __global__ __launch_bounds__(512, 1) void embed3_bwd_kernel(E3Params p) {
-  __shared__ __attribute__((aligned(16))) u16 lds[6 * E3_TILE];
+  __shared__ __attribute__((aligned(16))) u16 lds[7 * E3_TILE];
   __shared__ float red[3][32][64];
   u16* const XH = lds; u16* const XL = lds + E3_TILE; u16* const H0H = lds + 2 * E3_TILE; u16* const H0L = lds + 3 * E3_TILE;
   u16* const H1H = lds + 4 * E3_TILE; u16* const DYH = lds + 5 * E3_TILE;
-  u16* const DH1H = H0L;                   // h0's lo plane is dead once h1 is recomputed
+  u16* const DH1H = lds + 6 * E3_TILE;     // (its own plane: it is written while other waves still read h0's lo plane)
   u16* const DH0H = XL;                    // x's lo plane is dead once h0 is recomputed
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, q = lane >> 4;
   const int ct = wave & 3, ph = wave >> 2, pt0 = 2 * ph;
@@ -264,24 +264,6 @@ __global__ __launch_bounds__(512, 1) void embed3_bwd_kernel(E3Params p) {
     }
     return r;
   };
-  // (acc . [h > 0]) of this lane's pixels / channels: bf16 hi plane into `dst`, exact column sums into sb
-  auto gate_store = [&](const f32x4 (&acc)[2], const u16* hplane, u16* dst, float (&sb)[4]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int o = (16 * (pt0 + i) + fr) * E3_RS + 16 * ct + 4 * q;
-      const u32x2 hm = *reinterpret_cast<const u32x2*>(hplane + o);
-      u16 hi[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const u16 h = (u16)((e < 2 ? hm[0] : hm[1]) >> (16 * (e & 1)));
-        const float d = e3_f(h) > 0.f ? acc[i][e] : 0.f;
-        sb[e] += d;
-        hi[e] = e3_bf(d);
-      }
-      *reinterpret_cast<u32x2*>(dst + o) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
-    }
-  };
-
   int64_t t = blockIdx.x;
   E3XPre<512> pre;
   DyPre dpre;
@@ -304,21 +286,63 @@ __global__ __launch_bounds__(512, 1) void embed3_bwd_kernel(E3Params p) {
     const int64_t tn = t + gridDim.x;
     if (tn < ntiles) { pre = e3_load_x<512>(xr, tn * E3_TP, p.M, p.Cp0, tid); dpre = load_dy(tn * E3_TP); }
     __syncthreads();
-    f32x4 acc[2];
-    // ---- recompute h0, h1 (the forward's arithmetic)
+    // Five barriers per tile: the two GEMMs that depend on nothing but the staged tile run in ONE interval (h0 = W0 x and
+    // a = W2^T dy), and the ReLU gates are applied from registers -- the wave that multiplies cout tile ct of a layer for its
+    // pixel tiles is the wave that holds the same channels and pixels of the gradient (no gate read from LDS, no phase of
+    // its own for dh1).
+    f32x4 acc[2], acca[2];
+    unsigned m0bits = 0;                     // [h0 > 0] of this lane's 2 x 4 hidden units (bit 4 i + e)
+    // ---- h0 = relu(W0 x + b0) (the forward's arithmetic), a = W2^T dy
     e3_gemm<3, 2>(acc, w0, XH, XL, pt0, fr, q);
-    e3_store_relu_split<2>(acc, b0, H0H, H0L, ct, pt0, fr, q);
+    e3_gemm<2, 2>(acca, t2, DYH, nullptr, pt0, fr, q);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u16 hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t_ = acc[i][e] + b0[e];
+        const float v = t_ > 0.f ? t_ : 0.f;
+        hi[e] = e3_bf(v);
+        lo[e] = e3_bf(v - e3_f(hi[e]));
+        m0bits |= (e3_f(hi[e]) > 0.f ? 1u : 0u) << (4 * i + e);
+      }
+      const int o = (16 * (pt0 + i) + fr) * E3_RS + 16 * ct + 4 * q;
+      *reinterpret_cast<u32x2*>(H0H + o) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+      *reinterpret_cast<u32x2*>(H0L + o) = u32x2{(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
+    }
     __syncthreads();
+    // ---- h1 = relu(W1 h0 + b1) (hi plane: the weight gradient's operand), dh1 = a . [h1 > 0]
     e3_gemm<3, 2>(acc, w1, H0H, H0L, pt0, fr, q);
-    e3_store_relu_split<2>(acc, b1, H1H, nullptr, ct, pt0, fr, q);
-    __syncthreads();
-    // ---- dh1 = (W2^T dy) . [h1 > 0]   (this lane: channels 16 ct + 4 q .. of pixel 16 (pt0 + i) + fr)
-    e3_gemm<2, 2>(acc, t2, DYH, nullptr, pt0, fr, q);
-    gate_store(acc, H1H, DH1H, sb1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u16 hi[4], dh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t_ = acc[i][e] + b1[e];
+        hi[e] = e3_bf(t_ > 0.f ? t_ : 0.f);
+        const float d = e3_f(hi[e]) > 0.f ? acca[i][e] : 0.f;
+        sb1[e] += d;
+        dh[e] = e3_bf(d);
+      }
+      const int o = (16 * (pt0 + i) + fr) * E3_RS + 16 * ct + 4 * q;
+      *reinterpret_cast<u32x2*>(H1H + o) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+      *reinterpret_cast<u32x2*>(DH1H + o) = u32x2{(unsigned)dh[0] | ((unsigned)dh[1] << 16), (unsigned)dh[2] | ((unsigned)dh[3] << 16)};
+    }
     __syncthreads();
     // ---- dh0 = (W1^T dh1) . [h0 > 0]
     e3_gemm<2, 2>(acc, t1, DH1H, nullptr, pt0, fr, q);
-    gate_store(acc, H0H, DH0H, sb0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u16 dh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = ((m0bits >> (4 * i + e)) & 1u) ? acc[i][e] : 0.f;
+        sb0[e] += d;
+        dh[e] = e3_bf(d);
+      }
+      const int o = (16 * (pt0 + i) + fr) * E3_RS + 16 * ct + 4 * q;
+      *reinterpret_cast<u32x2*>(DH0H + o) = u32x2{(unsigned)dh[0] | ((unsigned)dh[1] << 16), (unsigned)dh[2] | ((unsigned)dh[3] << 16)};
+    }
     __syncthreads();
     // ---- weight gradients: D[co][ci] += sum over the tile's pixels; one MFMA per product (hi x hi)
 #pragma unroll
@@ -564,7 +588,8 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
       const int64_t m0 = (b * p.S + s) * p.HW + hw0;
       f2_store64_split(yp, CH, CL, 0, tid);
       u32x4 go = {0u, 0u, 0u, 0u};
-      if (BWD && tid < 64) go = __builtin_amdgcn_raw_buffer_load_b128(orr, (unsigned)(m0 * 16) + (unsigned)(tid * 16), 0, 0);
+      // (backward) d_out of pixel 16 wave + fr, for the lane that will hold out of that pixel: waves 0..3, lanes q == 0
+      if (BWD && wave < 4 && q == 0) go = __builtin_amdgcn_raw_buffer_load_b128(orr, (unsigned)(m0 * 16) + (unsigned)((16 * wave + fr) * 16), 0, 0);
       if (s + 1 < p.S) yp = f2_load64(yr, (b * p.S + s + 1) * p.HW + hw0, p.y_ps, tid);      // next sample's tile flies under the GEMMs
       __syncthreads();
       // ---- h = relu(W0 c + b0)
@@ -603,28 +628,18 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
         __syncthreads();                                         // h is consumed: the next sample may overwrite the tiles
         continue;
       }
-      // ---- backward.  d_o = d_out . [out > 0] (hi plane into its tile; exact sums = the output layer's bias gradient)
-      {
-        // the loader thread `tid` (pixel tid) needs the sign of out at pixel tid, which lane (wave = tid >> 4, q = 0, fr = tid & 15)
-        // holds: passed through the pad of the d_out tile's row (channels 32..35: beyond the 32-wide k step the GEMMs read)
-        if (wave < 4 && q == 0) {
-          const int px = 16 * wave + fr;
-          *reinterpret_cast<u32x2*>(DOH + px * F2_ORS + 32) = u32x2{(ov[0] > 0.f ? 1u : 0u) | (ov[1] > 0.f ? 0x10000u : 0u),
-                                                                    (ov[2] > 0.f ? 1u : 0u) | (ov[3] > 0.f ? 0x10000u : 0u)};
-        }
-      }
-      __syncthreads();
-      if (tid < 64) {
-        const u32x2 gt = *reinterpret_cast<const u32x2*>(DOH + tid * F2_ORS + 32);
+      // ---- backward.  d_o = d_out . [out > 0] (hi plane into its tile; exact sums = the output layer's bias gradient), by the
+      // lanes that hold out (no second phase, no gate bits through LDS)
+      if (wave < 4 && q == 0) {
+        const int px = 16 * wave + fr;
         u16 hi[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool on = ((e < 2 ? gt[0] : gt[1]) >> (16 * (e & 1))) & 1u;
-          const float d = on ? e3_u2f(go[e]) : 0.f;
+          const float d = ov[e] > 0.f ? e3_u2f(go[e]) : 0.f;
           sb1[e] += d;
           hi[e] = e3_bf(d);
         }
-        *reinterpret_cast<u32x2*>(DOH + tid * F2_ORS) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+        *reinterpret_cast<u32x2*>(DOH + px * F2_ORS) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
       }
       __syncthreads();
       // ---- dh = (W1^T d_o) . [h > 0]: this wave's hidden-channel tile, k = the 32-wide step whose channels >= 4 are zero
@@ -675,7 +690,8 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
                           __builtin_bit_cast(unsigned, o.w)};
         __builtin_amdgcn_raw_buffer_store_b128(o4, dyr, (unsigned)(m0 * 256) + (unsigned)(px * 256 + c4 * 4), 0, 0);
       }
-      __syncthreads();                                           // the staging tile (h's lo plane) and c / h / dh are free again
+      // (no barrier here: the next sample's y tile goes into c's planes, which nobody reads any more, and the barrier behind
+      // it orders these reads of the staging tile before h's lo plane is written again)
     }
     if (BWD && wave >= 4) {                                      // d_prop of the super-tile: the sum over its S samples
 #pragma unroll
@@ -698,9 +714,9 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
   float* redb = red;                                             // [16 pixel columns][128 channels], then [64 threads][4]
 #pragma unroll
   for (int e = 0; e < 4; ++e) redb[fr * F2_C + 16 * wave + 4 * q + e] = sb0[e];
-  if (tid < 64) {
+  if (wave < 4 && q == 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) redb[16 * F2_C + tid * 4 + e] = sb1[e];
+    for (int e = 0; e < 4; ++e) redb[16 * F2_C + (16 * wave + fr) * 4 + e] = sb1[e];
   }
   __syncthreads();
   if (tid < F2_C) {
