@@ -54,7 +54,7 @@ def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
     from wcmc_amd import ops
     from wcmc_amd.graph import GraphedTrainStep
     from wcmc_amd.synthetic import make_batch
-    assert ops.PRECISION == "bf16x321" and ops.USE_SIDE_STREAM and ops.USE_BRANCH_STREAM and ops.FUSE_CHAIN_GLUE, \
+    assert ops.PRECISION == "bf16x321" and not ops.USE_SIDE_STREAM and ops.USE_BRANCH_STREAM and ops.FUSE_CHAIN_GLUE, \
         "this test pins the DEFAULT switches (the ones bench.py runs with)"
     B, S, H = bench.B_PER_GPU, bench.SPP, bench.PATCH
     device = torch.device("cuda", 0)

@@ -30,10 +30,21 @@ PRECISION = os.environ.get("WCMC_PRECISION", "bf16x321")
 assert PRECISION in MODES, PRECISION
 
 
+def _side_stream_default(mode):
+    """Weight-gradient GEMMs on a stream of their own beside the data-gradient GEMMs?  Measured per mode on the graphed
+    benchmark step (scripts/time_streams.py, four stream configurations interleaved in one process): with the one-MFMA weight
+    gradients of the default mode the extra stream LOSES 3.4 % (13.47 against 13.05 ms: the short weight gradients only take
+    CUs from the data gradient they run beside), with three-MFMA ones it is even (18.9 ms either way), in exact fp32 it
+    wins 1.5 % (69.4 against 70.4 ms).  WCMC_SIDE_STREAM=0 / 1 overrides."""
+    e = os.environ.get("WCMC_SIDE_STREAM")
+    return (e != "0") if e is not None else (mode != "bf16x321")
+
+
 def set_precision(mode):
-    global PRECISION
+    global PRECISION, USE_SIDE_STREAM
     assert mode in MODES, mode
     PRECISION = mode
+    USE_SIDE_STREAM = _side_stream_default(mode)
 
 
 def split_path():
@@ -205,7 +216,7 @@ def act_backward_raw(dy, y, act):
 DEBUG_ACTS = None
 
 _SIDE_STREAMS = {}
-USE_SIDE_STREAM = True      # weight-gradient GEMMs run beside the data-gradient GEMMs
+USE_SIDE_STREAM = _side_stream_default(PRECISION)      # weight-gradient GEMMs beside the data-gradient GEMMs: by mode (see above)
 
 
 def _side_stream(device, of=None):
