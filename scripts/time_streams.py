@@ -9,7 +9,7 @@ from wcmc_amd.synthetic import make_batch
 dev = torch.device("cuda", 0)
 batch = make_batch(8, 8, 128, seed=0, device=dev)
 steps = {}
-for name, side, branch in (("side + branch (default)", True, True), ("branch only", False, True), ("side only", True, False), ("one stream", False, False)):
+for name, side, branch in (("side + branch", True, True), ("branch only (default mode)", False, True), ("side only", True, False), ("one stream", False, False)):
     ops.USE_SIDE_STREAM, ops.USE_BRANCH_STREAM = side, branch
     itf = bench.build_interface(dev, None, rng="device")
     steps[name] = GraphedTrainStep(itf, batch, side_stream=side)
