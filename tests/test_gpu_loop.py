@@ -35,17 +35,19 @@ def _params_vector(itf):
     return torch.cat([p.detach().reshape(-1) for m in itf.models.values() for p in m.parameters()]).cpu()
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True, "defer"])
 def test_epoch_loop_checkpoint_resume_gives_the_same_next_epoch(tmp_path, graph, monkeypatch):
     """train_kpcn.py:87-161 on the MI355X path: two epochs in one go == one epoch, ``latest_m.pth`` written by the loop,
     a NEW process state restored from it by ``init_model`` (train_kpcn.py:240-296: weights, Adam moments and step counts,
     learning rates), then the second epoch -- parameters bit for bit, epoch summaries equal.  Small KPCN (the launcher's
-    ``KPCN(n_in)`` is swapped for a 3-layer one to keep the test short); with and without ``--graph``."""
+    ``KPCN(n_in)`` is swapped for a 3-layer one to keep the test short); without ``--graph``, with it, and with ``--defer_check``."""
     from wcmc_amd import KPCN, train_kpcn as tk
     monkeypatch.setattr(tk, "KPCN", lambda n_in: KPCN(n_in, ksize=21, depth=3, width=24))
     monkeypatch.setattr(tk, "PathNet", lambda ic, outc, weight_norm=False: __import__("wcmc_amd.support.networks", fromlist=["PathNet"]).PathNet(ic, intermc=16, outc=outc, weight_norm=weight_norm))
     dev = torch.device(DEV, 0)
     extra = {"graph": True} if graph else {}
+    if graph == "defer":
+        extra["defer_check"] = True                           # (--defer_check: the epoch loop flushes the last step's check)
 
     def run(save_dir, start_epoch, num_epoch):
         args = _args(save_dir, **extra)
