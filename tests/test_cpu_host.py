@@ -650,6 +650,64 @@ def test_two_rank_gloo_fused_clip_adam_reduce_then_scale_then_clip():
         assert log["steps_diverged"] == [3.0, 2.0] and log["rejoin"] <= 1e-6, log
 
 
+def test_fused_clip_adam_adopts_an_optimizer_state_loaded_after_construction(monkeypatch):
+    """``optim.load_state_dict()`` AFTER ``FusedClipAdam`` was built brings fresh state dicts with 'step' tensors of
+    their own; the next step must adopt them (moments AND step counts) and keep ``optim.state_dict()`` current -- a checkpoint
+    written afterwards must carry step N + 1, and a rolled-back step N.  The kernel is emulated (no GPU here)."""
+    import copy
+    from wcmc_amd import ops, optim as wo
+    monkeypatch.setattr(ops, "clip_adam_", _emulated_clip_adam)
+
+    def build():
+        torch.manual_seed(5)
+        models = {"dncnn": torch.nn.Linear(7, 3), "backbone_diffuse": torch.nn.Linear(5, 2)}
+        optims = {"optim_" + n: torch.optim.Adam(m.parameters(), lr=1e-2) for n, m in models.items()}
+        return models, optims
+
+    def set_grads(models, step):
+        g = torch.Generator().manual_seed(step)
+        for m in models.values():
+            for p in m.parameters():
+                p.grad = torch.randn(p.shape, generator=g)
+
+    models, optims = build()
+    fused = wo.FusedClipAdam(models, optims)
+    for step in (1, 2):
+        set_grads(models, step)
+        fused.step(models, optims)
+    saved_w = {n: copy.deepcopy(m.state_dict()) for n, m in models.items()}
+    saved_o = {n: copy.deepcopy(o.state_dict()) for n, o in optims.items()}
+    assert all(float(st["step"]) == 2.0 for o in saved_o.values() for st in o["state"].values())
+
+    models2, optims2 = build()
+    for n, m in models2.items():
+        m.load_state_dict(saved_w[n])
+    fused2 = wo.FusedClipAdam(models2, optims2)              # built first (as init_model does) ...
+    for n, o in optims2.items():
+        o.load_state_dict(saved_o[n])                        # ... state loaded afterwards
+    for ms, os_, f in ((models, optims, fused), (models2, optims2, fused2)):
+        set_grads(ms, 3)
+        f.step(ms, os_)
+    for n in models:
+        for p, q in zip(models[n].parameters(), models2[n].parameters()):
+            assert torch.equal(p.detach(), q.detach()), n
+    for n, o in optims2.items():
+        sd = o.state_dict()
+        assert [float(st["step"]) for st in sd["state"].values()] == [3.0] * len(sd["state"]), (n, sd["state"])
+        for st, st_ref in zip(sd["state"].values(), optims[n].state_dict()["state"].values()):
+            assert torch.equal(st["exp_avg"], st_ref["exp_avg"]) and torch.equal(st["exp_avg_sq"], st_ref["exp_avg_sq"])
+    fused2.rollback()
+    assert all(float(st["step"]) == 2.0 for o in optims2.values() for st in o.state_dict()["state"].values())
+    # a model whose parameters do not share one step count: every 'step' tensor follows its own parameter
+    set_grads(models2, 4)
+    models2["dncnn"].bias.grad = None
+    fused2.step(models2, optims2)
+    st = optims2["optim_dncnn"].state
+    assert (float(st[models2["dncnn"].weight]["step"]), float(st[models2["dncnn"].bias]["step"])) == (3.0, 2.0)
+    fused2.rollback()
+    assert (float(st[models2["dncnn"].weight]["step"]), float(st[models2["dncnn"].bias]["step"])) == (2.0, 2.0)
+
+
 def _global_pairing_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import torch.distributed as dist

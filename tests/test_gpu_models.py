@@ -546,7 +546,54 @@ def test_deferred_check_raises_one_call_later_with_the_update_skipped():
     step(bad)
     with pytest.raises(RuntimeError, match="Non-finite loss at train time"):
         step(good)                                      # raised by the NEXT call when there is one
-    step.flush() if step._pending is None else None
+    # ... and that next step, enqueued behind the non-finite one before its flags were read, did NOT update either (ADVICE r3:
+    # the failed guard poisons the guards behind it until the error has been raised; interfaces.py:254-257 aborts before
+    # optim.step, so no update may follow a non-finite step unseen)
+    torch.cuda.synchronize()
+    assert torch.equal(flat(), p_before)
+    assert [fl.steps for fl in itf.fused_optim.flats.values()] == [2, 2, 2] and step._pending is None
+    sums = {k: v.item() for k, v in itf.m_losses.items()}
+    step(good)                                          # the poison is cleared with the raise: training goes on
+    step.flush()
+    assert [fl.steps for fl in itf.fused_optim.flats.values()] == [3, 3, 3] and not torch.equal(flat(), p_before)
+    assert all(itf.m_losses[k].item() > sums[k] for k in sums if k != "m_val")
+
+
+def test_captured_optimizer_adopts_state_loaded_after_construction():
+    """an optimiser state loaded AFTER ``FusedClipAdam`` was built (``init_model`` resumes that way) must be adopted
+    before the capture begins -- adopted inside it, the moment copies would be recorded into the hipGraph and every replay would
+    reset Adam's moments to the checkpoint's.  Two graphed steps, checkpoint, two more; against a fresh interface that loads
+    the checkpoint into already-built optimisers and runs the same two steps: parameters, moments and step counts bit-identical."""
+    import copy
+    import bench
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.synthetic import make_batch
+    device = torch.device("cuda", 0)
+    batches = [make_batch(2, 4, 64, seed=80 + i, device=device) for i in range(4)]
+    itf = bench.build_interface(device, None, rng="cpu")
+    step = GraphedTrainStep(itf, batches[0])
+    torch.manual_seed(81)
+    step(batches[0]); step(batches[1])
+    w = {n: copy.deepcopy(m.state_dict()) for n, m in itf.models.items()}
+    o = {n: copy.deepcopy(op.state_dict()) for n, op in itf.optims.items()}
+    torch.manual_seed(82)
+    step(batches[2]); step(batches[3])
+    flat = lambda i: torch.cat([torch.cat([fl.flat, fl.m, fl.v]) for fl in i.fused_optim.flats.values()]).clone()
+    want = flat(itf)
+
+    itf2 = bench.build_interface(device, None, rng="cpu")           # FusedClipAdam built here ...
+    for n, m in itf2.models.items():
+        m.load_state_dict(w[n])
+    for n, op in itf2.optims.items():
+        op.load_state_dict(o[n])                                   # ... the state arrives afterwards
+    assert not any(fl.bound(itf2.optims["optim_" + n]) for n, fl in itf2.fused_optim.flats.items())
+    step2 = GraphedTrainStep(itf2, batches[0])
+    assert step2.tail_captured and all(fl.bound(itf2.optims["optim_" + n]) for n, fl in itf2.fused_optim.flats.items())
+    torch.manual_seed(82)
+    step2(batches[2]); step2(batches[3])
+    assert torch.equal(flat(itf2), want)
+    for op in itf2.optims.values():
+        assert all(float(st["step"]) == 4.0 for st in op.state_dict()["state"].values())
 
 
 def test_graphed_unfused_step_with_grad_sync_equals_eager():

@@ -64,7 +64,11 @@ class GraphedTrainStep:
         self._pending, self._flag_bufs, self._n_calls = None, None, 0
         if self.tail_captured:
             assert warmup >= 1
-            fo.prepare_capture()
+            fo.prepare_capture(itf.optims)                            # (adopts optimiser state loaded since construction: not in the capture)
+            # 1 until a step's losses were non-finite, then 0 -- ANDed into every later guard -- until the host has raised the
+            # reference's error: with defer_check step t + 1 is already enqueued when step t's flags are read, and it must not
+            # update parameters the reference would never have stepped (interfaces.py:254-257 aborts before optim.step)
+            self.ok = torch.ones(1, device=dev)
             self.sums = torch.zeros(len(warm), device=dev)            # one slot per loss key (the warm-up's result has them)
             self._sum_views = [self.sums[i] for i in range(self.sums.numel())]
         self.graph = torch.cuda.CUDAGraph()
@@ -78,7 +82,8 @@ class GraphedTrainStep:
                     self.loss_keys = list(self.losses)
                     vals = torch.stack([self.losses[k].reshape(()) for k in self.loss_keys])
                     finite = torch.isfinite(vals)
-                    self.guard = finite.all().to(torch.float32).reshape(1)
+                    self.guard = finite.all().to(torch.float32).reshape(1) * self.ok
+                    self.ok.copy_(self.guard)
                     # the running sums of interfaces.py:263-267, in place on one persistent tensor (itf.m_losses holds views)
                     self.sums.add_(torch.where(self.guard > 0, vals, torch.zeros_like(vals)))
                     fo.capture_step(itf.models, itf.optims, self.guard)
@@ -144,28 +149,32 @@ class GraphedTrainStep:
             fo.last_guard = self.guard
             prev, self._pending = self._pending, slot
             if prev is not None:
-                self._check(prev)
+                self._check(prev, after=1)
             return
         self._raise_unless_finite(self.flags.tolist())    # the step's one sync
 
-    def _raise_unless_finite(self, flags, rollback=False):
+    def _raise_unless_finite(self, flags, rollback=0):
+        """rollback = 0: the counters of the step have not been advanced yet; k > 0: they were, optimistically, for this step
+        and the k - 1 steps enqueued behind it (which the poisoned guard skipped as well)."""
         fo = self.itf.fused_optim
         ok = flags[-1] != 0
         if rollback:
             if not ok:
-                fo.rollback()
+                fo.rollback(rollback)
         else:
             fo.after_replay(ok)
             fo.last_guard = self.guard
         if not ok:                                        # (the guard kept the sums, the moments and the parameters as they were)
+            self._pending = None                          # (a step enqueued behind this one was skipped: its flags say nothing)
+            self.ok.fill_(1.0)                            # the error is being raised: later steps may update again
             for k, f in zip(self.loss_keys, flags[:-1]):
                 if not f:
                     raise RuntimeError("%s: Non-finite loss at train time." % (k))
 
-    def _check(self, slot):
+    def _check(self, slot, after=0):
         host, ev = self._flag_bufs[slot]
         ev.synchronize()
-        self._raise_unless_finite(host.tolist(), rollback=True)
+        self._raise_unless_finite(host.tolist(), rollback=1 + after)
 
     def flush(self):
         """The deferred check of the last step (``defer_check=True``); a no-op otherwise."""

@@ -78,6 +78,8 @@ class _Flat:
     def _adopt_state(self, optim):
         """(Re)bind optim.state to views of the flat moments, importing loaded checkpoints."""
         mv, vv = self._views(self.m), self._views(self.v)
+        self.optim = optim
+        self._uniform_published = False                     # (a load_state_dict() brings state dicts with 'step' tensors of their own)
         for i, (p, m, v) in enumerate(zip(self.params, mv, vv)):
             st = optim.state[p]
             if "exp_avg" in st and st["exp_avg"].data_ptr() != m.data_ptr():
@@ -207,8 +209,11 @@ class FusedClipAdam:
         self._captured = []
         for i, (name, fl) in enumerate(self.flats.items()):
             optim = optims["optim_" + name]
+            # (adopting a loaded optimiser state here would RECORD its moment copies into the graph: every replay would reset
+            # the moments to the checkpoint's -- prepare_capture(optims) adopts before the capture begins)
             if not fl.bound(optim):
-                fl._adopt_state(optim)
+                raise RuntimeError("FusedClipAdam.capture_step: the state of optim_%s is not bound to the flat buffers (it was loaded "
+                                   "after FusedClipAdam was built): call prepare_capture(optims) before the capture" % name)
             have = [p.grad is not None for p in fl.params]
             fl.stepped = any(have)
             self._captured.append((name, fl, fl.stepped, have))
@@ -223,8 +228,13 @@ class FusedClipAdam:
                 ops.clip_adam_dev_(fl.flat[a:b], fl.g[a:b], fl.m[a:b], fl.v[a:b], self.hyper[i], clip=self.clip,
                                    grad_scale=1.0, guard=guard)
 
-    def prepare_capture(self):
-        """Buffers of the captured step, allocated BEFORE the capture begins (hipHostMalloc invalidates a stream capture)."""
+    def prepare_capture(self, optims=None):
+        """Buffers of the captured step, allocated BEFORE the capture begins (hipHostMalloc invalidates a stream capture), and
+        the adoption of optimiser state loaded since construction (its copies must run now, not be recorded into the graph)."""
+        if optims is not None:
+            for name, fl in self.flats.items():
+                if not fl.bound(optims["optim_" + name]):
+                    fl._adopt_state(optims["optim_" + name])
         dev = next(iter(self.flats.values())).flat.device
         self.hyper = torch.zeros(len(self.flats), 8, device=dev, dtype=torch.float32)
         # (a ring: with GraphedTrainStep(defer_check=True) the host prepares step t + 1 while step t's copy may still be queued)
@@ -254,14 +264,15 @@ class FusedClipAdam:
                 fl.steps += 1
                 fl.psteps = [n + 1 if h else n for n, h in zip(fl.psteps, have)]
                 fl.last_have = have
-                fl.step_t.fill_(float(fl.steps))          # (parameters outside `have` keep their own 'step' tensors)
+                fl._publish_steps(fl.optim)               # optim.state[p]['step'] of every parameter, uniform or not
 
-    def rollback(self):
-        """The guard turned the last step into a no-op (non-finite loss): take the step counters back, as the
-        reference never reaches ``optim.step()`` in that case (``interfaces.py:254-271``)."""
+    def rollback(self, n=1):
+        """The guard turned the last step (the last ``n`` steps: a deferred check finds step t non-finite after step t + 1 was
+        enqueued behind the same, now poisoned, guard) into a no-op: take the step counters back, as the reference never
+        reaches ``optim.step()`` in that case (``interfaces.py:254-271``)."""
         for fl in self.flats.values():
             if fl.stepped:
-                fl.steps -= 1
-                fl.psteps = [n - 1 if h else n for n, h in zip(fl.psteps, fl.last_have)]
-                fl.step_t.fill_(float(fl.steps))
+                fl.steps -= n
+                fl.psteps = [k - n if h else k for k, h in zip(fl.psteps, fl.last_have)]
+                fl._publish_steps(fl.optim)
                 fl.stepped = False
