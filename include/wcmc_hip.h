@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WCMC_ABI_VERSION 2     /* 2: `terms` of the GEMM entry points, packing mode 2 (round 3) */
+#define WCMC_ABI_VERSION 2     /* 2: `terms` of the GEMM entry points, packing mode 2 (round 3); round 4 widened the value ranges only (terms = 1, mode 3) */
 
 enum wcmc_status {
   WCMC_OK = 0,
@@ -155,7 +155,8 @@ int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t dsh, int64_t
                               void* out_split, float* colsum_partial, int N, int H, int W, int C, void* stream);
 /* mode: 0 = forward orientation (rows = Cout, k over Cin x taps); 1 = data-gradient orientation (rows = Cin, k over
  * Cout x flipped taps) for a three-term launch; 2 = the same orientation in the K order of a TWO-term launch
- * (wcmc_conv2d_igemm_bf16x3 with terms = 2: the channel slabs are twice as wide, see there). */
+ * (wcmc_conv2d_igemm_bf16x3 with terms = 2: the channel slabs are twice as wide, see there); 3 = the FORWARD orientation in
+ * that K order (a forward launch with terms = 2 or 1: round 4, the un-gated output layers of the "bf16x321o" mode). */
 size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks, int mode);
 int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
                                    void* stream);
@@ -173,7 +174,11 @@ int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* w, void* co
  * x rounded to its hi plane (8 mantissa bits), W exact to 16 -- the data gradient of the default mode, whose x operand is
  * dy (wp then packed with mode 2).  Where no two-term kernel instance exists for the shape the launch runs three terms
  * (the packing of mode 2 follows the same rule, so the pair stays consistent).  Replaces the data gradient of
- * `nn.Conv2d` under cuDNN (train_kpcn.py:349; TF32 by default on the reference's hardware: 10 bits on BOTH operands). */
+ * `nn.Conv2d` under cuDNN (train_kpcn.py:349; TF32 by default on the reference's hardware: 10 bits on BOTH operands).
+ * 1 = W_hi*x_hi only (8 bits on both operands; wp packed with mode 3; round 4): the forward of a 5x5 layer whose output no
+ * activation gates -- sbmc.KPCN's kernel-predicting output layers (call site support/interfaces.py:203-204) -- where a
+ * rounding cannot flip a ReLU unit; granted where the hi-plane instance of the 64-pixel 5x5 kernel exists (cout blocks of
+ * seven tiles, input channels not 24 mod 32), anywhere else the launch runs the plan's two or three terms. */
 int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              const void* wp, const float* bias,
                              float* y, int64_t ysn, int64_t ysh, int64_t ysw, void* y_split, int Cout,

@@ -23,7 +23,7 @@ Measured per rung, against an fp64 CPU run and the fp32 CPU oracle of the same s
 max|a-b|/max|b| of radiance / diffuse / specular, the relative error of every loss scalar, per-tensor relative L2 and 1 - cos
 of the parameter gradients, and the share of hidden ReLU units whose sign differs from rung A's.
 
-   python3 scripts/forward_ladder.py [B] [--chains kpcn,unet,pw,all  (comma list: one table per entry)] [--top 14]
+   python3 scripts/forward_ladder.py [B] [--chains kpcn,unet,pw,all,last  (comma list: one table per entry; last = the KPCN output layers only)] [--top 14]
 """
 import copy
 import math
@@ -51,7 +51,7 @@ argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(argv[0]) if argv and argv[0].isdigit() else 8
 CHAIN_SETS = (sys.argv[sys.argv.index("--chains") + 1] if "--chains" in sys.argv else "all").split(",")
 TOP = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 14
-KS_SETS = {"kpcn": (5,), "unet": (3,), "pw": (1,), "all": (5, 3, 1), "conv": (5, 3)}
+KS_SETS = {"kpcn": (5,), "unet": (3,), "pw": (1,), "all": (5, 3, 1), "conv": (5, 3), "last": ("last",)}
 KS_OF = [KS_SETS[CHAIN_SETS[0]]]
 assert ops.PRECISION == "bf16x321"
 
@@ -96,6 +96,10 @@ def active():
 
 
 def igemm(xs, dims, wp, bias, cout, ks, pad, act, out_split, *a, **kw):
+    if IN_FWD[0] and KS_OF[0] == ("last",) and ks == 5 and not out_split:
+        # "last": only the GEMM of the KPCN chains' OUTPUT layer (100 -> 441 logits, no ReLU behind it: nothing to flip) sees the
+        # rounded activation; what is stored (the weight gradient's x, the gates) stays as it is
+        xs = q_split(xs, dims, FMT["x"])
     out = _igemm(xs, dims, wp, bias, cout, ks, pad, act, out_split, *a, **kw)
     if active() and out_split:          # a hidden activation: stored in the rung's format
         n, _, h, w = dims
@@ -108,6 +112,8 @@ def igemm(xs, dims, wp, bias, cout, ks, pad, act, out_split, *a, **kw):
 
 
 def packx(weight, mode):
+    if mode == 0 and IN_FWD[0] and KS_OF[0] == ("last",) and weight.shape[0] == 441:
+        weight = q_values(weight.detach(), FMT["w"])
     if active() and mode == 0:
         weight = q_values(weight.detach(), FMT["w"])
     return _packx(weight, mode)

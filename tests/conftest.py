@@ -24,10 +24,11 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(params=["fp32", "bf16x3", "bf16x321"])
+@pytest.fixture(params=["fp32", "bf16x3", "bf16x321", "bf16x321o"])
 def precision(request):
-    """Runs a GPU test once per conv arithmetic: exact fp32 MFMA, split-bf16 with 3 bf16 MFMAs per product everywhere, and the
-    default mode (forward 3, data gradient 2, weight gradient 1: wcmc_amd/ops.py)."""
+    """Runs a GPU test once per conv arithmetic: exact fp32 MFMA, split-bf16 with 3 bf16 MFMAs per product everywhere, round 3's
+    default (forward 3, data gradient 2, weight gradient 1) and the default mode (the same with ONE MFMA per product in the
+    forward of un-gated 5x5 output layers: wcmc_amd/ops.py)."""
     from wcmc_amd import ops
     old = ops.PRECISION
     ops.set_precision(request.param)
@@ -57,7 +58,18 @@ def gtol(precision, fp32_tol, x3_tol, x321_tol=8e-3):
     out (profiles/r03_precision_ladder.txt: 1.09e-3 -> 1.22e-3 on the benchmarked step).  That each reduced-term kernel
     computes EXACTLY the gradient of the rounded operands is pinned separately (tests/test_gpu_ops.py::test_one_term_...,
     test_two_term_...)."""
-    return x321_tol if precision == "bf16x321" else ptol(precision, fp32_tol, x3_tol)
+    return x321_tol if precision in ("bf16x321", "bf16x321o") else ptol(precision, fp32_tol, x3_tol)
+
+
+def otol(precision, ks, act, cout, tol):
+    """Forward bar of a chain whose OUTPUT layer is (ks, act, cout): in the "bf16x321o" mode an un-gated 5x5 output layer of
+    seven-tile cout blocks multiplies x_hi x W_hi (one bf16 MFMA: both operands rounded to 8 bits, 2^-9 each) -- on the i.i.d.
+    test operands 2-3e-3 of the tensor's max; exactness against fp64 on the ROUNDED operands is pinned at 2e-5 by
+    tests/test_gpu_ops.py::test_one_term_output_layer_forward_*."""
+    tiles = (cout + 15) // 16
+    nt = min((7, 4, 2, 1), key=lambda t: (-(-tiles // t)) * (t + 2))          # x_pick_nt of csrc/conv_bf16x3.hip
+    granted = ks == 5 and act == "linear" and nt == 7
+    return 6e-3 if (precision == "bf16x321o" and granted) else tol
 
 
 def rel_l2(a, b):

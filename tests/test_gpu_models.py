@@ -156,7 +156,7 @@ def golden_l2(precision, flips=None):
         return 1e-4
     if flips is None:          # (tests that do not run the oracle forward beside the step: <= 1.7e-2 measured)
         return 1e-1
-    if precision == "bf16x321" and flips == 0:
+    if precision in ("bf16x321", "bf16x321o") and flips == 0:
         # the backward GEMMs round dy (and x in the weight gradient) to bf16, 2^-9 each: with 800 pixels per golden batch
         # there is little to average over (the benchmarked step has 107k per layer: profiles/r03_precision_ladder.txt)
         return 8e-3
@@ -362,7 +362,7 @@ def test_sbmc_and_lbmc_interfaces_against_reference_golden(golden_dir, case, pre
     # validation runs on the weights AFTER the Adam step, -lr * sign(g) on entries whose gradient is below the gradient noise:
     # in these 4-channel networks the bf16-rounded backward operands of the default mode turn more of them (one ReLU output
     # pixel of the P-buffer then differs by a few per cent of the tensor's max)
-    vt = 5e-2 if precision == "bf16x321" else 5e-3
+    vt = 5e-2 if precision in ("bf16x321", "bf16x321o") else 5e-3
     assert_close(out, T(d["val/out"]), tol=vt, what="validate output")
     np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=vt)
     if pb is not None:
@@ -724,16 +724,20 @@ _SWITCHES = [
 
 
 def test_default_mode_forward_is_the_three_term_forward_and_its_gradients_stay_close():
-    """The default mode ("bf16x321") changes the BACKWARD GEMMs only: loss scalars and denoised patches equal the all-three-term
+    """Round 3's default ("bf16x321") changes the BACKWARD GEMMs only: loss scalars and denoised patches equal the all-three-term
     mode's bit for bit; the gradients differ by the bf16 rounding of dy / x (2 x 4 x 64 x 64 patches here: little to average over);
-    and WCMC_DGRAD_AP1=0 (three-term data gradients, one-term weight gradients) lies between the two."""
+    and WCMC_DGRAD_AP1=0 (three-term data gradients, one-term weight gradients) lies between the two.  The default mode
+    ("bf16x321o") differs from it in the forward of the two KPCN OUTPUT layers only (x_hi x W_hi: exact on the rounded operands,
+    tests/test_gpu_ops.py::test_one_term_output_layer_forward_...): everything upstream of them -- the P-buffers, hence the
+    manifold losses -- is still bit-identical, the denoised patches and the image losses move by less than a third of
+    north_star's 1e-3 (the adoption bar of profiles/r04_forward_ladder.txt; measured there 1.1e-4 / 8e-6 at the bench shape)."""
     import os
     from conftest import rel_l2
     from wcmc_amd import ops
     runs = {}
     old = ops.PRECISION
     try:
-        for mode, env in (("bf16x3", None), ("bf16x321", None), ("bf16x321", "0")):
+        for mode, env in (("bf16x3", None), ("bf16x321", None), ("bf16x321", "0"), ("bf16x321o", None)):
             ops.set_precision(mode)
             if env is not None:
                 os.environ["WCMC_DGRAD_AP1"] = env
@@ -747,12 +751,16 @@ def test_default_mode_forward_is_the_three_term_forward_and_its_gradients_stay_c
     worst = {}
     for key, got in runs.items():
         for k, want in base.items():
-            if k.startswith(("loss/", "out/")):
+            if key[0] == "bf16x321o" and k.startswith(("loss/", "out/")) and "manif" not in k:
+                e = ((got[k] - want).abs().max() / want.abs().max()).item()
+                assert 0.0 < e <= 3e-4, (key, k, e)
+            elif k.startswith(("loss/", "out/")):
                 assert torch.equal(got[k], want), (key, k)
             else:
                 worst[key] = max(worst.get(key, 0.0), rel_l2(got[k], want))
     assert worst[("bf16x3", None)] == 0.0
     assert 0.0 < worst[("bf16x321", "0")] <= 6e-3 and 0.0 < worst[("bf16x321", None)] <= 6e-3, worst
+    assert 0.0 < worst[("bf16x321o", None)] <= 1.2e-2, worst      # (measured 6.9e-3: the output layers' rounded logits move d_logits)
 
 
 def _switch_step():

@@ -42,7 +42,7 @@ def test_sample_based_manifold_step_at_full_size_against_oracle(case):
     from wcmc_amd.support import interfaces as itf_mod
     from wcmc_amd.support import losses as pl
     from wcmc_amd.support.networks import PathNet
-    assert ops.PRECISION == "bf16x321"
+    assert ops.PRECISION == ops.MODES[0]
     kind, option, pout, recon, nfeat, clip = CASES[case]
     B, S, H, WIDTH, DEPTH = 8, 8, 128, 8, 2
     c_r = (pout // 2 if option in ("m10r01", "m11r01") else pout) + 1

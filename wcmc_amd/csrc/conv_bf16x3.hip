@@ -545,6 +545,7 @@ struct XIgemmParams {
   int CS, nslabs, SPS, PXS, tilesX, tilesY;   // halo kernel: channel slab, stages per slab, halo pixel stride
   int CSl, SPSl;                              // ... of the last slab
   int ap;                                     // planes of x multiplied: 2 = hi + lo, 1 = hi only (two MFMAs per product)
+  int wplanes;                                // planes of the weights multiplied: 2, or 1 with ap == 1 (ONE MFMA per product; conv_halo64 only)
   unsigned y_bytes, m_bytes;                  // pointwise kernel: extents of the output and of the 1-bit masks
   // pointwise kernel, optional tail layer (a second 1x1 conv of <= 4 couts applied to the tile while it is in LDS)
   const u16* wp2; const float* bias2; float* y2; int64_t y2sn, y2sh, y2sw;
@@ -1325,8 +1326,12 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 // AP: planes of the pixel operand that are multiplied -- 2: W_lo*A_hi + W_hi*A_lo + W_hi*A_hi; 1: the hi plane only (W_lo*A_hi +
 // W_hi*A_hi: the data gradient of the "bf16x321" mode, whose A operand is dy) -- the halo then holds no lo plane and a
 // pixel's PXS bytes carry twice the channels (x_plan_k).
-template <int NT, int NB, int PT = 4, int DBG = 0, int PXST = 0, int AP = 2>
+// WP: planes of the WEIGHTS that are multiplied -- 2: both; 1 (with AP = 1 only): W_hi*A_hi alone, ONE bf16 MFMA per product -- the
+// forward of an un-gated OUTPUT layer in the "bf16x321o" mode (the KPCN chains' 100 -> 441 logits: no ReLU behind it, so the
+// rounding flips no gate; profiles/r04_forward_ladder.txt, table "last").  The lo plane of the pack is neither fetched nor read.
+template <int NT, int NB, int PT = 4, int DBG = 0, int PXST = 0, int AP = 2, int WP = 2>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams p0) {
+  static_assert(WP == 2 || AP == 1, "one weight plane only together with one pixel plane");
   XIgemmParams p = p0;
   if (PXST) { p.PXS = PXST; p.ks = 5; }
   constexpr int BN = NT * 16, TH = 4 * PT, TW = 16, NTHR = 256, NWV = 4;
@@ -1461,7 +1466,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
         const unsigned off2 = dbase2[q] + sg;
         u16* d = bsm + buf * B_ELEMS + 16 * (wave + q * NWV) * XROW;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, off2, 0, 0, 0);
+        if (WP == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, off2, 0, 0, 0);
       }
     }
   };
@@ -1498,7 +1503,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   const u16* const bfrag = bsm + frow * XROW + fslot;
   auto read_b = [&](int buf, int j) {
     wh[j] = *reinterpret_cast<const bf16x8*>(bfrag + buf * B_ELEMS + j * 16 * XROW);
-    wl[j] = *reinterpret_cast<const bf16x8*>(bfrag + buf * B_ELEMS + B_LO + j * 16 * XROW);
+    if (WP == 2) wl[j] = *reinterpret_cast<const bf16x8*>(bfrag + buf * B_ELEMS + B_LO + j * 16 * XROW);
   };
 
 #pragma unroll
@@ -1521,8 +1526,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   rstamp(1);
   for (int g = 0; g < nstages; ++g) {
     const int b1 = bcur + 1 == NB ? 0 : bcur + 1;      // buffer of stage g+1; stage g's fragments are in registers
-    if (NGMAX == 1 || ngroups < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NB - 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 2)) : "memory");
+    if (NGMAX == 1 || ngroups < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP * (NB - 2)) : "memory");       // (WP DMA instructions per row group)
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WP * (NB - 2)) : "memory");
     pw_barrier();                                // stage g+1 has landed for everyone; everyone has read stage g's fragments
     // The two workgroups of a CU are dispatched one after the other (local block indices l and l + 32 of an XCD) and the
     // instruction arbiter prefers the older wave: stamps showed the first one through its stage loop in 114 us and the
@@ -1539,7 +1544,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
 #pragma unroll
       for (int i = 0; i < PT; ++i) {
         if (!(DBG & 1)) {
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
+          if (WP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
           if (AP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
         }
@@ -3376,22 +3381,25 @@ extern "C" int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t d
 
 // mode of a packed weight: 0 = forward orientation, 1 = data-gradient orientation (flipped taps, channels swapped), 2 = the
 // data-gradient orientation in the K order of a TWO-term launch (terms = 2 of wcmc_conv2d_igemm_bf16x3: x hi plane only)
-static inline int x_mode_ap(int mode) { return mode == 2 ? 1 : 2; }
+// 3 = the FORWARD orientation in the K order of a two- / one-term launch (terms <= 2 of a forward launch: the un-gated output layers
+// of the "bf16x321o" mode)
+static inline int x_mode_ap(int mode) { return mode >= 2 ? 1 : 2; }
+static inline bool x_mode_fwd(int mode) { return mode == 0 || mode == 3; }
 extern "C" size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks, int mode) {
-  if (rows <= 0 || kchan <= 0 || ks <= 0 || mode < 0 || mode > 2) return 0;
+  if (rows <= 0 || kchan <= 0 || ks <= 0 || mode < 0 || mode > 3) return 0;
   return (size_t)round_up(rows, 16) * 2 * x_plan_k(kchan, ks, x_mode_ap(mode), rows).Kt;
 }
 
 extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout, int Cin, int ks, int mode,
                                               void* stream) {
-  WCMC_REQUIRE(w && wp && Cout > 0 && Cin > 0 && ks > 0 && mode >= 0 && mode <= 2, WCMC_ERR_BAD_ARG,
+  WCMC_REQUIRE(w && wp && Cout > 0 && Cin > 0 && ks > 0 && mode >= 0 && mode <= 3, WCMC_ERR_BAD_ARG,
                "conv2d_pack_weight_bf16x3: bad argument");
-  const int rows = mode == 0 ? Cout : Cin, kchan = mode == 0 ? Cin : Cout;
+  const int rows = x_mode_fwd(mode) ? Cout : Cin, kchan = x_mode_fwd(mode) ? Cin : Cout;
   const int Np = round_up(rows, 16);
   const XKPlan q = x_plan_k(kchan, ks, x_mode_ap(mode), rows);
   const int64_t total = (int64_t)Np * q.Kt;
   hipLaunchKernelGGL(pack_weight_split_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, mode, rows, Np, q.CS, q.Ks, q.Kt, q.nslabs, q.CSl);
+                     (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, x_mode_fwd(mode) ? 0 : 1, rows, Np, q.CS, q.Ks, q.Kt, q.nslabs, q.CSl);
   return check_launch("conv2d_pack_weight_bf16x3");
 }
 
@@ -3403,12 +3411,12 @@ extern "C" int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* 
   t.n = n_entries; t.ks = ks;
   unsigned blocks = 0;
   for (int i = 0; i < n_entries; ++i) {
-    WCMC_REQUIRE(w[i] && wp[i] && Cout[i] > 0 && Cin[i] > 0 && mode[i] >= 0 && mode[i] <= 2, WCMC_ERR_BAD_ARG,
+    WCMC_REQUIRE(w[i] && wp[i] && Cout[i] > 0 && Cin[i] > 0 && mode[i] >= 0 && mode[i] <= 3, WCMC_ERR_BAD_ARG,
                  "conv2d_pack_chain_bf16x3: bad entry %d", i);
     XPackEntry& e = t.e[i];
-    e.w = w[i]; e.wp = (u16*)wp[i]; e.Cout = Cout[i]; e.Cin = Cin[i]; e.mode = mode[i];
-    e.rows = mode[i] == 0 ? Cout[i] : Cin[i];
-    const int kchan = mode[i] == 0 ? Cin[i] : Cout[i];
+    e.w = w[i]; e.wp = (u16*)wp[i]; e.Cout = Cout[i]; e.Cin = Cin[i]; e.mode = x_mode_fwd(mode[i]) ? 0 : 1;      // (the kernel knows orientations only)
+    e.rows = x_mode_fwd(mode[i]) ? Cout[i] : Cin[i];
+    const int kchan = x_mode_fwd(mode[i]) ? Cin[i] : Cout[i];
     e.Np = round_up(e.rows, 16);
     const XKPlan q = x_plan_k(kchan, ks, x_mode_ap(mode[i]), e.rows);
     e.CS = q.CS; e.Ks = q.Ks; e.Kt = q.Kt; e.nslabs = q.nslabs; e.CSl = q.CSl;
@@ -3484,16 +3492,16 @@ static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) 
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
-template <int NT, int NB, int PT, int PXST, int AP = 2>
+template <int NT, int NB, int PT, int PXST, int AP = 2, int WP = 2>
 static int launch_xhalo64c(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
-  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
 }
 template <int NT, int NB, int PT>
@@ -3501,6 +3509,7 @@ static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream
   // the halo pixel stride as a template constant for the two shipped values (NB = 3: 16-channel slabs, 80 B; NB = 2 with
   // 12x16 tiles: 32-channel slabs, 160 B); anything else (WCMC_HALO64_PXS, WCMC_HALO_NB experiments) reads it from the params
   if constexpr (NT == 7 && NB == 3) {
+    if (p.ap == 1 && p.wplanes == 1) return launch_xhalo64c<NT, NB, PT, 80, 1, 1>(p, lds, stream);      // one MFMA per product ("bf16x321o" output layers)
     if (p.ap == 1) return launch_xhalo64c<NT, NB, PT, 80, 1>(p, lds, stream);          // (x_plan_k grants ap = 1 with PXS = 80, ks = 5 only)
   }
   if (p.ks == 5 && p.PXS == 80 && NB == 3) return launch_xhalo64c<NT, NB, PT, NB == 3 ? 80 : 0>(p, lds, stream);
@@ -3680,8 +3689,8 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
                                         int terms, void* stream) {
   WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ks > 0 && pad >= 0 && x_split && wp,
                WCMC_ERR_BAD_ARG, "conv2d_igemm_bf16x3: bad argument");
-  WCMC_REQUIRE(terms == 3 || terms == 2, WCMC_ERR_BAD_ARG,
-               "conv2d_igemm_bf16x3: terms must be 3 or 2 (x hi plane only; wp packed with mode 2)");
+  WCMC_REQUIRE(terms >= 1 && terms <= 3, WCMC_ERR_BAD_ARG,
+               "conv2d_igemm_bf16x3: terms must be 3, 2 (x hi plane only; wp packed with mode 2 / 3) or 1 (hi planes of x and W only)");
   WCMC_REQUIRE(!colsum_partial || y_split, WCMC_ERR_BAD_ARG,
                "conv2d_igemm_bf16x3: column sums are produced with the split output only");
   WCMC_REQUIRE((y != nullptr) != (y_split != nullptr), WCMC_ERR_BAD_ARG,
@@ -3705,8 +3714,11 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   p.gate = (const u16*)gate_split; p.gate_act = gate_act; p.gate_slope = gate_slope;
   p.gate_mask = (const unsigned char*)gate_mask; p.mask_out = (unsigned char*)mask_out;
   p.ks = ks; p.pad = pad; p.act = act; p.slope = slope;
-  const XKPlan q = x_plan_k(Cin, ks, terms == 2 ? 1 : 2, Cout);
+  const XKPlan q = x_plan_k(Cin, ks, terms <= 2 ? 1 : 2, Cout);
   p.ap = q.ap;
+  // one term: where the plan grants the hi-plane instance of the 64-pixel 5x5 kernel (the only one with a one-plane weight path);
+  // anywhere else the launch multiplies what the plan's instance multiplies (two or three terms) -- more exact, never less
+  p.wplanes = (terms == 1 && q.ap == 1 && ks == 5 && q.PXS == 80) ? 1 : 2;
   p.Kp = p.Cpi; p.Kt = q.Kt; p.Np = round_up(Cout, 16);
   p.CS = q.CS; p.nslabs = q.nslabs; p.SPS = q.Ks / 32; p.PXS = q.halo ? q.PXS : 0;
   p.CSl = q.CSl; p.SPSl = q.Ksl / 32;
@@ -3785,7 +3797,7 @@ extern "C" int wcmc_conv1x1_pair_bf16x3(const void* x_split, int N, int H, int W
   p.mask_out = (unsigned char*)mask1;
   p.ks = 1; p.pad = 0; p.act = act1; p.slope = slope1;
   p.Kp = p.Cpi; p.Kt = round_up(p.Cpi, 32); p.Np = round_up(Cout1, 16);
-  p.CS = p.Kp; p.nslabs = 1; p.SPS = p.Kt / 32; p.PXS = 0; p.CSl = p.CS; p.SPSl = p.SPS; p.ap = 2;
+  p.CS = p.Kp; p.nslabs = 1; p.SPS = p.Kt / 32; p.PXS = 0; p.CSl = p.CS; p.SPSl = p.SPS; p.ap = 2; p.wplanes = 2;
   p.tilesY = p.tilesX = 0; p.G = x_colsum_rows(N, H, W); p.colsum = colsum1;
   p.M = (int64_t)N * H * W;
   const int cp2 = round_up(Cout2, 4);

@@ -18,6 +18,12 @@ ACT = {"linear": 0, "relu": 1, "leaky_relu": 2}
 LEAKY_SLOPE = 0.01
 
 # Arithmetic of the conv GEMMs (all HIP paths; WCMC_PRECISION):
+#   "bf16x321o" (opt-in)  "bf16x321" with ONE MFMA per product (x_hi x W_hi) in the forward of a chain's un-gated OUTPUT layer
+#                         where the library has the instance (5x5, linear output: the KPCN chains' 100 -> 441 logits, 30 % of the
+#                         KPCN forward's FLOPs).  The forward precision ladder (profiles/r04_forward_ladder.txt) shows why only
+#                         there: rounding a HIDDEN layer's operands below 16 bits flips ReLU gates and moves the parameter
+#                         gradients past their parity bars (no rung holds), an output layer has no gate behind it -- measured
+#                         on the benchmarked step: denoised patches 1.1e-4, loss scalars 8e-6, gradients 1.61e-3 (bar 2e-3)
 #   "bf16x321" (default)  split-bf16 operands (hi + lo planes, fp32 accumulate; conv_bf16x3.hip) with the number of bf16 MFMAs
 #                         per product chosen per GEMM role by the measured precision ladder (profiles/r03_precision_ladder.txt):
 #                         forward 3 (hi*hi + hi*lo + lo*hi), data gradient 2 (dy_hi x (W_hi + W_lo)), weight gradient 1
@@ -25,9 +31,14 @@ LEAKY_SLOPE = 0.01
 #                         the pixel sums, a rounded W would not; outputs and losses are those of "bf16x3" bit for bit
 #   "bf16x3"              three MFMAs per product in every role (rounds 1-2)
 #   "fp32"                exact fp32 MFMA (conv.hip)
-MODES = ("bf16x321", "bf16x3", "fp32")
-PRECISION = os.environ.get("WCMC_PRECISION", "bf16x321")
+MODES = ("bf16x321", "bf16x321o", "bf16x3", "fp32")
+PRECISION = os.environ.get("WCMC_PRECISION", MODES[0])
 assert PRECISION in MODES, PRECISION
+
+
+def reduced_backward(mode=None):
+    """True in the modes whose backward GEMMs run on two / one MFMAs per product."""
+    return (PRECISION if mode is None else mode) in ("bf16x321o", "bf16x321")
 
 
 def _side_stream_default(mode):
@@ -37,7 +48,7 @@ def _side_stream_default(mode):
     CUs from the data gradient they run beside), with three-MFMA ones it is even (18.9 ms either way), in exact fp32 it
     wins 1.5 % (69.4 against 70.4 ms).  WCMC_SIDE_STREAM=0 / 1 overrides."""
     e = os.environ.get("WCMC_SIDE_STREAM")
-    return (e != "0") if e is not None else (mode != "bf16x321")
+    return (e != "0") if e is not None else not reduced_backward(mode)
 
 
 def set_precision(mode):
@@ -53,11 +64,19 @@ def split_path():
 
 
 def wgrad_terms():
-    return 1 if PRECISION == "bf16x321" else 3
+    return 1 if reduced_backward() else 3
 
 
 def dgrad_terms():
-    return 2 if PRECISION == "bf16x321" else 3
+    return 2 if reduced_backward() else 3
+
+
+def out_layer_terms(ks, act):
+    """bf16 MFMAs per product in the FORWARD of a chain's output layer: 1 in the "bf16x321o" mode for a linear (un-gated) 5x5
+    output layer -- the shape the library's one-term instance and the measurement behind it cover -- else 3."""
+    if not (PRECISION == "bf16x321o" and ks == 5 and act == "linear"):
+        return 3
+    return int(os.environ.get("WCMC_OUT_TERMS", "1"))          # (A/B switch: 2 = x_hi x (W_hi + W_lo), 3 = the "bf16x321" forward)
 
 # Optional per-launch timing (bench.py): HIP events recorded on the launch stream around an op.
 _PROFILER = None
@@ -451,9 +470,10 @@ def _dgrad_mode(terms=None):
 
 
 def _pack_x(weight, mode):
-    """mode 0: forward orientation; 1 / 2: the data-gradient orientation for a three- / two-term launch (_dgrad_mode)."""
+    """mode 0: forward orientation; 1 / 2: the data-gradient orientation for a three- / two-term launch (_dgrad_mode); 3: the
+    forward orientation in the K order of a two- / one-term launch (an output layer of the "bf16x321o" mode)."""
     cout, cin, ks, _ = weight.shape
-    rows, kch = (cout, cin) if mode == 0 else (cin, cout)
+    rows, kch = (cout, cin) if mode in (0, 3) else (cin, cout)
     wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks, mode), device=weight.device, dtype=torch.int16)
     w = weight.detach()
     if not w.is_contiguous():
@@ -468,21 +488,22 @@ def _pack_x(weight, mode):
 PACK_CHAIN = os.environ.get("WCMC_PACK_CHAIN", "1") != "0"
 
 
-def _pack_chain_x(weights, ks):
-    """[(wp_mode0, wp_mode1)] of the OIHW weights of one chain, packed by ONE launch."""
+def _pack_chain_x(weights, ks, out_terms=3):
+    """[(wp_mode0, wp_mode1)] of the OIHW weights of one chain, packed by ONE launch.  out_terms < 3: the LAST layer's forward
+    pack is made in the K order of a hi-plane launch (mode 3)."""
     n = len(weights)
     assert 2 * n <= 20
     dev = weights[0].device
     ws, outs, couts, cins, modes, keep = [], [], [], [], [], []
-    for wt in weights:
+    for li, wt in enumerate(weights):
         w = wt.detach()
         if not w.is_contiguous():
             w = w.contiguous()
         keep.append(w)
         cout, cin = w.shape[0], w.shape[1]
         pair = []
-        for mode in (0, _dgrad_mode()):
-            rows, kch = (cout, cin) if mode == 0 else (cin, cout)
+        for mode in (3 if (out_terms < 3 and li == n - 1) else 0, _dgrad_mode()):
+            rows, kch = (cout, cin) if mode in (0, 3) else (cin, cout)
             wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks, mode), device=dev, dtype=torch.int16)
             ws.append(w.data_ptr()); outs.append(wp.data_ptr()); couts.append(cout); cins.append(cin); modes.append(mode)
             pair.append(wp)
@@ -498,7 +519,8 @@ def _igemm_class(cin, cout, ks, dims=None, terms=3):
     """Profiler class of a split-bf16 GEMM launch = the kernel the library's plan picks for it
     (csrc/conv_bf16x3.hip: x_plan_k, x_pick_nt, launch_xhalo64), so that a class average is one kernel's average.
     dims = (n, ho, wo) of the output selects between the two tile heights of the 5x5 kernel; terms = 2 (the data gradient of
-    the default mode) runs the AP = 1 instances where the plan grants them: classes with the suffix "_x2"."""
+    the default mode) runs the AP = 1 instances where the plan grants them: classes with the suffix "_x2"; terms = 1 (the output
+    layers' forward of the default mode): "_x1"."""
     tiles = (cout + 15) // 16
     nt = min((7, 4, 2, 1), key=lambda t: (-(-tiles // t)) * (t + 2))
     halo = 3 <= ks <= 5 and (cin + 7) // 8 * 8 >= 32
@@ -511,13 +533,14 @@ def _igemm_class(cin, cout, ks, dims=None, terms=3):
         return "conv_halo7"                 # conv_halo_bf16x3_kernel<7, 8, 16, 0, 2> (and the fp32 path's 5x5 class)
     n, ho, wo = dims                        # conv_halo64_bf16x3_kernel<7, NB, PT>: 16x16 tiles (PT = 4) or 12x16 (PT = 3)
     kp = (cin + 7) // 8 * 8
-    x2 = terms == 2 and kp % 32 != 24 and os.environ.get("WCMC_DGRAD_AP1", "1") != "0"     # x_plan_k grants ap = 1 (32-channel slabs, 80 B)
+    x2 = terms <= 2 and kp % 32 != 24 and os.environ.get("WCMC_DGRAD_AP1", "1") != "0"     # x_plan_k grants ap = 1 (32-channel slabs, 80 B)
+    x1 = x2 and terms == 1              # ... and the one-plane weight path: <7, 3, PT, 0, 80, 1, 1>, suffix "_x1"
     if not x2 and kp >= 256 and kp % 32 == 0 and os.environ.get("WCMC_HALO64_CS32", "1") != "0":
         return "conv_halo64_cs32"           # 32-channel slabs: <7, 2, 3> (two weight stages, 12x16 tiles)
     gy = -(-tiles // nt)
     rounds = lambda th: -(-(n * (-(-wo // 16)) * (-(-ho // th)) * gy) // 512) * th
     pt3 = os.environ.get("WCMC_HALO64_PT3", "1") != "0" and rounds(12) < rounds(16)
-    return ("conv_halo64_pt3" if pt3 else "conv_halo64_pt4") + ("_x2" if x2 else "")
+    return ("conv_halo64_pt3" if pt3 else "conv_halo64_pt4") + ("_x1" if x1 else "_x2" if x2 else "")
 
 
 def _wgrad_class(n, ho, cin, cout, ks):
@@ -528,8 +551,9 @@ def _wgrad_class(n, ho, cin, cout, ks):
 def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, gate_act="linear", colsum=False,
                  gate_mask=None, mask_out=False, terms=3):
     """One split-bf16 implicit-GEMM launch.  xs: split tensor of dims (n,cin,h,w).
-    terms: bf16 MFMAs per product -- 3, or 2 = the hi plane of xs only (wp packed with mode 2: the data gradient of the
-    "bf16x321" mode, whose xs is dy).
+    terms: bf16 MFMAs per product -- 3, 2 = the hi plane of xs only (wp packed with mode 2: the data gradient of the
+    "bf16x321" modes, whose xs is dy; or mode 3: a forward launch), 1 = the hi planes of xs and wp only (mode 3: the un-gated
+    output layer of the "bf16x321o" mode).
     Returns a split tensor when out_split else an fp32 NHWC view; with colsum=True also the per-tile
     column sums of the result (the consumer layer's bias gradient, see colsum_finish_raw); with mask_out=True
     also the (hi plane > 0) bit mask of the result, which a later launch can take as gate_mask instead of
@@ -639,9 +663,10 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
             lib().wcmc_conv1x1_pair_supported(params[2 * nl - 4].shape[1], params[2 * nl - 4].shape[0],
                                               params[2 * nl - 2].shape[0]))
     ctx.terms = (wgrad_terms(), dgrad_terms())     # the backward multiplies as the mode of ITS forward says
-    packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks) if PACK_CHAIN and 2 * nl <= 20 else None
+    oterms = 3 if pair else out_layer_terms(ks, acts[-1])      # MFMAs per product of the output layer's forward
+    packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks, oterms) if PACK_CHAIN and 2 * nl <= 20 else None
     ctx.wp1 = [pk[1] for pk in packs] if packs is not None else None      # the data-gradient orientation, for the backward
-    pack0 = (lambda l: packs[l][0]) if packs is not None else (lambda l: _pack_x(params[2 * l], 0))
+    pack0 = (lambda l: packs[l][0]) if packs is not None else (lambda l: _pack_x(params[2 * l], 3 if (oterms < 3 and l == nl - 1) else 0))
     for l in range(nl):
         wt, b = params[2 * l], params[2 * l + 1]
         cout = wt.shape[0]
@@ -659,7 +684,8 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
             xs.append(xs1)
             masks.append(mask1)
             break
-        out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=hidden, mask_out=hidden)
+        out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=hidden, mask_out=hidden,
+                           terms=3 if hidden else oterms)
         hh, ww = dims[l][2] + 2 * pad - ks + 1, dims[l][3] + 2 * pad - ks + 1
         dims.append((n, cout, hh, ww))
         if hidden:
@@ -1013,7 +1039,7 @@ FUSE_CHAIN_GLUE = os.environ.get("WCMC_FUSE_CHAIN_GLUE", "1") != "0"
 def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
     """``y = conv_chain(x, ...); return y, spp_mean(y, s)``; one autograd node on the split-bf16 path."""
     # (DEBUG_ACTS: the parity tests' hook wants the hidden activations, which the fused chain never materialises)
-    if (FUSE_EMBED and DEBUG_ACTS is None and FUSE_CHAIN_GLUE and PRECISION == "bf16x321" and ksize == 1 and pad == 0 and len(acts) == 3 and
+    if (FUSE_EMBED and DEBUG_ACTS is None and FUSE_CHAIN_GLUE and reduced_backward() and ksize == 1 and pad == 0 and len(acts) == 3 and
             tuple(acts) == ("relu", "relu", "linear") and not x.requires_grad and
             lib().wcmc_embed3_supported(params[0].shape[1], params[0].shape[0], params[2].shape[0], params[4].shape[0]) and
             (getattr(x, "_wcmc_split", None) is not None or is_nhwc_view(x))):
@@ -1029,7 +1055,7 @@ def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
 
 def cat_broadcast_chain(flat, prop, s, ksize, pad, acts, params):
     """``conv_chain(cat_broadcast(flat, prop, s), ...)``; fused into one autograd node on the split-bf16 path."""
-    if (FUSE_FINAL and DEBUG_ACTS is None and FUSE_CHAIN_GLUE and PRECISION == "bf16x321" and ksize == 1 and pad == 0 and
+    if (FUSE_FINAL and DEBUG_ACTS is None and FUSE_CHAIN_GLUE and reduced_backward() and ksize == 1 and pad == 0 and
             tuple(acts) == ("relu", "relu") and flat.is_cuda and prop.shape[0] * s == flat.shape[0] and
             lib().wcmc_final2_supported(flat.shape[1], prop.shape[1], params[0].shape[0], params[2].shape[0], flat.shape[2] * flat.shape[3])
             and params[0].shape[1] == 128):
