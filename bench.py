@@ -261,6 +261,45 @@ def c2_leg(device, steps, warmup):
             "losses_last_step": {k: round(float(v), 6) for k, v in itf.last_loss_dict.items()}}
 
 
+def extra_leg(device, steps, warmup, precision=None, group=None, force_collective=False):
+    """The benchmarked step once more in another configuration, graphed, same weights (seed 0) and batch: another arithmetic
+    (`other_precisions`), or the default one with the MULTI-RANK tail on a one-rank RCCL group (`multi_rank_path`)."""
+    from wcmc_amd import ops
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.optim import FusedClipAdam
+    from wcmc_amd.synthetic import make_batch
+    old = ops.PRECISION
+    if precision is not None:
+        ops.set_precision(precision)
+    try:
+        itf = build_interface(device, None, rng="device")
+        if force_collective:
+            itf.fused_optim = FusedClipAdam(itf.models, itf.optims, process_group=group, force_collective=True)
+        batch = make_batch(B_PER_GPU, SPP, PATCH, seed=0, device=device)
+        torch.manual_seed(1234)
+        graphed = GraphedTrainStep(itf, batch)
+        for _ in range(warmup):
+            graphed(batch)
+        if force_collective:
+            graphed.tail_events = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graphed(batch)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out = {"value": round(B_PER_GPU * steps / el, 3), "unit": "patches/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+               "warmup": warmup, "dtype": ops.PRECISION if ops.split_path() else "f32",
+               "losses_last_step": {k: round(float(v), 6) for k, v in itf.last_loss_dict.items()}}
+        if force_collective:
+            assert graphed.tail_split and not graphed.tail_captured
+            tails = [a.elapsed_time(b) for a, b in graphed.tail_events]
+            out["tail_ms"] = round(sum(tails) / len(tails), 4)
+        return out
+    finally:
+        ops.set_precision(old)
+
+
 def cpu_baseline():
     """The oracle's step (same architecture, same losses) on the host cores: C3 shape at batch 1."""
     from oracle import step as ostep
@@ -581,7 +620,44 @@ def main():
         line["measured_peaks"] = measured_peaks(device)
         if world == 1 and not args.eager:
             ops.USE_SIDE_STREAM, ops.USE_BRANCH_STREAM = stream_defaults
+            itf.fused_optim.leave_grads = False            # (back to the captured buffers: the long segment replays the graph)
+            # a longer segment of the SAME graphed step right behind the official one (the driver's 20 steps are 0.27 s of a 20 s
+            # process: a 5-second utilisation sampler sees nothing of them)
+            nlong = max(100, 5 * args.steps)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nlong):
+                graphed(batch)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            line["value_long"] = {"value": round(B_PER_GPU * nlong / el, 3), "unit": "patches/s", "steps": nlong,
+                                  "ms_per_step": round(el / nlong * 1e3, 3), "seconds": round(el, 3),
+                                  "note": "the same graphed step, %d more timed steps behind the official ones" % nlong}
             line["c2"] = c2_leg(device, args.steps, args.warmup)
+            if args.precision is None:
+                # the other arithmetics the library ships, same box, same process
+                line["other_precisions"] = {m: extra_leg(device, n, 3, precision=m)
+                                            for m, n in (("bf16x321o", args.steps), ("bf16x3", args.steps), ("fp32", max(3, args.steps // 4)))}
+            if args.backend == "nccl":
+                # The step exactly as rank k of N runs it -- graph A (forward, backward, gradient gather, guard flag), three eager
+                # asynchronous RCCL all-reduces of the gradient buckets (46.8 MB), graph B (global guard, sums, scale -> clip ->
+                # Adam) -- on a ONE-rank RCCL group: the same-box baseline of the first multi-GPU run.  What N ranks add to it is
+                # the wire time of the buckets (the `allreduce` object of an N-rank line) and rank skew; what it shows here is
+                # what the split tail itself costs against the single captured graph.  No scaling curve has been measured.
+                try:
+                    if not torch.distributed.is_initialized():
+                        torch.distributed.init_process_group("nccl", store=torch.distributed.HashStore(), rank=0, world_size=1)
+                    mr = extra_leg(device, args.steps, args.warmup, group=torch.distributed.group.WORLD, force_collective=True)
+                    mr["what"] = ("graph A | 3 async RCCL all-reduces (one-rank group) | graph B; tail_ms = HIP events around the "
+                                  "all-reduces + graph B")
+                    mr["rccl_ranks"] = torch.distributed.get_world_size()
+                    mr["predicted_weak_scaling_ceiling"] = round(line["ms_per_step"] / mr["ms_per_step"], 4)
+                    mr["ceiling_note"] = ("single-graph step time / multi-rank-path step time on this box: an upper bound of the "
+                                          "N-rank efficiency before any wire time or skew; no scaling curve has been measured")
+                    line["multi_rank_path"] = mr
+                    torch.distributed.destroy_process_group()
+                except Exception as err:                       # (reported, never fatal for the headline)
+                    line["multi_rank_path"] = {"error": repr(err)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -653,6 +653,81 @@ def test_graphed_unfused_step_with_grad_sync_equals_eager():
             dist.destroy_process_group()
 
 
+def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path():
+    """``FusedClipAdam.step``'s collective branch -- three asynchronous bucket all-reduces on RCCL's stream,
+    ``w.wait()`` per bucket, the guard flag in the first bucket's slot, scale -> clip -> Adam -- and ``GraphedTrainStep``'s
+    two-graph form of it (graph A ... gradient gather | eager all-reduces | graph B: global guard, sums, clip + Adam) had never
+    executed on RCCL: world 1 skips them.  ``force_collective=True`` runs them on a ONE-rank RCCL group, where the sum is the
+    identity: parameters, moments, loss sums and step counts must equal the world-1 path's BIT FOR BIT over three steps, eager
+    and graphed; a non-finite loss raises with everything untouched, and training goes on."""
+    import torch.distributed as dist
+    from wcmc_amd import KPCN
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.optim import FusedClipAdam
+    from wcmc_amd.support.interfaces import KPCNInterface
+    from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
+    from wcmc_amd.support.networks import PathNet
+    from wcmc_amd.synthetic import make_batch
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        results = {}
+        for coll in (False, True):
+            for graphed in (False, True):
+                torch.manual_seed(21)
+                kw = dict(ksize=21, depth=3, width=24)
+                models = {"dncnn": KPCN(39, **kw), "backbone_diffuse": PathNet(36, intermc=16),
+                          "backbone_specular": PathNet(36, intermc=16)}
+                for m in models.values():
+                    m.to(DEV)
+                optims = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-3) for k, m in models.items()}
+                lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+                      "l_test": RelativeMSE(), "l_manif": FeatureMSE(non_local=True, rng="cpu")}
+                itf = KPCNInterface(models, optims, lf, types.SimpleNamespace(model_name="g"), use_llpm_buf=True,
+                                    manif_learn=True, w_manif=0.1, train_branches=True)
+                fo = FusedClipAdam(models, optims, process_group=dist.group.WORLD if coll else None, force_collective=coll)
+                assert fo.collective == coll and fo.world == 1
+                itf.fused_optim = fo
+                itf.iters = 1
+                itf.to_train_mode()
+                batches = [make_batch(2, 4, 48, seed=30 + i, device=DEV) for i in range(3)]
+                if graphed:
+                    step = GraphedTrainStep(itf, batches[0])
+                    assert step.tail_split == coll and step.tail_captured == (not coll)
+                else:
+                    def step(b):
+                        itf.preprocess(b)
+                        itf.train_batch(b)
+                torch.manual_seed(22)
+                for b in batches:
+                    step(b)
+                state = lambda: torch.cat([torch.cat([fl.flat, fl.m, fl.v]) for fl in fo.flats.values()]).clone()
+                results[(coll, graphed)] = (state(), {k: v.item() for k, v in itf.m_losses.items()}, [fl.steps for fl in fo.flats.values()])
+                if coll:
+                    # the rank-global guard through the flag slot of the first bucket: nothing moves, the reference's error is raised
+                    before, sums = state(), {k: v.item() for k, v in itf.m_losses.items()}
+                    bad = {k: v.clone() for k, v in batches[0].items() if isinstance(v, torch.Tensor)}
+                    bad["target_total"][0, 0, 20, 20] = float("inf")        # (enters l_total and rmse only: FeatureMSE has its own check)
+                    with pytest.raises(RuntimeError, match="Non-finite loss at train time"):
+                        step(bad)
+                    torch.cuda.synchronize()
+                    assert torch.equal(state(), before) and [fl.steps for fl in fo.flats.values()] == [3, 3, 3]
+                    assert {k: v.item() for k, v in itf.m_losses.items()} == sums
+                    step(batches[1])
+                    assert [fl.steps for fl in fo.flats.values()] == [4, 4, 4] and not torch.equal(state(), before)
+        ref = results[(False, False)]
+        for key, got in results.items():
+            assert got[2] == [3, 3, 3], key
+            assert torch.equal(got[0], ref[0]), "parameters / moments differ: %s" % (key,)
+            for k in ref[1]:
+                np.testing.assert_allclose(got[1][k], ref[1][k], rtol=1e-6, err_msg="%s %s" % (key, k))
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 def test_nonfinite_loss_raises_and_skips_the_update():
     """interfaces.py:254-257: a non-finite loss raises RuntimeError; with the fused optimiser the raise comes
     after the (guarded, hence skipped) update has been enqueued -- parameters must be untouched."""

@@ -5,8 +5,9 @@ backward passes) is ~2,400 kernel launches whose shapes never change during trai
 (``train_kpcn.py:45`` feeds fixed-size batches).  Eagerly the host needs ~40 ms to enqueue them from
 Python -- as long as the MI355X needs to run them -- so the step is captured once with
 ``torch.cuda.graph`` (HIP stream capture) and replayed with one launch.  What stays eager is what
-talks to the host or other ranks: drawing the FeatureMSE pairings, the non-finite-loss check
-(``interfaces.py:254-257``), loss bookkeeping, the RCCL gradient all-reduce and the fused clip + Adam.
+talks to the host or other ranks: drawing the FeatureMSE pairings, reading the non-finite-loss flags
+(``interfaces.py:254-257``) and the RCCL gradient all-reduce; the optimiser tail is captured too -- into the same graph
+on one rank, into a second graph behind the all-reduces with several.
 """
 import torch
 
@@ -58,11 +59,17 @@ class GraphedTrainStep:
         # (a dozen small launches the host used to enqueue behind its sync on the losses: 0.5-0.7 ms per step with an idle
         # GPU, profiles/r03_step_trace_gaps.txt).  The update sits behind a DEVICE guard (all losses finite); the host reads the
         # flags after the replay and raises the reference's error (interfaces.py:254-257) -- the update was then skipped.
+        # Several ranks (or FusedClipAdam(force_collective=True)): the same tail as TWO captured pieces around the eager bucket
+        # all-reduces -- graph A ends with the gradient gather and this rank's guard flag, graph B holds the global guard, the
+        # loss sums and scale -> clip -> Adam (no RCCL kernel inside a capture; the host launches graph A, three collectives,
+        # graph B and reads the flags)
         fo = getattr(itf, 'fused_optim', None)
-        self.tail_captured = (capture_optimizer and fo is not None and fo.world == 1 and itf.grad_sync is None)
+        coll = fo is not None and getattr(fo, 'collective', fo.world > 1)
+        self.tail_captured = (capture_optimizer and fo is not None and not coll and itf.grad_sync is None)
+        self.tail_split = (capture_optimizer and coll and itf.grad_sync is None)
         self.defer_check = bool(defer_check) and self.tail_captured
         self._pending, self._flag_bufs, self._n_calls = None, None, 0
-        if self.tail_captured:
+        if self.tail_captured or self.tail_split:
             assert warmup >= 1
             fo.prepare_capture(itf.optims)                            # (adopts optimiser state loaded since construction: not in the capture)
             # 1 until a step's losses were non-finite, then 0 -- ANDed into every later guard -- until the host has raised the
@@ -78,15 +85,26 @@ class GraphedTrainStep:
             # ANY thread invalidates the capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.losses = itf._forward_backward(self.static)
-                if self.tail_captured:
+                if self.tail_captured or self.tail_split:
                     self.loss_keys = list(self.losses)
                     vals = torch.stack([self.losses[k].reshape(()) for k in self.loss_keys])
                     finite = torch.isfinite(vals)
-                    self.guard = finite.all().to(torch.float32).reshape(1) * self.ok
+                    local = finite.all().to(torch.float32).reshape(1) * self.ok
+                if self.tail_captured:
+                    self.guard = local
                     self.ok.copy_(self.guard)
                     # the running sums of interfaces.py:263-267, in place on one persistent tensor (itf.m_losses holds views)
                     self.sums.add_(torch.where(self.guard > 0, vals, torch.zeros_like(vals)))
                     fo.capture_step(itf.models, itf.optims, self.guard)
+                    self.flags = torch.cat([finite.to(torch.float32), self.guard])
+                elif self.tail_split:
+                    fo.capture_gather(itf.models, itf.optims, local)
+            if self.tail_split:
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                    self.guard = fo.capture_update()                  # 1 when NO rank saw a non-finite loss
+                    self.ok.copy_(self.guard)
+                    self.sums.add_(torch.where(self.guard > 0, vals, torch.zeros_like(vals)))
                     self.flags = torch.cat([finite.to(torch.float32), self.guard])
         finally:
             ops.USE_SIDE_STREAM = side
@@ -123,7 +141,7 @@ class GraphedTrainStep:
         if self.fm is not None:
             self._draw()
             self.fm._static_i = 0
-        if not self.tail_captured:
+        if not (self.tail_captured or self.tail_split):
             self.graph.replay()
             itf._logging(self.losses)
             itf._optimization()
@@ -136,6 +154,16 @@ class GraphedTrainStep:
                 itf.m_losses['m_' + k] = self._sum_views[i]
         fo.refresh_hyper(itf.optims)
         self.graph.replay()
+        if self.tail_split:
+            ev = getattr(self, 'tail_events', None)       # (bench.py: a list that receives (start, end) events of the tail)
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            fo.allreduce()                                # eager: three asynchronous RCCL sums, the launch stream waits for them
+            self.graph_b.replay()
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
         itf.last_loss_dict = self.losses
         if self.defer_check:
             if self._flag_bufs is None:
@@ -170,6 +198,7 @@ class GraphedTrainStep:
             for k, f in zip(self.loss_keys, flags[:-1]):
                 if not f:
                     raise RuntimeError("%s: Non-finite loss at train time." % (k))
+            raise RuntimeError("Non-finite loss at train time on another rank.")     # (every rank skipped the update)
 
     def _check(self, slot, after=0):
         host, ev = self._flag_bufs[slot]

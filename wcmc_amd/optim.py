@@ -131,11 +131,15 @@ class _Flat:
 
 
 class FusedClipAdam:
-    def __init__(self, models, optims, process_group=None, clip=1.0):
+    def __init__(self, models, optims, process_group=None, clip=1.0, force_collective=False):
+        """force_collective: run the bucket all-reduces even on a ONE-rank process group (a sum over one rank is the identity:
+        results are those of the world-1 path bit for bit) -- the multi-rank code path, exercised where only one GPU is at hand
+        (tests/test_gpu_models.py, the `multi_rank_path` leg of bench.py)."""
         self.clip = clip
         self.leave_grads = True      # re-point p.grad at the clipped flat gradient like clip_grad_value_ leaves it
         self.group = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.collective = self.world > 1 or (bool(force_collective) and process_group is not None)
         order = [n for n in BUCKET_ORDER if n in models] + [n for n in models if n not in BUCKET_ORDER]
         self.flats = {name: _Flat(models[name], optims["optim_" + name]) for name in order}
         self.last_guard = None       # device float: 1 when every rank's losses were finite at the last step
@@ -165,7 +169,7 @@ class FusedClipAdam:
             if first and guard is not None:
                 fl.g[fl.total:fl.total + 1].copy_((1.0 - guard).reshape(1))
                 n_msg = fl.total + _ALIGN
-            if self.world > 1:                               # RCCL sum on the communicator's stream
+            if self.collective:                              # RCCL sum on the communicator's stream
                 work.append(torch.distributed.all_reduce(fl.g[:n_msg], group=self.group, async_op=True))
             else:
                 work.append(None)
@@ -204,7 +208,7 @@ class FusedClipAdam:
         """Enqueue gather + clip + Adam of every model ONCE, under stream capture (``wcmc_amd.graph.GraphedTrainStep``):
         the kernels read step size / bias correction from ``self.hyper`` (device), which ``refresh_hyper`` fills before every
         replay.  The set of parameters that have a gradient is frozen with the capture (as the graph itself is)."""
-        assert self.world == 1, "a collective cannot be captured here: the multi-rank step stays eager"
+        assert not self.collective, "a collective cannot be captured: capture_gather / allreduce / capture_update split the tail around it"
         assert getattr(self, "hyper", None) is not None, "prepare_capture() first (no allocation of pinned memory inside a capture)"
         self._captured = []
         for i, (name, fl) in enumerate(self.flats.items()):
@@ -227,6 +231,54 @@ class FusedClipAdam:
             for a, b, _ in fl.segments(have):
                 ops.clip_adam_dev_(fl.flat[a:b], fl.g[a:b], fl.m[a:b], fl.v[a:b], self.hyper[i], clip=self.clip,
                                    grad_scale=1.0, guard=guard)
+
+    # ---- the multi-rank step as TWO captured pieces around the eager collectives (no RCCL kernel inside a capture):
+    #   graph A  ... backward, capture_gather: gradients -> buckets, this rank's (1 - guard) -> the flag slot of the first bucket
+    #   eager    allreduce(): the buckets summed over the ranks, asynchronously, in backward order; the launch stream waits
+    #   graph B  capture_update: global guard from the summed flag slot, then scale (1 / world) -> clip -> Adam per bucket
+    def capture_gather(self, models, optims, guard):
+        assert getattr(self, "hyper", None) is not None, "prepare_capture() first"
+        self._captured = []
+        first = True
+        for name, fl in self.flats.items():
+            optim = optims["optim_" + name]
+            if not fl.bound(optim):
+                raise RuntimeError("FusedClipAdam.capture_gather: call prepare_capture(optims) before the capture (optim_%s)" % name)
+            have = [p.grad is not None for p in fl.params]
+            fl.stepped = any(have)
+            self._captured.append((name, fl, fl.stepped, have))
+            if not fl.stepped:
+                continue
+            assert len({n for n, h in zip(fl.psteps, have) if h}) == 1, \
+                "a captured optimiser bias-corrects a model's parameters with ONE step count: they must have trained together"
+            gv = fl.grad_views()
+            idx = [j for j, h in enumerate(have) if h]
+            torch._foreach_copy_([gv[j] for j in idx], [fl.params[j].grad for j in idx])
+            fl.n_msg = fl.total
+            if first:
+                fl.g[fl.total:fl.total + 1].copy_((1.0 - guard).reshape(1))
+                fl.n_msg = fl.total + _ALIGN
+                self._first_fl = fl
+            first = False
+
+    def allreduce(self):
+        """Between the two graphs: one asynchronous all-reduce (SUM) per stepped bucket on the communicator's stream, issued in
+        backward order; the launch stream then waits for all of them (graph B reads every bucket)."""
+        works = [torch.distributed.all_reduce(fl.g[:fl.n_msg], group=self.group, async_op=True)
+                 for _, fl, stepped, _ in self._captured if stepped]
+        for w in works:
+            w.wait()
+
+    def capture_update(self):
+        """Graph B; returns the global guard (device float: 1 when no rank saw a non-finite loss)."""
+        gguard = (self._first_fl.g[self._first_fl.total] == 0).to(torch.float32).reshape(1)
+        for i, (name, fl, stepped, have) in enumerate(self._captured):
+            if not stepped:
+                continue
+            for a, b, _ in fl.segments(have):
+                ops.clip_adam_dev_(fl.flat[a:b], fl.g[a:b], fl.m[a:b], fl.v[a:b], self.hyper[i], clip=self.clip,
+                                   grad_scale=1.0 / self.world, guard=gguard)
+        return gguard
 
     def prepare_capture(self, optims=None):
         """Buffers of the captured step, allocated BEFORE the capture begins (hipHostMalloc invalidates a stream capture), and
