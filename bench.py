@@ -49,6 +49,8 @@ def rocprof_names(wgrad_terms):
             "conv_halo64_pt3_x2": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1>",
             "conv_halo64_pt4_x1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 1>",
             "conv_halo64_pt3_x1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1>",
+            "conv_halo64_pt4_h1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 1, 1>",
+            "conv_halo64_pt3_h1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 1>",
             "conv_wgrad_rows": ("wcmc::conv_wgrad_rows8_bf16x3_kernel<0, %d, %d>" % (_ROWS8_XE if wgrad_terms == 3 else 1, 1 if wgrad_terms == 1 else 2)) if _ROWS8
                                else "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, %d>" % (1 if wgrad_terms == 1 else 2),
             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)",
@@ -59,7 +61,7 @@ def rocprof_names(wgrad_terms):
 
 # bf16 MFMAs issued per algorithmic multiply-add, by profiler class (forward 3; "_x2" data gradients 2; weight gradient: the mode's)
 def mfma_terms(cls, wgrad_terms):
-    return 1.0 if cls.endswith("_x1") else 2.0 if cls.endswith("_x2") else float(wgrad_terms) if cls.startswith("conv_wgrad") else 3.0
+    return 1.0 if cls.endswith(("_x1", "_h1")) else 2.0 if cls.endswith("_x2") else float(wgrad_terms) if cls.startswith("conv_wgrad") else 3.0
 B_PER_GPU, SPP, PATCH = 8, 8, 128
 
 
@@ -396,7 +398,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="smoke test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL refuses two ranks "
                          "on one device); the printed throughput is then meaningless")
-    ap.add_argument("--precision", choices=("bf16x321o", "bf16x321", "bf16x3", "fp32"), default=None,
+    ap.add_argument("--precision", choices=("bf16x321h", "bf16x321o", "bf16x321", "bf16x3", "fp32"), default=None,
                     help="conv GEMM arithmetic: split-bf16 with 3 / 2 / 1 MFMAs per product in forward / data gradient / weight "
                          "gradient (default), 3 everywhere (rounds 1-2), or exact fp32 MFMA (roofline vs the 157.3 TF/s peak)")
     args = ap.parse_args()
@@ -546,7 +548,7 @@ def main():
         # dgrad: 16x16 tiles, 12x16 tiles, 12x16 with 32-channel slabs for the 441-channel data gradient; conv_halo7 = the 8x16
         # kernel they replace, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows8_bf16x3_kernel (WCMC_WGRAD_ROWS8=0: ..._rows_bf16x3_kernel<5,7,7>);
         # conv_igemm / conv_wgrad collect the other GEMM kernels
-        conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_pt3_x2", "conv_halo64_pt4_x2", "conv_halo64_pt3_x1", "conv_halo64_pt4_x1", "conv_halo64_cs32", "conv_halo7",
+        conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_pt3_x2", "conv_halo64_pt4_x2", "conv_halo64_pt3_x1", "conv_halo64_pt4_x1", "conv_halo64_pt3_h1", "conv_halo64_pt4_h1", "conv_halo64_cs32", "conv_halo7",
                                  "conv_wgrad_rows", "conv_igemm", "conv_wgrad")
                      if k in summ]
         # the roofline kernel: the single kernel (one rocprof name) with the most time per step; the two catch-all classes
@@ -595,9 +597,10 @@ def main():
                                       "weight gradients (dy_hi x x_hi) -- the rungs of profiles/r03_precision_ladder.txt (backward) and "
                                       "profiles/r04_forward_ladder.txt (forward) that hold every parity bar.  roofline counts algorithmic "
                                       "FLOPs once against the dense bf16 MFMA peak, so frac <= 1 / (MFMAs per product); everything else fp32") %
-                                     (" except the two un-gated KPCN output layers (100 -> 441 logits), which run ONE (x_hi x W_hi: no "
+                                     (" except the two un-gated KPCN output layers (100 -> 441 logits), which run ONE (%s: no "
                                       "ReLU behind them, so no gate can flip; every HIDDEN layer needs >= 16-bit operands to hold the "
-                                      "gradient bars)" if ops.PRECISION == "bf16x321o" else
+                                      "gradient bars)" % ("x_hi x W_hi, bf16" if ops.PRECISION == "bf16x321o" else "fp16(x) x fp16(W)")
+                                      if ops.PRECISION in ("bf16x321o", "bf16x321h") else
                                       "; outputs and losses are bit-identical to the all-three-term mode (--precision bf16x3)"))
                        if ops.reduced_backward() else
                        ("conv GEMMs: split-bf16 operands (hi+lo), 3 x v_mfma_f32_16x16x32_bf16 per product in every GEMM, fp32 "
@@ -637,7 +640,8 @@ def main():
             if args.precision is None:
                 # the other arithmetics the library ships, same box, same process
                 line["other_precisions"] = {m: extra_leg(device, n, 3, precision=m)
-                                            for m, n in (("bf16x321o", args.steps), ("bf16x3", args.steps), ("fp32", max(3, args.steps // 4)))}
+                                            for m, n in (("bf16x321h", args.steps), ("bf16x321o", args.steps), ("bf16x3", args.steps),
+                                                         ("fp32", max(3, args.steps // 4)))}
             if args.backend == "nccl":
                 # The step exactly as rank k of N runs it -- graph A (forward, backward, gradient gather, guard flag), three eager
                 # asynchronous RCCL all-reduces of the gradient buckets (46.8 MB), graph B (global guard, sums, scale -> clip ->

@@ -156,7 +156,8 @@ int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t dsh, int64_t
 /* mode: 0 = forward orientation (rows = Cout, k over Cin x taps); 1 = data-gradient orientation (rows = Cin, k over
  * Cout x flipped taps) for a three-term launch; 2 = the same orientation in the K order of a TWO-term launch
  * (wcmc_conv2d_igemm_bf16x3 with terms = 2: the channel slabs are twice as wide, see there); 3 = the FORWARD orientation in
- * that K order (a forward launch with terms = 2 or 1: round 4, the un-gated output layers of the "bf16x321o" mode). */
+ * that K order (a forward launch with terms = 2 or 1: round 4, the un-gated output layers of the "bf16x321o" mode); 4 = mode 3
+ * with the weights rounded once to fp16 in the hi rows (wcmc_conv2d_out_f16). */
 size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks, int mode);
 int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
                                    void* stream);
@@ -185,6 +186,18 @@ int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              int ks, int pad, int act, float slope,
                              const void* gate_split, int gate_act, float gate_slope,
                              float* colsum_partial, const void* gate_mask, void* mask_out, int terms, void* stream);
+/* Round 4: the forward of an un-gated 5x5 OUTPUT layer with ONE fp16 MFMA per product (the "bf16x321h" mode; sbmc.KPCN's
+ * kernel-predicting output layers, call site support/interfaces.py:203-204).  Both operands are rounded ONCE to fp16 (11 bits;
+ * the reference's own cuDNN path rounds both to TF32's 10, train_kpcn.py:349): x by wcmc_split_to_f16 (split tensor ->
+ * [N*H*W][round_up(C,8)] halfs, saturating), the weights by wcmc_conv2d_pack_weight_bf16x3 with mode 4.  No activation follows
+ * the layer, so no ReLU gate can flip (profiles/r04_forward_ladder.txt: every HIDDEN layer needs >= 16-bit operands).
+ * wcmc_conv2d_out_f16_supported: 5x5, cout blocks of seven tiles, input channels not 24 mod 32 (the hi-plane instance of the
+ * 64-pixel kernel); y = conv(x, W) + bias as an fp32 NHWC view, linear. */
+int wcmc_conv2d_out_f16_supported(int Cin, int Cout, int ks);
+size_t wcmc_split_to_f16_elems(int N, int H, int W, int C);
+int wcmc_split_to_f16(const void* x_split, int N, int H, int W, int C, void* out_f16, void* stream);
+int wcmc_conv2d_out_f16(const void* x_f16, int N, int H, int W, int Cin, const void* wp_f16, const float* bias, float* y,
+                        int64_t ysn, int64_t ysh, int64_t ysw, int Cout, int ks, int pad, void* stream);
 /* colsum_partial (optional, with y_split): [wcmc_conv2d_igemm_colsum_elems] floats that receive the
  * per-pixel-tile column sums of the result -- the bias gradient of the layer that consumes this
  * data gradient, finished by wcmc_colsum_finish (saves a pass over dy per layer).  The buffer ends with a trailer

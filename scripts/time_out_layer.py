@@ -20,15 +20,18 @@ x = o.to_nhwc_raw(xf)
 w = torch.randn(cout, cin, ks, ks, device=dev) * 0.02
 b = torch.randn(cout, device=dev) * 0.1
 xs = o.split_raw(x)
-packs = {3: o._pack_x(w, 0), 2: o._pack_x(w, 3), 1: o._pack_x(w, 3)}
-run = lambda t: o.conv2d_x_raw(xs, (n, cin, h, h), packs[t], b, cout, ks, 0, "linear", out_split=False, terms=t)
+packs = {3: o._pack_x(w, 0), 2: o._pack_x(w, 3), 1: o._pack_x(w, 3), "h": o._pack_x(w, 4)}
+run = lambda t: (o.conv2d_out_f16_raw(xs, (n, cin, h, h), packs[t], b, cout, ks, 0) if t == "h" else
+                 o.conv2d_x_raw(xs, (n, cin, h, h), packs[t], b, cout, ks, 0, "linear", out_split=False, terms=t))
 bf = lambda t: t.bfloat16().double()
+hf = lambda t: t.half().double()
 ref = {3: torch.nn.functional.conv2d(xf[:1].double().cpu(), w.double().cpu(), b.double().cpu()),
        2: torch.nn.functional.conv2d(bf(xf[:1]).cpu(), w.double().cpu(), b.double().cpu()),
-       1: torch.nn.functional.conv2d(bf(xf[:1]).cpu(), bf(w).cpu(), b.double().cpu())}
-for t in (3, 2, 1):
+       1: torch.nn.functional.conv2d(bf(xf[:1]).cpu(), bf(w).cpu(), b.double().cpu()),
+       "h": torch.nn.functional.conv2d(hf(xf[:1]).cpu(), hf(w).cpu(), b.double().cpu())}
+for t in (3, 2, 1, "h"):
     y = run(t)[:1].double().cpu()
-    print("terms %d: max|y - fp64(operands as multiplied)| / max|y| = %.2e   vs exact fp64: %.2e" %
+    print("terms %s: max|y - fp64(operands as multiplied)| / max|y| = %.2e   vs exact fp64: %.2e" %
           (t, float((y - ref[t]).abs().max() / ref[t].abs().max()), float((y - ref[3]).abs().max() / ref[3].abs().max())))
 for rep in range(3):
-    print("  ".join("terms %d: %6.1f us" % (t, timeit(lambda: run(t))) for t in (3, 2, 1)))
+    print("  ".join("terms %s: %6.1f us" % (t, timeit(lambda: run(t))) for t in (3, 2, 1, "h")) + "   (h = fp16, incl. the split -> fp16 conversion of x)")

@@ -24,11 +24,14 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(params=["fp32", "bf16x3", "bf16x321", "bf16x321o"])
+REDUCED = ("bf16x321h", "bf16x321", "bf16x321o")          # modes whose backward GEMMs run on two / one bf16 MFMAs per product
+
+
+@pytest.fixture(params=["fp32", "bf16x3", "bf16x321", "bf16x321o", "bf16x321h"])
 def precision(request):
     """Runs a GPU test once per conv arithmetic: exact fp32 MFMA, split-bf16 with 3 bf16 MFMAs per product everywhere, round 3's
-    default (forward 3, data gradient 2, weight gradient 1) and the default mode (the same with ONE MFMA per product in the
-    forward of un-gated 5x5 output layers: wcmc_amd/ops.py)."""
+    default -- still the default -- (forward 3, data gradient 2, weight gradient 1), and the two opt-in modes that run the forward
+    of un-gated 5x5 output layers on ONE bf16 / ONE fp16 MFMA per product (wcmc_amd/ops.py)."""
     from wcmc_amd import ops
     old = ops.PRECISION
     ops.set_precision(request.param)
@@ -47,6 +50,20 @@ def three_term_mode():
     ops.set_precision(old)
 
 
+@pytest.fixture(scope="session")
+def rccl_one_rank_group():
+    """ONE one-rank RCCL process group for the whole pytest session (torch.distributed backend "nccl"), destroyed when the
+    session ends.  A second init / destroy cycle of RCCL inside one process left the HIP runtime in a state in which a later,
+    unrelated hipGraphLaunch segfaulted (full GPU suite, round 4): tests that need the communicator share this one."""
+    import torch.distributed as dist
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1)
+    yield dist.group.WORLD
+    if own:
+        dist.destroy_process_group()
+
+
 def ptol(precision, fp32_tol, x3_tol):
     return fp32_tol if precision == "fp32" else x3_tol
 
@@ -58,7 +75,7 @@ def gtol(precision, fp32_tol, x3_tol, x321_tol=8e-3):
     out (profiles/r03_precision_ladder.txt: 1.09e-3 -> 1.22e-3 on the benchmarked step).  That each reduced-term kernel
     computes EXACTLY the gradient of the rounded operands is pinned separately (tests/test_gpu_ops.py::test_one_term_...,
     test_two_term_...)."""
-    return x321_tol if precision in ("bf16x321", "bf16x321o") else ptol(precision, fp32_tol, x3_tol)
+    return x321_tol if precision in REDUCED else ptol(precision, fp32_tol, x3_tol)
 
 
 def otol(precision, ks, act, cout, tol):
@@ -69,7 +86,8 @@ def otol(precision, ks, act, cout, tol):
     tiles = (cout + 15) // 16
     nt = min((7, 4, 2, 1), key=lambda t: (-(-tiles // t)) * (t + 2))          # x_pick_nt of csrc/conv_bf16x3.hip
     granted = ks == 5 and act == "linear" and nt == 7
-    return 6e-3 if (precision == "bf16x321o" and granted) else tol
+    # ("bf16x321h": fp16 on both operands, 2^-12 each: 3e-4 on these operands; exactness: test_fp16_output_layer_forward_...)
+    return 6e-3 if (precision == "bf16x321o" and granted) else 1e-3 if (precision == "bf16x321h" and granted) else tol
 
 
 def rel_l2(a, b):

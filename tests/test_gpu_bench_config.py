@@ -54,7 +54,7 @@ def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
     from wcmc_amd import ops
     from wcmc_amd.graph import GraphedTrainStep
     from wcmc_amd.synthetic import make_batch
-    assert ops.PRECISION == ops.MODES[0] and not ops.USE_SIDE_STREAM and ops.USE_BRANCH_STREAM and ops.FUSE_CHAIN_GLUE, \
+    assert ops.PRECISION == os.environ.get("WCMC_PRECISION", ops.MODES[0]) and not ops.USE_SIDE_STREAM and ops.USE_BRANCH_STREAM and ops.FUSE_CHAIN_GLUE, \
         "this test pins the DEFAULT switches (the ones bench.py runs with)"
     B, S, H = bench.B_PER_GPU, bench.SPP, bench.PATCH
     device = torch.device("cuda", 0)
@@ -174,7 +174,7 @@ def test_c2_vanilla_full_size_graphed_step_against_oracle():
     from wcmc_amd.support.interfaces import KPCNInterface
     from wcmc_amd.support.losses import RelativeMSE
     from wcmc_amd.synthetic import make_batch
-    assert ops.PRECISION == ops.MODES[0]
+    assert ops.PRECISION == os.environ.get("WCMC_PRECISION", ops.MODES[0])      # (the default; WCMC_PRECISION probes another mode against the same bars)
     torch.manual_seed(11)
     omod = {"dncnn": OKPCN(34)}
     g = torch.Generator().manual_seed(12)

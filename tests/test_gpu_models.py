@@ -156,7 +156,7 @@ def golden_l2(precision, flips=None):
         return 1e-4
     if flips is None:          # (tests that do not run the oracle forward beside the step: <= 1.7e-2 measured)
         return 1e-1
-    if precision in ("bf16x321", "bf16x321o") and flips == 0:
+    if precision in ("bf16x321h", "bf16x321", "bf16x321o") and flips == 0:
         # the backward GEMMs round dy (and x in the weight gradient) to bf16, 2^-9 each: with 800 pixels per golden batch
         # there is little to average over (the benchmarked step has 107k per layer: profiles/r03_precision_ladder.txt)
         return 8e-3
@@ -362,7 +362,7 @@ def test_sbmc_and_lbmc_interfaces_against_reference_golden(golden_dir, case, pre
     # validation runs on the weights AFTER the Adam step, -lr * sign(g) on entries whose gradient is below the gradient noise:
     # in these 4-channel networks the bf16-rounded backward operands of the default mode turn more of them (one ReLU output
     # pixel of the P-buffer then differs by a few per cent of the tensor's max)
-    vt = 5e-2 if precision in ("bf16x321", "bf16x321o") else 5e-3
+    vt = 5e-2 if precision in ("bf16x321h", "bf16x321", "bf16x321o") else 5e-3
     assert_close(out, T(d["val/out"]), tol=vt, what="validate output")
     np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=vt)
     if pb is not None:
@@ -413,7 +413,10 @@ def test_full_size_step_against_oracle(precision):
         for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
             # one patch: 1/8 of the benchmark's units, so sqrt(8) x its relative L2 (tests/test_gpu_bench_config.py holds
             # B=8 to 2e-3); measured here 3.9e-3 (exact-fp32 MFMA: fp32 against fp32 in another summation order) and 3.5e-3
-            grad_close(p.grad, q.grad, 8e-3, "full-size B=1 %s (%d flips) grad %s %s" % (precision, nfl, mn, k), cos=2e-5)
+            # (the opt-in output-layer modes move the outputs by 1e-5 .. 1e-4 and with them the sign of the L1 derivative at the
+            # pixels whose residual is that small: measured 1 - cos 2.1e-5 with the fp16 layer; the default's bar stays)
+            grad_close(p.grad, q.grad, 8e-3, "full-size B=1 %s (%d flips) grad %s %s" % (precision, nfl, mn, k),
+                       cos=3e-5 if precision in ("bf16x321h", "bf16x321o") else 2e-5)
 
 
 def test_graphed_step_equals_eager_step():
@@ -596,7 +599,7 @@ def test_captured_optimizer_adopts_state_loaded_after_construction():
         assert all(float(st["step"]) == 4.0 for st in op.state_dict()["state"].values())
 
 
-def test_graphed_unfused_step_with_grad_sync_equals_eager():
+def test_graphed_unfused_step_with_grad_sync_equals_eager(rccl_one_rank_group):
     """GraphedTrainStep on the UN-fused path INTEGRATION.md documents (itf.grad_sync = wd.average_gradients, torch's
     clip_grad_value_ + Adam.step): ``p.grad`` must keep pointing at the buffers the captured backward writes, so the
     gradient average is written back in place.  Three steps on three different batches against the eager step, bit for
@@ -609,9 +612,7 @@ def test_graphed_unfused_step_with_grad_sync_equals_eager():
     from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
     from wcmc_amd.support.networks import PathNet
     from wcmc_amd.synthetic import make_batch
-    own_group = not dist.is_initialized()
-    if own_group:
-        dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1)
+    own_group = False                                   # (the session's group: conftest.rccl_one_rank_group)
     try:
         results = []
         for graphed in (False, True):
@@ -653,7 +654,7 @@ def test_graphed_unfused_step_with_grad_sync_equals_eager():
             dist.destroy_process_group()
 
 
-def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path():
+def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path(rccl_one_rank_group):
     """``FusedClipAdam.step``'s collective branch -- three asynchronous bucket all-reduces on RCCL's stream,
     ``w.wait()`` per bucket, the guard flag in the first bucket's slot, scale -> clip -> Adam -- and ``GraphedTrainStep``'s
     two-graph form of it (graph A ... gradient gather | eager all-reduces | graph B: global guard, sums, clip + Adam) had never
@@ -668,9 +669,7 @@ def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path():
     from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
     from wcmc_amd.support.networks import PathNet
     from wcmc_amd.synthetic import make_batch
-    own_group = not dist.is_initialized()
-    if own_group:
-        dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1)
+    own_group = False                                   # (the session's group: conftest.rccl_one_rank_group)
     try:
         assert dist.get_backend() == "nccl"
         results = {}
@@ -802,17 +801,18 @@ def test_default_mode_forward_is_the_three_term_forward_and_its_gradients_stay_c
     """Round 3's default ("bf16x321") changes the BACKWARD GEMMs only: loss scalars and denoised patches equal the all-three-term
     mode's bit for bit; the gradients differ by the bf16 rounding of dy / x (2 x 4 x 64 x 64 patches here: little to average over);
     and WCMC_DGRAD_AP1=0 (three-term data gradients, one-term weight gradients) lies between the two.  The default mode
-    ("bf16x321o") differs from it in the forward of the two KPCN OUTPUT layers only (x_hi x W_hi: exact on the rounded operands,
-    tests/test_gpu_ops.py::test_one_term_output_layer_forward_...): everything upstream of them -- the P-buffers, hence the
-    manifold losses -- is still bit-identical, the denoised patches and the image losses move by less than a third of
-    north_star's 1e-3 (the adoption bar of profiles/r04_forward_ladder.txt; measured there 1.1e-4 / 8e-6 at the bench shape)."""
+    ("bf16x321h"; and the opt-in "bf16x321o") differs from it in the forward of the two KPCN OUTPUT layers only (one fp16 / bf16
+    MFMA per product: exact on the rounded operands, tests/test_gpu_ops.py::test_fp16_output_layer_forward_... /
+    test_one_term_output_layer_forward_...): everything upstream of them -- the P-buffers, hence the manifold losses -- is still
+    bit-identical, the denoised patches and the image losses move by less than 5e-5 (fp16) / a third of north_star's 1e-3 (bf16)
+    (profiles/r04_forward_ladder.txt: 1.3e-5 / 1.1e-4 at the bench shape)."""
     import os
     from conftest import rel_l2
     from wcmc_amd import ops
     runs = {}
     old = ops.PRECISION
     try:
-        for mode, env in (("bf16x3", None), ("bf16x321", None), ("bf16x321", "0"), ("bf16x321o", None)):
+        for mode, env in (("bf16x3", None), ("bf16x321", None), ("bf16x321", "0"), ("bf16x321o", None), ("bf16x321h", None)):
             ops.set_precision(mode)
             if env is not None:
                 os.environ["WCMC_DGRAD_AP1"] = env
@@ -826,9 +826,9 @@ def test_default_mode_forward_is_the_three_term_forward_and_its_gradients_stay_c
     worst = {}
     for key, got in runs.items():
         for k, want in base.items():
-            if key[0] == "bf16x321o" and k.startswith(("loss/", "out/")) and "manif" not in k:
+            if key[0] in ("bf16x321o", "bf16x321h") and k.startswith(("loss/", "out/")) and "manif" not in k:
                 e = ((got[k] - want).abs().max() / want.abs().max()).item()
-                assert 0.0 < e <= 3e-4, (key, k, e)
+                assert 0.0 < e <= (3e-4 if key[0] == "bf16x321o" else 5e-5), (key, k, e)
             elif k.startswith(("loss/", "out/")):
                 assert torch.equal(got[k], want), (key, k)
             else:
@@ -836,6 +836,7 @@ def test_default_mode_forward_is_the_three_term_forward_and_its_gradients_stay_c
     assert worst[("bf16x3", None)] == 0.0
     assert 0.0 < worst[("bf16x321", "0")] <= 6e-3 and 0.0 < worst[("bf16x321", None)] <= 6e-3, worst
     assert 0.0 < worst[("bf16x321o", None)] <= 1.2e-2, worst      # (measured 6.9e-3: the output layers' rounded logits move d_logits)
+    assert 0.0 < worst[("bf16x321h", None)] <= 6e-3, worst
 
 
 def _switch_step():

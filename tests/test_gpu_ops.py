@@ -456,6 +456,43 @@ def test_one_term_output_layer_forward_is_exact_on_the_rounded_operands(case):
                                                                   # network is measured end to end: profiles/r04_forward_ladder.txt)
 
 
+@pytest.mark.parametrize("case", ((8, 100, 96, 96, 441, 0, 5), (1, 100, 40, 37, 441, 0, 5), (2, 100, 36, 36, 100, 4, 5), (1, 104, 30, 30, 112, 0, 5),
+                                  (2, 72, 24, 27, 100, 0, 5)))
+def test_fp16_output_layer_forward_is_exact_on_the_rounded_operands(case):
+    """wcmc_split_to_f16 + wcmc_conv2d_out_f16 (the forward of an un-gated 5x5 output layer in the default mode "bf16x321h":
+    ``conv_halo64_bf16x3_kernel<7, 3, PT, 0, 80, 1, 1, 1>`` on ``v_mfma_f32_16x16x32_f16``): both operands rounded ONCE to fp16 --
+    x from its split value hi + lo, W by the mode-4 pack -- one MFMA per product.  fp16 x fp16 is exact in fp32, so the result
+    must equal fp64 on the operands rounded the same way at the kernels' usual 2e-5 (bias included); fp16 subnormals take part
+    (weights below 6.1e-5 are NOT flushed); values beyond +-65504 saturate; and the library refuses shapes without an instance."""
+    from wcmc_amd._lib import lib
+    o = ops()
+    n, cin, h, w, cout, pad, ks = case
+    assert lib().wcmc_conv2d_out_f16_supported(cin, cout, ks) == 1
+    x = torch.relu(gen(n, cin, h, w, seed=590) * 3.0)
+    wt = gen(cout, cin, ks, ks, seed=591, scale=(2.0 / (cin * ks * ks)) ** 0.5 * 1.7)
+    b = gen(cout, seed=592, scale=0.2)
+    xs = o.split_raw(o.to_nhwc_raw(x.to(DEV)))
+    y = o.conv2d_out_f16_raw(xs, (n, cin, h, w), o._pack_x(wt.to(DEV), 4), b.to(DEV), cout, ks, pad)
+    x16 = o.unsplit_debug(xs, n, cin, h, w).half().double().cpu()          # the kernel's operand: fp16 of the split value
+    want = F.conv2d(x16, wt.half().double(), b.double(), padding=pad)
+    assert_close(y, want, tol=2e-5, what="fp16 output layer = conv(fp16(x), fp16(W)) + b")
+    full = F.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    assert 1e-5 < rel_err(y, full) < 1e-3                                   # (2^-12 per operand on i.i.d. test data)
+    if case[0] == 1 and cout == 112:
+        # subnormal weights are multiplied, not flushed: 3e-6 is below fp16's smallest normal (6.1e-5)
+        tiny = torch.full((cout, cin, ks, ks), 3e-6)
+        ones = o.split_raw(o.to_nhwc_raw(torch.ones(n, cin, h, w, device=DEV)))
+        yt = o.conv2d_out_f16_raw(ones, (n, cin, h, w), o._pack_x(tiny.to(DEV), 4), None, cout, ks, pad)
+        np.testing.assert_allclose(yt[0, 0, 0, 0].item(), float(torch.tensor(3e-6).half()) * cin * ks * ks, rtol=1e-5)
+        # saturation instead of inf
+        big = o.split_raw(o.to_nhwc_raw(torch.full((n, cin, h, w), 1e6, device=DEV)))
+        wone = torch.zeros(cout, cin, ks, ks); wone[:, 0, 0, 0] = 1.0
+        yb = o.conv2d_out_f16_raw(big, (n, cin, h, w), o._pack_x(wone.to(DEV), 4), None, cout, ks, pad)
+        assert torch.isfinite(yb).all() and yb[0, 0, 0, 0].item() == 65504.0
+    assert lib().wcmc_conv2d_out_f16_supported(100, 39, 5) == 0 and lib().wcmc_conv2d_out_f16_supported(120, 100, 5) == 0
+    assert lib().wcmc_conv2d_out_f16_supported(64, 128, 3) == 0
+
+
 PW_CASES = [
     # N, H, W, widths of a 1x1 chain, output activation -- the PathNet chains (support/networks.py:22-27)
     (5, 37, 41, (36, 64, 64, 64), "linear"),     # embedding: 7585 pixels = 118 tiles + 33 (ragged last tile)

@@ -69,6 +69,31 @@ __global__ void split_kernel(const float* __restrict__ x, int64_t xsn, int64_t x
   }
 }
 
+// ------------------------------------------------------------------ split -> one fp16 plane
+// x = hi + lo of a split tensor, rounded once to fp16 (11 bits; saturating at +-65504): the A operand of the one-MFMA fp16 forward
+// of an un-gated output layer ("bf16x321h" mode).  [N*H*W][Cp] halfs, Cp = round_up(C, 8).
+typedef _Float16 xf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u16 f2h_sat(float v) {
+  v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+  return __builtin_bit_cast(u16, (_Float16)v);
+}
+__global__ __launch_bounds__(256) void split_to_f16_kernel(const u16* __restrict__ xs, u16* __restrict__ out, int Cp, int64_t total) {
+  const int V = Cp / 8;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % V); const int64_t px = idx / V;
+    const uint4 h = *reinterpret_cast<const uint4*>(xs + px * 2 * Cp + v * 8), l = *reinterpret_cast<const uint4*>(xs + px * 2 * Cp + Cp + v * 8);
+    const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+    u16 o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = __builtin_bit_cast(float, hw[e] << 16) + __builtin_bit_cast(float, lw[e] << 16);
+      const float b = __builtin_bit_cast(float, hw[e] & 0xffff0000u) + __builtin_bit_cast(float, lw[e] & 0xffff0000u);
+      o[2 * e] = f2h_sat(a); o[2 * e + 1] = f2h_sat(b);
+    }
+    *reinterpret_cast<uint4*>(out + px * Cp + v * 8) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
 // ------------------------------------------------------------------ strided (N,C,H,W) -> split
 // The per-sample path descriptors arrive channel-first (`paths` (B,S,36,H,W), support/networks.py:31-33) and are only
 // ever read as the embedding chain's split input: transpose and split in one pass (64 pixels of one image row x all
@@ -297,7 +322,7 @@ __global__ __launch_bounds__(256) void split_dy_colsum_kernel(const float* __res
 // kernel uses one slab of all (padded) channels (CS = Kp, Ks = Kt); the halo kernel cuts the channels into
 // slabs of CS <= 64 that fit in LDS with their halo (x_plan_k below decides, from (kchan, ks) alone).
 __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __restrict__ wp, int Cout, int Cin,
-                                         int ks, int mode, int rows, int Np, int CS, int Ks, int Kt, int nslabs, int CSl) {
+                                         int ks, int mode, int rows, int Np, int CS, int Ks, int Kt, int nslabs, int CSl, int f16) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)Np * Kt) return;
   const int n = (int)(idx / Kt), k = (int)(idx - (int64_t)n * Kt);
@@ -316,6 +341,7 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __res
   }
   u16 hi, lo;
   split1(v, hi, lo);
+  if (f16) { hi = f2h_sat(v); lo = 0; }          // (mode 4: ONE fp16 plane in the hi rows; the lo rows are never read)
   wp[((int64_t)n * 2) * Kt + k] = hi;
   wp[((int64_t)n * 2 + 1) * Kt + k] = lo;
 }
@@ -423,7 +449,7 @@ static XKPlan x_plan_k(int kchan, int ks, int ap_req = 2, int rows = 0) {
 // finds its entry by its block range and runs pack_weight_split_kernel's body on it.  (114 packing launches of ~4 us per
 // step become 16.)
 constexpr int XPACK_MAX = 20;
-struct XPackEntry { const float* w; u16* wp; int Cout, Cin, mode, rows, Np, CS, Ks, Kt, nslabs, CSl; unsigned block0; };
+struct XPackEntry { const float* w; u16* wp; int Cout, Cin, mode, rows, Np, CS, Ks, Kt, nslabs, CSl; unsigned block0; int f16; };
 struct XPackTable { XPackEntry e[XPACK_MAX]; int n, ks; };
 __global__ __launch_bounds__(256) void pack_weight_split_multi_kernel(XPackTable t) {
   int k = 0;
@@ -449,6 +475,7 @@ __global__ __launch_bounds__(256) void pack_weight_split_multi_kernel(XPackTable
   }
   u16 hi, lo;
   split1(v, hi, lo);
+  if (q.f16) { hi = f2h_sat(v); lo = 0; }
   q.wp[((int64_t)n * 2) * q.Kt + kk0] = hi;
   q.wp[((int64_t)n * 2 + 1) * q.Kt + kk0] = lo;
 }
@@ -546,6 +573,7 @@ struct XIgemmParams {
   int CSl, SPSl;                              // ... of the last slab
   int ap;                                     // planes of x multiplied: 2 = hi + lo, 1 = hi only (two MFMAs per product)
   int wplanes;                                // planes of the weights multiplied: 2, or 1 with ap == 1 (ONE MFMA per product; conv_halo64 only)
+  int f16;                                    // with ap == wplanes == 1: x is ONE fp16 plane [pixel][Cpi], the pack's hi rows are fp16
   unsigned y_bytes, m_bytes;                  // pointwise kernel: extents of the output and of the 1-bit masks
   // pointwise kernel, optional tail layer (a second 1x1 conv of <= 4 couts applied to the tile while it is in LDS)
   const u16* wp2; const float* bias2; float* y2; int64_t y2sn, y2sh, y2sw;
@@ -1329,9 +1357,13 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 // WP: planes of the WEIGHTS that are multiplied -- 2: both; 1 (with AP = 1 only): W_hi*A_hi alone, ONE bf16 MFMA per product -- the
 // forward of an un-gated OUTPUT layer in the "bf16x321o" mode (the KPCN chains' 100 -> 441 logits: no ReLU behind it, so the
 // rounding flips no gate; profiles/r04_forward_ladder.txt, table "last").  The lo plane of the pack is neither fetched nor read.
-template <int NT, int NB, int PT = 4, int DBG = 0, int PXST = 0, int AP = 2, int WP = 2>
+// F16 (with AP = 1, WP = 1): the operands are ONE fp16 plane each -- x as [pixel][Cpi] halfs (wcmc_split_to_f16), the weights' hi rows
+// as fp16 (pack mode 4) -- multiplied by v_mfma_f32_16x16x32_f16: 11 bits per operand instead of bf16's 8 at the same MFMA count
+// (the "bf16x321h" mode's output layers; same data movement as the bf16 one-term instance, half the halo bytes per channel pair).
+template <int NT, int NB, int PT = 4, int DBG = 0, int PXST = 0, int AP = 2, int WP = 2, int F16 = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams p0) {
   static_assert(WP == 2 || AP == 1, "one weight plane only together with one pixel plane");
+  static_assert(!F16 || (AP == 1 && WP == 1), "fp16 operands: one plane each");
   XIgemmParams p = p0;
   if (PXST) { p.PXS = PXST; p.ks = 5; }
   constexpr int BN = NT * 16, TH = 4 * PT, TW = 16, NTHR = 256, NWV = 4;
@@ -1370,7 +1402,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
-  const int pixb = 4 * p.Cpi;
+  const int pixb = (F16 ? 2 : 4) * p.Cpi;                // bytes per pixel of x: two bf16 planes, or one fp16 plane
 
   // ---- halo: [pixel][hi cs][lo cs] at stride PXS, one linear run of 16-byte vectors filled by LDS-DMA
   const int VP = p.PXS / 16;
@@ -1546,7 +1578,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
         if (!(DBG & 1)) {
           if (WP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
           if (AP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
+          if (F16) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xf16x8, wh[j]), __builtin_bit_cast(xf16x8, ah[i]), acc[j][i], 0, 0, 0);
+          else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
         }
         // the pixel tile's fragments of stage g+1 replace it as soon as its last MFMAs of this stage have issued
         if (j == NT - 1 && !last_of_slab && !(DBG & 8)) read_a1(i, aoff);
@@ -3383,23 +3416,24 @@ extern "C" int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t d
 // data-gradient orientation in the K order of a TWO-term launch (terms = 2 of wcmc_conv2d_igemm_bf16x3: x hi plane only)
 // 3 = the FORWARD orientation in the K order of a two- / one-term launch (terms <= 2 of a forward launch: the un-gated output layers
 // of the "bf16x321o" mode)
+// 4 = mode 3 with the weights rounded ONCE to fp16 in the hi rows (wcmc_conv2d_out_f16; the lo rows are zero and never read)
 static inline int x_mode_ap(int mode) { return mode >= 2 ? 1 : 2; }
-static inline bool x_mode_fwd(int mode) { return mode == 0 || mode == 3; }
+static inline bool x_mode_fwd(int mode) { return mode == 0 || mode == 3 || mode == 4; }
 extern "C" size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks, int mode) {
-  if (rows <= 0 || kchan <= 0 || ks <= 0 || mode < 0 || mode > 3) return 0;
+  if (rows <= 0 || kchan <= 0 || ks <= 0 || mode < 0 || mode > 4) return 0;
   return (size_t)round_up(rows, 16) * 2 * x_plan_k(kchan, ks, x_mode_ap(mode), rows).Kt;
 }
 
 extern "C" int wcmc_conv2d_pack_weight_bf16x3(const float* w, void* wp, int Cout, int Cin, int ks, int mode,
                                               void* stream) {
-  WCMC_REQUIRE(w && wp && Cout > 0 && Cin > 0 && ks > 0 && mode >= 0 && mode <= 3, WCMC_ERR_BAD_ARG,
+  WCMC_REQUIRE(w && wp && Cout > 0 && Cin > 0 && ks > 0 && mode >= 0 && mode <= 4, WCMC_ERR_BAD_ARG,
                "conv2d_pack_weight_bf16x3: bad argument");
   const int rows = x_mode_fwd(mode) ? Cout : Cin, kchan = x_mode_fwd(mode) ? Cin : Cout;
   const int Np = round_up(rows, 16);
   const XKPlan q = x_plan_k(kchan, ks, x_mode_ap(mode), rows);
   const int64_t total = (int64_t)Np * q.Kt;
   hipLaunchKernelGGL(pack_weight_split_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, x_mode_fwd(mode) ? 0 : 1, rows, Np, q.CS, q.Ks, q.Kt, q.nslabs, q.CSl);
+                     (hipStream_t)stream, w, (u16*)wp, Cout, Cin, ks, x_mode_fwd(mode) ? 0 : 1, rows, Np, q.CS, q.Ks, q.Kt, q.nslabs, q.CSl, mode == 4 ? 1 : 0);
   return check_launch("conv2d_pack_weight_bf16x3");
 }
 
@@ -3411,10 +3445,11 @@ extern "C" int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* 
   t.n = n_entries; t.ks = ks;
   unsigned blocks = 0;
   for (int i = 0; i < n_entries; ++i) {
-    WCMC_REQUIRE(w[i] && wp[i] && Cout[i] > 0 && Cin[i] > 0 && mode[i] >= 0 && mode[i] <= 3, WCMC_ERR_BAD_ARG,
+    WCMC_REQUIRE(w[i] && wp[i] && Cout[i] > 0 && Cin[i] > 0 && mode[i] >= 0 && mode[i] <= 4, WCMC_ERR_BAD_ARG,
                  "conv2d_pack_chain_bf16x3: bad entry %d", i);
     XPackEntry& e = t.e[i];
     e.w = w[i]; e.wp = (u16*)wp[i]; e.Cout = Cout[i]; e.Cin = Cin[i]; e.mode = x_mode_fwd(mode[i]) ? 0 : 1;      // (the kernel knows orientations only)
+    e.f16 = mode[i] == 4 ? 1 : 0;
     e.rows = x_mode_fwd(mode[i]) ? Cout[i] : Cin[i];
     const int kchan = x_mode_fwd(mode[i]) ? Cin[i] : Cout[i];
     e.Np = round_up(e.rows, 16);
@@ -3492,16 +3527,16 @@ static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) 
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
-template <int NT, int NB, int PT, int PXST, int AP = 2, int WP = 2>
+template <int NT, int NB, int PT, int PXST, int AP = 2, int WP = 2, int F16 = 0>
 static int launch_xhalo64c(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
-  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
 }
 template <int NT, int NB, int PT>
@@ -3509,6 +3544,7 @@ static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream
   // the halo pixel stride as a template constant for the two shipped values (NB = 3: 16-channel slabs, 80 B; NB = 2 with
   // 12x16 tiles: 32-channel slabs, 160 B); anything else (WCMC_HALO64_PXS, WCMC_HALO_NB experiments) reads it from the params
   if constexpr (NT == 7 && NB == 3) {
+    if (p.ap == 1 && p.wplanes == 1 && p.f16) return launch_xhalo64c<NT, NB, PT, 80, 1, 1, 1>(p, lds, stream);      // one fp16 MFMA per product ("bf16x321h" output layers)
     if (p.ap == 1 && p.wplanes == 1) return launch_xhalo64c<NT, NB, PT, 80, 1, 1>(p, lds, stream);      // one MFMA per product ("bf16x321o" output layers)
     if (p.ap == 1) return launch_xhalo64c<NT, NB, PT, 80, 1>(p, lds, stream);          // (x_plan_k grants ap = 1 with PXS = 80, ks = 5 only)
   }
@@ -3719,6 +3755,7 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   // one term: where the plan grants the hi-plane instance of the 64-pixel 5x5 kernel (the only one with a one-plane weight path);
   // anywhere else the launch multiplies what the plan's instance multiplies (two or three terms) -- more exact, never less
   p.wplanes = (terms == 1 && q.ap == 1 && ks == 5 && q.PXS == 80) ? 1 : 2;
+  p.f16 = 0;
   p.Kp = p.Cpi; p.Kt = q.Kt; p.Np = round_up(Cout, 16);
   p.CS = q.CS; p.nslabs = q.nslabs; p.SPS = q.Ks / 32; p.PXS = q.halo ? q.PXS : 0;
   p.CSl = q.CSl; p.SPSl = q.Ksl / 32;
@@ -3754,6 +3791,57 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
     case 2: return launch_xigemm<2>(p, st);
     default: return launch_xigemm<1>(p, st);
   }
+}
+
+// ---- the fp16 one-MFMA forward of an un-gated 5x5 output layer ("bf16x321h" mode; profiles/r04_forward_ladder.txt, table "last", rung E)
+static bool x_out_f16_plan(int Cin, int Cout, int ks, XKPlan* q) {
+  if (ks != 5 || Cin <= 0 || Cout <= 0) return false;
+  *q = x_plan_k(Cin, ks, 1, Cout);
+  return q->ap == 1 && q->halo && q->PXS == 80 && x_pick_nt(round_up(Cout, 16) / 16) == 7;
+}
+extern "C" int wcmc_conv2d_out_f16_supported(int Cin, int Cout, int ks) {
+  XKPlan q;
+  return x_out_f16_plan(Cin, Cout, ks, &q) ? 1 : 0;
+}
+extern "C" size_t wcmc_split_to_f16_elems(int N, int H, int W, int C) {
+  return (N > 0 && H > 0 && W > 0 && C > 0) ? (size_t)N * H * W * round_up(C, 8) : 0;
+}
+extern "C" int wcmc_split_to_f16(const void* x_split, int N, int H, int W, int C, void* out_f16, void* stream) {
+  WCMC_REQUIRE(x_split && out_f16 && N > 0 && H > 0 && W > 0 && C > 0, WCMC_ERR_BAD_ARG, "split_to_f16: bad argument");
+  WCMC_REQUIRE(aligned16(x_split) && aligned16(out_f16), WCMC_ERR_ALIGNMENT, "split_to_f16: buffers must be 16-byte aligned");
+  const int Cp = round_up(C, 8);
+  const int64_t total = (int64_t)N * H * W * (Cp / 8);
+  const int64_t blocks = ceil_div64(total, 256);
+  hipLaunchKernelGGL(split_to_f16_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)x_split, (u16*)out_f16, Cp, total);
+  return check_launch("split_to_f16");
+}
+extern "C" int wcmc_conv2d_out_f16(const void* x_f16, int N, int H, int W, int Cin, const void* wp_f16, const float* bias, float* y,
+                                   int64_t ysn, int64_t ysh, int64_t ysw, int Cout, int ks, int pad, void* stream) {
+  WCMC_REQUIRE(x_f16 && wp_f16 && y && N > 0 && H > 0 && W > 0 && pad >= 0, WCMC_ERR_BAD_ARG, "conv2d_out_f16: bad argument");
+  XKPlan q;
+  WCMC_REQUIRE(x_out_f16_plan(Cin, Cout, ks, &q), WCMC_ERR_BAD_ARG,
+               "conv2d_out_f16: no fp16 instance for this shape (ask wcmc_conv2d_out_f16_supported; 5x5, cout blocks of seven tiles)");
+  const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
+  WCMC_REQUIRE(Ho > 0 && Wo > 0, WCMC_ERR_BAD_ARG, "conv2d_out_f16: empty output");
+  WCMC_REQUIRE(aligned16(x_f16) && aligned16(wp_f16) && nhwc_view_ok(y, ysn, ysh, ysw, Cout), WCMC_ERR_ALIGNMENT,
+               "conv2d_out_f16: unaligned operand or y violates the NHWC-view contract");
+  XIgemmParams p = {};
+  p.x = (const u16*)x_f16; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cpi = round_up(Cin, 8);
+  p.wp = (const u16*)wp_f16; p.bias = bias;
+  p.yf = y; p.ysn = ysn; p.ysh = ysh; p.ysw = ysw; p.ys = nullptr; p.Cpo = round_up(Cout, 4);
+  p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+  p.gate = nullptr; p.gate_act = WCMC_ACT_LINEAR; p.gate_slope = 0.f; p.gate_mask = nullptr; p.mask_out = nullptr;
+  p.ks = ks; p.pad = pad; p.act = WCMC_ACT_LINEAR; p.slope = 0.f;
+  p.ap = 1; p.wplanes = 1; p.f16 = 1;
+  p.Kp = p.Cpi; p.Kt = q.Kt; p.Np = round_up(Cout, 16);
+  p.CS = q.CS; p.nslabs = q.nslabs; p.SPS = q.Ks / 32; p.PXS = q.PXS; p.CSl = q.CSl; p.SPSl = q.Ksl / 32;
+  p.tilesY = (Ho + 15) / 16; p.tilesX = (Wo + 15) / 16;
+  p.G = x_colsum_rows(N, Ho, Wo); p.M = (int64_t)N * Ho * Wo;
+  const size_t xb = (size_t)N * H * W * p.Cpi * sizeof(u16), wb = (size_t)p.Np * 2 * p.Kt * sizeof(u16);
+  WCMC_REQUIRE(xb < 0x7ff00000u && wb < 0x40000000u, WCMC_ERR_BAD_ARG, "conv2d_out_f16: operand too large (split the batch)");
+  p.x_bytes = (unsigned)xb; p.wp_bytes = (unsigned)wb; p.colsum = nullptr;
+  return launch_xigemm<7>(p, (hipStream_t)stream);
 }
 
 static bool x_pair_enabled() {
@@ -3797,7 +3885,7 @@ extern "C" int wcmc_conv1x1_pair_bf16x3(const void* x_split, int N, int H, int W
   p.mask_out = (unsigned char*)mask1;
   p.ks = 1; p.pad = 0; p.act = act1; p.slope = slope1;
   p.Kp = p.Cpi; p.Kt = round_up(p.Cpi, 32); p.Np = round_up(Cout1, 16);
-  p.CS = p.Kp; p.nslabs = 1; p.SPS = p.Kt / 32; p.PXS = 0; p.CSl = p.CS; p.SPSl = p.SPS; p.ap = 2; p.wplanes = 2;
+  p.CS = p.Kp; p.nslabs = 1; p.SPS = p.Kt / 32; p.PXS = 0; p.CSl = p.CS; p.SPSl = p.SPS; p.ap = 2; p.wplanes = 2; p.f16 = 0;
   p.tilesY = p.tilesX = 0; p.G = x_colsum_rows(N, H, W); p.colsum = colsum1;
   p.M = (int64_t)N * H * W;
   const int cp2 = round_up(Cout2, 4);

@@ -18,6 +18,14 @@ ACT = {"linear": 0, "relu": 1, "leaky_relu": 2}
 LEAKY_SLOPE = 0.01
 
 # Arithmetic of the conv GEMMs (all HIP paths; WCMC_PRECISION):
+#   "bf16x321h" (opt-in)  "bf16x321" with ONE fp16 MFMA per product (fp16(x) x fp16(W): 11 bits each, the last hidden activation
+#                         converted once by wcmc_split_to_f16) in the forward of a chain's un-gated OUTPUT layer where the library
+#                         has the instance (5x5, linear output: the KPCN chains' 100 -> 441 logits, 30 % of the KPCN forward's
+#                         FLOPs): +2 % step throughput, denoised patches within 1.3e-5.  Not the default: ANY change of the
+#                         outputs, even at 1e-5, moves the sign of the L1 loss' derivative at the pixels whose residual is
+#                         that small, and the parameter gradients move by 1-2e-3 of their norm with it -- C3 1.20e-3 -> 1.41e-3,
+#                         C2 1.42e-3 -> 1.63e-3 against the 2e-3 bar of tests/test_gpu_bench_config.py (green), 1 - cos 2.1e-5
+#                         against 2e-5 in the one-patch test (profiles/r04_forward_ladder.txt)
 #   "bf16x321o" (opt-in)  "bf16x321" with ONE MFMA per product (x_hi x W_hi) in the forward of a chain's un-gated OUTPUT layer
 #                         where the library has the instance (5x5, linear output: the KPCN chains' 100 -> 441 logits, 30 % of the
 #                         KPCN forward's FLOPs).  The forward precision ladder (profiles/r04_forward_ladder.txt) shows why only
@@ -31,14 +39,14 @@ LEAKY_SLOPE = 0.01
 #                         the pixel sums, a rounded W would not; outputs and losses are those of "bf16x3" bit for bit
 #   "bf16x3"              three MFMAs per product in every role (rounds 1-2)
 #   "fp32"                exact fp32 MFMA (conv.hip)
-MODES = ("bf16x321", "bf16x321o", "bf16x3", "fp32")
+MODES = ("bf16x321", "bf16x321h", "bf16x321o", "bf16x3", "fp32")
 PRECISION = os.environ.get("WCMC_PRECISION", MODES[0])
 assert PRECISION in MODES, PRECISION
 
 
 def reduced_backward(mode=None):
     """True in the modes whose backward GEMMs run on two / one MFMAs per product."""
-    return (PRECISION if mode is None else mode) in ("bf16x321o", "bf16x321")
+    return (PRECISION if mode is None else mode) in ("bf16x321h", "bf16x321o", "bf16x321")
 
 
 def _side_stream_default(mode):
@@ -74,6 +82,8 @@ def dgrad_terms():
 def out_layer_terms(ks, act):
     """bf16 MFMAs per product in the FORWARD of a chain's output layer: 1 in the "bf16x321o" mode for a linear (un-gated) 5x5
     output layer -- the shape the library's one-term instance and the measurement behind it cover -- else 3."""
+    if PRECISION == "bf16x321h" and ks == 5 and act == "linear":
+        return "h"                                              # one fp16 MFMA where wcmc_conv2d_out_f16_supported (decided per shape)
     if not (PRECISION == "bf16x321o" and ks == 5 and act == "linear"):
         return 3
     return int(os.environ.get("WCMC_OUT_TERMS", "1"))          # (A/B switch: 2 = x_hi x (W_hi + W_lo), 3 = the "bf16x321" forward)
@@ -473,7 +483,7 @@ def _pack_x(weight, mode):
     """mode 0: forward orientation; 1 / 2: the data-gradient orientation for a three- / two-term launch (_dgrad_mode); 3: the
     forward orientation in the K order of a two- / one-term launch (an output layer of the "bf16x321o" mode)."""
     cout, cin, ks, _ = weight.shape
-    rows, kch = (cout, cin) if mode in (0, 3) else (cin, cout)
+    rows, kch = (cout, cin) if mode in (0, 3, 4) else (cin, cout)
     wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks, mode), device=weight.device, dtype=torch.int16)
     w = weight.detach()
     if not w.is_contiguous():
@@ -486,6 +496,11 @@ def _pack_x(weight, mode):
 # One packing launch per chain (all layers, both orientations: wcmc_conv2d_pack_chain_bf16x3) instead of two per layer:
 # 114 launches per step become 16.  WCMC_PACK_CHAIN=0: A/B switch back to per-layer packing (bit-identical either way).
 PACK_CHAIN = os.environ.get("WCMC_PACK_CHAIN", "1") != "0"
+
+
+def _fwd_pack_mode(out_terms):
+    """Packing mode of an output layer's forward weights: 0 (three terms), 3 (hi-plane K order: two / one bf16 term), 4 (fp16)."""
+    return 4 if out_terms == "h" else 0 if out_terms == 3 else 3
 
 
 def _pack_chain_x(weights, ks, out_terms=3):
@@ -502,8 +517,8 @@ def _pack_chain_x(weights, ks, out_terms=3):
         keep.append(w)
         cout, cin = w.shape[0], w.shape[1]
         pair = []
-        for mode in (3 if (out_terms < 3 and li == n - 1) else 0, _dgrad_mode()):
-            rows, kch = (cout, cin) if mode in (0, 3) else (cin, cout)
+        for mode in (_fwd_pack_mode(out_terms) if li == n - 1 else 0, _dgrad_mode()):
+            rows, kch = (cout, cin) if mode in (0, 3, 4) else (cin, cout)
             wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks, mode), device=dev, dtype=torch.int16)
             ws.append(w.data_ptr()); outs.append(wp.data_ptr()); couts.append(cout); cins.append(cin); modes.append(mode)
             pair.append(wp)
@@ -587,6 +602,19 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     return ret if len(ret) > 1 else out
 
 
+def conv2d_out_f16_raw(xs, dims, wp16, bias, cout, ks, pad):
+    """The forward of an un-gated 5x5 output layer with one fp16 MFMA per product (wcmc_split_to_f16 + wcmc_conv2d_out_f16): xs the
+    split input of dims (n, cin, h, w), wp16 packed with mode 4; returns conv(x, W) + bias as an fp32 NHWC view."""
+    n, cin, h, w = dims
+    ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+    x16 = torch.empty(lib().wcmc_split_to_f16_elems(n, h, w, cin), device=xs.device, dtype=torch.int16)
+    check(lib().wcmc_split_to_f16(_ptr(xs), n, h, w, cin, _ptr(x16), _stream()), "split_to_f16")
+    y = nhwc_empty(n, cout, ho, wo, xs.device)
+    with _Timed(_igemm_class(cin, cout, ks, (n, ho, wo), 1).replace("_x1", "_h1"), 2.0 * n * min(ho * wo, h * w) * cout * cin * ks * ks, "flop"):
+        check(lib().wcmc_conv2d_out_f16(_ptr(x16), n, h, w, cin, _ptr(wp16), _ptr(bias), *_v(y), cout, ks, pad, _stream()), "conv2d_out_f16")
+    return y
+
+
 def conv1x1_pair_x_raw(xs, dims, wp1, b1, cout1, act1, wp2, b2, cout2, act2, gate_mask=None, gate_act="linear",
                        colsum=False, mask_out=True):
     """Two 1x1 layers in one launch (wcmc_conv1x1_pair_bf16x3): returns (split result of the first layer, its 1-bit
@@ -663,10 +691,12 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
             lib().wcmc_conv1x1_pair_supported(params[2 * nl - 4].shape[1], params[2 * nl - 4].shape[0],
                                               params[2 * nl - 2].shape[0]))
     ctx.terms = (wgrad_terms(), dgrad_terms())     # the backward multiplies as the mode of ITS forward says
-    oterms = 3 if pair else out_layer_terms(ks, acts[-1])      # MFMAs per product of the output layer's forward
+    oterms = 3 if pair else out_layer_terms(ks, acts[-1])      # MFMAs per product of the output layer's forward ("h": one, fp16)
+    if oterms == "h" and not lib().wcmc_conv2d_out_f16_supported(params[2 * nl - 2].shape[1], params[2 * nl - 2].shape[0], ks):
+        oterms = 3
     packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks, oterms) if PACK_CHAIN and 2 * nl <= 20 else None
     ctx.wp1 = [pk[1] for pk in packs] if packs is not None else None      # the data-gradient orientation, for the backward
-    pack0 = (lambda l: packs[l][0]) if packs is not None else (lambda l: _pack_x(params[2 * l], 3 if (oterms < 3 and l == nl - 1) else 0))
+    pack0 = (lambda l: packs[l][0]) if packs is not None else (lambda l: _pack_x(params[2 * l], _fwd_pack_mode(oterms) if l == nl - 1 else 0))
     for l in range(nl):
         wt, b = params[2 * l], params[2 * l + 1]
         cout = wt.shape[0]
@@ -684,8 +714,11 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
             xs.append(xs1)
             masks.append(mask1)
             break
-        out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=hidden, mask_out=hidden,
-                           terms=3 if hidden else oterms)
+        if not hidden and oterms == "h":
+            out = conv2d_out_f16_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad)
+        else:
+            out = conv2d_x_raw(xs[l], dims[l], wp, b.detach(), cout, ks, pad, acts[l], out_split=hidden, mask_out=hidden,
+                               terms=3 if hidden else oterms)
         hh, ww = dims[l][2] + 2 * pad - ks + 1, dims[l][3] + 2 * pad - ks + 1
         dims.append((n, cout, hh, ww))
         if hidden:
