@@ -235,9 +235,10 @@ int wcmc_embed3_bwd(const void* x_split, int64_t M, int Cin, const void* wp0, co
                     const float* gm, int gm_pixel_stride, int S, int64_t HW, float gm_scale, float* dw0, float* db0,
                     float* dw1, float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
 /* ---------------------------------------------------------------- PathNet.final, fused (support/networks.py:39-42)
- * out = ConvChain(128 -> 128 -> outc <= 4, ksize 1, ReLU, ReLU)(cat([y, repeat_S(prop)], 1)): y fp32 over M = B*S*HW pixels
- * (64 channels, pixel stride y_pixel_stride floats), prop fp32 over B*HW pixels (64 channels), out fp32 [M][4] (an NHWC view of
- * outc channels); HW % 64 == 0.  Neither the concatenation nor the hidden activation is written: the backward recomputes
+ * out = ConvChain(128 -> 128 -> outc <= 8, ksize 1, ReLU, ReLU)(cat([y, repeat_S(prop)], 1)): y fp32 over M = B*S*HW pixels
+ * (64 channels, pixel stride y_pixel_stride floats), prop fp32 over B*HW pixels (64 channels), out / gout fp32 [M][os] with
+ * os = 4 for outc <= 4, else 8 (an NHWC view of outc channels; round 4: up to eight, the reference's --pnet_out_size 6 runs,
+ * train_kpcn.py:209-212); HW % 64 == 0.  Neither the concatenation nor the hidden activation is written: the backward recomputes
  * them, writes dy [M][64] and dprop [B*HW][64] (the sum over the S samples) and the weight / bias gradients (OIHW, ks = 1) in the
  * default mode's arithmetic.  Forward bit-identical to wcmc_cat_broadcast_split + wcmc_conv1x1_pair_bf16x3.
  *   wp0 / wp1  forward packs (mode 0) of the two layers, wt0 / wt1 their data-gradient packs (mode 1). */

@@ -362,7 +362,8 @@ def test_checkpoint_format_round_trip_and_reference_layouts(tmp_path):
     ck_mod.save_checkpoint(path, itf, epoch=4, args=args, params={"vis": object, "batch_size": 8})
     ck = ck_mod.load_checkpoint(path)
     assert set(ck) == {"description", "start_epoch", "model", "params", "optims", "args", "best_err",
-                       "state_dict_dncnn", "state_dict_backbone_diffuse"}                    # train_kpcn.py:110-121
+                       "state_dict_dncnn", "state_dict_backbone_diffuse",                    # train_kpcn.py:110-121
+                       "wcmc_precision"}                                                     # + this build's one extra key
     assert ck["start_epoch"] == 5 and ck["model"] == str(models["dncnn"]) and ck["params"]["vis"] is None
     assert ck["description"] == "unit" and ck["args"].model_name == "m" and ck["params"]["batch_size"] == 8
 
@@ -392,6 +393,15 @@ def test_checkpoint_format_round_trip_and_reference_layouts(tmp_path):
     ck_mod.restore_optims(old, o3, {"optim_dncnn": 1e-3, "optim_backbone_diffuse": 2e-3}, log=logs.append)
     assert any("No state for the optimizer for backbone_diffuse" in l for l in logs)
     assert len(o3["optim_dncnn"].state_dict()["state"]) > 0 and len(o3["optim_backbone_diffuse"].state_dict()["state"]) == 0
+    # the conv arithmetic of the run travels with the file; a resume under another one says so, a reference file is silent
+    from wcmc_amd import ops
+    assert ck["wcmc_precision"] == ops.PRECISION
+    logs.clear()
+    assert ck_mod.precision_note(ck, log=logs.append) == ops.PRECISION and not logs
+    assert ck_mod.precision_note(dict(ck, wcmc_precision="bf16x3" if ops.PRECISION != "bf16x3" else "fp32"), log=logs.append) is not None
+    assert len(logs) == 1 and "conv arithmetic" in logs[0]
+    logs.clear()
+    assert ck_mod.precision_note(old if "wcmc_precision" not in old else {}, log=logs.append) in (None, ops.PRECISION)
 
 
 def test_tiled_inference_stitches_every_pixel_once():

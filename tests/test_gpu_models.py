@@ -89,6 +89,38 @@ def test_pathnet_matches_oracle(precision):
         fc.check(p.grad, q.grad, 1e-3, what="PathNet grad " + k, l2=2e-2)    # 16-channel test network: 37k units / layer
 
 
+def test_pathnet_with_six_output_channels_runs_the_fused_chains_and_matches_the_oracle():
+    """``--pnet_out_size 6`` (the reference's m10r01 / m11r01 runs, ``train_kpcn.py:209-212``; ``networks.py:23-24``): the default
+    64-wide PathNet with SIX P-buffer channels takes the fused embedding and the fused final chain (round 4 widened
+    ``wcmc_final2_*`` from four to eight output channels) and matches the CPU oracle, forward and gradients."""
+    from wcmc_amd import ops
+    from wcmc_amd.support.networks import PathNet
+    torch.manual_seed(0)
+    ref = OPathNet(36, outc=6)
+    randomize_bias(ref, 1)
+    mod = PathNet(36, outc=6)
+    mod.load_state_dict(ref.state_dict())
+    mod.to(DEV)
+    g = torch.Generator().manual_seed(2)
+    paths = torch.rand(2, 4, 36, 16, 24, generator=g) - 0.4
+    out_r = ref({"paths": paths})
+    gout = torch.rand(out_r.shape, generator=g) - 0.5
+    out_r.backward(gout)
+    calls = []
+    real = ops._FinalFusedX.apply
+    ops._FinalFusedX.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+    try:
+        out = mod({"paths": paths.to(DEV)})
+    finally:
+        ops._FinalFusedX.apply = real
+    assert calls == [1], "the six-channel final chain must take the fused kernel in the default mode"
+    assert out.shape == out_r.shape == (2, 4, 6, 16, 24) and (out >= 0).all()
+    out.backward(gout.to(DEV))
+    assert_close(out, out_r, what="PathNet(outc=6) fwd")
+    for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        grad_close(p.grad, q.grad, 2e-2, "PathNet(outc=6) grad " + k)
+
+
 def test_pathnet_weight_norm_option_matches_oracle():
     """The explicit ``weight_norm=True`` option of the chains (oracle/modules.py ConvChain docstring): forward, and the
     gradients of ``weight_g`` / ``weight_v`` through the HIP chains, against ``torch.nn.utils.weight_norm`` convolutions."""

@@ -779,7 +779,9 @@ def test_fused_embedding_chain_forward_is_bit_identical_and_backward_matches_its
             np.testing.assert_allclose(ps[5].grad.cpu().numpy(), gm.double().sum(dim=(0, 2, 3)).numpy(), rtol=2e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("case", [(2, 3, 8, 8, 3), (1, 1, 16, 12, 4), (2, 8, 16, 16, 3), (8, 8, 64, 64, 3), (3, 2, 8, 24, 1)])
+@pytest.mark.parametrize("case", [(2, 3, 8, 8, 3), (1, 1, 16, 12, 4), (2, 8, 16, 16, 3), (8, 8, 64, 64, 3), (3, 2, 8, 24, 1),
+                                  # round 4: up to eight output channels (--pnet_out_size 6 of the reference's m10r01 / m11r01 runs)
+                                  (2, 8, 16, 16, 6), (1, 2, 8, 24, 8), (2, 3, 8, 8, 5), (8, 8, 32, 32, 6)])
 def test_fused_final_chain_forward_is_bit_identical_and_backward_matches_its_fp64_emulation(case, monkeypatch):
     """``wcmc_final2_fwd`` / ``_bwd`` (PathNet.final with the broadcast concatenation, one launch per direction: concatenation
     and hidden activation on chip / recomputed, d_prop summed over the samples in registers) against the layer-by-layer path
@@ -807,6 +809,8 @@ def test_fused_final_chain_forward_is_bit_identical_and_backward_matches_its_fp6
         out.backward(g.to(DEV))
         res[fused] = (out.detach().clone(), [fd.grad.clone(), pd.grad.clone()] + [t.grad.clone() for t in ps])
     monkeypatch.setattr(o, "DEBUG_ACTS", None)
+    from wcmc_amd._lib import lib
+    assert lib().wcmc_final2_supported(64, 64, 128, outc, h * w) == 1
     assert torch.equal(res[True][0], res[False][0])
     bf = lambda t: t.float().bfloat16().double()
     W0, b0, W1, b1 = [t.double() for t in params]

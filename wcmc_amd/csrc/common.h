@@ -42,6 +42,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, DEVICE): a process-wide "already set" flag leaves the kernel at
+// the 64 KB default on every other GPU of the process.  One LdsAttr per launch site remembers the largest value set
+// per device ordinal; ordinals beyond the table set the attribute on every launch.
+struct LdsAttr { size_t v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
+static inline void set_max_lds(const void* fn, size_t lds, LdsAttr& a) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16) {
+    if (lds <= a.v[dev]) return;
+    a.v[dev] = lds;
+  }
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 }  // namespace wcmc
 
 #define WCMC_REQUIRE(cond, code, ...)  \

@@ -2107,14 +2107,12 @@ static int launch_xpw2(const XIgemmParams& p, hipStream_t stream) {
   constexpr size_t lds = 3 * stage + (stg > red ? stg : red);
   static_assert(lds <= 160 * 1024, "LDS");
   static int cus = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_bf16x3_kernel<NTW, U, SPLIT, TAIL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static LdsAttr attr_set;
+  set_max_lds(reinterpret_cast<const void*>(&conv_pw_bf16x3_kernel<NTW, U, SPLIT, TAIL>), lds, attr_set);
+  if (cus == 0) {                     // (one node holds one kind of GPU: the CU count is read once)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    attr_set = true;
   }
   const int64_t ntiles = ceil_div64(p.M, 64);
   int64_t nb = (int64_t)cus * (U >= 32 ? 1 : 2);
@@ -3114,16 +3112,12 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
     // two stages of NI = 8 (PL = 1: 4) instructions x 8 waves x 1 KB (> the 52 KB staging tile of the slab write)
     constexpr size_t lds8 = (size_t)2 * ((PL * (64 * 14 + 68 * 14) + 511) / 512) * 512 * 16;
     if (PL == 1) {
-      static bool attr81_set = false;
-      if (!attr81_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-        attr81_set = true;
-      }
+      static LdsAttr attr81_set;
+      set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>), (size_t)lds8, attr81_set);
       hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>), grid, dim3(512), lds8, st, q);
       return check_launch("conv2d_wgrad_bf16x3(rows8, one plane)");
     }
-    static bool attr8_set = false;
+    static LdsAttr attr8_set, attr80_set;
 #ifdef WCMC_DEBUG_BUILD
     { const char* e = getenv("WCMC_DEBUG_ABLATE");
       const int ab = e ? atoi(e) : 0;
@@ -3136,13 +3130,8 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
         return check_launch("conv2d_wgrad_bf16x3(rows8 ablation / stamps)");
       } }
 #endif
-    if (!attr8_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-      attr8_set = true;
-    }
+    set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1>), (size_t)lds8, attr8_set);
+    set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 0>), (size_t)lds8, attr80_set);
     if (x_env_on("WCMC_WGRAD_ROWS8_XE")) hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0, 1>), grid, dim3(512), lds8, st, q);
     else hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0, 0>), grid, dim3(512), lds8, st, q);
     return check_launch("conv2d_wgrad_bf16x3(rows8)");
@@ -3161,12 +3150,8 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
     }
   }
 #endif
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<KS, TM, NW, 0, PL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<KS, TM, NW, 0, PL>), (size_t)lds, attr_set);
   hipLaunchKernelGGL((conv_wgrad_rows_bf16x3_kernel<KS, TM, NW, 0, PL>), grid, dim3(NW * 64), lds, st, q);
   return check_launch("conv2d_wgrad_bf16x3(rows)");
 }
@@ -3468,12 +3453,8 @@ static int launch_xigemm3(const XIgemmParams& p, hipStream_t stream) {
   const size_t lds_stage = (size_t)(DBUF ? 2 : 1) * (2 * XBM * XROW + 64 + 2 * NT * 16 * XROW + 64) * sizeof(u16);
   const size_t lds_out = (size_t)XBM * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)16 * NT * 16 * sizeof(float);   // epilogue staging tile + column-sum partials
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  set_max_lds(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>), (size_t)lds, attr_set);
   const dim3 grid((unsigned)ceil_div64(p.M, XBM), (unsigned)((p.Np / 16 + NT - 1) / NT));
   hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3");
@@ -3517,24 +3498,16 @@ static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
 template <int NT, int NB, int AP = 2>
 static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   constexpr int TH = 16, TW = 16;
-  static size_t attr = 0;
-  if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
+  static LdsAttr attr;
+  set_max_lds(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>), lds, attr);
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
 }
 template <int NT, int NB, int PT, int PXST, int AP = 2, int WP = 2, int F16 = 0>
 static int launch_xhalo64c(const XIgemmParams& p, size_t lds, hipStream_t stream) {
-  static size_t attr = 0;
-  if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
+  static LdsAttr attr;
+  set_max_lds(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>), lds, attr);
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
   hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
@@ -3687,22 +3660,14 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)((q.Np / 16 + NT - 1) / NT));
     if constexpr (NT == 4 || NT == 7) {
       if (p.ap == 1) {                           // (x_plan_k grants ap = 1 to this kernel for ks = 3 and NT = 4 or 7 only)
-        static size_t attr81 = 0;
-        if (lds8 > attr81) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2, 1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-          attr81 = lds8;
-        }
+        static LdsAttr attr81;
+        set_max_lds(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2, 1>), lds8, attr81);
         hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2, 1>), grid, dim3(TH8 * TW * 2), lds8, stream, q);
         return check_launch("conv2d_igemm_bf16x3(halo, 8x16, x hi plane)");
       }
     }
-    static size_t attr8 = 0;
-    if (lds8 > attr8) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-      attr8 = lds8;
-    }
+    static LdsAttr attr8;
+    set_max_lds(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>), lds8, attr8);
     hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>), grid, dim3(TH8 * TW * 2), lds8, stream, q);
     return check_launch("conv2d_igemm_bf16x3(halo, 8x16)");
   }

@@ -417,7 +417,9 @@ __global__ __launch_bounds__(256) void embed3_bwd_finish_kernel(const float* __r
 }
 
 // ================================================================== PathNet.final, fused
-//   support/networks.py:39-42:  out = ConvChain(128 -> 128 -> outc <= 4, ksize 1, ReLU, ReLU)(cat([y, repeat_S(prop)], 1))
+//   support/networks.py:39-42:  out = ConvChain(128 -> 128 -> outc <= 8, ksize 1, ReLU, ReLU)(cat([y, repeat_S(prop)], 1))
+// (outc = 3 is the default P-buffer; the reference's m10r01 / m11r01 runs use --pnet_out_size 6, train_kpcn.py:209-212: round 4 widened the
+// output to eight channels -- the lanes q = 0, 1 of the output tile hold couts 0..3, 4..7; out / gout are [M][round_up(outc, 4)] fp32)
 // The layer-by-layer path writes the 128-channel concatenation (537 MB, split) and the 128-channel hidden activation
 // (537 MB + mask) per backbone and direction, re-reads both in the backward, and materialises the 128-channel input
 // gradient (537 MB fp32) only to slice it into d_y and sum the other half over the samples.  Here a workgroup (eight
@@ -437,10 +439,10 @@ struct F2Params {
   int B, S; int64_t HW;
   const u16* wp0; const u16* wp1;          // forward packs: [128][2][128], [16][2][128]
   const float* b0; const float* b1; int outc;
-  float* out;                              // fp32 [M][4]
+  float* out; int os;                      // fp32 [M][os], os = round_up(outc, 4) = 4 or 8
   // backward
   const u16* wt0; const u16* wt1;          // data-gradient packs: [128][2][128] (rows = concat channels), [128][2][32] (rows = hidden channels)
-  const float* gout;                       // fp32 [M][4]
+  const float* gout;                       // fp32 [M][os]
   float* dy; float* dprop;                 // fp32 [M][64], [B*HW][64]
   float* ws;
   unsigned y_bytes, p_bytes, o_bytes, dy_bytes, dp_bytes;
@@ -538,12 +540,12 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
   u16* const DHH = lds + 4 * F2_TILE;                            // (backward) dh, hi plane
   u16* const DOH = lds + 5 * F2_TILE;                            // (backward) gated d_out, hi plane, [64][F2_ORS]
   float* const stg = reinterpret_cast<float*>(HL);               // (backward) d_y tile [64][68] over h's lo plane
-  float* const red = reinterpret_cast<float*>(lds + 5 * F2_TILE + E3_TP * F2_ORS);    // (backward) bias sums [16][128] + [64][4]
+  float* const red = reinterpret_cast<float*>(lds + 5 * F2_TILE + E3_TP * F2_ORS);    // (backward) bias sums [16][128] + [64][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, q = lane >> 4;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)p.prop, 0, (int)p.p_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)(BWD ? (void*)p.gout : (void*)p.out), 0, (int)p.o_bytes, 0x00020000);
-  u16* const W1S = reinterpret_cast<u16*>(red + 16 * F2_C + 64 * 4);                  // (backward) the output layer's pack, [16][F2_W1RS]
+  u16* const W1S = reinterpret_cast<u16*>(red + 16 * F2_C + 64 * 8);                  // (backward) the output layer's pack, [16][F2_W1RS]
   const F2W w0 = f2_load_w(p.wp0, 16 * wave + fr, q);
   // the output layer's one cout tile (rows >= outc are zero): registers in the forward; the backward, which has none to spare
   // (it spilled with them), keeps the 8 KB pack in LDS and reads the fragments where waves 0..3 multiply
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
   if (!BWD) w1 = f2_load_w(p.wp1, fr, q);
   float b0[4], b1[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { b0[e] = p.b0[16 * wave + 4 * q + e]; b1[e] = (q == 0 && e < p.outc) ? p.b1[e] : 0.f; }
+  for (int e = 0; e < 4; ++e) { b0[e] = p.b0[16 * wave + 4 * q + e]; b1[e] = (4 * q + e < p.outc) ? p.b1[4 * q + e] : 0.f; }
+  const int oq = p.os >> 2;                                      // lanes q < oq hold (and move) output channels 4 q .. 4 q + 3
   const int64_t tpi = p.HW / E3_TP;                              // 64-pixel tiles per image (HW % 64 == 0: checked by the host)
   const int64_t nsuper = (int64_t)p.B * tpi;
 
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
     gw1 = f32x4{0.f, 0.f, 0.f, 0.f};
     dyr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
     dpr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dprop, 0, (int)p.dp_bytes, 0x00020000);
-    for (int i = tid; i < E3_TP * F2_ORS / 2; i += 512) reinterpret_cast<unsigned*>(DOH)[i] = 0u;     // channels >= 4 stay zero
+    for (int i = tid; i < E3_TP * F2_ORS / 2; i += 512) reinterpret_cast<unsigned*>(DOH)[i] = 0u;     // channels >= os stay zero
     *reinterpret_cast<u32x4*>(W1S + (tid >> 5) * F2_W1RS + (tid & 31) * 8) = *reinterpret_cast<const u32x4*>(p.wp1 + tid * 8);
   }
 
@@ -588,8 +591,9 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
       const int64_t m0 = (b * p.S + s) * p.HW + hw0;
       f2_store64_split(yp, CH, CL, 0, tid);
       u32x4 go = {0u, 0u, 0u, 0u};
-      // (backward) d_out of pixel 16 wave + fr, for the lane that will hold out of that pixel: waves 0..3, lanes q == 0
-      if (BWD && wave < 4 && q == 0) go = __builtin_amdgcn_raw_buffer_load_b128(orr, (unsigned)(m0 * 16) + (unsigned)((16 * wave + fr) * 16), 0, 0);
+      // (backward) d_out of pixel 16 wave + fr, for the lanes that will hold out of that pixel: waves 0..3, lanes q < oq
+      if (BWD && wave < 4 && q < oq)
+        go = __builtin_amdgcn_raw_buffer_load_b128(orr, (unsigned)(m0 * p.os * 4) + (unsigned)((16 * wave + fr) * p.os * 4 + q * 16), 0, 0);
       if (s + 1 < p.S) yp = f2_load64(yr, (b * p.S + s + 1) * p.HW + hw0, p.y_ps, tid);      // next sample's tile flies under the GEMMs
       __syncthreads();
       // ---- h = relu(W0 c + b0)
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
       f2_gemm<3, 4>(acc, w0, CH, CL, 0, fr, q);
       f2_store_relu_split(acc, b0, HH, HL, wave, fr, q);
       __syncthreads();
-      // ---- out = relu(W1 h + b1): wave w < 4 multiplies pixel tile w; lanes q == 0 hold couts 0..3 of pixel 16 w + fr
+      // ---- out = relu(W1 h + b1): wave w < 4 multiplies pixel tile w; lanes q hold couts 4 q .. 4 q + 3 of pixel 16 w + fr
       float ov[4] = {0.f, 0.f, 0.f, 0.f};
       if (wave < 4) {
         f32x4 a2[1];
@@ -617,20 +621,20 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
           f2_gemm<3, 1>(a2, w1, HH, HL, wave, fr, q);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float t = a2[0][e] + b1[e]; ov[e] = (e < p.outc && t > 0.f) ? t : 0.f; }
+        for (int e = 0; e < 4; ++e) { const float t = a2[0][e] + b1[e]; ov[e] = (4 * q + e < p.outc && t > 0.f) ? t : 0.f; }
       }
       if (!BWD) {
-        if (wave < 4 && q == 0) {
+        if (wave < 4 && q < oq) {
           const u32x4 o4 = {__builtin_bit_cast(unsigned, ov[0]), __builtin_bit_cast(unsigned, ov[1]), __builtin_bit_cast(unsigned, ov[2]),
                             __builtin_bit_cast(unsigned, ov[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(o4, orr, (unsigned)(m0 * 16) + (unsigned)((16 * wave + fr) * 16), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o4, orr, (unsigned)(m0 * p.os * 4) + (unsigned)((16 * wave + fr) * p.os * 4 + q * 16), 0, 0);
         }
         __syncthreads();                                         // h is consumed: the next sample may overwrite the tiles
         continue;
       }
       // ---- backward.  d_o = d_out . [out > 0] (hi plane into its tile; exact sums = the output layer's bias gradient), by the
       // lanes that hold out (no second phase, no gate bits through LDS)
-      if (wave < 4 && q == 0) {
+      if (wave < 4 && q < oq) {
         const int px = 16 * wave + fr;
         u16 hi[4];
 #pragma unroll
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
           sb1[e] += d;
           hi[e] = e3_bf(d);
         }
-        *reinterpret_cast<u32x2*>(DOH + px * F2_ORS) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+        *reinterpret_cast<u32x2*>(DOH + px * F2_ORS + 4 * q) = u32x2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
       }
       __syncthreads();
       // ---- dh = (W1^T d_o) . [h > 0]: this wave's hidden-channel tile, k = the 32-wide step whose channels >= 4 are zero
@@ -714,9 +718,9 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
   float* redb = red;                                             // [16 pixel columns][128 channels], then [64 threads][4]
 #pragma unroll
   for (int e = 0; e < 4; ++e) redb[fr * F2_C + 16 * wave + 4 * q + e] = sb0[e];
-  if (wave < 4 && q == 0) {
+  if (wave < 4 && q < 2) {                                       // (lanes q = 1 hold zeros when os == 4)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) redb[16 * F2_C + (16 * wave + fr) * 4 + e] = sb1[e];
+    for (int e = 0; e < 4; ++e) redb[16 * F2_C + (16 * wave + fr) * 8 + 4 * q + e] = sb1[e];
   }
   __syncthreads();
   if (tid < F2_C) {
@@ -727,8 +731,8 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
   } else if (tid < F2_C + 16) {
     const int c = tid - F2_C;
     float sacc = 0.f;
-    if (c < 4)
-      for (int r = 0; r < 64; ++r) sacc += redb[16 * F2_C + r * 4 + c];
+    if (c < 8)
+      for (int r = 0; r < 64; ++r) sacc += redb[16 * F2_C + r * 8 + c];
     ws[F2_C * F2_C + 16 * F2_C + F2_C + c] = sacc;
   }
 }
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(256) void final2_bwd_finish_kernel(const float* __r
 
 static int f2_grid() { return 256; }
 constexpr size_t F2_LDS_FWD = (size_t)4 * F2_TILE * sizeof(u16);
-constexpr size_t F2_LDS_BWD = (size_t)5 * F2_TILE * sizeof(u16) + (size_t)E3_TP * F2_ORS * sizeof(u16) + (size_t)(16 * F2_C + 64 * 4) * sizeof(float) +
+constexpr size_t F2_LDS_BWD = (size_t)5 * F2_TILE * sizeof(u16) + (size_t)E3_TP * F2_ORS * sizeof(u16) + (size_t)(16 * F2_C + 64 * 8) * sizeof(float) +
                               (size_t)16 * F2_W1RS * sizeof(u16);
 
 static int e3_grid_bwd() { return 256; }
@@ -828,20 +832,20 @@ extern "C" int wcmc_embed3_bwd(const void* x_split, int64_t M, int Cin, const vo
 
 // ---------------------------------------------------------------- PathNet.final, fused
 extern "C" int wcmc_final2_supported(int C1, int C2, int Chid, int outc, int64_t HW) {
-  return C1 == 64 && C2 == 64 && Chid == 128 && outc >= 1 && outc <= 4 && HW > 0 && HW % 64 == 0;
+  return C1 == 64 && C2 == 64 && Chid == 128 && outc >= 1 && outc <= 8 && HW > 0 && HW % 64 == 0;
 }
 extern "C" size_t wcmc_final2_bwd_workspace_bytes(void) { return (size_t)f2_grid() * F2_WS_PER_BLOCK * sizeof(float); }
 
 static int f2_fill(F2Params& p, const float* y, int y_ps, const float* prop, int p_ps, int B, int S, int64_t HW, const void* wp0,
                    const float* b0, const void* wp1, const float* b1, int outc) {
   WCMC_REQUIRE(y && prop && wp0 && wp1 && b0 && b1 && B > 0 && S > 0 && wcmc_final2_supported(64, 64, 128, outc, HW), WCMC_ERR_BAD_ARG,
-               "final2: bad argument (64 + 64 -> 128 -> <= 4 channels, H*W a multiple of 64)");
+               "final2: bad argument (64 + 64 -> 128 -> <= 8 channels, H*W a multiple of 64)");
   WCMC_REQUIRE(aligned16(y) && aligned16(prop) && aligned16(wp0) && aligned16(wp1) && y_ps >= 64 && y_ps % 4 == 0 && p_ps >= 64 && p_ps % 4 == 0,
                WCMC_ERR_ALIGNMENT, "final2: views must be 16-byte aligned with pixel strides that are multiples of 4 floats");
   p.y = y; p.y_ps = y_ps; p.prop = prop; p.p_ps = p_ps; p.B = B; p.S = S; p.HW = HW;
-  p.wp0 = (const u16*)wp0; p.wp1 = (const u16*)wp1; p.b0 = b0; p.b1 = b1; p.outc = outc;
+  p.wp0 = (const u16*)wp0; p.wp1 = (const u16*)wp1; p.b0 = b0; p.b1 = b1; p.outc = outc; p.os = outc <= 4 ? 4 : 8;
   const int64_t M = (int64_t)B * S * HW;
-  const int64_t yb = ((M - 1) * y_ps + 64) * 4, pb = (((int64_t)B * HW - 1) * p_ps + 64) * 4, ob = M * 16;
+  const int64_t yb = ((M - 1) * y_ps + 64) * 4, pb = (((int64_t)B * HW - 1) * p_ps + 64) * 4, ob = M * p.os * 4;
   WCMC_REQUIRE(yb < 0x7ff00000ll && pb < 0x7ff00000ll && M * 256 < 0x7ff00000ll, WCMC_ERR_BAD_ARG, "final2: more than 2 GiB per tensor");
   p.y_bytes = (unsigned)yb; p.p_bytes = (unsigned)pb; p.o_bytes = (unsigned)ob;
   return 0;
@@ -853,11 +857,8 @@ extern "C" int wcmc_final2_fwd(const float* y, int y_pixel_stride, const float* 
   if (int rc = f2_fill(p, y, y_pixel_stride, prop, prop_pixel_stride, B, S, HW, wp0, b0, wp1, b1, outc)) return rc;
   WCMC_REQUIRE(out && aligned16(out), WCMC_ERR_BAD_ARG, "final2_fwd: bad output");
   p.out = out;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&final2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2_LDS_FWD);
-    attr = true;
-  }
+  static LdsAttr attr;
+  set_max_lds(reinterpret_cast<const void*>(&final2_kernel<false>), (size_t)F2_LDS_FWD, attr);
   const int64_t nsuper = (int64_t)B * (HW / 64);
   hipLaunchKernelGGL(final2_kernel<false>, dim3((unsigned)(nsuper < f2_grid() ? nsuper : f2_grid())), dim3(512), F2_LDS_FWD, (hipStream_t)stream, p);
   return check_launch("final2_fwd");
@@ -876,11 +877,8 @@ extern "C" int wcmc_final2_bwd(const float* y, int y_pixel_stride, const float* 
   p.wt0 = (const u16*)wt0; p.wt1 = (const u16*)wt1; p.gout = gout; p.dy = dy; p.dprop = dprop; p.ws = (float*)workspace;
   const int64_t M = (int64_t)B * S * HW;
   p.dy_bytes = (unsigned)(M * 256); p.dp_bytes = (unsigned)((int64_t)B * HW * 256);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&final2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2_LDS_BWD);
-    attr = true;
-  }
+  static LdsAttr attr;
+  set_max_lds(reinterpret_cast<const void*>(&final2_kernel<true>), (size_t)F2_LDS_BWD, attr);
   const int nblk = f2_grid();
   hipLaunchKernelGGL(final2_kernel<true>, dim3((unsigned)nblk), dim3(512), F2_LDS_BWD, (hipStream_t)stream, p);
   if (int rc = check_launch("final2_bwd")) return rc;

@@ -954,8 +954,9 @@ class _FinalFusedX(torch.autograd.Function):
         b = prop.shape[0]
         outc = params[2].shape[0]
         packs = _pack_chain_x([params[0], params[2]], 1)
-        buf = torch.empty((bs, h, w, 4), device=flat.device, dtype=torch.float32)
-        with _Timed("final2_fwd", 4.0 * bs * h * w * (64 + 64 // s + 4), "byte"):
+        osz = 4 if outc <= 4 else 8                           # pixel stride of the output: round_up(outc, 4)
+        buf = torch.empty((bs, h, w, osz), device=flat.device, dtype=torch.float32)
+        with _Timed("final2_fwd", 4.0 * bs * h * w * (64 + 64 // s + osz), "byte"):
             check(lib().wcmc_final2_fwd(_ptr(flat), _dense_pixel_stride(flat), _ptr(prop), _dense_pixel_stride(prop), b, s, h * w,
                                         _ptr(packs[0][0]), _ptr(params[1].detach()), _ptr(packs[1][0]), _ptr(params[3].detach()), outc,
                                         _ptr(buf), _stream()), "final2_fwd")
@@ -968,7 +969,8 @@ class _FinalFusedX(torch.autograd.Function):
         b, s, h, w, outc = ctx.geom
         flat, prop, w0, b0, w1, b1 = ctx.saved_tensors
         g = _as_nhwc_nograd(g)
-        if not (_dense_pixel_stride(g) == 4):
+        osz = 4 if outc <= 4 else 8
+        if not (_dense_pixel_stride(g) == osz):
             g = to_nhwc_raw(g)
         dev = flat.device
         dy = torch.empty((b * s, h, w, 64), device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
@@ -977,7 +979,7 @@ class _FinalFusedX(torch.autograd.Function):
         nb = lib().wcmc_final2_bwd_workspace_bytes()
         ws = torch.empty(nb // 4, device=dev, dtype=torch.float32)
         packs = ctx.packs
-        with _Timed("final2_bwd", 4.0 * b * s * h * w * (64 + 64 // s + 4 + 64 + 64 // s), "byte"):
+        with _Timed("final2_bwd", 4.0 * b * s * h * w * (64 + 64 // s + osz + 64 + 64 // s), "byte"):
             check(lib().wcmc_final2_bwd(_ptr(flat), _dense_pixel_stride(flat), _ptr(prop), _dense_pixel_stride(prop), b, s, h * w,
                                         _ptr(packs[0][0]), _ptr(b0), _ptr(packs[1][0]), _ptr(b1), outc, _ptr(packs[0][1]), _ptr(packs[1][1]),
                                         _ptr(g), _ptr(dy), _ptr(dprop), _ptr(dw0), _ptr(db0), _ptr(dw1), _ptr(db1), _ptr(ws), nb,

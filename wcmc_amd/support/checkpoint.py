@@ -32,10 +32,30 @@ def make_checkpoint(itf, epoch, args, params=None):
         'optims': itf.optims,
         'args': args,
         'best_err': itf.best_err,
+        # not a reference key (the reference's loader ignores it): the conv arithmetic the run trained in (wcmc_amd.ops.MODES) --
+        # the modes differ in the rounding of the backward GEMMs, and a resume under another one is a (legitimate) change of the
+        # optimisation's noise that should not happen unnoticed
+        'wcmc_precision': _precision(),
     }
     for name, model in itf.models.items():
         state['state_dict_' + name] = model.state_dict()
     return state
+
+
+def _precision():
+    from .. import ops
+    return ops.PRECISION
+
+
+def precision_note(ck, log=print):
+    """Say so when a checkpoint is resumed under another conv arithmetic than it was written in; returns the stored
+    mode (None for files of the reference or of rounds 1-3)."""
+    stored = ck.get('wcmc_precision')
+    now = _precision()
+    if stored is not None and stored != now:
+        log("Note: the checkpoint was trained with conv arithmetic '%s'; this run uses '%s' (WCMC_PRECISION / ops.set_precision): "
+            "same model and optimiser state, another rounding of the GEMMs." % (stored, now))
+    return stored
 
 
 def save_checkpoint(path, itf, epoch, args, params=None):

@@ -170,6 +170,8 @@ def init_model(sizes, args, device, group=None):
         assert args.start_epoch != 0 or not os.path.isfile(model_fn), 'Model %s already exists.' % (model_fn)
         is_pretrained = args.start_epoch != 0 and os.path.isfile(model_fn)
         ck = ckpt.load_checkpoint(model_fn) if is_pretrained else None
+        if ck is not None:
+            ckpt.precision_note(ck)
         # upstream sbmc's ConvChain is believed to default to weight normalisation (which sbmc.KPCN switches off and PathNet,
         # support/networks.py:18-24, does not): a checkpoint trained there carries `weight_g` / `weight_v` per PathNet layer
         wn = bool(getattr(args, 'pathnet_weight_norm', False))
