@@ -437,6 +437,12 @@ int wcmc_clip_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
 void wcmc_clip_adam_hyper(double lr, double beta1, double beta2, double eps, int step, float* out7);
 int wcmc_clip_adam_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float clip,
                        float grad_scale, const float* hyper7, const float* guard, void* stream);
+/* The head of the step's captured tail in one launch: losses = n (<= 16) device pointers to the 0-d loss scalars of loss_dict.
+ * flags[i] = isfinite(loss_i) (the reference's check, support/interfaces.py:254-257), flags[n] = guard = all finite AND *ok;
+ * *ok <- guard (a non-finite step keeps the steps enqueued behind it from updating until the host has raised the error and reset
+ * *ok to 1); sums[i] += loss_i when the guard holds (the running sums of interfaces.py:263-267).  flags + n is what
+ * wcmc_clip_adam_dev takes as its guard. */
+int wcmc_step_guard(const float* const* losses, int n, float* ok, float* sums, float* flags, void* stream);
 
 /* ---------------------------------------------------------------- per-image preprocessing (data step before the path)
  * support/datasets.py: DenoiseDataset._preprocess_llpm :302-361, ._preprocess_kpcn :487-582,

@@ -61,9 +61,40 @@ __global__ void clip_adam_kernel(float* __restrict__ param, float* __restrict__ 
   }
 }
 
+// The head of the captured optimiser tail in ONE launch (round 4; it replaced ~10 five-microsecond torch kernels: stack,
+// isfinite, all, cast, multiply, copy, where, add, cat): the reference's non-finite check of loss_dict (interfaces.py:254-257),
+// the device guard of this step's update, and the running loss sums of interfaces.py:263-267.
+//   flags[i] = isfinite(loss_i), flags[n] = guard = (all finite) * ok;  ok <- guard (a failed step poisons the steps enqueued
+//   behind it until the host has raised);  sums[i] += guard ? loss_i : 0.
+constexpr int GUARD_MAX = 16;
+struct GuardArgs { const float* loss[GUARD_MAX]; int n; };
+__global__ __launch_bounds__(64) void step_guard_kernel(GuardArgs a, float* __restrict__ ok, float* __restrict__ sums, float* __restrict__ flags) {
+  const int t = threadIdx.x;
+  const float v = t < a.n ? a.loss[t][0] : 0.f;
+  const bool fin = !(v != v) && fabsf(v) != INFINITY;
+  const unsigned long long bad = __ballot(t < a.n && !fin);
+  const float guard = (bad == 0ull) ? ok[0] : 0.f;             // (ok is 1 or 0)
+  if (t < a.n) {
+    flags[t] = fin ? 1.f : 0.f;
+    if (guard != 0.f) sums[t] += v;
+  }
+  __syncthreads();                                             // (every lane has read ok[0])
+  if (t == 0) { flags[a.n] = guard; ok[0] = guard; }
+}
+
 }  // namespace wcmc
 
 using namespace wcmc;
+
+extern "C" int wcmc_step_guard(const float* const* losses, int n, float* ok, float* sums, float* flags, void* stream) {
+  WCMC_REQUIRE(losses && ok && sums && flags && n >= 1 && n <= GUARD_MAX, WCMC_ERR_BAD_ARG, "step_guard: bad argument (1 <= n <= %d)", GUARD_MAX);
+  GuardArgs a;
+  a.n = n;
+  for (int i = 0; i < GUARD_MAX; ++i) a.loss[i] = i < n ? losses[i] : nullptr;
+  for (int i = 0; i < n; ++i) WCMC_REQUIRE(a.loss[i], WCMC_ERR_BAD_ARG, "step_guard: null loss pointer %d", i);
+  hipLaunchKernelGGL(step_guard_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, ok, sums, flags);
+  return check_launch("step_guard");
+}
 
 extern "C" int wcmc_clip_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float clip,
                               double lr, double beta1, double beta2, double eps, int step, float grad_scale,

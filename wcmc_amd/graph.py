@@ -85,19 +85,30 @@ class GraphedTrainStep:
             # ANY thread invalidates the capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.losses = itf._forward_backward(self.static)
-                if self.tail_captured or self.tail_split:
+                if self.tail_captured:
+                    # finite flags, guard (AND the poison flag), poison update and the running sums of interfaces.py:263-267 (in
+                    # place on one persistent tensor: itf.m_losses holds views) in ONE launch
+                    self.loss_keys = list(self.losses)
+                    fused_guard = all(v.is_cuda and v.dtype == torch.float32 and v.numel() == 1 for v in self.losses.values()) \
+                        and len(self.loss_keys) <= 16
+                    if fused_guard:
+                        self._loss_refs = [self.losses[k].reshape(()) for k in self.loss_keys]
+                        self.flags = torch.empty(len(self.loss_keys) + 1, device=dev)
+                        ops.step_guard_(self._loss_refs, self.ok, self.sums, self.flags)
+                        self.guard = self.flags[len(self.loss_keys):]
+                    else:
+                        vals = torch.stack([self.losses[k].reshape(()) for k in self.loss_keys])
+                        finite = torch.isfinite(vals)
+                        self.guard = finite.all().to(torch.float32).reshape(1) * self.ok
+                        self.ok.copy_(self.guard)
+                        self.sums.add_(torch.where(self.guard > 0, vals, torch.zeros_like(vals)))
+                        self.flags = torch.cat([finite.to(torch.float32), self.guard])
+                    fo.capture_step(itf.models, itf.optims, self.guard)
+                elif self.tail_split:
                     self.loss_keys = list(self.losses)
                     vals = torch.stack([self.losses[k].reshape(()) for k in self.loss_keys])
                     finite = torch.isfinite(vals)
                     local = finite.all().to(torch.float32).reshape(1) * self.ok
-                if self.tail_captured:
-                    self.guard = local
-                    self.ok.copy_(self.guard)
-                    # the running sums of interfaces.py:263-267, in place on one persistent tensor (itf.m_losses holds views)
-                    self.sums.add_(torch.where(self.guard > 0, vals, torch.zeros_like(vals)))
-                    fo.capture_step(itf.models, itf.optims, self.guard)
-                    self.flags = torch.cat([finite.to(torch.float32), self.guard])
-                elif self.tail_split:
                     fo.capture_gather(itf.models, itf.optims, local)
             if self.tail_split:
                 self.graph_b = torch.cuda.CUDAGraph()

@@ -413,6 +413,34 @@ class _ConvChain(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None, None, *grads)
 
 
+# ---- gradient sinks --------------------------------------------------------------------------
+# FusedClipAdam keeps one flat gradient bucket per model (the RCCL message, the clip + Adam kernel's input).  Autograd hands a
+# parameter's gradient to it as whatever tensor the backward returns -- so the weight-gradient kernels write their result
+# STRAIGHT INTO the parameter's slice of the bucket and return that view: AccumulateGrad adopts it (p.grad was None) and the
+# optimiser's gather (three multi-tensor copies, 60 us per step) has nothing left to move.  A parameter whose .grad is already
+# set (a second backward without zero_grad) gets a fresh tensor instead, which autograd accumulates as usual.
+import weakref
+
+_GRAD_SINK = {}
+
+
+def register_grad_sinks(params, views):
+    for p, v in zip(params, views):
+        _GRAD_SINK[p.data_ptr()] = (weakref.ref(p), weakref.ref(v))
+
+
+def _sink(param_ptr, shape, device):
+    """The bucket view a gradient of `shape` for the parameter at `param_ptr` may be written into, or a fresh tensor."""
+    e = _GRAD_SINK.get(param_ptr)
+    if e is not None:
+        p, v = e[0](), e[1]()
+        if p is None or v is None or p.data_ptr() != param_ptr:
+            del _GRAD_SINK[param_ptr]
+        elif p.grad is None and tuple(v.shape) == tuple(shape) and v.device == device:
+            return v.detach()                   # (a new tensor object on the same memory: AccumulateGrad may adopt it)
+    return torch.empty(shape, device=device, dtype=torch.float32)
+
+
 # ---- split-bf16 chain ----------------------------------------------------------------------
 def _split_empty(n, c, h, w, device):
     return torch.empty(lib().wcmc_split_elems(n, h, w, c), device=device, dtype=torch.int16)
@@ -642,15 +670,16 @@ def colsum_finish_raw(part, dims):
     return db
 
 
-def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=True, colsum_part=None, terms=None):
+def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=True, colsum_part=None, terms=None, sinks=(0, 0)):
     """dw (and db) of one layer.  colsum_part: the per-tile column sums of dys that the launch producing dys left; the bias
-    gradient is then finished by the slab-reduction launch itself (no column-sum pass, no finish launch)."""
+    gradient is then finished by the slab-reduction launch itself (no column-sum pass, no finish launch).  sinks: data_ptr of the
+    weight / bias PARAMETER (0: none) -- their gradients go straight into the optimiser's bucket where one is registered."""
     n, cin, h, w = xdims
     ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
     nbytes = lib().wcmc_conv2d_wgrad_bf16x3_workspace_bytes(n, ho, wo, cout, cin, ks)
     ws = torch.empty((nbytes + 3) // 4, device=xs.device, dtype=torch.float32)
-    dw = torch.empty(weight_shape, device=xs.device, dtype=torch.float32)
-    db = torch.empty(cout, device=xs.device, dtype=torch.float32) if (want_bias or colsum_part is not None) else None
+    dw = _sink(sinks[0], weight_shape, xs.device)
+    db = _sink(sinks[1], (cout,), xs.device) if (want_bias or colsum_part is not None) else None
     args = (_ptr(xs), n, h, w, cin, _ptr(dys), cout, ks, pad, _ptr(dw), _ptr(db), _ptr(ws), ws.numel() * 4)
     cs = _ptr(colsum_part)
     terms = wgrad_terms() if terms is None else terms
@@ -727,6 +756,7 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
         else:
             y = out
     ctx.spec, ctx.dims = spec, dims
+    ctx.bias_ptrs = [params[2 * l + 1].data_ptr() if isinstance(params[2 * l + 1], torch.nn.Parameter) else 0 for l in range(nl)]
     keep_y = [y] if acts[-1] != "linear" else []
     extra = tuple(extra_saved(y)) if extra_saved is not None else ()
     ctx.n_extra = len(extra)
@@ -769,6 +799,8 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
     keep = []
     wp1 = getattr(ctx, "wp1", None)
     wterms, dterms = ctx.terms
+    bptrs = getattr(ctx, "bias_ptrs", None) or [0] * nl
+    sink_of = lambda l: (ws[l].data_ptr() if isinstance(ws[l], torch.nn.Parameter) else 0, bptrs[l])
     pack1 = (lambda l: wp1[l]) if wp1 is not None else (lambda l: _pack_x(ws[l], _dgrad_mode(dterms)))
     for l in range(nl - 1, -1, -1):
         wt = ws[l]
@@ -777,7 +809,7 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None,
-                                            colsum_part=part if FUSE_BIAS_GRAD else None, terms=wterms)
+                                            colsum_part=part if FUSE_BIAS_GRAD else None, terms=wterms, sinks=sink_of(l))
                 if part is not None and not FUSE_BIAS_GRAD:
                     db = colsum_finish_raw(part, dims[l + 1])
             dw.record_stream(main)
@@ -786,7 +818,7 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
             keep.append(part)
         else:
             dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None,
-                                        colsum_part=part if FUSE_BIAS_GRAD else None, terms=wterms)
+                                        colsum_part=part if FUSE_BIAS_GRAD else None, terms=wterms, sinks=sink_of(l))
             if part is not None and not FUSE_BIAS_GRAD:
                 db = colsum_finish_raw(part, dims[l + 1])
         grads[2 * l], grads[2 * l + 1] = dw, db
@@ -929,8 +961,8 @@ class _EmbedSppMeanFusedX(torch.autograd.Function):
         if gm is not None and _dense_pixel_stride(gm) is None:
             gm = to_nhwc_raw(gm)
         dev = xs.device
-        dw0, dw1, dw2 = torch.empty_like(w0), torch.empty_like(w1), torch.empty_like(w2)
-        db0, db1, db2 = torch.empty_like(b0), torch.empty_like(b1), torch.empty_like(b2)
+        sk = lambda t: _sink(t.data_ptr() if isinstance(t, torch.nn.Parameter) else 0, t.shape, dev)
+        dw0, dw1, dw2, db0, db1, db2 = sk(w0), sk(w1), sk(w2), sk(b0), sk(b1), sk(b2)
         nb = lib().wcmc_embed3_bwd_workspace_bytes()
         ws = torch.empty(nb // 4, device=dev, dtype=torch.float32)
         packs = ctx.packs
@@ -975,7 +1007,8 @@ class _FinalFusedX(torch.autograd.Function):
         dev = flat.device
         dy = torch.empty((b * s, h, w, 64), device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
         dprop = nhwc_empty(b, 64, h, w, dev)
-        dw0, dw1, db0, db1 = torch.empty_like(w0), torch.empty_like(w1), torch.empty_like(b0), torch.empty_like(b1)
+        sk = lambda t: _sink(t.data_ptr() if isinstance(t, torch.nn.Parameter) else 0, t.shape, dev)
+        dw0, dw1, db0, db1 = sk(w0), sk(w1), sk(b0), sk(b1)
         nb = lib().wcmc_final2_bwd_workspace_bytes()
         ws = torch.empty(nb // 4, device=dev, dtype=torch.float32)
         packs = ctx.packs
@@ -1502,6 +1535,16 @@ def clip_adam_dev_(param, grad, exp_avg, exp_avg_sq, hyper, clip=1.0, grad_scale
     assert hyper.numel() >= 7 and hyper.is_contiguous()
     check(lib().wcmc_clip_adam_dev(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), clip,
                                    grad_scale, _ptr(hyper), _ptr(guard), _stream()), "clip_adam_dev")
+
+
+def step_guard_(losses, ok, sums, flags):
+    """``wcmc_step_guard``: flags[i] = isfinite(losses[i]), flags[n] = guard = all finite and ok; ok <- guard; sums[i] += losses[i]
+    under the guard.  losses: 0-d fp32 device tensors; ok (1), sums (n), flags (n + 1): fp32 device tensors."""
+    n = len(losses)
+    _need_cuda(ok, sums, flags, *losses)
+    assert sums.numel() == n and flags.numel() == n + 1 and sums.is_contiguous() and flags.is_contiguous()
+    arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in losses])
+    check(lib().wcmc_step_guard(arr, n, _ptr(ok), _ptr(sums), _ptr(flags), _stream()), "step_guard")
 
 
 # ---------------------------------------------------------------------------------- data step (SURVEY.md 8f rank 3)

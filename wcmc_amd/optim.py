@@ -70,10 +70,21 @@ class _Flat:
 
     def grad_views(self):
         """Views of the gradient bucket, one per parameter -- built once (a hundred slice + view calls per model and step
-        were ~170 us of host time during which the GPU had nothing to do)."""
+        were ~170 us of host time during which the GPU had nothing to do) and registered as the parameters' gradient sinks
+        (``ops.register_grad_sinks``: the weight-gradient kernels then write into the bucket directly)."""
         if getattr(self, "_gviews", None) is None:
             self._gviews = self._views(self.g)
+            if self.params[0].is_cuda:
+                ops.register_grad_sinks(self.params, self._gviews)
         return self._gviews
+
+    def gather(self, have):
+        """Copy the gradients that are NOT already in the bucket (a gradient a sink received IS its bucket view)."""
+        gv = self.grad_views()
+        idx = [j for j, h in enumerate(have) if h and self.params[j].grad.data_ptr() != gv[j].data_ptr()]
+        if idx:
+            torch._foreach_copy_([gv[j] for j in idx], [self.params[j].grad for j in idx])
+        return len(idx)
 
     def _adopt_state(self, optim):
         """(Re)bind optim.state to views of the flat moments, importing loaded checkpoints."""
@@ -142,6 +153,8 @@ class FusedClipAdam:
         self.collective = self.world > 1 or (bool(force_collective) and process_group is not None)
         order = [n for n in BUCKET_ORDER if n in models] + [n for n in models if n not in BUCKET_ORDER]
         self.flats = {name: _Flat(models[name], optims["optim_" + name]) for name in order}
+        for fl in self.flats.values():
+            fl.grad_views()          # (built now: registers the gradient sinks before the first backward)
         self.last_guard = None       # device float: 1 when every rank's losses were finite at the last step
 
     def step(self, models, optims, guard=None):
@@ -159,12 +172,7 @@ class FusedClipAdam:
                 work.append(None)
                 continue
             # (several ranks must show the same pattern of gradients: the buckets are collectives, one per stepped model)
-            gv = fl.grad_views()
-            if all(have):
-                torch._foreach_copy_(gv, [p.grad for p in fl.params])                       # the gather (device copies)
-            else:
-                idx = [i for i, h in enumerate(have) if h]
-                torch._foreach_copy_([gv[i] for i in idx], [fl.params[i].grad for i in idx])
+            fl.gather(have)                                  # (device copies of whatever a sink did not receive)
             n_msg = fl.total
             if first and guard is not None:
                 fl.g[fl.total:fl.total + 1].copy_((1.0 - guard).reshape(1))
@@ -225,9 +233,7 @@ class FusedClipAdam:
                 continue
             assert len({n for n, h in zip(fl.psteps, have) if h}) == 1, \
                 "a captured optimiser bias-corrects a model's parameters with ONE step count: they must have trained together"
-            gv = fl.grad_views()
-            idx = [j for j, h in enumerate(have) if h]
-            torch._foreach_copy_([gv[j] for j in idx], [fl.params[j].grad for j in idx])
+            fl.gather(have)
             for a, b, _ in fl.segments(have):
                 ops.clip_adam_dev_(fl.flat[a:b], fl.g[a:b], fl.m[a:b], fl.v[a:b], self.hyper[i], clip=self.clip,
                                    grad_scale=1.0, guard=guard)
@@ -251,9 +257,7 @@ class FusedClipAdam:
                 continue
             assert len({n for n, h in zip(fl.psteps, have) if h}) == 1, \
                 "a captured optimiser bias-corrects a model's parameters with ONE step count: they must have trained together"
-            gv = fl.grad_views()
-            idx = [j for j, h in enumerate(have) if h]
-            torch._foreach_copy_([gv[j] for j in idx], [fl.params[j].grad for j in idx])
+            fl.gather(have)
             fl.n_msg = fl.total
             if first:
                 fl.g[fl.total:fl.total + 1].copy_((1.0 - guard).reshape(1))
