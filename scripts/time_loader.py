@@ -8,11 +8,15 @@ import make_golden as mg
 import bench
 from wcmc_amd.support.loader import PatchLoader
 dev = torch.device("cuda", 0)
+if os.environ.get("WCMC_SWITCH"):                      # experiment: the interpreter's thread switch interval (default 5 ms)
+    sys.setswitchinterval(float(os.environ["WCMC_SWITCH"]))
+WORKERS = int(os.environ.get("WCMC_LOADER_WORKERS", "2"))
 H = W = 512; S = 8
 images = [{"raw": mg.raw_samples(H, W, S, 10 + i), "gt": np.random.rand(H, W, 9).astype(np.float32), "prob": None} for i in range(2)]
 reader = lambda i: images[i % 2]
 n_img = 6
-loader = PatchLoader(reader, range(n_img), dev, batch_size=8, patch_size=128)
+loader = PatchLoader(reader, range(n_img), dev, batch_size=8, patch_size=128, workers=WORKERS)
+print("reader / staging workers: %d, switch interval %.4f s" % (WORKERS, sys.getswitchinterval()))
 for _ in loader: pass                                   # warm-up (pinned allocations)
 torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
 for b in loader: nb += 1

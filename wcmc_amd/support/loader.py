@@ -6,8 +6,10 @@ pageable tensors to ``batch[k].cuda()``.  Here the per-image arithmetic runs on 
 ``DenoisePreprocessor``, ``PatchBatcher``), so what is left for the host is to get an image's raw renderer output across
 PCIe without stalling the training stream:
 
-  * ``ImageStager``: a background thread calls the user's ``reader(index)`` (file format and I/O are the caller's: SURVEY.md
-    8 keeps the dataset files out of scope), copies the arrays into a ring of PINNED staging buffers, enqueues the
+  * ``HostReaderPool``: ``workers`` (default 2) reader threads call the user's ``reader(index)`` (file format and I/O are the
+    caller's: SURVEY.md 8 keeps the dataset files out of scope) and copy the arrays into a ring of PINNED staging buffers,
+    several images at once, handed out in order;
+  * ``ImageStager``: a background thread takes the staged images, enqueues the
     host -> device copies and the two preprocessing kernels on a COPY STREAM, and hands over device-resident
     ``(kpcn, llpm, gt, prob)`` behind an event -- image i + 1 crosses PCIe and is preprocessed while the training stream
     is still drawing patches from image i;
@@ -29,13 +31,85 @@ import torch
 from .datasets import DenoisePreprocessor, PatchBatcher
 
 
+class HostReaderPool:
+    """The HOST half of the stager: ``workers`` threads call ``reader(index)`` and copy its arrays into a ring of staging buffers
+    (pinned when a GPU is present), concurrently, while results are handed out IN ORDER of ``indices``.  The reference's
+    ``DataLoader(num_workers=...)`` (``train_kpcn.py:177-188``) is the model: several images are read and staged at once, the
+    training thread never touches a file.  No GPU call in here (``tests/test_cpu_host.py`` runs eight of these side by side).
+
+    Iterating yields ``(slot, prob, nbytes)``: ``slot['raw']`` / ``slot['gt']`` hold the staged arrays; give the slot back with
+    ``release(slot)`` once its contents have been consumed (after the host -> device copy's event, for a pinned slot)."""
+
+    def __init__(self, reader, indices, workers=2, depth=2, pin=None):
+        assert workers >= 1 and depth >= 1
+        self.reader, self.indices = reader, list(indices)
+        self.workers, self.depth = int(workers), int(depth)
+        self.pin = torch.cuda.is_available() if pin is None else bool(pin)
+        self.free_q = queue.Queue()
+        for _ in range(self.depth + self.workers):                    # `depth` handed out + one being filled per worker
+            self.free_q.put({})
+        self.stop = threading.Event()
+
+    def release(self, slot):
+        self.free_q.put(slot)
+
+    def _buffer(self, slot, key, arr):
+        buf = slot.get(key)
+        if buf is None or buf.shape != arr.shape:
+            buf = torch.empty(arr.shape, dtype=torch.float32, pin_memory=self.pin)
+            slot[key] = buf
+        return buf
+
+    def _load(self, i):
+        slot = ImageStager._get(self.free_q, self.stop)               # a staging slot whose last consumer is done with it
+        if slot is None:
+            return None
+        if slot.get('event') is not None:
+            slot['event'].synchronize()                               # (the previous host -> device copy out of this slot)
+        item = self.reader(i)
+        raw = np.ascontiguousarray(item['raw'], dtype=np.float32)
+        gt = np.ascontiguousarray(item['gt'], dtype=np.float32)
+        p_raw, p_gt = self._buffer(slot, 'raw', raw), self._buffer(slot, 'gt', gt)
+        # pageable -> staging through ctypes: the foreign call runs WITHOUT the interpreter lock.  ``Tensor.copy_`` held it for the
+        # whole 0.9 GB memcpy of a 512x512x8-spp image -- the training thread could not enqueue a step meanwhile: +1.4 ms per
+        # step (scripts/time_loader.py)
+        ctypes.memmove(p_raw.data_ptr(), raw.ctypes.data, raw.nbytes)
+        ctypes.memmove(p_gt.data_ptr(), gt.ctypes.data, gt.nbytes)
+        return slot, item.get('prob'), raw.nbytes + gt.nbytes
+
+    def __iter__(self):
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="wcmc-reader")
+        pending, it = collections.deque(), iter(self.indices)
+        try:
+            for i in self.indices[:self.workers]:
+                pending.append(pool.submit(self._load, next(it)))
+            while pending:
+                res = pending.popleft().result()                      # in order of `indices`; reader errors surface here
+                nxt = next(it, None)
+                if nxt is not None and not self.stop.is_set():
+                    pending.append(pool.submit(self._load, nxt))
+                if res is None:
+                    return
+                yield res
+        finally:
+            self.stop.set()
+            for f in pending:
+                f.cancel()
+            pool.shutdown(wait=True)
+
+
 class ImageStager:
     """Iterate ``(kpcn (H,W,44), llpm (H,W,S,37) | None, gt (H,W,9), prob (H,W) numpy | None)`` device buffers of the images
     ``indices``; ``reader(i)`` returns ``{'raw': (H,W,S,C>=104) float32, 'gt': (H,W,9) float32, 'prob': (H,W) | None}`` numpy
     arrays (any object with the buffer protocol that ``torch.from_numpy`` / ``np.asarray`` accepts, e.g. a memmap)."""
 
-    def __init__(self, reader, indices, device, depth=2, use_llpm=True, max_depth=DenoisePreprocessor.MAX_DEPTH):
+    def __init__(self, reader, indices, device, depth=2, use_llpm=True, max_depth=DenoisePreprocessor.MAX_DEPTH, workers=2):
+        """workers: reader / staging threads (``HostReaderPool``): images i + 1 .. i + workers are read from disk and copied
+        into pinned memory concurrently while image i crosses PCIe."""
         assert depth >= 2, "double buffering needs two staging slots"
+        self.workers = max(1, int(workers))
         self.reader, self.indices, self.device = reader, list(indices), torch.device(device)
         if self.device.index is None:                                 # 'cuda' -> the current device, by index (threads need it)
             self.device = torch.device(self.device.type, torch.cuda.current_device())
@@ -43,13 +117,6 @@ class ImageStager:
         self.pre = DenoisePreprocessor(max_depth)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.bytes_moved = 0
-
-    def _pinned_like(self, slot, key, arr):
-        buf = slot.get(key)
-        if buf is None or buf.shape != arr.shape:
-            buf = torch.empty(arr.shape, dtype=torch.float32, pin_memory=True)
-            slot[key] = buf
-        return buf
 
     @staticmethod
     def _get(q, stop):
@@ -72,24 +139,11 @@ class ImageStager:
                 continue
         return False
 
-    def _produce(self, out_q, free_q, stop):
+    def _produce(self, out_q, hostpool, stop):
         try:
             torch.cuda.set_device(self.device)
-            for i in self.indices:
-                slot = self._get(free_q, stop)                        # a staging slot whose last copy has completed
-                if slot is None:                                      # (the consumer abandoned the iteration)
-                    return
-                if slot.get('event') is not None:
-                    slot['event'].synchronize()
-                item = self.reader(i)
-                raw = np.ascontiguousarray(item['raw'], dtype=np.float32)
-                gt = np.ascontiguousarray(item['gt'], dtype=np.float32)
-                p_raw, p_gt = self._pinned_like(slot, 'raw', raw), self._pinned_like(slot, 'gt', gt)
-                # pageable -> pinned on this thread, through ctypes: the foreign call runs WITHOUT the interpreter lock.
-                # ``Tensor.copy_`` held it for the whole 0.9 GB memcpy of a 512x512x8-spp image -- the training thread
-                # could not enqueue a step meanwhile: +1.4 ms per step (scripts/time_loader.py)
-                ctypes.memmove(p_raw.data_ptr(), raw.ctypes.data, raw.nbytes)
-                ctypes.memmove(p_gt.data_ptr(), gt.ctypes.data, gt.nbytes)
+            for slot, prob, nbytes in hostpool:                       # staged images, in order; several are in flight
+                p_raw, p_gt = slot['raw'], slot['gt']
                 with torch.cuda.stream(self.copy_stream):
                     d_raw = p_raw.to(self.device, non_blocking=True)
                     d_gt = p_gt.to(self.device, non_blocking=True)
@@ -98,18 +152,17 @@ class ImageStager:
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
                 slot['event'] = ev
-                self.bytes_moved += raw.nbytes + gt.nbytes
-                if not self._put(out_q, (kpcn, llpm, d_gt, item.get('prob'), ev, slot), stop):
+                self.bytes_moved += nbytes
+                if not self._put(out_q, (kpcn, llpm, d_gt, prob, ev, slot), stop):
                     return
             self._put(out_q, None, stop)
         except BaseException as exc:                                  # surface reader / CUDA errors in the consumer
             self._put(out_q, exc, stop)
 
     def __iter__(self):
-        out_q, free_q, stop = queue.Queue(maxsize=self.depth), queue.Queue(), threading.Event()
-        for _ in range(self.depth):
-            free_q.put({})
-        worker = threading.Thread(target=self._produce, args=(out_q, free_q, stop), daemon=True)
+        out_q, stop = queue.Queue(maxsize=self.depth), threading.Event()
+        hostpool = HostReaderPool(self.reader, self.indices, workers=self.workers, depth=self.depth, pin=True)
+        worker = threading.Thread(target=self._produce, args=(out_q, hostpool, stop), daemon=True)
         worker.start()
         try:
             while True:
@@ -124,11 +177,12 @@ class ImageStager:
                 for t in (kpcn, llpm, gt):
                     if t is not None:
                         t.record_stream(cur)
-                free_q.put(slot)                                      # (its event guards the pinned buffers' reuse)
+                hostpool.release(slot)                                # (its event guards the pinned buffers' reuse)
                 yield kpcn, llpm, gt, prob
         finally:
             stop.set()                                                # the producer's queue waits poll this flag ...
-            free_q.put(None)                                          # ... and a sentinel wakes one that is blocked right now
+            hostpool.stop.set()
+            hostpool.release(None)                                    # ... and a sentinel wakes a reader blocked on the ring
             worker.join(timeout=5.0)
 
 
@@ -136,8 +190,8 @@ class PatchLoader:
     """Batches of the KPCN base model over the staged images; ``len()`` = batches per epoch."""
 
     def __init__(self, reader, indices, device, batch_size=8, patch_size=PatchBatcher.PATCH_SIZE, use_llpm=True, depth=2,
-                 patches_per_image=None, prefetch=2):
-        self.stager = ImageStager(reader, indices, device, depth=depth, use_llpm=use_llpm)
+                 patches_per_image=None, prefetch=2, workers=2):
+        self.stager = ImageStager(reader, indices, device, depth=depth, use_llpm=use_llpm, workers=workers)
         self.batcher = PatchBatcher(patch_size, batch_size)
         if patches_per_image is not None:
             self.batcher.patches_per_image = (patches_per_image // batch_size) * batch_size
