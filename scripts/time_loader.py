@@ -28,6 +28,8 @@ itf = bench.build_interface(dev, None, rng="device")
 from wcmc_amd.graph import GraphedTrainStep
 first = next(iter(loader))
 step = GraphedTrainStep(itf, first)
+if os.environ.get("WCMC_LOADER_PACE", "1") != "0":
+    step.after_enqueue = loader.kick                    # the producer assembles the next batch while this step runs on the GPU
 for b in loader: step(b)                                # warm-up
 # where the difference to resident inputs goes: (a) the same step on one resident batch, (b) on that batch while the loader
 # runs beside it (its batches are drawn and dropped), (c) fed by the loader
@@ -46,6 +48,8 @@ torch.cuda.synchronize(); t = time.perf_counter() - t0
 print("loader feeding the graphed KPCN-Manifold step: %d steps in %.3f s = %.1f patches/s (bench.py on resident inputs: see its line)"
       % (nb, t, nb * 8 / t))
 step2 = GraphedTrainStep(itf, first, defer_check=True)
+if os.environ.get("WCMC_LOADER_PACE", "1") != "0":
+    step2.after_enqueue = loader.kick
 for b in loader: step2(b)
 step2.flush()
 torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0

@@ -176,6 +176,9 @@ class GraphedTrainStep:
                 e1.record()
                 ev.append((e0, e1))
         itf.last_loss_dict = self.losses
+        cb = getattr(self, 'after_enqueue', None)         # (a loader's ``kick``: the step is enqueued, the host is about to wait)
+        if cb is not None:
+            cb()
         if self.defer_check:
             if self._flag_bufs is None:
                 self._flag_bufs = [(torch.empty(self.flags.numel(), dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(2)]

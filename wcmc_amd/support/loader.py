@@ -198,6 +198,19 @@ class PatchLoader:
         self.batch_size = batch_size
         self.assemble_stream = torch.cuda.Stream(device=self.stager.device)
         self.prefetch = max(1, int(prefetch))                         # batches assembled ahead of the consumer
+        # Pacing (``kick``): the producer's Python work for batch t + prefetch competes with the training thread for the
+        # interpreter -- and it used to start exactly when the consumer popped batch t, i.e. while the training thread was
+        # enqueueing step t (copy-in, pairings, hipGraphLaunch: ~1.2 ms of host work with the GPU idle behind it).  A consumer
+        # that calls ``kick()`` once its step is enqueued (``GraphedTrainStep.after_enqueue``) moves that work under the
+        # step's GPU time; without kicks the producer proceeds after a short timeout.
+        self._tick = threading.Semaphore(0)
+        self._paced = False                                           # becomes True with the first kick: un-kicked consumers are not throttled
+        self.pace_timeout = 0.05
+
+    def kick(self):
+        """The consumer has enqueued its step and is about to wait for it: assemble the next batch now."""
+        self._paced = True
+        self._tick.release()
 
     def __len__(self):
         return len(self.stager.indices) * (self.batcher.patches_per_image // self.batch_size)
@@ -235,6 +248,10 @@ class PatchLoader:
                 with torch.cuda.stream(side):
                     origins_dev = torch.as_tensor(origins, dtype=torch.int32).to(dev)      # one copy per image
                     for k in range(0, len(origins), self.batch_size):
+                        if self._paced:
+                            self._tick.acquire(timeout=self.pace_timeout)                  # (see ``kick``)
+                        if stop.is_set():
+                            return
                         batch = self.batcher.batch(kpcn, llpm, gt, origins_dev[k:k + self.batch_size], check=False)
                         ev = torch.cuda.Event()
                         ev.record(side)

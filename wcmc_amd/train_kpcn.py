@@ -66,6 +66,9 @@ def train_epoch_kpcn(epoch, interfaces, dataloaders, params, args):
                 if i not in steps:
                     from .graph import GraphedTrainStep
                     steps[i] = GraphedTrainStep(itf, batch, defer_check=getattr(args, 'defer_check', False))
+                    kick = getattr(dataloaders['train'], 'kick', None)      # support/loader.py: pace the producer thread
+                    if kick is not None and i == len(interfaces) - 1:
+                        steps[i].after_enqueue = kick
                 steps[i](batch)
             else:
                 itf.preprocess(batch)
