@@ -34,21 +34,21 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (not 
 PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
 _ROWS8 = os.environ.get("WCMC_WGRAD_ROWS8", "1")[:1] != "0"     # which filter-row weight-gradient kernel the library launches
 _ROWS8_XE = 0 if os.environ.get("WCMC_WGRAD_ROWS8_XE", "1")[:1] == "0" else 1
-PROFILE_ROUND = "r03"              # profiles/<round>_pmc_summary.json, <round>_bench_kernel_stats.csv: the evidence of THIS binary
+PROFILE_ROUND = "r04"              # profiles/<round>_pmc_summary.json, <round>_bench_kernel_stats.csv: the evidence of THIS binary
 
 
 def rocprof_names(wgrad_terms):
     """profiler class -> the rocprofv3 name of the ONE kernel its launches run (tests/test_cpu_host.py checks every name
     against the committed kernel stats).  Template arguments of conv_halo64: <cout tiles, weight stages, pixel tiles per wave,
-    debug, halo stride, planes of x multiplied>; of conv_wgrad_rows8: <debug, dealing of the left-over tiles, planes multiplied>."""
+    debug, halo stride, planes of x multiplied, planes of W multiplied, fp16 operands>; of conv_wgrad_rows8: <debug, dealing of the left-over tiles, planes multiplied>."""
     return {"conv_halo7": "wcmc::conv_halo_bf16x3_kernel<7, 8, 16, 0, 2, 2>",
-            "conv_halo64_pt4": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 2>",
-            "conv_halo64_pt3": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 2>",
-            "conv_halo64_cs32": "wcmc::conv_halo64_bf16x3_kernel<7, 2, 3, 0, 160, 2>",
-            "conv_halo64_pt4_x2": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1>",
-            "conv_halo64_pt3_x2": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1>",
-            "conv_halo64_pt4_x1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 1>",
-            "conv_halo64_pt3_x1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1>",
+            "conv_halo64_pt4": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 2, 2, 0>",
+            "conv_halo64_pt3": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 2, 2, 0>",
+            "conv_halo64_cs32": "wcmc::conv_halo64_bf16x3_kernel<7, 2, 3, 0, 160, 2, 2, 0>",
+            "conv_halo64_pt4_x2": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 2, 0>",
+            "conv_halo64_pt3_x2": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 2, 0>",
+            "conv_halo64_pt4_x1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 1, 0>",
+            "conv_halo64_pt3_x1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 0>",
             "conv_halo64_pt4_h1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 1, 1>",
             "conv_halo64_pt3_h1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 1>",
             "conv_wgrad_rows": ("wcmc::conv_wgrad_rows8_bf16x3_kernel<0, %d, %d>" % (_ROWS8_XE if wgrad_terms == 3 else 1, 1 if wgrad_terms == 1 else 2)) if _ROWS8
@@ -207,9 +207,10 @@ def pmc_traffic():
         d = json.load(f)
     pick = {}
     for k, v in d.items():
-        for tag, key in (("conv_halo_bf16x3_kernel<7, 8, 16", "conv_halo7"), ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 2>", "conv_halo64_pt4"),
-                         ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 2>", "conv_halo64_pt3"), ("conv_halo64_bf16x3_kernel<7, 2, 3", "conv_halo64_cs32"),
-                         ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1>", "conv_halo64_pt4_x2"), ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1>", "conv_halo64_pt3_x2"),
+        for tag, key in (("conv_halo_bf16x3_kernel<7, 8, 16", "conv_halo7"), ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 2, 2, 0>", "conv_halo64_pt4"),
+                         ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 2, 2, 0>", "conv_halo64_pt3"), ("conv_halo64_bf16x3_kernel<7, 2, 3", "conv_halo64_cs32"),
+                         ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 2, 0>", "conv_halo64_pt4_x2"), ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 2, 0>", "conv_halo64_pt3_x2"),
+                         ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 0>", "conv_halo64_pt3_x1"), ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 1>", "conv_halo64_pt3_h1"),
                          ("conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>" if _ROWS8 else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, 1>", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("embed3_fwd_kernel", "embed3_fwd"), ("embed3_bwd_kernel", "embed3_bwd"),
@@ -219,6 +220,8 @@ def pmc_traffic():
                 shape = ("64x128x128 64->64 1x1 hidden layer (PathNet embedding): 536.9 MB algorithmic" if key == "conv_pw" else
                          "64x128x128: PathNet.embedding 36->64->64->64 (+ spp mean) / PathNet.final 64+64->128->3, the benchmark's shape"
                          if key.startswith(("embed3", "final2")) else
+                         "8x96x96 100->441 5x5 (the KPCN output layer, 92x92 outputs)" if key.endswith(("_x1", "_h1")) else
+                         "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles) and the 100->441 output layer" if key == "conv_halo64_pt3" else
                          "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles)" if key.startswith("conv_halo64_pt3") else
                          "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else "logits (8,441,92,92)")
                 pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "shape": shape,
