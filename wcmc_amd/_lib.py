@@ -45,7 +45,6 @@ SIGNATURES = {
     "wcmc_split_to_f16_elems": (Z, [I, I, I, I]),
     "wcmc_split_to_f16": (I, [P, I, I, I, I, P, P]),
     "wcmc_conv2d_out_f16": (I, [P, I, I, I, I, P, P, P, L, L, L, I, I, I, P]),
-    "wcmc_conv3x3_regw_fwd": (I, [P, I, I, I, P, P, P, I, F, P]),
     "wcmc_conv1x1_pair_supported": (I, [I, I, I]),
     "wcmc_conv1x1_pair_bf16x3": (I, [P, I, I, I, I, P, P, I, I, F, P, P, P, I, F, P, P, P, I, I, F, P, L, L, L, P]),
     "wcmc_conv2d_igemm_colsum_elems": (Z, [I, I, I, I]),
