@@ -443,6 +443,12 @@ int wcmc_clip_adam_dev(float* param, float* grad, float* exp_avg, float* exp_avg
  * *ok to 1); sums[i] += loss_i when the guard holds (the running sums of interfaces.py:263-267).  flags + n is what
  * wcmc_clip_adam_dev takes as its guard. */
 int wcmc_step_guard(const float* const* losses, int n, float* ok, float* sums, float* flags, void* stream);
+/* The same in two halves for several ranks (the reference's nn.DataParallel, train_kpcn.py:256-271, sees one process; here every rank
+ * checks its own losses and all must agree): `local` writes flags[0..n) and this rank's 1 - (all finite AND *ok) into flag_slot -- the
+ * float behind the first gradient bucket, summed over the ranks by the bucket's all-reduce; `global` reads the summed slot: guard =
+ * (slot == 0) -> flags[n], *ok, and sums[i] += loss_i under the guard. */
+int wcmc_step_guard_local(const float* const* losses, int n, const float* ok, float* flags, float* flag_slot, void* stream);
+int wcmc_step_guard_global(const float* const* losses, int n, const float* flag_slot, float* ok, float* sums, float* flags, void* stream);
 
 /* ---------------------------------------------------------------- per-image preprocessing (data step before the path)
  * support/datasets.py: DenoiseDataset._preprocess_llpm :302-361, ._preprocess_kpcn :487-582,

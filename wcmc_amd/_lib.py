@@ -87,6 +87,8 @@ SIGNATURES = {
     "wcmc_clip_adam_hyper": (None, [D, D, D, D, I, P]),
     "wcmc_clip_adam_dev": (I, [P, P, P, P, L, F, F, P, P, P]),
     "wcmc_step_guard": (I, [P, I, P, P, P, P]),
+    "wcmc_step_guard_local": (I, [P, I, P, P, P, P]),
+    "wcmc_step_guard_global": (I, [P, I, P, P, P, P, P]),
     "wcmc_preprocess_llpm": (I, [P, L, I, I, P, P]),
     "wcmc_preprocess_kpcn_workspace_bytes": (Z, [I, I]),
     "wcmc_preprocess_kpcn": (I, [P, I, I, I, I, I, P, P, Z, P]),

@@ -82,9 +82,51 @@ __global__ __launch_bounds__(64) void step_guard_kernel(GuardArgs a, float* __re
   if (t == 0) { flags[a.n] = guard; ok[0] = guard; }
 }
 
+// The same head for the MULTI-RANK tail, in its two halves (wcmc_amd/graph.py: graph A | eager RCCL all-reduces | graph B):
+//   local   flags[i] = isfinite(loss_i); *slot = 1 - (all finite) * ok -- this rank's entry of the flag slot that travels with the first
+//           gradient bucket (after the SUM over the ranks the slot holds the number of ranks that must not update)
+//   global  guard = (*slot == 0): flags[n] = guard, ok <- guard, sums[i] += guard ? loss_i : 0
+__global__ __launch_bounds__(64) void step_guard_local_kernel(GuardArgs a, const float* __restrict__ ok, float* __restrict__ flags, float* __restrict__ slot) {
+  const int t = threadIdx.x;
+  const float v = t < a.n ? a.loss[t][0] : 0.f;
+  const bool fin = !(v != v) && fabsf(v) != INFINITY;
+  const unsigned long long bad = __ballot(t < a.n && !fin);
+  if (t < a.n) flags[t] = fin ? 1.f : 0.f;
+  if (t == 0) slot[0] = 1.f - ((bad == 0ull) ? ok[0] : 0.f);
+}
+__global__ __launch_bounds__(64) void step_guard_global_kernel(GuardArgs a, const float* __restrict__ slot, float* __restrict__ ok, float* __restrict__ sums,
+                                                               float* __restrict__ flags) {
+  const int t = threadIdx.x;
+  const float guard = slot[0] == 0.f ? 1.f : 0.f;
+  if (t < a.n && guard != 0.f) sums[t] += a.loss[t][0];
+  if (t == 0) { flags[a.n] = guard; ok[0] = guard; }
+}
+
 }  // namespace wcmc
 
 using namespace wcmc;
+
+static int guard_args(GuardArgs& a, const float* const* losses, int n) {
+  a.n = n;
+  for (int i = 0; i < GUARD_MAX; ++i) a.loss[i] = i < n ? losses[i] : nullptr;
+  for (int i = 0; i < n; ++i)
+    if (!a.loss[i]) return -1;
+  return 0;
+}
+extern "C" int wcmc_step_guard_local(const float* const* losses, int n, const float* ok, float* flags, float* flag_slot, void* stream) {
+  WCMC_REQUIRE(losses && ok && flags && flag_slot && n >= 1 && n <= GUARD_MAX, WCMC_ERR_BAD_ARG, "step_guard_local: bad argument (1 <= n <= %d)", GUARD_MAX);
+  GuardArgs a;
+  WCMC_REQUIRE(guard_args(a, losses, n) == 0, WCMC_ERR_BAD_ARG, "step_guard_local: null loss pointer");
+  hipLaunchKernelGGL(step_guard_local_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, ok, flags, flag_slot);
+  return check_launch("step_guard_local");
+}
+extern "C" int wcmc_step_guard_global(const float* const* losses, int n, const float* flag_slot, float* ok, float* sums, float* flags, void* stream) {
+  WCMC_REQUIRE(losses && ok && sums && flags && flag_slot && n >= 1 && n <= GUARD_MAX, WCMC_ERR_BAD_ARG, "step_guard_global: bad argument (1 <= n <= %d)", GUARD_MAX);
+  GuardArgs a;
+  WCMC_REQUIRE(guard_args(a, losses, n) == 0, WCMC_ERR_BAD_ARG, "step_guard_global: null loss pointer");
+  hipLaunchKernelGGL(step_guard_global_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, flag_slot, ok, sums, flags);
+  return check_launch("step_guard_global");
+}
 
 extern "C" int wcmc_step_guard(const float* const* losses, int n, float* ok, float* sums, float* flags, void* stream) {
   WCMC_REQUIRE(losses && ok && sums && flags && n >= 1 && n <= GUARD_MAX, WCMC_ERR_BAD_ARG, "step_guard: bad argument (1 <= n <= %d)", GUARD_MAX);

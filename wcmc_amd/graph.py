@@ -106,17 +106,29 @@ class GraphedTrainStep:
                     fo.capture_step(itf.models, itf.optims, self.guard)
                 elif self.tail_split:
                     self.loss_keys = list(self.losses)
-                    vals = torch.stack([self.losses[k].reshape(()) for k in self.loss_keys])
-                    finite = torch.isfinite(vals)
-                    local = finite.all().to(torch.float32).reshape(1) * self.ok
-                    fo.capture_gather(itf.models, itf.optims, local)
+                    fused_guard = all(v.is_cuda and v.dtype == torch.float32 and v.numel() == 1 for v in self.losses.values()) \
+                        and len(self.loss_keys) <= 16
+                    if fused_guard:                                   # finite flags + this rank's flag-slot entry in one launch
+                        self._loss_refs = [self.losses[k].reshape(()) for k in self.loss_keys]
+                        self.flags = torch.empty(len(self.loss_keys) + 1, device=dev)
+                        fo.capture_gather(itf.models, itf.optims, None)
+                        ops.step_guard_local_(self._loss_refs, self.ok, self.flags, fo.flag_slot())
+                    else:
+                        vals = torch.stack([self.losses[k].reshape(()) for k in self.loss_keys])
+                        finite = torch.isfinite(vals)
+                        local = finite.all().to(torch.float32).reshape(1) * self.ok
+                        fo.capture_gather(itf.models, itf.optims, local)
             if self.tail_split:
                 self.graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode="thread_local"):
-                    self.guard = fo.capture_update()                  # 1 when NO rank saw a non-finite loss
-                    self.ok.copy_(self.guard)
-                    self.sums.add_(torch.where(self.guard > 0, vals, torch.zeros_like(vals)))
-                    self.flags = torch.cat([finite.to(torch.float32), self.guard])
+                    if fused_guard:                                   # global guard, poison flag, loss sums in one launch
+                        ops.step_guard_global_(self._loss_refs, fo.flag_slot(), self.ok, self.sums, self.flags)
+                        self.guard = fo.capture_update(self.flags[len(self.loss_keys):])
+                    else:
+                        self.guard = fo.capture_update()              # 1 when NO rank saw a non-finite loss
+                        self.ok.copy_(self.guard)
+                        self.sums.add_(torch.where(self.guard > 0, vals, torch.zeros_like(vals)))
+                        self.flags = torch.cat([finite.to(torch.float32), self.guard])
         finally:
             ops.USE_SIDE_STREAM = side
         if fo is not None:

@@ -1547,6 +1547,24 @@ def step_guard_(losses, ok, sums, flags):
     check(lib().wcmc_step_guard(arr, n, _ptr(ok), _ptr(sums), _ptr(flags), _stream()), "step_guard")
 
 
+def step_guard_local_(losses, ok, flags, flag_slot):
+    """``wcmc_step_guard_local`` (multi-rank tail, graph A): flags[i] = isfinite(losses[i]); flag_slot[0] = 1 - (all finite and ok)."""
+    n = len(losses)
+    _need_cuda(ok, flags, flag_slot, *losses)
+    assert flags.numel() == n + 1 and flags.is_contiguous()
+    arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in losses])
+    check(lib().wcmc_step_guard_local(arr, n, _ptr(ok), _ptr(flags), _ptr(flag_slot), _stream()), "step_guard_local")
+
+
+def step_guard_global_(losses, flag_slot, ok, sums, flags):
+    """``wcmc_step_guard_global`` (multi-rank tail, graph B): guard = (flag_slot[0] == 0) -> flags[n], ok; sums[i] += losses[i] under it."""
+    n = len(losses)
+    _need_cuda(ok, sums, flags, flag_slot, *losses)
+    assert sums.numel() == n and flags.numel() == n + 1
+    arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in losses])
+    check(lib().wcmc_step_guard_global(arr, n, _ptr(flag_slot), _ptr(ok), _ptr(sums), _ptr(flags), _stream()), "step_guard_global")
+
+
 # ---------------------------------------------------------------------------------- data step (SURVEY.md 8f rank 3)
 def _need_dense(t, ndim):
     if not t.is_cuda or t.dtype != torch.float32 or t.dim() != ndim or not t.is_contiguous():

@@ -260,7 +260,8 @@ class FusedClipAdam:
             fl.gather(have)
             fl.n_msg = fl.total
             if first:
-                fl.g[fl.total:fl.total + 1].copy_((1.0 - guard).reshape(1))
+                if guard is not None:                        # (None: the caller fills flag_slot() itself -- ops.step_guard_local_)
+                    fl.g[fl.total:fl.total + 1].copy_((1.0 - guard).reshape(1))
                 fl.n_msg = fl.total + _ALIGN
                 self._first_fl = fl
             first = False
@@ -273,9 +274,15 @@ class FusedClipAdam:
         for w in works:
             w.wait()
 
-    def capture_update(self):
-        """Graph B; returns the global guard (device float: 1 when no rank saw a non-finite loss)."""
-        gguard = (self._first_fl.g[self._first_fl.total] == 0).to(torch.float32).reshape(1)
+    def flag_slot(self):
+        """The float behind the first stepped bucket that carries 1 - guard of every rank through that bucket's all-reduce."""
+        return self._first_fl.g[self._first_fl.total:self._first_fl.total + 1]
+
+    def capture_update(self, gguard=None):
+        """Graph B; returns the global guard (device float: 1 when no rank saw a non-finite loss).  gguard: that guard when the caller
+        has already formed it (ops.step_guard_global_)."""
+        if gguard is None:
+            gguard = (self._first_fl.g[self._first_fl.total] == 0).to(torch.float32).reshape(1)
         for i, (name, fl, stepped, have) in enumerate(self._captured):
             if not stepped:
                 continue
