@@ -90,6 +90,7 @@ if __name__ == "__main__":
         d = deviations(res[a][0], res[b][0])
         print("# %-8s vs %-6s: " % (a, b) + "  ".join("%s %.1e|%.1e|%.1e|%.1e" % ((k,) + d[k]) for k in KEYS))
     print("%5s | %s" % ("step", " | ".join("%-38s" % (k + " (fp32, bf16x3, %s)" % DEF) for k in KEYS)))
+    every = 1 if steps <= 250 else 10
     for i in range(steps):
-        if True:
+        if i < 20 or i % every == every - 1:
             print("%5d | %s" % (i + 1, " | ".join("%.6f %.6f %.6f              " % tuple(res[m][0][k][i] for m in ("fp32", "bf16x3", DEF)) for k in KEYS)))
