@@ -592,7 +592,10 @@ def main():
                        "launch": ("eager" if args.eager else
                                   "one hipGraph replay per step, optimiser tail (finite check, loss sums, gradient gather, clip + Adam) captured in it"
                                   if graphed.tail_captured else
-                                  "one hipGraph replay per step (forward + backward) + eager RCCL all-reduce of three buckets + eager clip + Adam"),
+                                  "two hipGraph replays per step around three eager asynchronous all-reduces of the gradient buckets: graph A = forward, "
+                                  "backward, gradient hand-over, guard flag; graph B = global guard, loss sums, scale -> clip -> Adam"
+                                  if graphed.tail_split else
+                                  "one hipGraph replay per step (forward + backward) + eager all-reduce of three buckets + eager clip + Adam"),
                        "feature_mse_rng": "cpu (reference stream)" if args.cpu_rng else "device",
                        "precision": (("conv GEMMs: split-bf16 operands (hi + lo planes), v_mfma_f32_16x16x32_bf16, fp32 accumulate; per "
                                       "product 3 MFMAs in the forward (hi*hi + hi*lo + lo*hi)%s, 2 in the data gradients that have a "

@@ -99,4 +99,5 @@ def time_allreduce(fused_optim, group, device, iters=10):
             "algbw_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1), "ranks": dist.get_world_size(group),
             "backend": dist.get_backend(group),
             "note": "the three gradient buckets alone, back to back, outside the timed region; inside a step they are issued "
-                    "asynchronously and the clip + Adam of bucket i runs while buckets i+1.. are on the wire"}
+                    "asynchronously in backward order between the step's two graphs (eager steps: the clip + Adam of bucket i runs "
+                    "while buckets i+1.. are on the wire)"}
