@@ -266,7 +266,7 @@ def c2_leg(device, steps, warmup):
             "losses_last_step": {k: round(float(v), 6) for k, v in itf.last_loss_dict.items()}}
 
 
-def extra_leg(device, steps, warmup, precision=None, group=None, force_collective=False):
+def extra_leg(device, steps, warmup, precision=None, group=None, force_collective=False, overlap=False):
     """The benchmarked step once more in another configuration, graphed, same weights (seed 0) and batch: another arithmetic
     (`other_precisions`), or the default one with the MULTI-RANK tail on a one-rank RCCL group (`multi_rank_path`)."""
     from wcmc_amd import ops
@@ -279,10 +279,11 @@ def extra_leg(device, steps, warmup, precision=None, group=None, force_collectiv
     try:
         itf = build_interface(device, None, rng="device")
         if force_collective:
-            itf.fused_optim = FusedClipAdam(itf.models, itf.optims, process_group=group, force_collective=True)
+            itf.fused_optim = FusedClipAdam(itf.models, itf.optims, process_group=group, force_collective=True,
+                                            order=("dncnn", "backbone_diffuse", "backbone_specular") if overlap else None)
         batch = make_batch(B_PER_GPU, SPP, PATCH, seed=0, device=device)
         torch.manual_seed(1234)
-        graphed = GraphedTrainStep(itf, batch)
+        graphed = GraphedTrainStep(itf, batch, overlap_allreduce=overlap)
         for _ in range(warmup):
             graphed(batch)
         if force_collective:
@@ -664,6 +665,14 @@ def main():
                     mr["predicted_weak_scaling_ceiling"] = round(line["ms_per_step"] / mr["ms_per_step"], 4)
                     mr["ceiling_note"] = ("single-graph step time / multi-rank-path step time on this box: an upper bound of the "
                                           "N-rank efficiency before any wire time or skew; no scaling curve has been measured")
+                    # the same with the backward cut at the P-buffers (three graphs: the dncnn bucket is on the wire while the PathNets'
+                    # backward runs) -- what the overlap COSTS on one rank (its benefit needs a wire to hide)
+                    ov = extra_leg(device, args.steps, args.warmup, group=torch.distributed.group.WORLD, force_collective=True, overlap=True)
+                    mr["overlap_allreduce"] = {"value": ov["value"], "ms_per_step": ov["ms_per_step"], "tail_ms": ov["tail_ms"],
+                                               "losses_last_step": ov["losses_last_step"],
+                                               "what": "graph A1 (... dncnn backward) | async all-reduce of the dncnn bucket || graph A2 (PathNet "
+                                                       "backward) | all-reduces of the PathNet buckets | graph B; GraphedTrainStep(overlap_allreduce=True), "
+                                                       "off by default"}
                     line["multi_rank_path"] = mr
                     torch.distributed.destroy_process_group()
                 except Exception as err:                       # (reported, never fatal for the headline)

@@ -706,7 +706,9 @@ def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path(rccl
         assert dist.get_backend() == "nccl"
         results = {}
         for coll in (False, True):
-            for graphed in (False, True):
+            for graphed in (False, True, "overlap"):
+                if graphed == "overlap" and not coll:
+                    continue
                 torch.manual_seed(21)
                 kw = dict(ksize=21, depth=3, width=24)
                 models = {"dncnn": KPCN(39, **kw), "backbone_diffuse": PathNet(36, intermc=16),
@@ -718,15 +720,18 @@ def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path(rccl
                       "l_test": RelativeMSE(), "l_manif": FeatureMSE(non_local=True, rng="cpu")}
                 itf = KPCNInterface(models, optims, lf, types.SimpleNamespace(model_name="g"), use_llpm_buf=True,
                                     manif_learn=True, w_manif=0.1, train_branches=True)
-                fo = FusedClipAdam(models, optims, process_group=dist.group.WORLD if coll else None, force_collective=coll)
+                # "overlap": the backward cut at the P-buffers, the dncnn bucket's all-reduce issued while the PathNets' backward
+                # (a third graph) runs -- SURVEY 8e's overlap, again on the one-rank group
+                fo = FusedClipAdam(models, optims, process_group=dist.group.WORLD if coll else None, force_collective=coll,
+                                   order=("dncnn", "backbone_diffuse", "backbone_specular") if graphed == "overlap" else None)
                 assert fo.collective == coll and fo.world == 1
                 itf.fused_optim = fo
                 itf.iters = 1
                 itf.to_train_mode()
                 batches = [make_batch(2, 4, 48, seed=30 + i, device=DEV) for i in range(3)]
                 if graphed:
-                    step = GraphedTrainStep(itf, batches[0])
-                    assert step.tail_split == coll and step.tail_captured == (not coll)
+                    step = GraphedTrainStep(itf, batches[0], overlap_allreduce=(graphed == "overlap"))
+                    assert step.tail_split == coll and step.tail_captured == (not coll) and step.overlap == (graphed == "overlap")
                 else:
                     def step(b):
                         itf.preprocess(b)
@@ -734,7 +739,7 @@ def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path(rccl
                 torch.manual_seed(22)
                 for b in batches:
                     step(b)
-                state = lambda: torch.cat([torch.cat([fl.flat, fl.m, fl.v]) for fl in fo.flats.values()]).clone()
+                state = lambda: torch.cat([torch.cat([fo.flats[n].flat, fo.flats[n].m, fo.flats[n].v]) for n in sorted(fo.flats)]).clone()
                 results[(coll, graphed)] = (state(), {k: v.item() for k, v in itf.m_losses.items()}, [fl.steps for fl in fo.flats.values()])
                 if coll:
                     # the rank-global guard through the flag slot of the first bucket: nothing moves, the reference's error is raised

@@ -17,12 +17,22 @@ from . import ops
 class GraphedTrainStep:
     """``step = GraphedTrainStep(itf, example_batch); step(batch)`` == ``itf.preprocess(batch); itf.train_batch(batch)``."""
 
-    def __init__(self, itf, batch, warmup=2, side_stream=True, capture_optimizer=True, defer_check=False):
+    def __init__(self, itf, batch, warmup=2, side_stream=True, capture_optimizer=True, defer_check=False, overlap_allreduce=False,
+                 cut_backward=False):
         """``defer_check`` (captured optimiser only): the non-finite-loss check of step t -- the step's one host sync -- is made
         after step t + 1 has been enqueued, so the host prepares the next batch while the GPU runs (a loader-fed loop gains
         what the sync-then-prepare gap cost).  The device guard still skips the update of a non-finite step at once; the
         reference's error (``interfaces.py:254-257``) is raised one call later, or by ``flush()``, which the epoch loop calls
-        after its last step."""
+        after its last step.
+
+        ``overlap_allreduce`` (several ranks, PathNets in use; build ``FusedClipAdam(order=('dncnn', ...))``): the backward is cut at
+        the P-buffers -- graph A1 ends when the gradients of ``dncnn`` are complete, their bucket's all-reduce is issued, graph A2
+        (the PathNets' backward) runs while it is on the wire, then the PathNet buckets follow, then graph B.  SURVEY 8e's
+        "bucketed in backward order, overlapped with the remaining backward"; bit-identical to the two-graph step
+        (``tests/test_gpu_models.py::test_collective_branch_...``).  Off by default: what it hides (half of 46.8 MB over xGMI) has
+        never been measured against what the extra graph boundary costs (both halves of the step join there).
+        ``cut_backward``: the same cut inside ONE graph (an experiment switch: it buys nothing once both branch losses share one
+        engine run, ``KPCNInterface._backward``)."""
         self.itf = itf
         self.static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
         self.keys = list(self.static)                     # (PathNet stashes a converted copy of `paths` in the dict)
@@ -67,6 +77,10 @@ class GraphedTrainStep:
         coll = fo is not None and getattr(fo, 'collective', fo.world > 1)
         self.tail_captured = (capture_optimizer and fo is not None and not coll and itf.grad_sync is None)
         self.tail_split = (capture_optimizer and coll and itf.grad_sync is None)
+        self.overlap = bool(overlap_allreduce) and self.tail_split and itf.use_llpm_buf
+        if self.overlap:
+            assert next(iter(fo.flats)) == 'dncnn', "overlap_allreduce: build FusedClipAdam(order=('dncnn', ...)) -- its bucket goes first"
+        self.cut = self.overlap or bool(cut_backward)
         self.defer_check = bool(defer_check) and self.tail_captured
         self._pending, self._flag_bufs, self._n_calls = None, None, 0
         if self.tail_captured or self.tail_split:
@@ -84,7 +98,9 @@ class GraphedTrainStep:
             # stream) may allocate while this thread captures -- in the default 'global' mode a hipHostMalloc / hipMalloc from
             # ANY thread invalidates the capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.losses = itf._forward_backward(self.static)
+                self.losses = itf._forward_backward(self.static, cut=self.cut)
+                if self.cut and not self.overlap:
+                    itf._backward_stage2()                            # (same graph: the PathNets' backward as one more engine run)
                 if self.tail_captured:
                     # finite flags, guard (AND the poison flag), poison update and the running sums of interfaces.py:263-267 (in
                     # place on one persistent tensor: itf.m_losses holds views) in ONE launch
@@ -111,13 +127,20 @@ class GraphedTrainStep:
                     if fused_guard:                                   # finite flags + this rank's flag-slot entry in one launch
                         self._loss_refs = [self.losses[k].reshape(()) for k in self.loss_keys]
                         self.flags = torch.empty(len(self.loss_keys) + 1, device=dev)
-                        fo.capture_gather(itf.models, itf.optims, None)
+                        fo.capture_gather(itf.models, itf.optims, None, names=('dncnn',) if self.overlap else None)
                         ops.step_guard_local_(self._loss_refs, self.ok, self.flags, fo.flag_slot())
                     else:
                         vals = torch.stack([self.losses[k].reshape(()) for k in self.loss_keys])
                         finite = torch.isfinite(vals)
                         local = finite.all().to(torch.float32).reshape(1) * self.ok
-                        fo.capture_gather(itf.models, itf.optims, local)
+                        fo.capture_gather(itf.models, itf.optims, local, names=('dncnn',) if self.overlap else None)
+            if self.overlap:
+                self._rest = tuple(n for n in fo.flats if n != 'dncnn')
+                self.graph_a2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_a2, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                    itf._backward_stage2()                            # through the PathNets, from the P-buffers' gradients
+                    fo.capture_gather(itf.models, itf.optims, None, names=self._rest)
+                fo._gather_open = False
             if self.tail_split:
                 self.graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode="thread_local"):
@@ -182,7 +205,14 @@ class GraphedTrainStep:
             if ev is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            fo.allreduce()                                # eager: three asynchronous RCCL sums, the launch stream waits for them
+            if self.overlap:
+                works = fo.allreduce_async(('dncnn',))    # on the wire while the PathNets' backward runs
+                self.graph_a2.replay()
+                works += fo.allreduce_async(self._rest)
+                for w in works:
+                    w.wait()
+            else:
+                fo.allreduce()                            # eager: three asynchronous RCCL sums, the launch stream waits for them
             self.graph_b.replay()
             if ev is not None:
                 e1.record()

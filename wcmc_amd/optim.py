@@ -142,7 +142,7 @@ class _Flat:
 
 
 class FusedClipAdam:
-    def __init__(self, models, optims, process_group=None, clip=1.0, force_collective=False):
+    def __init__(self, models, optims, process_group=None, clip=1.0, force_collective=False, order=None):
         """force_collective: run the bucket all-reduces even on a ONE-rank process group (a sum over one rank is the identity:
         results are those of the world-1 path bit for bit) -- the multi-rank code path, exercised where only one GPU is at hand
         (tests/test_gpu_models.py, the `multi_rank_path` leg of bench.py)."""
@@ -151,7 +151,10 @@ class FusedClipAdam:
         self.group = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.collective = self.world > 1 or (bool(force_collective) and process_group is not None)
-        order = [n for n in BUCKET_ORDER if n in models] + [n for n in models if n not in BUCKET_ORDER]
+        # order: the bucket order (default BUCKET_ORDER: the order the reference's two backward passes complete the models); a
+        # step whose backward is cut at the P-buffers (GraphedTrainStep(overlap_allreduce=True)) finishes `dncnn` first
+        base = tuple(order) if order is not None else BUCKET_ORDER
+        order = [n for n in base if n in models] + [n for n in models if n not in base]
         self.flats = {name: _Flat(models[name], optims["optim_" + name]) for name in order}
         for fl in self.flats.values():
             fl.grad_views()          # (built now: registers the gradient sinks before the first backward)
@@ -242,11 +245,17 @@ class FusedClipAdam:
     #   graph A  ... backward, capture_gather: gradients -> buckets, this rank's (1 - guard) -> the flag slot of the first bucket
     #   eager    allreduce(): the buckets summed over the ranks, asynchronously, in backward order; the launch stream waits
     #   graph B  capture_update: global guard from the summed flag slot, then scale (1 / world) -> clip -> Adam per bucket
-    def capture_gather(self, models, optims, guard):
+    def capture_gather(self, models, optims, guard, names=None):
+        """names: the models whose gradients are complete at this point of the capture (None: all).  The first call starts the list
+        of captured buckets (its first stepped bucket carries the flag slot), later calls append to it."""
         assert getattr(self, "hyper", None) is not None, "prepare_capture() first"
-        self._captured = []
-        first = True
+        first = names is None or not getattr(self, "_gather_open", False)
+        if first:
+            self._captured = []
+        self._gather_open = names is not None
         for name, fl in self.flats.items():
+            if names is not None and name not in names:
+                continue
             optim = optims["optim_" + name]
             if not fl.bound(optim):
                 raise RuntimeError("FusedClipAdam.capture_gather: call prepare_capture(optims) before the capture (optim_%s)" % name)
@@ -266,12 +275,15 @@ class FusedClipAdam:
                 self._first_fl = fl
             first = False
 
+    def allreduce_async(self, names=None):
+        """One asynchronous all-reduce (SUM) per stepped bucket (of `names`) on the communicator's stream; returns the work handles."""
+        return [torch.distributed.all_reduce(fl.g[:fl.n_msg], group=self.group, async_op=True)
+                for name, fl, stepped, _ in self._captured if stepped and (names is None or name in names)]
+
     def allreduce(self):
         """Between the two graphs: one asynchronous all-reduce (SUM) per stepped bucket on the communicator's stream, issued in
         backward order; the launch stream then waits for all of them (graph B reads every bucket)."""
-        works = [torch.distributed.all_reduce(fl.g[:fl.n_msg], group=self.group, async_op=True)
-                 for _, fl, stepped, _ in self._captured if stepped]
-        for w in works:
+        for w in self.allreduce_async():
             w.wait()
 
     def flag_slot(self):
