@@ -49,6 +49,7 @@ def run(mode, steps=200, nb=16, b=8, s=8, h=128, seed=1234, lr=1e-4, batches=Non
         with torch.no_grad():
             itf.validate_batch({k: v.clone() for k, v in held_out.items()})
         val = float(itf.m_losses["m_val"])
+        step.close()
         return curves, val
     finally:
         ops.set_precision(old)

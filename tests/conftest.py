@@ -174,3 +174,5 @@ class FlipCounter:
             a, b = got.detach().double().cpu(), want.detach().double().cpu()
             m = ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
             assert m <= tight, "%s: max-norm %.3e > %.1e with no flipped unit" % (what, m, tight)
+
+

@@ -753,6 +753,9 @@ def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path(rccl
                     assert {k: v.item() for k, v in itf.m_losses.items()} == sums
                     step(batches[1])
                     assert [fl.steps for fl in fo.flats.values()] == [4, 4, 4] and not torch.equal(state(), before)
+                if graphed:
+                    step.close()                                        # one graphed step alive at a time
+                del step, itf, fo, models, optims
         ref = results[(False, False)]
         for key, got in results.items():
             assert got[2] == [3, 3, 3], key

@@ -261,6 +261,24 @@ class GraphedTrainStep:
         ev.synchronize()
         self._raise_unless_finite(host.tolist(), rollback=1 + after)
 
+    def close(self):
+        """Release the captured graphs (last captured first), their memory pool and the static batch NOW instead of whenever the
+        last reference to this object goes: a process that builds one graphed step after another (a test session, a sweep over
+        configurations) keeps at most one alive.  The object cannot be called afterwards."""
+        torch.cuda.synchronize()
+        for name in ("graph_b", "graph_a2", "graph"):
+            g = self.__dict__.pop(name, None)
+            if g is not None:
+                g.reset()
+        for name in ("losses", "static", "flags", "guard", "sums", "_sum_views", "perms", "_loss_refs", "_flag_bufs", "_pending"):
+            self.__dict__.pop(name, None)
+        if self.fm is not None and getattr(self.fm, "static_perms", None) is not None:
+            self.fm.static_perms, self.fm.check_finite = None, True       # (the eager loss draws and checks for itself again)
+        self.itf.last_loss_dict = None
+        self.itf.last_out = None
+        self.itf = None
+        torch.cuda.synchronize()
+
     def flush(self):
         """The deferred check of the last step (``defer_check=True``); a no-op otherwise."""
         prev, self._pending = self._pending, None

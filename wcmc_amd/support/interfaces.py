@@ -275,7 +275,10 @@ class KPCNInterface(BaseInterface):
             torch.autograd.backward(list(losses))
             return
         ins = [p for p in self.models['dncnn'].parameters() if p.requires_grad] + [t for t in raw.values() if t.requires_grad]
-        torch.autograd.backward(list(losses), inputs=ins, retain_graph=True)      # (the PathNets' part of the graph is walked by stage 2)
+        # (no retain_graph: the engine frees what it walks, and with `inputs` it walks only the nodes above the P-buffers -- the
+        # PathNets' part keeps its saved tensors for stage 2.  A retained graph would also keep the walked part's buffers, which
+        # live in the hipGraph's memory pool, until Python's cycle collector gets to them: during some later capture)
+        torch.autograd.backward(list(losses), inputs=ins)
 
     def _backward_stage2(self):
         """The second stage of a cut backward: through the PathNets, from the gradients stage 1 left on their outputs."""
