@@ -257,13 +257,15 @@ def c2_leg(device, steps, warmup):
         graphed(batch)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    last = {k: round(float(v), 6) for k, v in itf.last_loss_dict.items()}
+    graphed.close()
     flops = 374.0e9 * B_PER_GPU                       # 3 x 124.7 GF per patch
     peak = PEAK_BF16_MFMA_TFLOPS if ops.PRECISION != "fp32" else PEAK_FP32_MFMA_TFLOPS
     return {"workload": "BASELINE configs[1]: KPCN-Vanilla diffuse+specular (n_in=34), 128x128, batch %d, 1 GPU" % B_PER_GPU,
             "value": round(B_PER_GPU * steps / el, 3), "unit": "patches/s", "ms_per_step": round(el / steps * 1e3, 3),
             "steps": steps, "warmup": warmup, "dtype": ops.PRECISION,
             "whole_step_mfma_frac": round(flops / (el / steps) / 1e12 / peak, 4),
-            "losses_last_step": {k: round(float(v), 6) for k, v in itf.last_loss_dict.items()}}
+            "losses_last_step": last}
 
 
 def extra_leg(device, steps, warmup, precision=None, group=None, force_collective=False, overlap=False):
@@ -301,6 +303,7 @@ def extra_leg(device, steps, warmup, precision=None, group=None, force_collectiv
             assert graphed.tail_split and not graphed.tail_captured
             tails = [a.elapsed_time(b) for a, b in graphed.tail_events]
             out["tail_ms"] = round(sum(tails) / len(tails), 4)
+        graphed.close()                                   # (one graphed step alive at a time: GraphedTrainStep.close)
         return out
     finally:
         ops.set_precision(old)
@@ -643,6 +646,7 @@ def main():
             line["value_long"] = {"value": round(B_PER_GPU * nlong / el, 3), "unit": "patches/s", "steps": nlong,
                                   "ms_per_step": round(el / nlong * 1e3, 3), "seconds": round(el, 3),
                                   "note": "the same graphed step, %d more timed steps behind the official ones" % nlong}
+            graphed.close()
             line["c2"] = c2_leg(device, args.steps, args.warmup)
             if args.precision is None:
                 # the other arithmetics the library ships, same box, same process
