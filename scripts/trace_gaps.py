@@ -32,6 +32,25 @@ for a, b in list(zip(steps[:-1], steps[1:]))[8:14]:
     ksum = sum(e - s for s, e, *_ in seg)
     print("step: %d kernels, wall %.2f ms, busy (>=1 kernel) %.2f ms, idle %.2f ms in %d gaps (largest: %s us), >=2 kernels in flight %.2f ms, sum of kernel times %.2f ms" %
           (len(seg), (t1 - t0) / 1e6, busy / 1e6, (t1 - t0 - busy) / 1e6, len(gaps), ", ".join("%.0f@%.1fms" % (g / 1e3, at / 1e6) for g, at in gaps[:6]), multi / 1e6, ksum / 1e6))
+# what runs ALONE (one kernel in flight) and for how long, per kernel name, over the same steps: the serial part of the schedule
+solo = collections.Counter(); tot = collections.Counter(); nsteps = 0
+for a, b in list(zip(steps[:-1], steps[1:]))[8:14]:
+    seg = rows[a:b]; nsteps += 1
+    ev = []
+    for i, (s, e, *_) in enumerate(seg):
+        ev.append((s, 1, i)); ev.append((e, -1, i))
+        tot[seg[i][2]] += e - s
+    ev.sort()
+    live = set(); last = ev[0][0]
+    for t, d, i in ev:
+        if len(live) == 1:
+            solo[seg[next(iter(live))][2]] += t - last
+        (live.add if d > 0 else live.discard)(i); last = t
+if nsteps:
+    print("time with exactly ONE kernel in flight, by kernel (ms per step alone | ms per step in total), %d steps:" % nsteps)
+    for nm, v in solo.most_common(14):
+        print("  %6.3f | %6.3f  %s" % (v / nsteps / 1e6, tot[nm] / nsteps / 1e6, nm[:110]))
+    print("  %6.3f alone in total" % (sum(solo.values()) / nsteps / 1e6))
 if len(steps) > 12:
     a, b = steps[10], steps[11]
     a = max(0, b - 30)

@@ -65,7 +65,8 @@ def train_epoch_kpcn(epoch, interfaces, dataloaders, params, args):
             if getattr(args, 'graph', False):
                 if i not in steps:
                     from .graph import GraphedTrainStep
-                    steps[i] = GraphedTrainStep(itf, batch, defer_check=getattr(args, 'defer_check', False))
+                    steps[i] = GraphedTrainStep(itf, batch, defer_check=getattr(args, 'defer_check', False),
+                                                overlap_allreduce=getattr(args, 'overlap_allreduce', False))
                     kick = getattr(dataloaders['train'], 'kick', None)      # support/loader.py: pace the producer thread
                     if kick is not None and i == len(interfaces) - 1:
                         steps[i].after_enqueue = kick
@@ -224,7 +225,8 @@ def init_model(sizes, args, device, group=None):
             itf = KPCNInterface(models, optims, loss_funcs, args, visual=args.visual, use_llpm_buf=args.use_llpm_buf,
                                 manif_learn=args.manif_learn, w_manif=w_manif, train_branches=args.train_branches,
                                 disentanglement_option=args.disentangle)
-            itf.fused_optim = FusedClipAdam(models, optims, process_group=group)      # clip + Adam (+ RCCL sum), fused
+            order = ('dncnn', 'backbone_diffuse', 'backbone_specular') if getattr(args, 'overlap_allreduce', False) else None
+            itf.fused_optim = FusedClipAdam(models, optims, process_group=group, order=order)      # clip + Adam (+ RCCL sum), fused
             if group is not None:
                 for fl in itf.fused_optim.flats.values():
                     torch.distributed.broadcast(fl.flat, 0, group=group)              # every rank starts from rank 0's weights
@@ -285,6 +287,10 @@ def build_parser():
                    help="with --graph: check a step's losses for non-finite values after the NEXT step has been enqueued (the "
                         "device guard still skips the update at once; the error is raised one step later) -- the host prepares "
                         "the next batch while the GPU runs")
+    p.add_argument('--overlap_allreduce', action='store_true',
+                   help="with --graph on several ranks and --use_llpm_buf: cut the backward at the P-buffers and put the dncnn "
+                        "gradient bucket on the wire while the PathNets' backward runs (three graphs; bit-identical; not measured "
+                        "on a multi-GPU node yet, hence off by default)")
     p.add_argument('--pairing_rng', choices=('cpu', 'device'), default='cpu',
                    help="FeatureMSE pairings: the reference's CPU randperm stream, or a keyed permutation on the GPU")
     p.add_argument('--pathnet_weight_norm', action='store_true',
