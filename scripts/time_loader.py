@@ -36,25 +36,28 @@ for b in loader: step(b)                                # warm-up
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(96): step(first)
 torch.cuda.synchronize(); ta = (time.perf_counter() - t0) / 96
-torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
-for b in loader:
-    step(first); nb += 1
-torch.cuda.synchronize(); tb = (time.perf_counter() - t0) / nb
-print("graphed step on a resident batch: %.2f ms; the same with the loader running beside it: %.2f ms" % (ta * 1e3, tb * 1e3))
-torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
-for b in loader:
-    step(b); nb += 1
-torch.cuda.synchronize(); t = time.perf_counter() - t0
-print("loader feeding the graphed KPCN-Manifold step: %d steps in %.3f s = %.1f patches/s (bench.py on resident inputs: see its line)"
-      % (nb, t, nb * 8 / t))
+def epoch(run_step, feed):
+    """One pass over the loader; the clock starts when the FIRST batch is there (an epoch's start-up -- thread start, the first
+    image read, staged over PCIe and preprocessed: ~50 ms, once per epoch whatever its length -- is reported on its own)."""
+    torch.cuda.synchronize(); s0 = time.perf_counter()
+    it = iter(loader); b = next(it)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
+    while b is not None:
+        run_step(b if feed else first); nb += 1
+        b = next(it, None)
+    if hasattr(run_step, "flush"): run_step.flush()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    return (t1 - t0) / nb, nb, t0 - s0
+tb, nb, start = epoch(step, False)
+print("graphed step on a resident batch: %.2f ms; the same with the loader running beside it: %.2f ms (epoch start-up %.0f ms, not included)"
+      % (ta * 1e3, tb * 1e3, start * 1e3))
+t, nb, start = epoch(step, True)
+print("loader feeding the graphed KPCN-Manifold step: %d steps at %.3f ms = %.1f patches/s = %.3f of the resident step (+ %.0f ms of start-up per epoch)"
+      % (nb, t * 1e3, 8 / t, ta / t, start * 1e3))
 step2 = GraphedTrainStep(itf, first, defer_check=True)
 if os.environ.get("WCMC_LOADER_PACE", "1") != "0":
     step2.after_enqueue = loader.kick
 for b in loader: step2(b)
 step2.flush()
-torch.cuda.synchronize(); t0 = time.perf_counter(); nb = 0
-for b in loader:
-    step2(b); nb += 1
-step2.flush()
-torch.cuda.synchronize(); t = time.perf_counter() - t0
-print("the same with defer_check=True (non-finite check of step t after step t + 1 is enqueued): %.1f patches/s" % (nb * 8 / t))
+t, nb, start = epoch(step2, True)
+print("the same with defer_check=True (non-finite check of step t after step t + 1 is enqueued): %.1f patches/s = %.3f of the resident step" % (8 / t, ta / t))

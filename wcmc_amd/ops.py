@@ -8,6 +8,7 @@ only -- all arithmetic of the hot path runs in the HIP library.  Nothing in this
 file has a CPU path: a tensor that is not on ``cuda`` raises.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -1608,14 +1609,21 @@ def assemble_kpcn_patches(kpcn, llpm, gt, origins, patch):
         assert llpm.shape[:2] == (h, w) and llpm.shape[3] == 37 and llpm.is_contiguous()
         s = llpm.shape[2]
     dev = kpcn.device
-    new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
     cin = 35 if llpm is not None else 34
-    out = {"kpcn_diffuse_in": new(b, cin, patch, patch), "kpcn_specular_in": new(b, cin, patch, patch),
-           "kpcn_diffuse_buffer": new(b, 3, patch, patch), "kpcn_specular_buffer": new(b, 3, patch, patch),
-           "kpcn_albedo": new(b, 3, patch, patch), "target_diffuse": new(b, 3, patch, patch),
-           "target_specular": new(b, 3, patch, patch), "target_total": new(b, 3, patch, patch)}
+    shapes = {"kpcn_diffuse_in": (b, cin, patch, patch), "kpcn_specular_in": (b, cin, patch, patch),
+              "kpcn_diffuse_buffer": (b, 3, patch, patch), "kpcn_specular_buffer": (b, 3, patch, patch),
+              "kpcn_albedo": (b, 3, patch, patch), "target_diffuse": (b, 3, patch, patch),
+              "target_specular": (b, 3, patch, patch), "target_total": (b, 3, patch, patch)}
     if llpm is not None:
-        out["paths"] = new(b, s, 36, patch, patch)
+        shapes["paths"] = (b, s, 36, patch, patch)
+    # ONE allocation, the entries are views of it: a consumer on another stream keeps the batch alive with one
+    # `record_stream` and frees one block (nine of each cost the training thread 0.25 ms per step: scripts/diag_loader_gap.py)
+    sizes = {k: (math.prod(v) + 63) // 64 * 64 for k, v in shapes.items()}          # (every entry starts on a 256-byte boundary)
+    flat = torch.empty(sum(sizes.values()), device=dev, dtype=torch.float32)
+    out, off = {}, 0
+    for k, shp in shapes.items():
+        out[k] = flat[off:off + math.prod(shp)].view(shp)
+        off += sizes[k]
     check(lib().wcmc_assemble_kpcn_patches(_ptr(kpcn), _ptr(llpm), _ptr(gt), ctypes.c_void_p(origins.data_ptr()), b, h, w,
                                            s, patch, _ptr(out["kpcn_diffuse_in"]), _ptr(out["kpcn_specular_in"]),
                                            _ptr(out["kpcn_diffuse_buffer"]), _ptr(out["kpcn_specular_buffer"]),

@@ -284,9 +284,13 @@ class PatchLoader:
                 batch, ev = got
                 cur = torch.cuda.current_stream(dev)
                 cur.wait_event(ev)
-                for t in batch.values():
+                seen = set()
+                for t in batch.values():                          # (the entries are views of one allocation: one call)
                     if isinstance(t, torch.Tensor):
-                        t.record_stream(cur)
+                        key = t.untyped_storage().data_ptr()
+                        if key not in seen:
+                            seen.add(key)
+                            t.record_stream(cur)
                 yield batch
         finally:
             stop.set()
