@@ -512,6 +512,40 @@ def test_graphed_step_equals_eager_step():
         ops.set_precision(old)
 
 
+def test_graphed_step_close_releases_its_graphs_and_memory():
+    """``GraphedTrainStep.close()``: the graphs, their memory pool and the static batch go at once (a session that builds one
+    graphed step after another keeps one alive); the interface trains on eagerly or under a new capture, the closed object
+    refuses to be called."""
+    import gc
+    import bench
+    from wcmc_amd.graph import GraphedTrainStep
+    from wcmc_amd.synthetic import make_batch
+    device = torch.device("cuda", 0)
+    itf = bench.build_interface(device, None, rng="device")
+    batch = make_batch(2, 4, 64, seed=72, device=device)
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    before = torch.cuda.memory_reserved(device)
+    step = GraphedTrainStep(itf, batch)
+    torch.manual_seed(73)
+    step(batch)
+    held = torch.cuda.memory_reserved(device) - before
+    assert held > 50e6                                   # the captured step's activations live in the graph's private pool
+    step.close()
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert torch.cuda.memory_reserved(device) - before < 0.25 * held
+    with pytest.raises((AttributeError, TypeError)):
+        step(batch)
+    again = GraphedTrainStep(itf, batch)                 # the interface is reusable: a new capture, more steps
+    again(batch)
+    assert torch.isfinite(again.losses["l_total"]).item() and itf.iters >= 3
+    again.close()
+    itf.preprocess(batch)
+    itf.train_batch(batch)                               # and eagerly (the loss draws its own pairings again)
+
+
 def test_captured_optimizer_tail_guard_and_epoch_summary():
     """The step's tail inside the hipGraph (one rank): a non-finite loss raises the reference's error
     (``interfaces.py:254-257``) with parameters, moments, step counters and running sums untouched -- the update sits behind a

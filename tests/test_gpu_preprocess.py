@@ -146,6 +146,10 @@ def test_patch_loader_stages_images_and_equals_the_direct_path():
         for o in range(0, 8, B):
             want = bat.batch(kp, ll, gt, origins[o:o + B])
             assert want.keys() == got[k].keys()
+            # one allocation per batch (its entries are views, each on a 256-byte boundary): a consumer on another stream keeps it
+            # alive with one record_stream and frees one block
+            assert len({v.untyped_storage().data_ptr() for v in want.values()}) == 1
+            assert all(v.is_contiguous() and v.data_ptr() % 256 == 0 for v in want.values())
             for name in want:
                 assert torch.equal(want[name], got[k][name]), (k, name)
             k += 1
