@@ -230,6 +230,13 @@ int wcmc_embed3_supported(int Cin, int C1, int C2, int C3);
 size_t wcmc_embed3_bwd_workspace_bytes(void);
 int wcmc_embed3_fwd(const void* x_split, int64_t M, int Cin, const void* wp0, const float* b0, const void* wp1,
                     const float* b1, const void* wp2, const float* b2, float* y, void* stream);
+/* The same forward with the spp mean of y leaving in the same launch (support/networks.py:35-36: y.view(B, S, ...).mean(1)):
+ * y_mean fp32 [M / S][64], the sums formed s ascending in fp32 and multiplied by 1 / S -- bit-identical to wcmc_spp_reduce on
+ * the stored y, which is then not read again.  M = B * S * HW with HW % 64 == 0 (wcmc_embed3_mean_supported). */
+int wcmc_embed3_mean_supported(int S, int64_t HW);
+int wcmc_embed3_mean_fwd(const void* x_split, int64_t M, int Cin, const void* wp0, const float* b0, const void* wp1,
+                         const float* b1, const void* wp2, const float* b2, float* y, float* y_mean, int S, int64_t HW,
+                         void* stream);
 int wcmc_embed3_bwd(const void* x_split, int64_t M, int Cin, const void* wp0, const float* b0, const void* wp1,
                     const float* b1, const void* wt1, const void* wt2, const float* gy, int gy_pixel_stride,
                     const float* gm, int gm_pixel_stride, int S, int64_t HW, float gm_scale, float* dw0, float* db0,

@@ -82,6 +82,8 @@ SIGNATURES = {
     "wcmc_embed3_supported": (I, [I, I, I, I]),
     "wcmc_embed3_bwd_workspace_bytes": (Z, []),
     "wcmc_embed3_fwd": (I, [P, L, I, P, P, P, P, P, P, P, P]),
+    "wcmc_embed3_mean_supported": (I, [I, L]),
+    "wcmc_embed3_mean_fwd": (I, [P, L, I, P, P, P, P, P, P, P, P, I, L, P]),
     "wcmc_embed3_bwd": (I, [P, L, I, P, P, P, P, P, P, P, I, P, I, I, L, F, P, P, P, P, P, P, P, Z, P]),
     "wcmc_clip_adam": (I, [P, P, P, P, L, F, D, D, D, D, I, F, P, P]),
     "wcmc_clip_adam_hyper": (None, [D, D, D, D, I, P]),

@@ -48,6 +48,7 @@ struct E3Params {
   const u16* wp0; const u16* wp1; const u16* wp2;     // forward packs [64][2][64]
   const float* b0; const float* b1; const float* b2;
   float* y;                                           // forward: fp32 [M][64]
+  float* ym; unsigned ym_bytes;                       // forward, optional: the spp mean of y, fp32 [M / S][64] (S, HW, gm_scale = 1 / S)
   // backward
   const u16* wt1; const u16* wt2;                     // data-gradient packs of W1, W2: [64][2][64]
   const float* gy; const float* gm; int S; int64_t HW; float gm_scale;
@@ -142,53 +143,96 @@ __device__ __forceinline__ void e3_store_x(const E3XPre<NT>& r, u16* xh, u16* xl
 }
 
 // ------------------------------------------------------------------ forward
+// MEAN: the spp mean of y (support/networks.py:35-36) leaves with it.  A workgroup then walks SUPER-tiles -- the same 64 pixels
+// of an image's S samples, one after the other -- and keeps the running sum of its y fragments in registers: s ascending, fp32
+// adds, one multiply by 1 / S at the end, i.e. the sums wcmc_spp_reduce forms from the stored y (bit-identical), without
+// reading y (268 MB at the benchmark shape) again.  Needs HW % 64 == 0.
+template <bool MEAN>
 __global__ __launch_bounds__(256, 3) void embed3_fwd_kernel(E3Params p) {
   __shared__ __attribute__((aligned(16))) u16 lds[4 * E3_TILE];
   u16* const XH = lds; u16* const XL = lds + E3_TILE; u16* const AH = lds + 2 * E3_TILE; u16* const AL = lds + 3 * E3_TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, q = lane >> 4;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void*)(MEAN ? p.ym : p.y), 0, (int)(MEAN ? p.ym_bytes : 0u), 0x00020000);
   const E3W w0 = e3_load_w(p.wp0, 16 * wave + fr, q, p.Kt0), w1 = e3_load_w(p.wp1, 16 * wave + fr, q), w2 = e3_load_w(p.wp2, 16 * wave + fr, q);
   float b0[4], b1[4], b2[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { const int co = 16 * wave + 4 * q + e; b0[e] = p.b0[co]; b1[e] = p.b1[co]; b2[e] = p.b2[co]; }
-  const int64_t ntiles = (p.M + E3_TP - 1) / E3_TP;
-  int64_t t = blockIdx.x;
+  // a unit of work: one 64-pixel tile, or (MEAN) the S tiles of one super-tile
+  const int per = MEAN ? p.S : 1;
+  const int64_t tpi = MEAN ? p.HW / E3_TP : 1;                                   // tiles per image
+  const int64_t nunits = MEAN ? (p.M / ((int64_t)p.S * p.HW)) * tpi : (p.M + E3_TP - 1) / E3_TP;
+  auto first_pixel = [&](int64_t u, int sidx) -> int64_t {
+    if (!MEAN) return u * E3_TP;
+    const int64_t b = u / tpi;
+    return (b * p.S + sidx) * p.HW + (u - b * tpi) * E3_TP;
+  };
+  int64_t u = blockIdx.x;
   E3XPre<256> pre;
-  if (t < ntiles) pre = e3_load_x<256>(xr, t * E3_TP, p.M, p.Cp0, tid);
-  for (; t < ntiles; t += gridDim.x) {
-    e3_store_x<256>(pre, XH, XL, tid);
-    const int64_t tn = t + gridDim.x;
-    if (tn < ntiles) pre = e3_load_x<256>(xr, tn * E3_TP, p.M, p.Cp0, tid);       // next tile's loads fly under this tile's GEMMs
-    __syncthreads();
-    f32x4 acc[4];
-    e3_gemm<3, 4>(acc, w0, XH, XL, 0, fr, q);
-    e3_store_relu_split<4>(acc, b0, AH, AL, wave, 0, fr, q);
-    __syncthreads();
-    e3_gemm<3, 4>(acc, w1, AH, AL, 0, fr, q);
-    e3_store_relu_split<4>(acc, b1, XH, XL, wave, 0, fr, q);                         // h1 takes the x tile's place
-    __syncthreads();
-    e3_gemm<3, 4>(acc, w2, XH, XL, 0, fr, q);
-    // y tile through LDS (fp32 [64][68] over the h0 tiles) so that it leaves as whole 256-byte rows
-    float* stg = reinterpret_cast<float*>(AH);
+  if (u < nunits) pre = e3_load_x<256>(xr, first_pixel(u, 0), p.M, p.Cp0, tid);
+  for (; u < nunits; u += gridDim.x) {
+    f32x4 msum[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(stg + (16 * i + fr) * 68 + 16 * wave + 4 * q) =
-          make_float4(acc[i][0] + b2[0], acc[i][1] + b2[1], acc[i][2] + b2[2], acc[i][3] + b2[3]);
-    __syncthreads();
-    const int64_t m0 = t * E3_TP;
-    const unsigned ybase = (unsigned)(m0 * 256);
-    const int left = (int)(p.M - m0 < E3_TP ? p.M - m0 : E3_TP);
+    for (int i = 0; i < 4; ++i) msum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sidx = 0; sidx < per; ++sidx) {
+      e3_store_x<256>(pre, XH, XL, tid);
+      {                                                                          // next tile's loads fly under this tile's GEMMs
+        const bool more = sidx + 1 < per;
+        const int64_t un = more ? u : u + gridDim.x;
+        if (un < nunits) pre = e3_load_x<256>(xr, first_pixel(un, more ? sidx + 1 : 0), p.M, p.Cp0, tid);
+      }
+      __syncthreads();
+      f32x4 acc[4];
+      e3_gemm<3, 4>(acc, w0, XH, XL, 0, fr, q);
+      e3_store_relu_split<4>(acc, b0, AH, AL, wave, 0, fr, q);
+      __syncthreads();
+      e3_gemm<3, 4>(acc, w1, AH, AL, 0, fr, q);
+      e3_store_relu_split<4>(acc, b1, XH, XL, wave, 0, fr, q);                       // h1 takes the x tile's place
+      __syncthreads();
+      e3_gemm<3, 4>(acc, w2, XH, XL, 0, fr, q);
+      // y tile through LDS (fp32 [64][68] over the h0 tiles) so that it leaves as whole 256-byte rows
+      float* stg = reinterpret_cast<float*>(AH);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int v = tid + 256 * k, px = v >> 4, c4 = (v & 15) * 4;
-      const float4 o = *reinterpret_cast<const float4*>(stg + px * 68 + c4);
-      const u32x4 ov = {__builtin_bit_cast(unsigned, o.x), __builtin_bit_cast(unsigned, o.y), __builtin_bit_cast(unsigned, o.z),
-                        __builtin_bit_cast(unsigned, o.w)};
-      __builtin_amdgcn_raw_buffer_store_b128(ov, yr, px < left ? ybase + (unsigned)(px * 256 + c4 * 4) : E3_OOB, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const float4 yv = make_float4(acc[i][0] + b2[0], acc[i][1] + b2[1], acc[i][2] + b2[2], acc[i][3] + b2[3]);
+        *reinterpret_cast<float4*>(stg + (16 * i + fr) * 68 + 16 * wave + 4 * q) = yv;
+        if (MEAN) { msum[i][0] += yv.x; msum[i][1] += yv.y; msum[i][2] += yv.z; msum[i][3] += yv.w; }
+      }
+      __syncthreads();
+      const int64_t m0 = first_pixel(u, sidx);
+      const unsigned ybase = (unsigned)(m0 * 256);
+      const int left = (int)(p.M - m0 < E3_TP ? p.M - m0 : E3_TP);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int v = tid + 256 * k, px = v >> 4, c4 = (v & 15) * 4;
+        const float4 o = *reinterpret_cast<const float4*>(stg + px * 68 + c4);
+        const u32x4 ov = {__builtin_bit_cast(unsigned, o.x), __builtin_bit_cast(unsigned, o.y), __builtin_bit_cast(unsigned, o.z),
+                          __builtin_bit_cast(unsigned, o.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(ov, yr, px < left ? ybase + (unsigned)(px * 256 + c4 * 4) : E3_OOB, 0, 0);
+      }
+      // (the next iteration's x stores touch XH / XL only, which every wave finished reading before the barrier above;
+      // the staging tile is read here and first written again behind the next tile's first barrier)
     }
-    // (the next iteration's x stores touch XH / XL only, which every wave finished reading before the barrier above;
-    // the staging tile is read here and first written again behind the next tile's first barrier)
+    if (MEAN) {                                                                  // the super-tile's mean, the same way
+      float* stg = reinterpret_cast<float*>(AH);
+      __syncthreads();                                                           // (the last y tile has left the staging tile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(stg + (16 * i + fr) * 68 + 16 * wave + 4 * q) =
+            make_float4(p.gm_scale * msum[i][0], p.gm_scale * msum[i][1], p.gm_scale * msum[i][2], p.gm_scale * msum[i][3]);
+      __syncthreads();
+      const int64_t b = u / tpi;
+      const unsigned mbase = (unsigned)((b * p.HW + (u - b * tpi) * E3_TP) * 256);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int v = tid + 256 * k, px = v >> 4, c4 = (v & 15) * 4;
+        const float4 o = *reinterpret_cast<const float4*>(stg + px * 68 + c4);
+        const u32x4 ov = {__builtin_bit_cast(unsigned, o.x), __builtin_bit_cast(unsigned, o.y), __builtin_bit_cast(unsigned, o.z),
+                          __builtin_bit_cast(unsigned, o.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(ov, mr, mbase + (unsigned)(px * 256 + c4 * 4), 0, 0);
+      }
+    }
   }
 }
 
@@ -797,8 +841,26 @@ extern "C" int wcmc_embed3_fwd(const void* x_split, int64_t M, int Cin, const vo
   p.wp2 = (const u16*)wp2; p.b2 = b2; p.y = y;
   const int64_t ntiles = (M + E3_TP - 1) / E3_TP;
   const unsigned grid = (unsigned)(ntiles < 768 ? ntiles : 768);
-  hipLaunchKernelGGL(embed3_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(embed3_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("embed3_fwd");
+}
+
+extern "C" int wcmc_embed3_mean_supported(int S, int64_t HW) { return S >= 1 && HW > 0 && HW % E3_TP == 0; }
+
+extern "C" int wcmc_embed3_mean_fwd(const void* x_split, int64_t M, int Cin, const void* wp0, const float* b0, const void* wp1,
+                                    const float* b1, const void* wp2, const float* b2, float* y, float* y_mean, int S, int64_t HW,
+                                    void* stream) {
+  E3Params p = {};
+  if (int rc = e3_fill(p, x_split, M, Cin, wp0, b0, wp1, b1)) return rc;
+  WCMC_REQUIRE(wp2 && b2 && y && y_mean && aligned16(wp2) && aligned16(y) && aligned16(y_mean), WCMC_ERR_BAD_ARG, "embed3_mean_fwd: bad argument");
+  WCMC_REQUIRE(wcmc_embed3_mean_supported(S, HW) && M % ((int64_t)S * HW) == 0, WCMC_ERR_BAD_ARG,
+               "embed3_mean_fwd: M must be B * S * HW with HW a multiple of 64 (ask wcmc_embed3_mean_supported)");
+  p.wp2 = (const u16*)wp2; p.b2 = b2; p.y = y; p.ym = y_mean; p.ym_bytes = (unsigned)((M / S) * 256);
+  p.S = S; p.HW = HW; p.gm_scale = 1.0f / (float)S;
+  const int64_t nsuper = M / ((int64_t)S * E3_TP);
+  const unsigned grid = (unsigned)(nsuper < 768 ? nsuper : 768);
+  hipLaunchKernelGGL(embed3_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("embed3_mean_fwd");
 }
 
 extern "C" int wcmc_embed3_bwd(const void* x_split, int64_t M, int Cin, const void* wp0, const float* b0, const void* wp1,

@@ -926,6 +926,11 @@ def _dense_pixel_stride(g):
     return None
 
 
+# The spp mean of the embedding inside the fused forward launch (round 4; WCMC_FUSE_EMBED_MEAN=0: A/B switch back to the
+# separate wcmc_spp_reduce pass over y)
+FUSE_EMBED_MEAN = os.environ.get("WCMC_FUSE_EMBED_MEAN", "1") != "0"
+
+
 class _EmbedSppMeanFusedX(torch.autograd.Function):
     """``y = chain3(x); m = y.view(B,S,...).mean(1)`` (networks.py:33-36) with the three 1x1 layers in ONE launch
     (``wcmc_embed3_fwd``) and a backward that recomputes the hidden activations (``wcmc_embed3_bwd``): nothing but x, y and
@@ -939,12 +944,17 @@ class _EmbedSppMeanFusedX(torch.autograd.Function):
         ws_ = [params[0], params[2], params[4]]
         packs = _pack_chain_x(ws_, 1)                        # [(forward, data-gradient orientation)] per layer
         y = torch.empty((n, h, w, 64), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
-        with _Timed("embed3_fwd", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64), "byte"):
-            check(lib().wcmc_embed3_fwd(_ptr(xs), n * h * w, cin, _ptr(packs[0][0]), _ptr(params[1].detach()),
-                                        _ptr(packs[1][0]), _ptr(params[3].detach()), _ptr(packs[2][0]), _ptr(params[5].detach()),
-                                        _ptr(y), _stream()), "embed3_fwd")
         m = nhwc_empty(n // s, 64, h, w, y.device)
-        check(lib().wcmc_spp_reduce(*_v(y), *_v(m), n // s, s, h, w, 64, 1.0 / s, _stream()), "spp_reduce")
+        wb = (_ptr(packs[0][0]), _ptr(params[1].detach()), _ptr(packs[1][0]), _ptr(params[3].detach()), _ptr(packs[2][0]),
+              _ptr(params[5].detach()))
+        if FUSE_EMBED_MEAN and lib().wcmc_embed3_mean_supported(s, h * w):
+            # the mean leaves with y (the kernel walks the S samples of a pixel tile and keeps their sum in registers)
+            with _Timed("embed3_fwd", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64 + 64 // s), "byte"):
+                check(lib().wcmc_embed3_mean_fwd(_ptr(xs), n * h * w, cin, *wb, _ptr(y), _ptr(m), s, h * w, _stream()), "embed3_mean_fwd")
+        else:
+            with _Timed("embed3_fwd", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64), "byte"):
+                check(lib().wcmc_embed3_fwd(_ptr(xs), n * h * w, cin, *wb, _ptr(y), _stream()), "embed3_fwd")
+            check(lib().wcmc_spp_reduce(*_v(y), *_v(m), n // s, s, h, w, 64, 1.0 / s, _stream()), "spp_reduce")
         ctx.s, ctx.dims = s, (n, cin, h, w)
         ctx.packs = packs
         ctx.save_for_backward(xs, *params)
