@@ -41,9 +41,8 @@ __global__ void split_kernel(const float* __restrict__ x, int64_t xsn, int64_t x
   const int V = Cp / 8;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    const int v = (int)(idx % V); int64_t t = idx / V;
-    const int xx = (int)(t % W); t /= W;
-    const int y = (int)(t % H); const int n = (int)(t / H);
+    const NhwvIndex ix_ = decode_nhwv(idx, total, H, W, V);
+    const int v = ix_.v, xx = ix_.x, y = ix_.y, n = ix_.n;
     const float* src = x + n * xsn + y * xsh + xx * xsw + v * 8;
     float f[8];
     const int c0 = v * 8;
@@ -136,9 +135,8 @@ __global__ void cat_broadcast_split_kernel(const float* __restrict__ flat, int64
   const int V = Cp / 8;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    const int v = (int)(idx % V); int64_t t = idx / V;
-    const int xx = (int)(t % W); t /= W;
-    const int y = (int)(t % H); const int n = (int)(t / H);
+    const NhwvIndex ix_ = decode_nhwv(idx, total, H, W, V);
+    const int v = ix_.v, xx = ix_.x, y = ix_.y, n = ix_.n;
     const int c0 = v * 8;
     float f[8];
     if (c0 < C1 && up) {
@@ -150,12 +148,17 @@ __global__ void cat_broadcast_split_kernel(const float* __restrict__ flat, int64
       const float* p01 = b0 + iy * fsh + nx * fsw;
       const float* p10 = b0 + ny * fsh + ix * fsw;
       const float* p11 = b0 + ny * fsh + nx * fsw;
+      __attribute__((aligned(16))) float t00[8], t01[8], t10[8], t11[8];      // (two 16-byte loads per tap; the same fma chain per element)
+      *reinterpret_cast<float4*>(t00) = *reinterpret_cast<const float4*>(p00); *reinterpret_cast<float4*>(t00 + 4) = *reinterpret_cast<const float4*>(p00 + 4);
+      *reinterpret_cast<float4*>(t01) = *reinterpret_cast<const float4*>(p01); *reinterpret_cast<float4*>(t01 + 4) = *reinterpret_cast<const float4*>(p01 + 4);
+      *reinterpret_cast<float4*>(t10) = *reinterpret_cast<const float4*>(p10); *reinterpret_cast<float4*>(t10 + 4) = *reinterpret_cast<const float4*>(p10 + 4);
+      *reinterpret_cast<float4*>(t11) = *reinterpret_cast<const float4*>(p11); *reinterpret_cast<float4*>(t11 + 4) = *reinterpret_cast<const float4*>(p11 + 4);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float r = 0.5625f * p00[e];
-        r = fmaf(0.1875f, p01[e], r);
-        r = fmaf(0.1875f, p10[e], r);
-        r = fmaf(0.0625f, p11[e], r);
+        float r = 0.5625f * t00[e];
+        r = fmaf(0.1875f, t01[e], r);
+        r = fmaf(0.1875f, t10[e], r);
+        r = fmaf(0.0625f, t11[e], r);
         f[e] = r;
       }
     } else if (c0 < C1) {                            // C1 % 8 == 0: a vector never straddles the two sources
@@ -164,8 +167,13 @@ __global__ void cat_broadcast_split_kernel(const float* __restrict__ flat, int64
       f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
     } else {
       const float* src = prop + (n / S) * psn + y * psh + xx * psw + (c0 - C1);
+      if (c0 - C1 + 8 <= C2) {
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = (c0 - C1 + e < C2) ? src[e] : 0.f;
+        for (int e = 0; e < 8; ++e) f[e] = (c0 - C1 + e < C2) ? src[e] : 0.f;
+      }
     }
     u16 hi[8], lo[8];
 #pragma unroll
@@ -188,9 +196,8 @@ __global__ void add_broadcast_split_kernel(const float* __restrict__ g, int64_t 
   const int V = Cp / 8;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    const int v = (int)(idx % V); int64_t t = idx / V;
-    const int xx = (int)(t % W); t /= W;
-    const int y = (int)(t % H); const int n = (int)(t / H);
+    const NhwvIndex ix_ = decode_nhwv(idx, total, H, W, V);
+    const int v = ix_.v, xx = ix_.x, y = ix_.y, n = ix_.n;
     const int c0 = v * 8;
     float f[8];
     if (c0 + 8 <= C) {                               // whole vector: two 16-byte loads per operand

@@ -93,10 +93,9 @@ __device__ __forceinline__ float4 f4_mask(float4 a, int c, int C) {
   const int64_t total_ = (int64_t)(N) * (H) * (W) * (C4);                                            \
   for (int64_t idx_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx_ < total_;                 \
        idx_ += (int64_t)gridDim.x * blockDim.x)
-#define WCMC_DECODE_NHWC(H, W, C4)                           \
-  const int c = (int)(idx_ % (C4)) * 4; int64_t t_ = idx_ / (C4); \
-  const int x = (int)(t_ % (W)); t_ /= (W);                  \
-  const int y = (int)(t_ % (H)); const int n = (int)(t_ / (H));
+#define WCMC_DECODE_NHWC(H, W, C4)                                              \
+  const NhwvIndex ix_ = decode_nhwv(idx_, total_, (H), (W), (C4));              \
+  const int c = ix_.v * 4, x = ix_.x, y = ix_.y, n = ix_.n;
 
 __global__ void maxpool2_fwd_kernel(View in, MView out, int N, int Ho, int Wo, int C4, int C) {
   WCMC_ITER_NHWC(N, Ho, Wo, C4) {
