@@ -43,3 +43,10 @@ a_ = steps[9]
 print("the first kernels of a step (start offset us, duration us, queue, name):")
 for s, e, nm, q, st in rows[a_:a_ + 44]:
     print("  %8.1f %7.1f  q%s  %s" % ((s - rows[a_][0]) / 1e3, (e - s) / 1e3, q, nm[:100]))
+# per kernel name: launches per step, mean duration, ms per step (over the six steps above)
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, nm, q, st in rows[steps[8]:steps[14]]:
+    agg[nm][0] += 1; agg[nm][1] += e - s
+print("kernels of the step by time (launches per step, mean us, ms per step):")
+for nm, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:48]:
+    print("  %5.1f x %7.1f us = %6.3f ms  %s" % (c / 6, t / c / 1e3, t / 6e6, nm[:120]))
