@@ -370,7 +370,10 @@ static XKPlan x_plan_k(int kchan, int ks, int ap_req = 2, int rows = 0) {
   q.ap = 2;
   q.Kp = round_up(kchan, 8);
   q.halo = enable && ks >= 3 && ks <= 5 && q.Kp >= 32;
-  if (ap_req == 1 && q.halo && ks == 5 && x_env_on("WCMC_HALO64") && rows > 0 && x_pick_nt(round_up(rows, 16) / 16) == 7 &&
+  // (rows: seven cout tiles per block -- the KPCN layers -- or ONE: the first layer's data gradient restricted to the 8 input
+  // channels whose gradient is read, ops.conv_chain)
+  const int nt_rows = rows > 0 ? x_pick_nt(round_up(rows, 16) / 16) : 0;
+  if (ap_req == 1 && q.halo && ks == 5 && x_env_on("WCMC_HALO64") && (nt_rows == 7 || nt_rows == 1) &&
       q.Kp % 32 != 24 && x_env_on("WCMC_DGRAD_AP1")) {
     // conv_halo64_bf16x3_kernel<7, 3, PT, 0, 80, 1>: the halo holds the hi plane only, so a pixel's 80 bytes carry 32 channels
     // instead of 16 -- half the slabs (104 channels = 32 + 32 + 32 + 8: K = 3 x 800 + 224 = 2624 of 2500 useful, three halo
@@ -3526,6 +3529,8 @@ static int launch_xhalo64b(const XIgemmParams& p, size_t lds, hipStream_t stream
   if constexpr (NT == 7 && NB == 3) {
     if (p.ap == 1 && p.wplanes == 1 && p.f16) return launch_xhalo64c<NT, NB, PT, 80, 1, 1, 1>(p, lds, stream);      // one fp16 MFMA per product ("bf16x321h" output layers)
     if (p.ap == 1 && p.wplanes == 1) return launch_xhalo64c<NT, NB, PT, 80, 1, 1>(p, lds, stream);      // one MFMA per product ("bf16x321o" output layers)
+  }
+  if constexpr ((NT == 7 || NT == 1) && NB == 3) {
     if (p.ap == 1) return launch_xhalo64c<NT, NB, PT, 80, 1>(p, lds, stream);          // (x_plan_k grants ap = 1 with PXS = 80, ks = 5 only)
   }
   if (p.ks == 5 && p.PXS == 80 && NB == 3) return launch_xhalo64c<NT, NB, PT, NB == 3 ? 80 : 0>(p, lds, stream);
@@ -3726,7 +3731,7 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
   p.ap = q.ap;
   // one term: where the plan grants the hi-plane instance of the 64-pixel 5x5 kernel (the only one with a one-plane weight path);
   // anywhere else the launch multiplies what the plan's instance multiplies (two or three terms) -- more exact, never less
-  p.wplanes = (terms == 1 && q.ap == 1 && ks == 5 && q.PXS == 80) ? 1 : 2;
+  p.wplanes = (terms == 1 && q.ap == 1 && ks == 5 && q.PXS == 80 && x_pick_nt(round_up(Cout, 16) / 16) == 7) ? 1 : 2;
   p.f16 = 0;
   p.Kp = p.Cpi; p.Kt = q.Kt; p.Np = round_up(Cout, 16);
   p.CS = q.CS; p.nslabs = q.nslabs; p.SPS = q.Ks / 32; p.PXS = q.halo ? q.PXS : 0;

@@ -593,7 +593,7 @@ def _wgrad_class(n, ho, cin, cout, ks):
 
 
 def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, gate_act="linear", colsum=False,
-                 gate_mask=None, mask_out=False, terms=3):
+                 gate_mask=None, mask_out=False, terms=3, out=None):
     """One split-bf16 implicit-GEMM launch.  xs: split tensor of dims (n,cin,h,w).
     terms: bf16 MFMAs per product -- 3, 2 = the hi plane of xs only (wp packed with mode 2: the data gradient of the
     "bf16x321" modes, whose xs is dy; or mode 3: a forward launch), 1 = the hi planes of xs and wp only (mode 3: the un-gated
@@ -608,7 +608,9 @@ def conv2d_x_raw(xs, dims, wp, bias, cout, ks, pad, act, out_split, gate=None, g
     if out_split:
         ysp, yf, yv = _split_empty(n, cout, ho, wo, dev), None, (_ptr(None), 0, 0, 0)
     else:
-        yf = nhwc_empty(n, cout, ho, wo, dev)
+        # (out: an fp32 NHWC view of (n, cout, ho, wo) to write into -- e.g. a channel slice of a wider tensor)
+        yf = nhwc_empty(n, cout, ho, wo, dev) if out is None else out
+        assert tuple(yf.shape) == (n, cout, ho, wo)
         ysp, yv = None, _v(yf)
     pix = min(ho * wo, h * w)
     part = None
@@ -708,7 +710,12 @@ FUSE_BIAS_GRAD = os.environ.get("WCMC_FUSE_BIAS_GRAD", "1") != "0"
 def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
     """Shared forward of the split-bf16 chains: xs0 is the chain input as a split tensor of dims0.  extra_saved: a
     callable y -> tensors saved behind the chain's own (a fused consumer of the chain's output)."""
-    ks, pad, acts = spec
+    ks, pad, acts = spec[:3]
+    # spec[3] (optional): the input channels [c0, c1) whose gradient the producer of x will read (``pbuffer_cat``: only the
+    # P-buffer's mean carries gradient, 3 of KPCN's 39 input channels) -- the first layer's data gradient is then formed for
+    # the 8-aligned range round them only
+    ctx.dx_channels = spec[3] if len(spec) > 3 else None
+    spec = tuple(spec[:3])
     nl = len(acts)
     n = dims0[0]
     dims = [dims0]
@@ -837,9 +844,20 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
             dys, part = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
                                      out_split=True, gate_act=acts[l - 1], colsum=True, terms=dterms, **g)
         elif need_dx and dx is None:
-            wpt = pack1(l)
-            dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
-                              out_split=False, terms=dterms)
+            sub = getattr(ctx, "dx_channels", None)
+            if sub is not None and DX_SLICE and (sub[1] + 7) // 8 * 8 - sub[0] // 8 * 8 <= wt.shape[1] // 2:
+                # the consumer reads channels [c0, c1) only: a GEMM over the 8-aligned rows round them (KPCN's first layer: 16 of
+                # 48 padded rows, one cout tile instead of four); the rest of dx is zero, never read
+                a0, a1 = sub[0] // 8 * 8, min((sub[1] + 7) // 8 * 8, wt.shape[1])
+                nn_, _, hh_, ww_ = dims[0]
+                dx = nhwc_empty(nn_, wt.shape[1], hh_, ww_, dys.device, zero=True)
+                wsub = _pack_x(wt.detach()[:, a0:a1].contiguous(), _dgrad_mode(dterms))
+                conv2d_x_raw(dys, dims[l + 1], wsub, None, a1 - a0, ks, ks - 1 - pad, "linear", out_split=False, terms=dterms,
+                             out=dx[:, a0:a1])
+            else:
+                wpt = pack1(l)
+                dx = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
+                                  out_split=False, terms=dterms)
     if side is not None:
         main.wait_stream(side)
     del keep
@@ -1106,9 +1124,16 @@ def cat_upsample_chain(deep, skip, ksize, pad, acts, params):
     return cat_broadcast_chain(upsample2(deep), skip, 1, ksize, pad, acts, params)
 
 
+# The first layer's data gradient restricted to the input channels its consumer reads (round 4; WCMC_DX_SLICE=0: A/B switch)
+DX_SLICE = os.environ.get("WCMC_DX_SLICE", "1") != "0"
+
+
 def conv_chain(x, ksize, pad, acts, params):
-    fn = _ConvChainX if split_path() else _ConvChain
-    return fn.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
+    if not split_path():
+        return _ConvChain.apply(as_nhwc(x), (ksize, pad, tuple(acts)), *params)
+    hint = getattr(x, "_wcmc_grad_channels", None)          # left by pbuffer_cat on its output
+    spec = (ksize, pad, tuple(acts)) + ((tuple(hint),) if hint is not None else ())
+    return _ConvChainX.apply(as_nhwc(x), spec, *params)
 
 
 # A/B switch for the two PathNet glue fusions below (WCMC_FUSE_CHAIN_GLUE=0: separate spp-mean / concat nodes)
@@ -1424,7 +1449,11 @@ class _PBufferCat(torch.autograd.Function):
 
 
 def pbuffer_cat(base, p):
-    return _PBufferCat.apply(base, p)
+    out = _PBufferCat.apply(base, p)
+    # the backward reads the gradient of channels [cb, cb + cp) only (the variance channel is detached, the base is data): a
+    # conv chain that consumes `out` forms no more of its input gradient than that (conv_chain)
+    out._wcmc_grad_channels = (base.shape[1], base.shape[1] + p.shape[2])
+    return out
 
 
 class _SampleCat(torch.autograd.Function):
