@@ -335,6 +335,11 @@ int wcmc_maxpool2_fwd(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
                       float* y, int64_t ysn, int64_t ysh, int64_t ysw,
                       int N, int H, int W, int C, void* stream);
 /* dx[n,2y+i,2x+j] = dy[n,y,x] where x[...] is the (first) maximum of its window, else 0. */
+/* dx = maxpool2's gradient + add: the pooled tensor also feeds a skip connection, whose gradient `add` (fp32 NHWC view of x's
+ * geometry) is summed in by the same pass (the sum autograd would form with one more elementwise launch). */
+int wcmc_maxpool2_bwd_add(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, const float* dy, int64_t dsn, int64_t dsh,
+                          int64_t dsw, const float* add, int64_t asn, int64_t ash, int64_t asw, float* dx, int64_t gsn,
+                          int64_t gsh, int64_t gsw, int N, int H, int W, int C, void* stream);
 int wcmc_maxpool2_bwd(const float* x, int64_t xsn, int64_t xsh, int64_t xsw,
                       const float* dy, int64_t dsn, int64_t dsh, int64_t dsw,
                       float* dx, int64_t gsn, int64_t gsh, int64_t gsw,

@@ -878,6 +878,36 @@ def test_pool_upsample_cat():
     assert_close(xd.grad, xr.grad, tol=1e-6, what="pool/upsample/cat backward")
 
 
+def test_maxpool2_skip_sums_both_gradients_in_the_pooling_backward():
+    """``ops.maxpool2_skip`` (a U-Net level's skip + pooled copy as one node): outputs and the input gradient BIT FOR BIT those of
+    the separate ``maxpool2`` node plus autograd's add -- also with a strided skip gradient (a channel slice of a wider tensor),
+    an odd channel count, and either gradient missing."""
+    o = ops()
+    for n, c, h, w in ((2, 20, 12, 16), (1, 7, 8, 8), (3, 64, 32, 32)):
+        x = gen(n, c, h, w, seed=46)
+        gs_wide, gp = gen(n, c + 12, h, w, seed=47), gen(n, c, h // 2, w // 2, seed=48)
+        res = []
+        for fused in (False, True):
+            xd = x.to(DEV).requires_grad_(True)
+            xn = o.as_nhwc(xd)
+            skip, pooled = o.maxpool2_skip(xn) if fused else (xn, o.maxpool2(xn))
+            gw = o.to_nhwc_raw(gs_wide.to(DEV))
+            torch.autograd.backward([skip, pooled], [gw[:, 4:4 + c], gp.to(DEV)])
+            res.append((pooled.detach().clone(), xd.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (n, c, h, w)
+        xr = x.double().requires_grad_(True)
+        pr = F.max_pool2d(xr, 2, 2)
+        torch.autograd.backward([xr * 1, pr], [gs_wide[:, 4:4 + c].double(), gp.double()])
+        assert_close(res[1][1], xr.grad, tol=1e-6, what="skip + pool backward")
+        for which in (0, 1):                                  # one of the two outputs unused
+            xd = x.to(DEV).requires_grad_(True)
+            outs = o.maxpool2_skip(o.as_nhwc(xd))
+            (outs[which] * (gs_wide[:, 4:4 + c] if which == 0 else gp).to(DEV)).sum().backward()
+            xr = x.double().requires_grad_(True)
+            ((xr if which == 0 else F.max_pool2d(xr, 2, 2)) * (gs_wide[:, 4:4 + c] if which == 0 else gp).double()).sum().backward()
+            assert_close(xd.grad, xr.grad, tol=1e-6, what="one output only")
+
+
 def test_spp_mean_and_cat_broadcast():
     o = ops()
     b, s, c, h, w = 2, 3, 8, 6, 10

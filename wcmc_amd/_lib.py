@@ -62,6 +62,7 @@ SIGNATURES = {
     "wcmc_recombine_bwd": (I, [P, P, L, L, L, L, P, L, L, L, L, P, P, I, I, I, I, P]),
     "wcmc_maxpool2_fwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),
     "wcmc_maxpool2_bwd": (I, [P, L, L, L, P, L, L, L, P, L, L, L, I, I, I, I, P]),
+    "wcmc_maxpool2_bwd_add": (I, [P, L, L, L, P, L, L, L, P, L, L, L, P, L, L, L, I, I, I, I, P]),
     "wcmc_upsample2_fwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),
     "wcmc_upsample2_bwd": (I, [P, L, L, L, P, L, L, L, I, I, I, I, P]),
     "wcmc_sample_cat_fwd": (I, [P, L, L, L, L, L, P, L, L, L, L, L, P, I, I, I, I, I, I, P]),

@@ -118,7 +118,9 @@ __device__ __forceinline__ void route4(float a, float b, float d, float e, float
   if (e > m) { m = e; k = 3; }
   if (k == 0) ga = g; else if (k == 1) gb = g; else if (k == 2) gd = g; else ge = g;
 }
-__global__ void maxpool2_bwd_kernel(View in, View dy, MView dx, int N, int Ho, int Wo, int C4, int C) {
+// add.p != null: dx = route(dy) + add -- the pooled tensor's input also feeds a skip connection (sbmc Autoencoder), whose gradient
+// `add` autograd would otherwise sum in with one more pass over three tensors of this size
+__global__ void maxpool2_bwd_kernel(View in, View dy, View add, MView dx, int N, int Ho, int Wo, int C4, int C) {
   WCMC_ITER_NHWC(N, Ho, Wo, C4) {
     WCMC_DECODE_NHWC(Ho, Wo, C4)
     const float4 a = ld4(in, n, 2 * y, 2 * x, c), b = ld4(in, n, 2 * y, 2 * x + 1, c);
@@ -129,6 +131,10 @@ __global__ void maxpool2_bwd_kernel(View in, View dy, MView dx, int N, int Ho, i
     route4(a.y, b.y, d.y, e.y, g.y, ga.y, gb.y, gd.y, ge.y);
     route4(a.z, b.z, d.z, e.z, g.z, ga.z, gb.z, gd.z, ge.z);
     route4(a.w, b.w, d.w, e.w, g.w, ga.w, gb.w, gd.w, ge.w);
+    if (add.p) {
+      ga = f4_add(f4_mask(ld4(add, n, 2 * y, 2 * x, c), c, C), ga); gb = f4_add(f4_mask(ld4(add, n, 2 * y, 2 * x + 1, c), c, C), gb);
+      gd = f4_add(f4_mask(ld4(add, n, 2 * y + 1, 2 * x, c), c, C), gd); ge = f4_add(f4_mask(ld4(add, n, 2 * y + 1, 2 * x + 1, c), c, C), ge);
+    }
     st4(dx, n, 2 * y, 2 * x, c, ga); st4(dx, n, 2 * y, 2 * x + 1, c, gb);
     st4(dx, n, 2 * y + 1, 2 * x, c, gd); st4(dx, n, 2 * y + 1, 2 * x + 1, c, ge);
   }
@@ -397,9 +403,23 @@ extern "C" int wcmc_maxpool2_bwd(const float* x, int64_t xsn, int64_t xsh, int64
                WCMC_ERR_ALIGNMENT, "maxpool2_bwd: a view violates the NHWC-view contract");
   const int C4 = (C + 3) / 4;
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * C4)), dim3(256), 0,
-                     (hipStream_t)stream, View{x, xsn, xsh, xsw}, View{dy, dsn, dsh, dsw}, MView{dx, gsn, gsh, gsw}, N,
+                     (hipStream_t)stream, View{x, xsn, xsh, xsw}, View{dy, dsn, dsh, dsw}, View{nullptr, 0, 0, 0}, MView{dx, gsn, gsh, gsw}, N,
                      H / 2, W / 2, C4, C);
   return check_launch("maxpool2_bwd");
+}
+
+extern "C" int wcmc_maxpool2_bwd_add(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, const float* dy, int64_t dsn, int64_t dsh,
+                                     int64_t dsw, const float* add, int64_t asn, int64_t ash, int64_t asw, float* dx, int64_t gsn,
+                                     int64_t gsh, int64_t gsw, int N, int H, int W, int C, void* stream) {
+  WCMC_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, WCMC_ERR_BAD_ARG,
+               "maxpool2_bwd_add: bad shape (H,W must be even)");
+  WCMC_REQUIRE(VIEW_OK(x, xsn, xsh, xsw, C) && VIEW_OK(dy, dsn, dsh, dsw, C) && VIEW_OK(add, asn, ash, asw, C) && VIEW_OK(dx, gsn, gsh, gsw, C),
+               WCMC_ERR_ALIGNMENT, "maxpool2_bwd_add: a view violates the NHWC-view contract");
+  const int C4 = (C + 3) / 4;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * C4)), dim3(256), 0,
+                     (hipStream_t)stream, View{x, xsn, xsh, xsw}, View{dy, dsn, dsh, dsw}, View{add, asn, ash, asw}, MView{dx, gsn, gsh, gsw}, N,
+                     H / 2, W / 2, C4, C);
+  return check_launch("maxpool2_bwd_add");
 }
 
 extern "C" int wcmc_upsample2_fwd(const float* x, int64_t xsn, int64_t xsh, int64_t xsw, float* y, int64_t ysn,

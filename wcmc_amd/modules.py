@@ -118,10 +118,12 @@ class _Level(nn.Module):
         left = self.left(x)
         if self.is_last:
             return left
-        deeper = self.next_level(ops.maxpool2(left))
+        # one node: the skip's and the pooled copy's gradients are summed in one pass (WCMC_POOL_SKIP=0: A/B switch)
+        skip, pooled = ops.maxpool2_skip(left) if ops.POOL_SKIP else (left, ops.maxpool2(left))
+        deeper = self.next_level(pooled)
         # cat([upsample2(deeper), skip], 1) is written once, directly as the right chain's split input, the bilinear
         # upsampling evaluated inside that kernel
-        return self.right.forward_cat_upsample(deeper, left)
+        return self.right.forward_cat_upsample(deeper, skip)
 
 
 class Autoencoder(nn.Module):

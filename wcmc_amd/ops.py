@@ -1317,6 +1317,43 @@ class _MaxPool2(torch.autograd.Function):
         return dx
 
 
+class _MaxPool2Skip(torch.autograd.Function):
+    """``(x, maxpool2(x))`` as ONE node (a U-Net level: x feeds the skip connection, its pooled copy the level below): the two
+    gradients of x arrive together and are summed inside the pooling backward's pass (``wcmc_maxpool2_bwd_add``) instead of by
+    autograd's elementwise add -- one launch and one pass over the tensor less per level."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        y = nhwc_empty(n, c, h // 2, w // 2, x.device)
+        check(lib().wcmc_maxpool2_fwd(*_v(x), *_v(y), n, h, w, c, _stream()), "maxpool2_fwd")
+        ctx.save_for_backward(x)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g_skip, g_pool):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        if g_pool is None:
+            return g_skip
+        g_pool = _as_nhwc_nograd(g_pool)
+        dx = nhwc_empty(n, c, h, w, x.device)
+        if g_skip is None:
+            check(lib().wcmc_maxpool2_bwd(*_v(x), *_v(g_pool), *_v(dx), n, h, w, c, _stream()), "maxpool2_bwd")
+        else:
+            g_skip = _as_nhwc_nograd(g_skip)
+            check(lib().wcmc_maxpool2_bwd_add(*_v(x), *_v(g_pool), *_v(g_skip), *_v(dx), n, h, w, c, _stream()), "maxpool2_bwd_add")
+        return dx
+
+
+POOL_SKIP = os.environ.get("WCMC_POOL_SKIP", "1") != "0"
+
+
+def maxpool2_skip(x):
+    """``(x, maxpool2(x))``: see ``_MaxPool2Skip``."""
+    return _MaxPool2Skip.apply(as_nhwc(x))
+
+
 class _Upsample2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
