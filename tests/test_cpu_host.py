@@ -875,6 +875,9 @@ def test_launcher_flag_surface_and_argument_errors():
                 disentangle="m11r11", single_gpu=False, device_id=0, kpcn_ref=False, kpcn_pre=False, not_save=False, local=False)
     for k, v in want.items():
         assert getattr(a, k) == v, k
+    # this build's own switches are off unless asked for
+    assert not a.graph and not a.defer_check and not a.overlap_allreduce and a.pairing_rng == "cpu"
+    assert p.parse_args(["--desc", "d", "--graph", "--overlap_allreduce"]).overlap_allreduce
     with pytest.raises(SystemExit):
         p.parse_args([])                                                     # --desc is required
     full = "--single_gpu --batch_size 8 --val_epoch 1 --data_dir /d --model_name M --desc x --num_epoch 8 --manif_loss FMSE " \

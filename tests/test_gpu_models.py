@@ -512,6 +512,34 @@ def test_graphed_step_equals_eager_step():
         ops.set_precision(old)
 
 
+def test_first_layer_data_gradient_restricted_to_the_pbuffer_channels_changes_nothing_downstream(monkeypatch):
+    """``ops.pbuffer_cat`` marks the channels of its output whose gradient its backward reads (the P-buffer's mean: 3 of 39);
+    ``ops.conv_chain`` then forms the first layer's data gradient for the 8-aligned rows round them only.  The gradients of the
+    P-buffer and of every chain parameter must equal those of the full data gradient (same arithmetic per element; the sliced
+    launch runs another tile shape, hence rounding-level differences only)."""
+    from wcmc_amd import ops
+    from wcmc_amd.modules import ConvChain
+    torch.manual_seed(5)
+    chain = ConvChain(39, 24, depth=3, width=48, ksize=5, pad=False, output_type="linear").to(DEV)
+    base = torch.randn(2, 35, 40, 40, device=DEV)
+    p0 = torch.rand(2, 4, 3, 40, 40, device=DEV)
+    gout = torch.randn(2, 24, 28, 28, device=DEV)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "DX_SLICE", on)
+        chain.zero_grad()
+        p = p0.clone().requires_grad_(True)
+        x = ops.pbuffer_cat(base, p)
+        assert x._wcmc_grad_channels == (35, 38)
+        y = chain(x)
+        y.backward(gout)
+        res[on] = (y.detach().clone(), p.grad.clone(), [q.grad.clone() for q in chain.parameters()])
+    assert torch.equal(res[True][0], res[False][0])
+    assert rel_l2(res[True][1], res[False][1]) <= (2e-3 if ops.reduced_backward() else 1e-5)       # (two-term instance against the generic three-term one)
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)                              # the weight gradients do not see the slice at all
+
+
 def test_graphed_step_close_releases_its_graphs_and_memory():
     """``GraphedTrainStep.close()``: the graphs, their memory pool and the static batch go at once (a session that builds one
     graphed step after another keeps one alive); the interface trains on eagerly or under a new capture, the closed object
