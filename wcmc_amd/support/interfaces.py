@@ -272,6 +272,10 @@ class KPCNInterface(BaseInterface):
         whose gradients stay in their ``.grad``."""
         raw = getattr(self, '_p_raw', None)
         if raw is None:
+            if os.environ.get('WCMC_JOINT_BACKWARD', '1') == '0':      # A/B switch: the reference's one engine run per loss
+                for loss in losses:
+                    loss.backward()
+                return
             torch.autograd.backward(list(losses))
             return
         ins = [p for p in self.models['dncnn'].parameters() if p.requires_grad] + [t for t in raw.values() if t.requires_grad]
