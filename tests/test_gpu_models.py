@@ -879,7 +879,7 @@ _SWITCHES = [
                                                          # dgrad pair: the bias sums group per tile, not per workgroup)
     ("attr", "FUSE_CHAIN_GLUE", False, "exact"),         # separate spp-mean / concat / upsample nodes
     ("attr", "USE_BRANCH_STREAM", False, "exact"),       # specular half on the main stream
-    ("attr", "USE_SIDE_STREAM", False, "exact"),         # weight gradients on the main stream
+    ("attr", "USE_SIDE_STREAM", True, "exact"),          # weight gradients on a forked stream (off in every mode since round 4)
     ("env", "WCMC_IGEMM_PW", "0", "close"),              # tiled kernel for the 1x1 layers (bias sums group per tile)
     ("env", "WCMC_PW_TAIL", "0", "exact"),               # no fused 1x1 layer pairs
     ("env", "WCMC_KA_TILE", "1", "exact"),               # tile kernel-apply instead of the strip kernel

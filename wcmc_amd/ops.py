@@ -51,13 +51,12 @@ def reduced_backward(mode=None):
 
 
 def _side_stream_default(mode):
-    """Weight-gradient GEMMs on a stream of their own beside the data-gradient GEMMs?  Measured per mode on the graphed
-    benchmark step (scripts/time_streams.py, four stream configurations interleaved in one process): with the one-MFMA weight
-    gradients of the default mode the extra stream LOSES 3.4 % (13.47 against 13.05 ms: the short weight gradients only take
-    CUs from the data gradient they run beside), with three-MFMA ones it is even (18.9 ms either way), in exact fp32 it
-    wins 1.5 % (69.4 against 70.4 ms).  WCMC_SIDE_STREAM=0 / 1 overrides."""
-    e = os.environ.get("WCMC_SIDE_STREAM")
-    return (e != "0") if e is not None else not reduced_backward(mode)
+    """Weight-gradient GEMMs on a stream of their own beside the data-gradient GEMMs?  Not since both branch losses share one
+    autograd engine run (round 4): the two halves of the backward already overlap on two streams, and a third chain that forks
+    and joins per layer loses in every mode -- default mode 11.68 -> 13.2 ms (``profiles/r04_schedule.txt``), ``bf16x3``
+    17.0 -> 18.55 ms, exact fp32 62.5 -> 69.3 ms (same box, ``scripts/time_step_env.py``).  Rounds 2-3, with the halves'
+    backward passes in series, had it on for the three-term and fp32 modes (even / +1.5 % there).  WCMC_SIDE_STREAM=1 turns it on."""
+    return os.environ.get("WCMC_SIDE_STREAM") == "1"
 
 
 def set_precision(mode):
