@@ -32,7 +32,8 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse figure)
 PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
-_ROWS8 = os.environ.get("WCMC_WGRAD_ROWS8", "1")[:1] != "0"     # which filter-row weight-gradient kernel the library launches
+_ROWS8_ENV = os.environ.get("WCMC_WGRAD_ROWS8")                 # which filter-row weight-gradient kernel the library launches:
+_rows8 = lambda terms: (_ROWS8_ENV[:1] != "0") if _ROWS8_ENV else terms == 3      # eight waves for three-term launches, seven for one-term ones
 _ROWS8_XE = 0 if os.environ.get("WCMC_WGRAD_ROWS8_XE", "1")[:1] == "0" else 1
 PROFILE_ROUND = "r04"              # profiles/<round>_pmc_summary.json, <round>_bench_kernel_stats.csv: the evidence of THIS binary
 
@@ -51,7 +52,7 @@ def rocprof_names(wgrad_terms):
             "conv_halo64_pt3_x1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 0>",
             "conv_halo64_pt4_h1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 1, 1>",
             "conv_halo64_pt3_h1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 1>",
-            "conv_wgrad_rows": ("wcmc::conv_wgrad_rows8_bf16x3_kernel<0, %d, %d>" % (_ROWS8_XE if wgrad_terms == 3 else 1, 1 if wgrad_terms == 1 else 2)) if _ROWS8
+            "conv_wgrad_rows": ("wcmc::conv_wgrad_rows8_bf16x3_kernel<0, %d, %d>" % (_ROWS8_XE if wgrad_terms == 3 else 1, 1 if wgrad_terms == 1 else 2)) if _rows8(wgrad_terms)
                                else "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, %d>" % (1 if wgrad_terms == 1 else 2),
             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)",
             # the fused PathNet chains (csrc/pathnet_fused.hip); the backward brackets include their small finish kernels
@@ -211,7 +212,7 @@ def pmc_traffic():
                          ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 2, 2, 0>", "conv_halo64_pt3"), ("conv_halo64_bf16x3_kernel<7, 2, 3", "conv_halo64_cs32"),
                          ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 2, 0>", "conv_halo64_pt4_x2"), ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 2, 0>", "conv_halo64_pt3_x2"),
                          ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 0>", "conv_halo64_pt3_x1"), ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 1>", "conv_halo64_pt3_h1"),
-                         ("conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>" if _ROWS8 else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, 1>", "conv_wgrad_rows"),
+                         ("conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>" if _rows8(1) else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, 1>", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("embed3_fwd_kernel", "embed3_fwd"), ("embed3_bwd_kernel", "embed3_bwd"),
                          ("final2_kernel<false>", "final2_fwd"), ("final2_kernel<true>", "final2_bwd"),
@@ -553,7 +554,7 @@ def main():
 
         # classes = kernels: conv_halo64_pt4 / _pt3 / _cs32 are the instances of conv_halo64_bf16x3_kernel<7,NB,PT> (KPCN 5x5 fwd +
         # dgrad: 16x16 tiles, 12x16 tiles, 12x16 with 32-channel slabs for the 441-channel data gradient; conv_halo7 = the 8x16
-        # kernel they replace, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows8_bf16x3_kernel (WCMC_WGRAD_ROWS8=0: ..._rows_bf16x3_kernel<5,7,7>);
+        # kernel they replace, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows_bf16x3_kernel<5,7,7> for one-term launches, conv_wgrad_rows8_bf16x3_kernel for three-term ones (WCMC_WGRAD_ROWS8=0|1: one of them for both);
         # conv_igemm / conv_wgrad collect the other GEMM kernels
         conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_pt3_x2", "conv_halo64_pt4_x2", "conv_halo64_pt3_x1", "conv_halo64_pt4_x1", "conv_halo64_pt3_h1", "conv_halo64_pt4_h1", "conv_halo64_cs32", "conv_halo7",
                                  "conv_wgrad_rows", "conv_igemm", "conv_wgrad")

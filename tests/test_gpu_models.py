@@ -893,7 +893,8 @@ _SWITCHES = [
     ("env", "WCMC_HALO64_CS32", "0", "close"),           # 16-channel slabs for the 441-channel data gradient too (another K order)
     ("env", "WCMC_WGRAD_ROWS_3X3", "0", "close"),        # filter-row weight gradient only from 256 input channels up
     ("env", "WCMC_WGRAD_ROWS_1X1", "0", "close"),        # one-tap kernel for the 128->128 1x1 weight gradient
-    ("env", "WCMC_WGRAD_ROWS8", "0", "exact"),           # seven-wave filter-row kernel for the 100 -> 100 5x5 layers (same slabs)
+    ("env", "WCMC_WGRAD_ROWS8", "1", "exact"),           # eight-wave filter-row kernel for the 100 -> 100 5x5 layers (same slabs; the
+                                                         # one-plane launches of the default mode run the seven-wave one)
     ("env", "WCMC_WGRAD_ROWS8_PRIO", "0", "exact"),      # no priority hand-over between the two waves of a SIMD
     ("env", "WCMC_WGRAD_ROWS8_XE", "0", "exact"),        # left-over tiles as three pairs x one cout tile per wave
 ]

@@ -3118,7 +3118,12 @@ template <int KS, int TM, int NW, int PL = 2>
 static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
   constexpr size_t lds = xwr_lds_bytes<KS, TM, NW, PL>();
   const dim3 grid((unsigned)(((q.S * q.coBlocks * q.ciBlocks + 7) / 8) * 8 * KS));
-  if (KS == 5 && TM == 7 && NW == 7 && x_env_on("WCMC_WGRAD_ROWS8")) {   // =0: A/B switch back to the seven-wave kernel
+  // The eight-wave kernel for the two-plane (three-term) launches, the seven-wave one for the one-plane launches of the default
+  // mode: there the seven waves are faster alone (0.311 against 0.295 of the bf16 peak in the eager profile) and beside the other
+  // half of the step (+0.9 % per step, round 4).  WCMC_WGRAD_ROWS8=1 / 0: eight / seven waves for both.
+  const char* r8e = getenv("WCMC_WGRAD_ROWS8");
+  const bool rows8 = r8e ? r8e[0] != '0' : PL == 2;
+  if (KS == 5 && TM == 7 && NW == 7 && rows8) {
     // two stages of NI = 8 (PL = 1: 4) instructions x 8 waves x 1 KB (> the 52 KB staging tile of the slab write)
     constexpr size_t lds8 = (size_t)2 * ((PL * (64 * 14 + 68 * 14) + 511) / 512) * 512 * 16;
     if (PL == 1) {
