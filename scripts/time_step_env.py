@@ -16,6 +16,6 @@ for _ in range(4):
 v = []
 for rnd in range(5):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(30): st(batch)
+    for _ in range(30): st(st.static if "static" in sys.argv else batch)      # ("static": no hand-over copy -- the caller fills the graph's own input buffers)
     st.flush(); torch.cuda.synchronize(); v.append((time.perf_counter() - t0) / 30 * 1e3)
 print(sys.argv[1:], " ".join("%.3f" % x for x in v), "ms -> %.1f patches/s" % (8e3 / sorted(v)[2]), [repr(x) for x in ls])
