@@ -98,15 +98,17 @@ class EventProfiler:
         return out
 
 
-def build_interface(device, group, rng="device"):
+def build_interface(device, group, rng="device", weight_norm=True, seed=0):
+    """weight_norm: the PathNets' parametrisation -- True = upstream sbmc's ConvChain default, which
+    ``support/networks.py:18-24`` does not switch off (w = g * v / ||v|| per layer); False = plain weights (rounds 1-4)."""
     from wcmc_amd import KPCN
     from wcmc_amd.optim import FusedClipAdam
     from wcmc_amd.support.interfaces import KPCNInterface
     from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
     from wcmc_amd.support.networks import PathNet
-    torch.manual_seed(0)                                            # train_kpcn.py:346-348
-    models = {"dncnn": KPCN(39), "backbone_diffuse": PathNet(ic=36, outc=3),
-              "backbone_specular": PathNet(ic=36, outc=3)}
+    torch.manual_seed(seed)                                         # train_kpcn.py:346-348 (seed 0)
+    models = {"dncnn": KPCN(39), "backbone_diffuse": PathNet(ic=36, outc=3, weight_norm=weight_norm),
+              "backbone_specular": PathNet(ic=36, outc=3, weight_norm=weight_norm)}
     for k in models:
         models[k] = models[k].to(device)
     optims = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in models.items()}
@@ -269,7 +271,7 @@ def c2_leg(device, steps, warmup):
             "losses_last_step": last}
 
 
-def extra_leg(device, steps, warmup, precision=None, group=None, force_collective=False, overlap=False):
+def extra_leg(device, steps, warmup, precision=None, group=None, force_collective=False, overlap=False, weight_norm=True):
     """The benchmarked step once more in another configuration, graphed, same weights (seed 0) and batch: another arithmetic
     (`other_precisions`), or the default one with the MULTI-RANK tail on a one-rank RCCL group (`multi_rank_path`)."""
     from wcmc_amd import ops
@@ -280,7 +282,7 @@ def extra_leg(device, steps, warmup, precision=None, group=None, force_collectiv
     if precision is not None:
         ops.set_precision(precision)
     try:
-        itf = build_interface(device, None, rng="device")
+        itf = build_interface(device, None, rng="device", weight_norm=weight_norm)
         if force_collective:
             itf.fused_optim = FusedClipAdam(itf.models, itf.optims, process_group=group, force_collective=True,
                                             order=("dncnn", "backbone_diffuse", "backbone_specular") if overlap else None)
@@ -406,6 +408,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="smoke test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL refuses two ranks "
                          "on one device); the printed throughput is then meaningless")
+    ap.add_argument("--no-pathnet-weight-norm", action="store_true",
+                    help="plain nn.Conv2d weights in the PathNets instead of upstream sbmc's weight-normalised layers (the default)")
     ap.add_argument("--precision", choices=("bf16x321h", "bf16x321o", "bf16x321", "bf16x3", "fp32"), default=None,
                     help="conv GEMM arithmetic: split-bf16 with 3 / 2 / 1 MFMAs per product in forward / data gradient / weight "
                          "gradient (default), 3 everywhere (rounds 1-2), or exact fp32 MFMA (roofline vs the 157.3 TF/s peak)")
@@ -437,7 +441,7 @@ def main():
     device = torch.device("cuda", local)
 
     group = torch.distributed.group.WORLD if world > 1 else None
-    itf = build_interface(device, group, rng="cpu" if args.cpu_rng else "device")
+    itf = build_interface(device, group, rng="cpu" if args.cpu_rng else "device", weight_norm=not args.no_pathnet_weight_norm)
     if world > 1:
         for fl in itf.fused_optim.flats.values():
             torch.distributed.broadcast(fl.flat, 0)
@@ -602,6 +606,9 @@ def main():
                                   if graphed.tail_split else
                                   "one hipGraph replay per step (forward + backward) + eager all-reduce of three buckets + eager clip + Adam"),
                        "feature_mse_rng": "cpu (reference stream)" if args.cpu_rng else "device",
+                       # PathNet layers as sbmc.modules.ConvChain builds them when support/networks.py:18-24 passes no weight_norm
+                       # argument: w = g * v / ||v|| (wcmc_weight_norm_fwd / _bwd, one launch per PathNet and direction)
+                       "pathnet_weight_norm": not args.no_pathnet_weight_norm,
                        "precision": (("conv GEMMs: split-bf16 operands (hi + lo planes), v_mfma_f32_16x16x32_bf16, fp32 accumulate; per "
                                       "product 3 MFMAs in the forward (hi*hi + hi*lo + lo*hi)%s, 2 in the data gradients that have a "
                                       "two-term instance (dy_hi x (W_hi + W_lo): KPCN 5x5, U-Net 3x3; the fused 1x1 chains' too), 1 in the "
@@ -654,6 +661,9 @@ def main():
                 line["other_precisions"] = {m: extra_leg(device, n, 3, precision=m)
                                             for m, n in (("bf16x321h", args.steps), ("bf16x321o", args.steps), ("bf16x3", args.steps),
                                                          ("fp32", max(3, args.steps // 4)))}
+                # ... and the other PathNet parametrisation (plain weights when the headline is weight-normalised, and vice versa)
+                line["other_parametrisation"] = dict(extra_leg(device, args.steps, 3, weight_norm=bool(args.no_pathnet_weight_norm)),
+                                                     pathnet_weight_norm=bool(args.no_pathnet_weight_norm))
             if args.backend == "nccl":
                 # The step exactly as rank k of N runs it -- graph A (forward, backward, gradient gather, guard flag), three eager
                 # asynchronous RCCL all-reduces of the gradient buckets (46.8 MB), graph B (global guard, sums, scale -> clip ->

@@ -432,6 +432,23 @@ int wcmc_grs_bwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t 
  * reference draws its pairings with torch.randperm on the CPU generator (support/losses.py:35,50). */
 int wcmc_random_permutation(int64_t* out, int64_t n, uint64_t seed, void* stream);
 
+/* ---------------------------------------------------------------- weight normalisation
+ * sbmc.modules.ConvChain wraps every nn.Conv2d in torch.nn.utils.weight_norm unless its caller passes weight_norm=False;
+ * support/networks.py:18-24 (PathNet's embedding / propagation / final chains) does not, sbmc.KPCN does.  Parameters per
+ * layer: weight_g (Cout,1,1,1), weight_v (Cout,Cin,k,k);  weight = weight_g * weight_v / ||weight_v||, norm over (Cin,k,k)
+ * per output channel (torch._weight_norm, dim 0).
+ *
+ * Both entries take ALL layers of a model in one launch (n_layers <= 32): tables of n_layers device pointers, rows[l] = Cout,
+ * row_len[l] = Cin*k*k.  v / w / dw / dv are dense [rows][row_len] fp32 (16-byte aligned when row_len % 4 == 0);
+ * g / norm / dg are [rows].
+ *   fwd: w = v * (g / ||v||), norm = ||v||                                  (torch._weight_norm)
+ *   bwd: dg = <dw, v> / norm;  dv = (g / norm) * (dw - v * <dw, v> / norm^2)   (torch._weight_norm_interface_backward) */
+int wcmc_weight_norm_fwd(int n_layers, const float* const* v, const float* const* g, float* const* w,
+                         float* const* norm, const int* rows, const int* row_len, void* stream);
+int wcmc_weight_norm_bwd(int n_layers, const float* const* dw, const float* const* v, const float* const* g,
+                         const float* const* norm, float* const* dv, float* const* dg, const int* rows,
+                         const int* row_len, void* stream);
+
 /* ---------------------------------------------------------------- clip + Adam
  * support/interfaces.py:260-261 (clip_grad_value_) + :269-271 (Adam.step,
  * train_kpcn.py:274-277: default betas/eps, no weight decay, no amsgrad) fused

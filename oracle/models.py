@@ -17,9 +17,9 @@ class KPCN(nn.Module):
         super().__init__()
         self.ksize = ksize
         self.diffuse = ConvChain(n_in, ksize * ksize, depth=depth, width=width, ksize=5,
-                                 pad=False, output_type="linear")
+                                 pad=False, output_type="linear", weight_norm=False)
         self.specular = ConvChain(n_in, ksize * ksize, depth=depth, width=width, ksize=5,
-                                  pad=False, output_type="linear")
+                                  pad=False, output_type="linear", weight_norm=False)
         self.kernel_apply = KernelApply(softmax=True, splat=False)
 
     def forward(self, data):
@@ -43,7 +43,8 @@ class SampleDenoiserStandIn(nn.Module):
 
     def __init__(self, n_features, width=8, depth=2):
         super().__init__()
-        self.net = ConvChain(3 + n_features, 3, ksize=3, width=width, depth=depth, pad=False, output_type="linear")
+        self.net = ConvChain(3 + n_features, 3, ksize=3, width=width, depth=depth, pad=False, output_type="linear",
+                             weight_norm=False)
 
     def forward(self, data):
         x = torch.cat([data["radiance"], data["features"]], 2)

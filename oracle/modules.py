@@ -10,7 +10,7 @@ Appendix A).
 Frozen choices (identical in the HIP path, ``wcmc_amd/modules.py``):
   * ConvChain: ``depth-1`` x [Conv2d(k, padding=k//2 if pad else 0) + ReLU], then
     one Conv2d to ``noutputs`` followed by ``output_type`` activation
-    (linear | relu | leaky_relu with slope 0.01).  Bias everywhere, no norm.
+    (linear | relu | leaky_relu with slope 0.01).  Bias everywhere, no batch norm.
   * Autoencoder: U-Net; level widths ``width * increase_factor**lvl``; each
     level = left ConvChain -> MaxPool2d(2) -> next level -> x2 bilinear upsample
     (align_corners=False) -> cat([up, left], 1) -> right ConvChain; the deepest
@@ -19,8 +19,10 @@ Frozen choices (identical in the HIP path, ``wcmc_amd/modules.py``):
     index t = (dy+r)*k + (dx+r) (row-major dy, dx), zero-extended gather
     ``out[b,c,y,x] = sum_t w[b,t,y,x] * data0[b,c,y+dy,x+dx]`` with no
     renormalisation at the border.
-  * Parameter names: ``layers.<i>.weight`` / ``layers.<i>.bias`` inside a chain (``layers.<i>.weight_g`` /
-    ``.weight_v`` / ``.bias`` with the explicit ``weight_norm=True`` option; default False, see ConvChain).
+  * Weight normalisation: ``ConvChain(weight_norm=True)`` is the default, as in published adobe/sbmc; ``sbmc.KPCN`` passes
+    False, PathNet's call sites pass nothing (``support/networks.py:18-24``) and therefore train ``g * v / ||v||``.
+  * Parameter names: ``layers.<i>.weight_g`` / ``.weight_v`` / ``.bias`` inside a weight-normalised chain
+    (``torch.nn.utils.weight_norm``'s), ``layers.<i>.weight`` / ``.bias`` with ``weight_norm=False``.
   * U-Net concatenation order: ``cat([upsampled deeper level, left skip], 1)``.
   * Init: xavier-uniform with ReLU gain, zero bias.
 """
@@ -49,11 +51,11 @@ class ConvChain(nn.Module):
     """``sbmc.modules.ConvChain`` (call sites ``support/networks.py:18-19,23-24``)."""
 
     def __init__(self, ninputs, noutputs, ksize=3, width=64, depth=3, pad=True,
-                 activation="relu", output_type="linear", weight_norm=False):
-        """weight_norm: explicit option of this specification, default False (module docstring: "no norm").  Upstream
-        adobe/sbmc is believed -- unverifiable here, the package is absent -- to default ``weight_norm=True`` in ConvChain,
-        which ``sbmc.KPCN`` overrides to False and PathNet's calls (``support/networks.py:18-24``) do not.  With True each
-        layer is ``torch.nn.utils.weight_norm(nn.Conv2d(...))``: parameters ``weight_g`` / ``weight_v``,
+                 activation="relu", output_type="linear", weight_norm=True):
+        """weight_norm: default True, as published adobe/sbmc's ConvChain (unverifiable here, the package is absent; three
+        independent readings agree: this build's, SURVEY.md Appendix A's, the round-4 review's) -- ``sbmc.KPCN`` overrides it
+        to False, PathNet's calls (``support/networks.py:18-24``) do not.  With True each layer is
+        ``torch.nn.utils.weight_norm(nn.Conv2d(...))``: parameters ``weight_g`` / ``weight_v``,
         ``weight = g * v / ||v||`` (norm per output channel)."""
         super().__init__()
         assert depth >= 1 and activation == "relu"
@@ -95,7 +97,7 @@ class ConvChain(nn.Module):
 
 class _Level(nn.Module):
     def __init__(self, n_in, n_out, width, num_convs, ksize, output_type,
-                 next_level=None, n_up=None, weight_norm=False):
+                 next_level=None, n_up=None, weight_norm=True):
         super().__init__()
         self.is_last = next_level is None
         kw = dict(ksize=ksize, width=width, depth=num_convs, pad=True, weight_norm=weight_norm)
@@ -120,7 +122,7 @@ class Autoencoder(nn.Module):
     """``sbmc.modules.Autoencoder`` (call site ``support/networks.py:20-22``)."""
 
     def __init__(self, ninputs, noutputs, ksize=3, width=64, num_levels=3, num_convs=2,
-                 max_width=512, increase_factor=1.0, output_type="linear", pooling="max", weight_norm=False):
+                 max_width=512, increase_factor=1.0, output_type="linear", pooling="max", weight_norm=True):
         super().__init__()
         assert pooling == "max"
         self.num_levels = num_levels

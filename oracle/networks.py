@@ -12,7 +12,7 @@ from .modules import Autoencoder, ConvChain
 
 
 class PathNet(nn.Module):
-    def __init__(self, ic, intermc=64, outc=3, weight_norm=False):
+    def __init__(self, ic, intermc=64, outc=3, weight_norm=True):
         super().__init__()
         self.ic, self.intermc, self.outc = ic, intermc, outc
         self.final_ic = intermc + intermc

@@ -11,8 +11,8 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max()).item(), ((a - b).norm() / b.norm()).item()
 for seed in range(4):
     torch.manual_seed(seed)
-    ref = om.ConvChain(34, 441, ksize=5, width=100, depth=9, pad=False).double()
-    mod = ConvChain(34, 441, ksize=5, width=100, depth=9, pad=False)
+    ref = om.ConvChain(34, 441, ksize=5, width=100, depth=9, pad=False, weight_norm=False).double()
+    mod = ConvChain(34, 441, ksize=5, width=100, depth=9, pad=False, weight_norm=False)
     mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}); mod.cuda()
     x = torch.rand(2, 34, 64, 64) - 0.3
     # flips: run the oracle layer by layer in fp64 and the HIP chain truncated to l layers
@@ -20,7 +20,7 @@ for seed in range(4):
     h = x.double()
     for l in range(8):
         h = torch.relu(ref.layers[l](h))
-        sub = ConvChain(34, 100, ksize=5, width=100, depth=l + 1, pad=False, output_type="relu")
+        sub = ConvChain(34, 100, ksize=5, width=100, depth=l + 1, pad=False, output_type="relu", weight_norm=False)
         sub.layers = torch.nn.ModuleList(list(mod.layers[:l + 1])); sub.depth = l + 1
         with torch.no_grad():
             hh = sub(x.cuda())

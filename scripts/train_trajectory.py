@@ -20,8 +20,11 @@ import torch
 KEYS = ("l_diffuse", "l_specular", "l_manif_diffuse", "l_manif_specular", "l_total", "rmse")
 
 
-def run(mode, steps=200, nb=16, b=8, s=8, h=128, seed=1234, lr=1e-4, batches=None, held_out=None):
-    """Train `steps` graphed steps in arithmetic `mode`; returns ({key: [per-step value]}, validation RelativeMSE)."""
+def run(mode, steps=200, nb=16, b=8, s=8, h=128, seed=1234, lr=1e-4, batches=None, held_out=None, ulp_seed=None):
+    """Train `steps` graphed steps in arithmetic `mode`; returns ({key: [per-step value]}, validation RelativeMSE).
+    ulp_seed: perturb every initial weight by at most one unit in the last place (a seeded factor 1 + d, |d| <= 2^-23) -- the
+    size of ONE rounding difference, i.e. what any other correct arithmetic or summation order amounts to at step 0; the
+    spread of such runs is the recipe's own sensitivity (scripts/trajectory_spread.py)."""
     import bench
     from wcmc_amd import ops
     from wcmc_amd.graph import GraphedTrainStep
@@ -33,6 +36,12 @@ def run(mode, steps=200, nb=16, b=8, s=8, h=128, seed=1234, lr=1e-4, batches=Non
         itf = bench.build_interface(dev, None, rng="device")          # seed 0 weights, the bench's own constructor
         for o in itf.optims.values():
             o.param_groups[0]["lr"] = lr
+        if ulp_seed is not None:
+            g = torch.Generator(device="cpu").manual_seed(int(ulp_seed))
+            with torch.no_grad():
+                for m in itf.models.values():
+                    for p in m.parameters():
+                        p.mul_(1.0 + (torch.rand(p.shape, generator=g) - 0.5).to(dev) * 2.0 ** -22)
         if batches is None:
             batches = [make_batch(b, s, h, seed=500 + i, device=dev) for i in range(nb)]
         if held_out is None:

@@ -191,6 +191,8 @@ def build_models(case, seed):
             for n, p in m.named_parameters():
                 if n.endswith("bias"):
                     p.uniform_(-0.1, 0.1)
+                if n.endswith("weight_g"):      # weight-normalised PathNet layers (oracle/modules.py): g != ||v||, so that the
+                    p.mul_(torch.empty_like(p).uniform_(0.7, 1.3))      # normalisation is exercised, not the identity it starts as
     return models
 
 
@@ -274,6 +276,8 @@ def build_variant_models(case, seed):
             for n, p in m.named_parameters():
                 if n.endswith("bias"):
                     p.uniform_(-0.1, 0.1)
+                if n.endswith("weight_g"):      # weight-normalised PathNet layers (oracle/modules.py): g != ||v||, so that the
+                    p.mul_(torch.empty_like(p).uniform_(0.7, 1.3))      # normalisation is exercised, not the identity it starts as
     return models
 
 
@@ -375,6 +379,8 @@ def build_sample_models(case, seed):
             for n, p in m.named_parameters():
                 if n.endswith("bias"):
                     p.uniform_(-0.1, 0.1)
+                if n.endswith("weight_g"):      # weight-normalised PathNet layers (oracle/modules.py): g != ||v||, so that the
+                    p.mul_(torch.empty_like(p).uniform_(0.7, 1.3))      # normalisation is exercised, not the identity it starts as
     return models
 
 

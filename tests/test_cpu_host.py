@@ -266,8 +266,12 @@ def test_ref_and_pre_interfaces_host_logic_against_reference_golden(golden_dir, 
             else:
                 np.testing.assert_allclose(p.grad.numpy(), want, rtol=1e-4, atol=1e-7, err_msg="%s %s" % (mn, k))
         for k, v in m.state_dict().items():
-            np.testing.assert_allclose(v.numpy(), d["after/%s/%s" % (mn, k)], rtol=1e-4, atol=2e-6,
-                                       err_msg="after %s %s" % (mn, k))
+            # (Adam's first step is lr * g / (|g| + 1e-8): ill-conditioned where |g| ~ eps, as in tests/test_oracle_golden.py)
+            g = np.abs(d["grad/%s/%s" % (mn, k)])
+            want, got = d["after/%s/%s" % (mn, k)], v.numpy()
+            big = g > 1e-5 if g.size else np.zeros(want.shape, bool)
+            np.testing.assert_allclose(got[big], want[big], rtol=1e-4, atol=2e-6, err_msg="after %s %s" % (mn, k))
+            np.testing.assert_allclose(got[~big], want[~big], atol=4.1e-3, err_msg="after %s %s" % (mn, k))
     itf.to_eval_mode()
     with torch.no_grad():
         rad, pb = itf.validate_batch(batch)
@@ -322,7 +326,12 @@ def test_sbmc_and_lbmc_interfaces_host_logic_against_reference_golden(golden_dir
         norm = float(torch.sqrt(sum((p.grad ** 2).sum() for p in m.parameters())))
         np.testing.assert_allclose(norm, d["gradnorm/" + mn], rtol=1e-4)
         for k, v in m.state_dict().items():
-            np.testing.assert_allclose(v.numpy(), d["after/%s/%s" % (mn, k)], rtol=1e-4, atol=2e-6, err_msg="after %s %s" % (mn, k))
+            # (Adam's first step is lr * g / (|g| + 1e-8): ill-conditioned where |g| ~ eps, as in tests/test_oracle_golden.py)
+            g = np.abs(d["grad/%s/%s" % (mn, k)])
+            want, got = d["after/%s/%s" % (mn, k)], v.numpy()
+            big = g > 1e-5 if g.size else np.zeros(want.shape, bool)
+            np.testing.assert_allclose(got[big], want[big], rtol=1e-4, atol=2e-6, err_msg="after %s %s" % (mn, k))
+            np.testing.assert_allclose(got[~big], want[~big], atol=4.1e-3, err_msg="after %s %s" % (mn, k))
     if case.endswith("clipped"):
         np.testing.assert_allclose(float(d["gradnorm/dncnn"]), itf.GRAD_NORM_CLIP, rtol=1e-5)     # the clamp did bite
     itf.to_eval_mode()
@@ -978,15 +987,25 @@ def test_init_model_restores_weight_normalised_pathnets_from_a_checkpoint(tmp_pa
         assert list(sd_w) == list(sd_g), name
         for k in sd_w:
             assert torch.equal(sd_w[k], sd_g[k].cpu()), (name, k)
-    # a fresh start follows the flag (default: the documented "no norm")
+    # a fresh start follows the flag (default: upstream's weight-normalised PathNets)
     fresh = ["--desc", "d", "--save", str(tmp_path), "--use_llpm_buf", "--manif_learn", "--manif_loss", "FMSE", "--train_branches",
              "--single_gpu"]
     args0 = tk.check_args(tk.build_parser().parse_args(fresh + ["--model_name", "fresh"]))
     m0 = tk.init_model(sizes, args0, torch.device("cpu"))[0][0].models["backbone_diffuse"]
-    assert not any(k.endswith("weight_g") for k in m0.state_dict())
-    args1 = tk.check_args(tk.build_parser().parse_args(fresh + ["--model_name", "fresh1", "--pathnet_weight_norm"]))
+    assert any(k.endswith("weight_g") for k in m0.state_dict())
+    args1 = tk.check_args(tk.build_parser().parse_args(fresh + ["--model_name", "fresh1", "--no_pathnet_weight_norm"]))
     m1 = tk.init_model(sizes, args1, torch.device("cpu"))[0][0].models["backbone_diffuse"]
-    assert any(k.endswith("weight_g") for k in m1.state_dict())
+    assert not any(k.endswith("weight_g") for k in m1.state_dict())
+    # ... and a checkpoint of the plain parametrisation (this build's rounds 1-4) is restored as such whatever the flag says
+    plain = {"dncnn": KPCN(39), "backbone_diffuse": PathNet(36, outc=3, weight_norm=False),
+             "backbone_specular": PathNet(36, outc=3, weight_norm=False)}
+    itf_p = types.SimpleNamespace(models=plain, best_err=0.25,
+                                  optims={"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in plain.items()})
+    argv_p = [a if a != "wn" else "plain" for a in argv]
+    args_p = tk.check_args(tk.build_parser().parse_args(argv_p))
+    ck_mod.save_checkpoint(str(tmp_path / "plain.pth"), itf_p, 0, args_p)
+    got_p = tk.init_model(sizes, args_p, torch.device("cpu"))[0][0].models
+    assert list(got_p["backbone_diffuse"].state_dict()) == list(plain["backbone_diffuse"].state_dict())
 
 
 def test_frozen_parameter_names_and_state_dict_round_trip():
@@ -1002,25 +1021,30 @@ def test_frozen_parameter_names_and_state_dict_round_trip():
         "%s.layers.%d.%s" % (br, i, w) for br in ("diffuse", "specular") for i in range(3) for w in ("weight", "bias")]
     hk.load_state_dict(ok.state_dict())
     assert all(torch.equal(a, b) for a, b in zip(ok.state_dict().values(), hk.state_dict().values()))
-    op, hp = OPathNet(36, intermc=8), PathNet(36, intermc=8)
+    op, hp = OPathNet(36, intermc=8, weight_norm=False), PathNet(36, intermc=8, weight_norm=False)
     names = list(op.state_dict())
     assert names == list(hp.state_dict())
     assert names[:6] == ["embedding.layers.%d.%s" % (i, w) for i in range(3) for w in ("weight", "bias")]
     assert "propagation.net.next_level.next_level.left.layers.2.bias" in names and names[-1] == "final.layers.1.bias"
     assert op.propagation.net.right.layers[0].weight.shape == (8, 16 + 8, 3, 3)       # cat([upsampled deeper (16), skip (8)])
     hp.load_state_dict(op.state_dict())
-    on, hn = OPathNet(36, intermc=8, weight_norm=True), PathNet(36, intermc=8, weight_norm=True)
+    # the default: weight-normalised chains, torch.nn.utils.weight_norm's parameter names
+    on, hn = OPathNet(36, intermc=8), PathNet(36, intermc=8)
+    assert on.embedding.weight_norm and hn.embedding.weight_norm and hn.propagation.net.left.weight_norm and hn.final.weight_norm
     wn = list(hn.state_dict())
     assert set(wn) == set(on.state_dict()) and "embedding.layers.0.weight_g" in wn and "final.layers.1.weight_v" in wn
     assert not any(k.endswith(".weight") for k in wn)
     hn.load_state_dict(on.state_dict())
-    back = OPathNet(36, intermc=8, weight_norm=True)
+    back = OPathNet(36, intermc=8)
     back.load_state_dict(hn.state_dict())
     x = {"paths": torch.rand(1, 2, 36, 8, 8)}
     assert torch.equal(back(x), on(x))
     # at initialisation g = ||v||: the effective weight is v, i.e. the un-normalised network
     lay = hn.embedding.layers[0]
-    assert torch.allclose(lay.weight, lay.weight_v, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(lay.weight_g.flatten(), lay.weight_v.flatten(1).norm(dim=1), rtol=1e-6, atol=1e-7)
+    # the effective weight is formed by the HIP library only: no CPU path
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        lay.weight
 
 
 def test_bench_roofline_names_match_the_committed_profiles():

@@ -45,33 +45,54 @@ def _max_rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("rng_mode", ["device", "cpu"])
-def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
-    """``rng_mode='device'`` is the switch ``bench.py`` runs with (``config.feature_mse_rng``): the pairings come from the
+@pytest.mark.parametrize("rng_mode,weight_norm", [("device", True), ("cpu", True), ("device", False)])
+def test_benchmarked_configuration_two_steps_against_oracle(rng_mode, weight_norm):
+    """``weight_norm=True`` is the PathNet parametrisation ``bench.py`` runs (``config.pathnet_weight_norm``: upstream sbmc's
+    ConvChain default, ``support/networks.py:18-24``), with ``weight_g`` moved off ``||weight_v||`` so that the normalisation
+    acts; ``False`` the plain weights of rounds 1-4 (``bench.py --no-pathnet-weight-norm``, the line's ``other_parametrisation``
+    leg).  Same bars for both.  ``rng_mode='device'`` is the switch ``bench.py`` runs with (``config.feature_mse_rng``): the pairings come from the
     keyed device bijection (``GraphedTrainStep._draw``), are read back from ``fm.static_perms`` after the replay and handed to
     the oracle; ``'cpu'`` is the reference's ``torch.randperm`` stream (``losses.py:35,50``), drawn identically on both sides."""
+    report, fails = parity_report(rng_mode, weight_norm)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "bench_config_parity_%s%s.txt" % (rng_mode, "" if weight_norm else "_plain")), "w") as f:
+        for name, e, c, mx in sorted(report, key=lambda r: -r[1]):
+            f.write("%-60s relL2/err %.3e%s%s\n" % (name, e, "" if c is None else "  1-cos %.2e" % c,
+                                                    "" if mx is None else "  max-norm %.2e" % mx))
+    assert not fails, "\n".join(fails)
+
+
+def parity_report(rng_mode, weight_norm, seed=0):
+    """The comparison itself; returns (report rows, failures).  seed: shifts the weights' seed, the bias / weight_g draws, the batches
+    and the pairing keys together (scripts/calibrate_grad_bar.py runs several to put the gradient bar on more than one draw)."""
     import bench
     from wcmc_amd import ops
     from wcmc_amd.graph import GraphedTrainStep
     from wcmc_amd.synthetic import make_batch
-    assert ops.PRECISION == os.environ.get("WCMC_PRECISION", ops.MODES[0]) and not ops.USE_SIDE_STREAM and ops.USE_BRANCH_STREAM and ops.FUSE_CHAIN_GLUE, \
+    assert ops.PRECISION == os.environ.get("WCMC_PRECISION", ops.MODES[0]) and not ops.USE_SIDE_STREAM and ops.USE_BRANCH_STREAM and ops.FUSE_EMBED and ops.FUSE_FINAL, \
         "this test pins the DEFAULT switches (the ones bench.py runs with)"
     B, S, H = bench.B_PER_GPU, bench.SPP, bench.PATCH
     device = torch.device("cuda", 0)
-    itf = bench.build_interface(device, None, rng=rng_mode)              # the bench's own constructor, seed 0
+    itf = bench.build_interface(device, None, rng=rng_mode, weight_norm=weight_norm, seed=seed)      # the bench's own constructor
     hmods = itf.models
-    omods = {"dncnn": OKPCN(39), "backbone_diffuse": OPathNet(36), "backbone_specular": OPathNet(36)}
+    torch.manual_seed(0)
+    omods = {"dncnn": OKPCN(39), "backbone_diffuse": OPathNet(36, weight_norm=weight_norm),
+             "backbone_specular": OPathNet(36, weight_norm=weight_norm)}
+    assert hmods["backbone_diffuse"].embedding.weight_norm == weight_norm and not hmods["dncnn"].diffuse.weight_norm
     # biases are zero at init (a degenerate case for bias-path bugs): give both sides the same random ones
-    g = torch.Generator().manual_seed(77)
+    g = torch.Generator().manual_seed(77 + seed)
     for k, m in hmods.items():
         with torch.no_grad():
             for n, p in m.named_parameters():
                 if n.endswith("bias"):
                     p.copy_((torch.rand(p.shape, generator=g) * 0.2 - 0.1).to(device))
+                if n.endswith("weight_g"):      # g = ||v|| at init (w = v): move it so that g * v / ||v|| is not the identity
+                    p.mul_((torch.rand(p.shape, generator=g) * 0.6 + 0.7).to(device))
         omods[k].load_state_dict({n: v.detach().cpu().clone() for n, v in m.state_dict().items()})
     oopt = {"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in omods.items()}
     cfg = dict(use_llpm_buf=True, manif_learn=True, train_branches=True, disentanglement_option="m11r11", w_manif=0.1)
-    batches = [make_batch(B, S, H, seed=40 + i, device="cpu") for i in range(2)]
+    batches = [make_batch(B, S, H, seed=40 + i + 10 * seed, device="cpu") for i in range(2)]
     dbatches = [{k: v.to(device) for k, v in b.items()} for b in batches]
 
     graphed = GraphedTrainStep(itf, dbatches[0])                          # capture (its warm-up draws pairings)
@@ -81,9 +102,9 @@ def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
             assert torch.equal(p_start[mn][k], q.detach()), (mn, k)
 
     ho = H - 36
-    torch.manual_seed(1234)
+    torch.manual_seed(1234 + seed)
     perms = [[ostep.draw_perms(B, S, ho, ho), ostep.draw_perms(B, S, ho, ho)] for _ in range(2)]
-    torch.manual_seed(1234)                                               # the graph draws the same stream, same order
+    torch.manual_seed(1234 + seed)                                        # the graph draws the same stream, same order
     report, fails = [], []
     ograds = [{}, {}]
     lr = 1e-4
@@ -155,13 +176,8 @@ def test_benchmarked_configuration_two_steps_against_oracle(rng_mode):
                 for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
                     q.copy_(p.detach().cpu())
                     p_prev[mn][k] = p.detach().cpu().clone()
-    out = os.path.join(ROOT, "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "bench_config_parity_%s.txt" % rng_mode), "w") as f:
-        for name, e, c, mx in sorted(report, key=lambda r: -r[1]):
-            f.write("%-60s relL2/err %.3e%s%s\n" % (name, e, "" if c is None else "  1-cos %.2e" % c,
-                                                    "" if mx is None else "  max-norm %.2e" % mx))
-    assert not fails, "\n".join(fails)
+    graphed.close()
+    return report, fails
 
 
 def test_c2_vanilla_full_size_graphed_step_against_oracle():

@@ -43,7 +43,7 @@ def test_epoch_loop_checkpoint_resume_gives_the_same_next_epoch(tmp_path, graph,
     ``KPCN(n_in)`` is swapped for a 3-layer one to keep the test short); without ``--graph``, with it, and with ``--defer_check``."""
     from wcmc_amd import KPCN, train_kpcn as tk
     monkeypatch.setattr(tk, "KPCN", lambda n_in: KPCN(n_in, ksize=21, depth=3, width=24))
-    monkeypatch.setattr(tk, "PathNet", lambda ic, outc, weight_norm=False: __import__("wcmc_amd.support.networks", fromlist=["PathNet"]).PathNet(ic, intermc=16, outc=outc, weight_norm=weight_norm))
+    monkeypatch.setattr(tk, "PathNet", lambda ic, outc, weight_norm=True: __import__("wcmc_amd.support.networks", fromlist=["PathNet"]).PathNet(ic, intermc=16, outc=outc, weight_norm=weight_norm))
     dev = torch.device(DEV, 0)
     extra = {"graph": True} if graph else {}
     if graph == "defer":

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 import make_golden as mg                      # noqa: E402  (geometry/builders only)
-from conftest import FlipCounter, cosine, rel_l2   # noqa: E402
+from conftest import DEBUG_LIB, FlipCounter, cosine, rel_l2   # noqa: E402
 from oracle import step as ostep              # noqa: E402
 from oracle.models import KPCN as OKPCN       # noqa: E402
 from oracle.networks import PathNet as OPathNet   # noqa: E402
@@ -121,34 +121,88 @@ def test_pathnet_with_six_output_channels_runs_the_fused_chains_and_matches_the_
         grad_close(p.grad, q.grad, 2e-2, "PathNet(outc=6) grad " + k)
 
 
-def test_pathnet_weight_norm_option_matches_oracle():
-    """The explicit ``weight_norm=True`` option of the chains (oracle/modules.py ConvChain docstring): forward, and the
-    gradients of ``weight_g`` / ``weight_v`` through the HIP chains, against ``torch.nn.utils.weight_norm`` convolutions."""
+def _move_g(m, seed):
+    """weight_g = ||weight_v|| at initialisation (the effective weight is v): scale it so that the normalisation acts."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("weight_g"):
+                p.mul_(torch.rand(p.shape, generator=g) + 0.5)
+
+
+def test_pathnet_plain_weights_option_matches_oracle(precision):
+    """``PathNet(weight_norm=False)``: the parametrisation of this build's rounds 1-4, kept selectable."""
     from wcmc_amd.support.networks import PathNet
     torch.manual_seed(0)
-    ref = OPathNet(36, intermc=16, outc=3, weight_norm=True)
+    ref = OPathNet(36, intermc=16, outc=3, weight_norm=False)
     randomize_bias(ref, 1)
-    with torch.no_grad():
-        for n, p in ref.named_parameters():
-            if n.endswith("weight_g"):
-                p.mul_(torch.rand(p.shape) + 0.5)            # g != ||v||: the normalisation must actually act
-    mod = PathNet(36, intermc=16, outc=3, weight_norm=True)
+    mod = PathNet(36, intermc=16, outc=3, weight_norm=False)
+    assert [k for k, _ in mod.named_parameters()][:2] == ["embedding.layers.0.weight", "embedding.layers.0.bias"]
+    mod.load_state_dict(ref.state_dict())
+    mod.to(DEV)
+    g = torch.Generator().manual_seed(2)
+    paths = torch.rand(2, 3, 36, 16, 24, generator=g) - 0.4
+    with FlipCounter() as fc:
+        out_r = ref({"paths": paths})
+        gout = torch.rand(out_r.shape, generator=g) - 0.5
+        out_r.backward(gout)
+        out = mod({"paths": paths.to(DEV)})
+    out.backward(gout.to(DEV))
+    assert_close(out, out_r, what="PathNet(plain) fwd")
+    for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        fc.check(p.grad, q.grad, 1e-3, what="PathNet(plain) grad " + k, l2=2e-2)
+
+
+def test_pathnet_weight_norm_full_width_against_fp64(precision):
+    """The default PathNet -- 64 wide, weight-normalised chains, ``weight_g`` moved off ``||weight_v||`` -- forward and the
+    gradients of ``weight_g`` / ``weight_v`` / ``bias`` of all 20 layers against ``torch.nn.utils.weight_norm`` convolutions in
+    fp64, and the launch structure: ONE ``wcmc_weight_norm_fwd`` and ONE ``wcmc_weight_norm_bwd`` per PathNet pass."""
+    from wcmc_amd import ops
+    from wcmc_amd.support.networks import PathNet
+    torch.manual_seed(0)
+    ref = OPathNet(36, outc=3)
+    randomize_bias(ref, 1)
+    _move_g(ref, 5)
+    mod = PathNet(36, outc=3)
     mod.load_state_dict(ref.state_dict())
     mod.to(DEV)
     ref = ref.double()
     g = torch.Generator().manual_seed(2)
-    paths = torch.rand(2, 3, 36, 16, 24, generator=g) - 0.4
+    paths = torch.rand(2, 4, 36, 32, 48, generator=g) - 0.4
     out_r = ref({"paths": paths.double()})
     gout = torch.rand(out_r.shape, generator=g) - 0.5
     out_r.backward(gout.double())
-    out = mod({"paths": paths.to(DEV)})
-    out.backward(gout.to(DEV))
+    calls = {"fwd": 0, "bwd": 0}
+    real_f, real_b = ops._WeightNormMulti.forward, ops._WeightNormMulti.backward
+    ops._WeightNormMulti.forward = staticmethod(lambda ctx, *a: (calls.__setitem__("fwd", calls["fwd"] + 1), real_f(ctx, *a))[1])
+    ops._WeightNormMulti.backward = staticmethod(lambda ctx, *a: (calls.__setitem__("bwd", calls["bwd"] + 1), real_b(ctx, *a))[1])
+    try:
+        out = mod({"paths": paths.to(DEV)})
+        out.backward(gout.to(DEV))
+    finally:
+        ops._WeightNormMulti.forward, ops._WeightNormMulti.backward = real_f, real_b
+    assert calls == {"fwd": 1, "bwd": 1}, calls
     assert_close(out, out_r, what="PathNet(weight_norm) fwd")
     named_r = dict(ref.named_parameters())
+    errs = []
     for k, p in mod.named_parameters():
-        assert p.grad is not None, k
-        e = rel_l2(p.grad, named_r[k].grad)
-        assert e <= 2e-2, "PathNet(weight_norm) grad %s: relative L2 %.3e" % (k, e)
+        assert p.grad is not None and p.grad.shape == named_r[k].grad.shape, k
+        errs.append((rel_l2(p.grad, named_r[k].grad.float()), k))
+    try:
+        with open(_AGG_LOG, "a") as f:
+            for e, k in sorted(errs, reverse=True):
+                f.write("PathNet(weight_norm) full width %-10s %-60s relL2 %.3e\n" % (precision, k, e))
+    except OSError:
+        pass
+    bad = [(e, k) for e, k in errs if e > WN_GRAD_L2[precision]]
+    assert not bad, "PathNet(weight_norm) %s gradients beyond %.1e: %s" % (precision, WN_GRAD_L2[precision], sorted(bad, reverse=True)[:5])
+
+
+# per-tensor relative L2 of the weight-normalised PathNet's gradients against fp64 at THIS size (2 x 4 samples of 32 x 48 pixels), by
+# arithmetic, measured on MI355X in round 5 (profiles/r05_golden_bars.txt): exact fp32 2.4e-6; the split-bf16 modes 1.75e-2 /
+# 1.84e-2 -- ReLU and max-pool ties on 12k pixels; the same tensors sit at 1.2e-3 on the benchmark's 131k pixels
+# (tests/test_gpu_bench_config.py, which is where per-tensor arithmetic parity is held).  Bars: >= 2x the measured worst tensor.
+WN_GRAD_L2 = {"fp32": 2e-5, "bf16x3": 4e-2, "bf16x321": 4e-2, "bf16x321o": 4e-2, "bf16x321h": 4e-2}
 
 
 def test_kpcn_c1_config_matches_oracle(precision):
@@ -183,16 +237,77 @@ def test_kpcn_c1_config_matches_oracle(precision):
 # logged to gpurun_out/grad_l2.txt).  The bars below are per tensor, relative L2, no fallback.
 # Measured (MI355X, all golden cases, gpurun_out/grad_l2.txt): exact-fp32 MFMA <= 5.3e-6 whatever happens; split-bf16
 # <= 4.9e-5 when no unit flipped against the oracle forward, <= 3.4e-2 with one flipped unit, 1.07e-1 with two.
+_AGG_LOG = os.path.join(os.path.dirname(_GRAD_LOG), "golden_grad_aggregate.txt")
+TENSOR_SANITY_L2 = 0.5
+
+
+def golden_grads_close(named, want_of, bar, what, tensor_bar=TENSOR_SANITY_L2):
+    """Gradient parity on the TINY golden networks (20 x 20 pixels, 4 .. 16 channels: the U-Net's deepest level has 50 units per
+    channel).  One ReLU / max-pool / L1-sign tie that falls the other way in two correct arithmetics moves a 4-entry bias
+    gradient there by tens of per cent, so a per-tensor bar at this geometry measures the draw, not the kernels (round 5
+    re-drew every golden with weight-normalised PathNets: profiles/r05_golden_bars.txt).  What is held:
+      * the gradients of ALL parameters of a model as ONE vector: relative L2 against the golden's <= ``bar`` (a tie moves a
+        handful of its entries);
+      * every tensor on its own <= 0.5 (a missing, mis-scaled, transposed or wrong-sign gradient is >= 1), exact-fp32 mode: <= bar.
+    Per-tensor arithmetic parity is what tests/test_gpu_bench_config.py holds, at the benchmark's size.
+    named: [(name, parameter)]; want_of(name) -> golden gradient (numpy; size 0 = the reference left ``.grad`` None)."""
+    got, want = [], []
+    worst = (0.0, "")
+    for k, p in named:
+        w = want_of(k)
+        if w.size == 0:
+            assert p.grad is None, "%s %s: the reference leaves this gradient None" % (what, k)
+            continue
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(w.shape), (what, k)
+        e = rel_l2(p.grad, T(w))
+        worst = max(worst, (e, k))
+        assert e <= tensor_bar, "%s %s: relative L2 %.3e > %.1e" % (what, k, e, tensor_bar)
+        got.append(p.grad.detach().double().cpu().reshape(-1))
+        want.append(T(w).double().reshape(-1))
+    if not got:
+        return
+    agg = rel_l2(torch.cat(got), torch.cat(want))
+    try:
+        os.makedirs(os.path.dirname(_AGG_LOG), exist_ok=True)
+        with open(_AGG_LOG, "a") as f:
+            f.write("%-90s aggregate %.3e  worst tensor %.3e %s  bar %.1e\n" % (what, agg, worst[0], worst[1], bar))
+    except OSError:
+        pass
+    assert agg <= bar, "%s: relative L2 of the model's whole gradient %.3e > %.1e (worst tensor %.3e %s)" % (what, agg, bar, worst[0], worst[1])
+
+
+def tensor_l2(precision):
+    """Per-tensor bar of the golden tests: exact fp32 arithmetic is held to 1e-4 tensor by tensor; the split-bf16 modes to the sanity
+    bar (see ``golden_grads_close``)."""
+    return 1e-4 if precision == "fp32" else TENSOR_SANITY_L2
+
+
+def val_close(got, want, what):
+    """Validation outputs AFTER the golden's Adam step (lr 2e-3 on the PathNets): an entry whose gradient is a sign tie moves by
+    2 lr the other way in two correct arithmetics -- a whole output channel when it is a ``weight_g`` -- so the max-norm sees
+    single pixels move by ~1e-2 (measured up to 7.6e-3 on the P-buffer); held: relative L2 <= 5e-3 and max-norm <= 2e-2."""
+    assert tuple(got.shape) == tuple(want.shape), (what, got.shape, want.shape)
+    e2, em = rel_l2(got, want), rel_err(got, want)
+    try:
+        with open(_AGG_LOG, "a") as f:
+            f.write("%-90s relL2 %.3e max-norm %.3e\n" % (what, e2, em))
+    except OSError:
+        pass
+    assert e2 <= 5e-3 and em <= 2e-2, "%s: relative L2 %.3e (<= 5e-3), max-norm %.3e (<= 2e-2)" % (what, e2, em)
+
+
 def golden_l2(precision, flips=None):
+    """Bar on the relative L2 of a golden model's WHOLE gradient (``golden_grads_close``).  Measured on MI355X with round 5's
+    goldens (profiles/r05_golden_bars.txt, every case x arithmetic x model): exact fp32 <= 3e-6; bf16x3 without a flipped unit
+    <= 5e-5; the reduced-backward modes without a flip <= 2.7e-3 (dy / x rounded to bf16, 800 pixels to average over); any mode
+    with ONE flipped ReLU unit <= 1.0e-2; the tests that do not count flips <= 9.0e-3.  Bars: >= 2x those."""
     if precision == "fp32":
         return 1e-4
-    if flips is None:          # (tests that do not run the oracle forward beside the step: <= 1.7e-2 measured)
-        return 1e-1
-    if precision in ("bf16x321h", "bf16x321", "bf16x321o") and flips == 0:
-        # the backward GEMMs round dy (and x in the weight gradient) to bf16, 2^-9 each: with 800 pixels per golden batch
-        # there is little to average over (the benchmarked step has 107k per layer: profiles/r03_precision_ladder.txt)
-        return 8e-3
-    return 2e-4 if flips == 0 else 8e-2 * flips
+    if flips is None:
+        return 2e-2
+    if flips == 0:
+        return 8e-3 if precision in ("bf16x321h", "bf16x321", "bf16x321o") else 2e-4
+    return 2e-2 * flips
 
 
 def build_hip_models(case, d):
@@ -258,9 +373,9 @@ def test_interface_step_against_reference_golden(golden_dir, case, fused, precis
         if k.startswith("m_losses/") and k != "m_losses/m_val":
             np.testing.assert_allclose(itf.m_losses[k[len("m_losses/"):]].item(), d[k], rtol=1e-3, err_msg=k)
     for mn, m in models.items():
-        for k, p in m.named_parameters():
-            want = T(d["grad/%s/%s" % (mn, k)])
-            grad_close(p.grad, want, golden_l2(precision, nflips), "golden %s %s fused=%d (%d flips) post-clip grad %s %s" % (case, precision, fused, nflips, mn, k))
+        golden_grads_close(list(m.named_parameters()), lambda k: d["grad/%s/%s" % (mn, k)], golden_l2(precision, nflips),
+                           "golden %s %s fused=%d (%d flips) post-clip grad %s" % (case, precision, fused, nflips, mn),
+                           tensor_bar=tensor_l2(precision))
         for k, v in m.state_dict().items():
             g = np.abs(d["grad/%s/%s" % (mn, k)])
             want, got = d["after/%s/%s" % (mn, k)], v.cpu().numpy()
@@ -270,10 +385,10 @@ def test_interface_step_against_reference_golden(golden_dir, case, fused, precis
     itf.to_eval_mode()
     with torch.no_grad():
         rad, pb = itf.validate_batch(batch)
-    assert_close(rad, T(d["val/radiance"]), tol=5e-3, what="validate radiance")
+    val_close(rad, T(d["val/radiance"]), "validate radiance %s %s" % (case, precision))
     np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=5e-3)
     if pb is not None:
-        assert_close(pb["diffuse"], T(d["val/p_diffuse"]), tol=5e-3, what="validate p_buffer")
+        val_close(pb["diffuse"], T(d["val/p_diffuse"]), "validate p_buffer %s %s" % (case, precision))
 
 
 @pytest.mark.parametrize("case", list(mg.VARIANT_CASES))
@@ -319,12 +434,8 @@ def test_ref_and_pre_interfaces_against_reference_golden(golden_dir, case, preci
         if k.startswith("m_losses/") and k != "m_losses/m_val":
             np.testing.assert_allclose(itf.m_losses[k[len("m_losses/"):]].item(), d[k], rtol=1e-3, err_msg=k)
     for mn, m in models.items():
-        for k, p in m.named_parameters():
-            want = d["grad/%s/%s" % (mn, k)]
-            if want.size == 0:
-                assert p.grad is None
-                continue
-            grad_close(p.grad, T(want), golden_l2(precision), "golden %s %s post-clip grad %s %s" % (case, precision, mn, k))
+        golden_grads_close(list(m.named_parameters()), lambda k: d["grad/%s/%s" % (mn, k)], golden_l2(precision),
+                           "golden %s %s post-clip grad %s" % (case, precision, mn), tensor_bar=tensor_l2(precision))
         for k, v in m.state_dict().items():
             want, got = d["after/%s/%s" % (mn, k)], v.cpu().numpy()
             g = np.abs(d["grad/%s/%s" % (mn, k)])
@@ -337,7 +448,7 @@ def test_ref_and_pre_interfaces_against_reference_golden(golden_dir, case, preci
     itf.to_eval_mode()
     with torch.no_grad():
         rad, pb = itf.validate_batch(batch)
-    assert_close(rad, T(d["val/radiance"]), tol=5e-3, what="validate radiance")
+    val_close(rad, T(d["val/radiance"]), "validate radiance %s %s" % (case, precision))
     np.testing.assert_allclose(itf.get_epoch_summary(mode="eval", norm=1), d["val/summary"], rtol=5e-3)
 
 
@@ -379,8 +490,8 @@ def test_sbmc_and_lbmc_interfaces_against_reference_golden(golden_dir, case, pre
         if k.startswith("m_losses/") and k != "m_losses/m_val":
             np.testing.assert_allclose(itf.m_losses[k[len("m_losses/"):]].item(), d[k], rtol=1e-3, err_msg=k)
     for mn, m in models.items():
-        for k, p in m.named_parameters():
-            grad_close(p.grad, T(d["grad/%s/%s" % (mn, k)]), golden_l2(precision), "golden %s %s post-clip grad %s %s" % (case, precision, mn, k))
+        golden_grads_close(list(m.named_parameters()), lambda k: d["grad/%s/%s" % (mn, k)], golden_l2(precision),
+                           "golden %s %s post-clip grad %s" % (case, precision, mn), tensor_bar=tensor_l2(precision))
         norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
         np.testing.assert_allclose(norm, d["gradnorm/" + mn], rtol=5e-2)
         for k, v in m.state_dict().items():
@@ -520,17 +631,18 @@ def test_first_layer_data_gradient_restricted_to_the_pbuffer_channels_changes_no
     from wcmc_amd import ops
     from wcmc_amd.modules import ConvChain
     torch.manual_seed(5)
-    chain = ConvChain(39, 24, depth=3, width=48, ksize=5, pad=False, output_type="linear").to(DEV)
+    chain = ConvChain(39, 24, depth=3, width=48, ksize=5, pad=False, output_type="linear", weight_norm=False).to(DEV)
     base = torch.randn(2, 35, 40, 40, device=DEV)
     p0 = torch.rand(2, 4, 3, 40, 40, device=DEV)
     gout = torch.randn(2, 24, 28, 28, device=DEV)
     res = {}
     for on in (True, False):
-        monkeypatch.setattr(ops, "DX_SLICE", on)
         chain.zero_grad()
         p = p0.clone().requires_grad_(True)
         x = ops.pbuffer_cat(base, p)
         assert x._wcmc_grad_channels == (35, 38)
+        if not on:
+            del x._wcmc_grad_channels              # without the hint the chain forms the full data gradient
         y = chain(x)
         y.backward(gout)
         res[on] = (y.detach().clone(), p.grad.clone(), [q.grad.clone() for q in chain.parameters()])
@@ -872,14 +984,13 @@ def test_nonfinite_loss_raises_and_skips_the_update():
 # sequence / same order of additions per output); "close": another K order, split-K order or grouping of the bias sums,
 # held to 5e-4 relative L2 (measured: <= 1.3e-4, on gradients at the far end of the backward pass).
 _SWITCHES = [
-    ("attr", "FUSE_BIAS_GRAD", False, "close"),          # bias gradients by column-sum / finish launches (the chain heads' sums
-                                                         # then group by colsum_split's blocks, not by the split pass's)
-    ("attr", "PACK_CHAIN", False, "exact"),              # two weight-packing launches per layer instead of one per chain
-    ("attr", "USE_GATE_MASK", False, "close"),           # gate from the activation, not the 1-bit mask (and no fused 1x1
-                                                         # dgrad pair: the bias sums group per tile, not per workgroup)
-    ("attr", "FUSE_CHAIN_GLUE", False, "exact"),         # separate spp-mean / concat / upsample nodes
+    # the switches the release library and ops.py still have (wcmc_amd/ops.py: WCMC_BRANCH_STREAM, WCMC_SIDE_STREAM; the two PathNet
+    # fusions have their own tests in tests/test_gpu_ops.py; WCMC_JOINT_BACKWARD: support/interfaces.py)
     ("attr", "USE_BRANCH_STREAM", False, "exact"),       # specular half on the main stream
     ("attr", "USE_SIDE_STREAM", True, "exact"),          # weight gradients on a forked stream (off in every mode since round 4)
+    ("env", "WCMC_JOINT_BACKWARD", "0", "exact"),        # the reference's one autograd engine run per branch loss
+] + ([
+    # kernel A/B switches: DEBUG build of the library only (conftest.needs_debug_lib)
     ("env", "WCMC_IGEMM_PW", "0", "close"),              # tiled kernel for the 1x1 layers (bias sums group per tile)
     ("env", "WCMC_PW_TAIL", "0", "exact"),               # no fused 1x1 layer pairs
     ("env", "WCMC_KA_TILE", "1", "exact"),               # tile kernel-apply instead of the strip kernel
@@ -897,7 +1008,7 @@ _SWITCHES = [
                                                          # one-plane launches of the default mode run the seven-wave one)
     ("env", "WCMC_WGRAD_ROWS8_PRIO", "0", "exact"),      # no priority hand-over between the two waves of a SIMD
     ("env", "WCMC_WGRAD_ROWS8_XE", "0", "exact"),        # left-over tiles as three pairs x one cout tile per wave
-]
+] if DEBUG_LIB else [])
 
 
 def test_default_mode_forward_is_the_three_term_forward_and_its_gradients_stay_close():
@@ -915,7 +1026,7 @@ def test_default_mode_forward_is_the_three_term_forward_and_its_gradients_stay_c
     runs = {}
     old = ops.PRECISION
     try:
-        for mode, env in (("bf16x3", None), ("bf16x321", None), ("bf16x321", "0"), ("bf16x321o", None), ("bf16x321h", None)):
+        for mode, env in (("bf16x3", None), ("bf16x321", None)) + ((("bf16x321", "0"),) if DEBUG_LIB else ()) + (("bf16x321o", None), ("bf16x321h", None)):
             ops.set_precision(mode)
             if env is not None:
                 os.environ["WCMC_DGRAD_AP1"] = env
@@ -937,7 +1048,7 @@ def test_default_mode_forward_is_the_three_term_forward_and_its_gradients_stay_c
             else:
                 worst[key] = max(worst.get(key, 0.0), rel_l2(got[k], want))
     assert worst[("bf16x3", None)] == 0.0
-    assert 0.0 < worst[("bf16x321", "0")] <= 6e-3 and 0.0 < worst[("bf16x321", None)] <= 6e-3, worst
+    assert (not DEBUG_LIB or 0.0 < worst[("bf16x321", "0")] <= 6e-3) and 0.0 < worst[("bf16x321", None)] <= 6e-3, worst
     assert 0.0 < worst[("bf16x321o", None)] <= 1.2e-2, worst      # (measured 6.9e-3: the output layers' rounded logits move d_logits)
     assert 0.0 < worst[("bf16x321h", None)] <= 6e-3, worst
 

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+from conftest import DEBUG_LIB, needs_debug_lib      # noqa: E402
 from oracle import losses as ol            # noqa: E402
 from oracle import modules as om           # noqa: E402
 from oracle.step import assemble_input     # noqa: E402
@@ -130,9 +131,9 @@ def test_conv_chain_deep_matches_oracle_chain(precision):
     tol = ptol(precision, 2e-5, 2e-4)
     gt = gtol(precision, 2e-5, 2e-4)
     torch.manual_seed(11)
-    ref = om.ConvChain(13, 25, ksize=5, width=20, depth=4, pad=False, output_type="linear").double()
+    ref = om.ConvChain(13, 25, ksize=5, width=20, depth=4, pad=False, output_type="linear", weight_norm=False).double()
     from wcmc_amd.modules import ConvChain
-    mod = ConvChain(13, 25, ksize=5, width=20, depth=4, pad=False, output_type="linear")
+    mod = ConvChain(13, 25, ksize=5, width=20, depth=4, pad=False, output_type="linear", weight_norm=False)
     with torch.no_grad():
         for p in ref.parameters():
             if p.dim() == 1:
@@ -176,6 +177,7 @@ def test_conv_wgrad_is_bitwise_reproducible():
 
 @pytest.mark.parametrize("geom", [(8, 44, 44, 0), (4, 37, 70, 0), (3, 30, 101, 2), (16, 8, 8, 0), (8, 124, 124, 0),
                                   (2, 40, 40, 0, 100, 441), (2, 36, 52, 1, 224, 112), (2, 24, 24, 0, 210, 212)])
+@needs_debug_lib
 def test_eight_wave_filter_row_kernel_equals_seven_wave(geom, monkeypatch):
     """conv_wgrad_rows8_bf16x3_kernel (245 accumulator tiles dealt over eight waves, priority hand-over inside a stage)
     writes the slabs of conv_wgrad_rows_bf16x3_kernel<5, 7, 7> bit for bit: ragged chunks (Wo % 64 in {40, 2, 37, 4}),
@@ -264,27 +266,18 @@ def test_conv5x5_kernel_variants_agree_with_fp64(case, monkeypatch):
     bits = torch.zeros(n, ho, wo, cp, dtype=torch.bool)
     bits[..., :cout] = keep.permute(0, 2, 3, 1)
     mask = torch.from_numpy(np.packbits(bits.numpy().reshape(-1, cp), axis=1, bitorder="little").reshape(-1)).to(DEV)
-    outs = {}
-    for name, env in (("12x16 where it pays", {}), ("16x16 only", {"WCMC_HALO64_PT3": "0"}),
-                      ("8x16 kernel", {"WCMC_HALO64": "0"})):
-        for k in ("WCMC_HALO64_PT3", "WCMC_HALO64"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        wp = o._pack_x(wt.to(DEV), 0)                                  # (the packing follows the kernel's slab plan)
-        if split:
-            y, part = o.conv2d_x_raw(xs, (n, cin, h, w), wp, b.to(DEV), cout, ks, pad, "relu", out_split=True,
-                                     gate_mask=mask, gate_act="relu", colsum=True)
-            yd = o.unsplit_debug(y, n, cout, ho, wo)
-            db = o.colsum_finish_raw(part, (n, cout, ho, wo))
-            assert_close(db, ref.sum(dim=(0, 2, 3)), tol=2e-5, what=name + ": column sums")
-        else:
-            yd = o.conv2d_x_raw(xs, (n, cin, h, w), wp, b.to(DEV), cout, ks, pad, "relu", out_split=False)
-            yd = yd * keep.to(DEV)
-        assert_close(yd, ref, tol=2e-5, what=name)
-        outs[name] = yd
-    # same kernel, same K order: the tile height does not change a single bit
-    assert torch.equal(outs["12x16 where it pays"], outs["16x16 only"])
+    name = "conv_halo64 (the tile height the plan picks)"
+    wp = o._pack_x(wt.to(DEV), 0)                                  # (the packing follows the kernel's slab plan)
+    if split:
+        y, part = o.conv2d_x_raw(xs, (n, cin, h, w), wp, b.to(DEV), cout, ks, pad, "relu", out_split=True,
+                                 gate_mask=mask, gate_act="relu", colsum=True)
+        yd = o.unsplit_debug(y, n, cout, ho, wo)
+        db = o.colsum_finish_raw(part, (n, cout, ho, wo))
+        assert_close(db, ref.sum(dim=(0, 2, 3)), tol=2e-5, what=name + ": column sums")
+    else:
+        yd = o.conv2d_x_raw(xs, (n, cin, h, w), wp, b.to(DEV), cout, ks, pad, "relu", out_split=False)
+        yd = yd * keep.to(DEV)
+    assert_close(yd, ref, tol=2e-5, what=name)
 
 
 @pytest.mark.parametrize("case", [(16, 36, 64, 64, 64, 1), (12, 128, 48, 40, 128, 1), (16, 128, 64, 64, 3, 1), (4, 128, 40, 37, 128, 3)])
@@ -301,7 +294,7 @@ def test_weight_gradient_with_many_slabs_against_fp64(case, monkeypatch):
     dys = o.split_raw(o.to_nhwc_raw(dy.to(DEV)))
     want = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, ks, ks), dy.double(), padding=pad)
     got = {}
-    for name, env in (("shipped plan", {}), ("one-tap kernel", {"WCMC_WGRAD_ROWS": "0"})):
+    for name, env in (("shipped plan", {}),) + ((("one-tap kernel", {"WCMC_WGRAD_ROWS": "0"}),) if DEBUG_LIB else ()):
         for k in ("WCMC_WGRAD_ROWS",):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -312,7 +305,7 @@ def test_weight_gradient_with_many_slabs_against_fp64(case, monkeypatch):
         assert_close(dw, want, tol=2e-5, what=name + ": dw")
         assert_close(db, dy.double().sum(dim=(0, 2, 3)), tol=2e-5, what=name + ": db")
         got[name] = dw
-    assert rel_err(got["shipped plan"], got["one-tap kernel"]) < 1e-5
+    assert not DEBUG_LIB or rel_err(got["shipped plan"], got["one-tap kernel"]) < 1e-5
 
 
 def _bf16_round(t):
@@ -348,7 +341,7 @@ def test_one_term_weight_gradient_is_the_three_term_one_on_bf16_operands(case, m
     xb, dyb = _bf16_round(x), _bf16_round(dy)
     xs, dys = o.split_raw(o.to_nhwc_raw(xb.to(DEV))), o.split_raw(o.to_nhwc_raw(dyb.to(DEV)))
     want = torch.nn.grad.conv2d_weight(xb.double(), (cout, cin, ks, ks), dyb.double(), padding=pad)
-    for env in ({}, {"WCMC_WGRAD_ROWS": "0"}):
+    for env in ({},) + (({"WCMC_WGRAD_ROWS": "0"},) if DEBUG_LIB else ()):
         monkeypatch.delenv("WCMC_WGRAD_ROWS", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -532,27 +525,21 @@ def test_pointwise_chain_matches_fp64_and_the_tiled_kernel_bitwise(case, monkeyp
         kink = kink * (pre.detach().abs().amin(dim=1, keepdim=True) > 1e-5).double()
     gy = gen(*hcur.shape, seed=99).double() * kink
     hcur.backward(gy)
-    got = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("WCMC_IGEMM_PW", flag)
-        xd = x.to(DEV).requires_grad_(True)
-        pd = [t.to(DEV).requires_grad_(True) for t in params]
-        y = o.conv_chain(xd, 1, 0, acts, pd)
-        y.backward(gy.float().to(DEV))
-        got[flag] = [y.detach().clone(), xd.grad.clone()] + [t.grad.clone() for t in pd]
+    xd = x.to(DEV).requires_grad_(True)
+    pd = [t.to(DEV).requires_grad_(True) for t in params]
+    y = o.conv_chain(xd, 1, 0, acts, pd)
+    y.backward(gy.float().to(DEV))
+    got = [y.detach().clone(), xd.grad.clone()] + [t.grad.clone() for t in pd]
     names = ["fwd", "dx"] + ["dw%d" % (i // 2) if i % 2 == 0 else "db%d" % (i // 2) for i in range(len(params))]
     want = [hcur, xr.grad] + [t.grad for t in pr]
-    for nm, a, b, r in zip(names, got["1"], got["0"], want):
+    for nm, a, r in zip(names, got, want):
         assert_close(a, r, tol=1e-4, what="pointwise " + nm)
-        if nm.startswith("db"):
-            assert_close(a, b, tol=1e-5, what="pointwise vs tiled " + nm)
-        else:
-            assert torch.equal(a, b), "pointwise vs tiled kernel differ in " + nm
 
 
 def test_pointwise_kernel_repeats_bitwise_at_benchmark_size(monkeypatch):
     """Race screen for the persistent 1x1 kernel at full occupancy (1 M pixels, every ring stage reused
-    thousands of times): run-to-run identical, and identical to the tiled kernel."""
+    thousands of times): run-to-run identical.  (Its equality with the tiled kernel it replaced was held here through round 4;
+    that kernel is reachable in the debug build only now.)"""
     o = ops()
     n, h = 64, 128
     xs = o.split_raw(o.to_nhwc_raw(gen(n, 64, h, h, seed=40).to(DEV)))
@@ -567,16 +554,11 @@ def test_pointwise_kernel_repeats_bitwise_at_benchmark_size(monkeypatch):
         yf = o.conv2d_x_raw(xs, (n, 64, h, h), wp, b, 64, 1, 0, "relu", out_split=False)
         return y.clone(), mask.clone(), dx.clone(), o.colsum_finish_raw(part, (n, 64, h, h)).clone(), yf.clone()
 
-    monkeypatch.setenv("WCMC_IGEMM_PW", "0")
     ref = run()
-    monkeypatch.setenv("WCMC_IGEMM_PW", "1")
     for _ in range(6):
         cur = run()
         for a, bb, what in zip(ref, cur, ("split out", "mask", "gated dgrad", "column sums", "fp32 out")):
-            if what == "column sums":
-                assert_close(bb, a, tol=1e-5, what=what)
-            else:
-                assert torch.equal(a, bb), "pointwise kernel differs from the tiled kernel in " + what
+            assert torch.equal(a, bb), "the pointwise kernel does not repeat bit for bit in " + what
     del ref, cur
 
 
@@ -680,6 +662,7 @@ def test_kernel_apply_fwd_bwd(shape):
 
 @pytest.mark.parametrize("shape", [(2, 3, 37, 45), (1, 3, 5, 7), (3, 2, 16, 16), (1, 1, 92, 92), (2, 3, 21, 130),
                                    (70, 3, 92, 20)])       # (the last one: blocks that own rows of two strips / two images)
+@needs_debug_lib
 def test_kernel_apply_strip_equals_tile_kernel(shape, monkeypatch):
     """The persistent strip kernel (LDS-DMA ring per wave; the one the KPCN path runs: k = 21, C <= 3, no d_data) against
     the tile kernel it replaced (WCMC_KA_TILE=1), forward (result + log-sum-exp) and backward (d_logits), bit for bit:
@@ -945,16 +928,17 @@ def test_fused_chain_glue_matches_the_separate_ops(geom):
     g_out, g_mean = gen(b * s, 5, h, w, seed=66), gen(b, c1, h, w, seed=67)
     res = []
     for fused in (False, True):
-        o.FUSE_CHAIN_GLUE = fused
-        try:
-            ts = [t.to(DEV).requires_grad_(True) for t in (x, prop_in, w1, b1, w2, b2)]
-            xd, pd, w1d, b1d, w2d, b2d = ts
+        ts = [t.to(DEV).requires_grad_(True) for t in (x, prop_in, w1, b1, w2, b2)]
+        xd, pd, w1d, b1d, w2d, b2d = ts
+        if fused:
             flat, mean = o.conv_chain_spp_mean(xd, s, 1, 0, ["linear"], [w1d, b1d])
             out = o.cat_broadcast_chain(flat, pd, s, 1, 0, ["relu"], [w2d, b2d])
-            ((out * g_out.to(DEV)).sum() + (mean * g_mean.to(DEV)).sum()).backward()
-            res.append([out.detach(), mean.detach()] + [t.grad for t in ts])
-        finally:
-            o.FUSE_CHAIN_GLUE = True
+        else:           # the separate nodes (what the exact-fp32 mode runs): chain, spp mean, concatenation, chain
+            flat = o.conv_chain(xd, 1, 0, ["linear"], [w1d, b1d])
+            mean = o.spp_mean(flat, s)
+            out = o.conv_chain(o.cat_broadcast(flat, pd, s), 1, 0, ["relu"], [w2d, b2d])
+        ((out * g_out.to(DEV)).sum() + (mean * g_mean.to(DEV)).sum()).backward()
+        res.append([out.detach(), mean.detach()] + [t.grad for t in ts])
     names = ["final out", "spp mean", "d x", "d prop", "d w1", "d b1", "d w2", "d b2"]
     for a, bb, nm in zip(res[0], res[1], names):
         assert_close(bb, a, tol=2e-5, what="fused vs separate: " + nm)
@@ -1192,3 +1176,90 @@ def test_clip_adam_matches_torch():
     for i in (5, n - 1):
         assert torch.isnan(pr[i]) and torch.isnan(p[i]) and torch.isnan(m[i])
     assert int(torch.isnan(p).sum()) == 2
+
+
+# ------------------------------------------------------------------------ weight normalisation (round 5)
+def test_weight_norm_multi_matches_torch_weight_norm():
+    """``wcmc_weight_norm_fwd`` / ``_bwd`` (all layers of a model in one launch each) against ``torch._weight_norm`` in fp64:
+    PathNet's layer shapes plus a row length that is not a multiple of four (the scalar path) and a one-row layer."""
+    o = ops()
+    shapes = [(64, 36, 1, 1), (64, 64, 3, 3), (128, 384, 3, 3), (3, 128, 1, 1), (5, 7, 3, 3), (1, 9, 1, 1), (256, 256, 3, 3)]
+    gs, vs, rg, rv = [], [], [], []
+    for i, shp in enumerate(shapes):
+        v = gen(*shp, seed=100 + i)
+        g = gen(shp[0], 1, 1, 1, seed=200 + i) + 1.5
+        vs.append(v.to(DEV).requires_grad_(True)); gs.append(g.to(DEV).requires_grad_(True))
+        rv.append(v.double().requires_grad_(True)); rg.append(g.double().requires_grad_(True))
+    ws = o.weight_norm_multi(gs, vs)
+    wr = [torch._weight_norm(v, g, 0) for v, g in zip(rv, rg)]
+    dws = [gen(*shp, seed=300 + i) for i, shp in enumerate(shapes)]
+    torch.autograd.backward(ws, [d.to(DEV) for d in dws])
+    torch.autograd.backward(wr, [d.double() for d in dws])
+    for i, shp in enumerate(shapes):
+        assert ws[i].shape == torch.Size(shp) and ws[i].is_contiguous()
+        assert_close(ws[i], wr[i], tol=2e-6, what="weight_norm fwd %s" % (shp,))
+        assert_close(vs[i].grad, rv[i].grad, tol=5e-6, what="weight_norm dv %s" % (shp,))
+        assert_close(gs[i].grad, rg[i].grad, tol=5e-6, what="weight_norm dg %s" % (shp,))
+    # an unused layer's gradient stays None (as torch.autograd leaves it), the others are unaffected
+    for t in gs + vs:
+        t.grad = None
+    ws = o.weight_norm_multi(gs, vs)
+    (ws[1] * dws[1].to(DEV)).sum().backward()
+    assert vs[0].grad is None and gs[2].grad is None
+    assert_close(vs[1].grad, rv[1].grad, tol=5e-6, what="weight_norm dv, one live layer")
+
+
+def test_weight_norm_rejects_bad_arguments():
+    from wcmc_amd._lib import lib
+    import ctypes
+    h = lib()
+    one_p, one_i = (ctypes.c_void_p * 1)(0), (ctypes.c_int * 1)(4)
+    assert h.wcmc_weight_norm_fwd(0, one_p, one_p, one_p, one_p, one_i, one_i, None) == -1
+    assert h.wcmc_weight_norm_fwd(33, one_p, one_p, one_p, one_p, one_i, one_i, None) == -1
+    assert h.wcmc_weight_norm_fwd(1, one_p, one_p, one_p, one_p, one_i, one_i, None) == -1          # null layer pointers
+    assert b"layer 0" in h.wcmc_last_error()
+    assert h.wcmc_weight_norm_bwd(1, one_p, one_p, one_p, one_p, one_p, one_p, one_i, one_i, None) == -1
+
+
+@pytest.mark.parametrize("weight_norm", [False, True])
+def test_chain_applied_twice_in_one_backward_accumulates_both_weight_gradients(weight_norm, precision):
+    """with gradient sinks registered (FusedClipAdam), a chain applied to TWO inputs inside one autograd engine
+    run handed the same bucket view to both nodes -- the later node overwrote the earlier one's dw and the engine summed two
+    aliases (2 * dw_B instead of dw_A + dw_B).  A sink is now handed out once per accumulation window."""
+    from wcmc_amd.modules import ConvChain
+    from wcmc_amd.optim import FusedClipAdam
+    o = ops()
+    torch.manual_seed(31)
+    ref = om.ConvChain(12, 10, ksize=3, width=16, depth=2, pad=True, output_type="relu", weight_norm=weight_norm)
+    mod = ConvChain(12, 10, ksize=3, width=16, depth=2, pad=True, output_type="relu", weight_norm=weight_norm)
+    mod.load_state_dict(ref.state_dict())
+    mod.to(DEV)
+    ref = ref.double()
+    opt = {"optim_m": torch.optim.Adam(mod.parameters(), lr=1e-3)}
+    fo = FusedClipAdam({"m": mod}, opt)                       # registers the sinks
+    xa, xb = gen(2, 12, 20, 24, seed=32).to(DEV), (gen(2, 12, 20, 24, seed=33) * 3.0).to(DEV)
+    ga, gb = gen(2, 10, 20, 24, seed=34).to(DEV), gen(2, 10, 20, 24, seed=35).to(DEV)
+    # each use on its own (one producer per parameter: the sinks' normal case), the optimiser's window closed in between
+    alone = []
+    for x, g in ((xa, ga), (xb, gb)):
+        mod.zero_grad()
+        o.release_grad_sinks(list(mod.parameters()))
+        (mod(x) * g).sum().backward()
+        alone.append({k: p.grad.detach().clone() for k, p in mod.named_parameters()})
+    mod.zero_grad()
+    o.release_grad_sinks(list(mod.parameters()))
+    ((mod(xa) * ga).sum() + (mod(xb) * gb).sum()).backward()               # both uses in ONE engine run
+    for k, p in mod.named_parameters():
+        want = alone[0][k] + alone[1][k]
+        assert_close(p.grad, want, tol=1e-6, what="twice-applied chain: grad %s is not the sum of the two uses' gradients" % k)
+    if precision == "fp32":                                               # (and the sum is the right one: fp64 torch autograd)
+        (ref(xa.cpu().double()) * ga.cpu().double()).sum().add((ref(xb.cpu().double()) * gb.cpu().double()).sum()).backward()
+        named_r = dict(ref.named_parameters())
+        for k, p in mod.named_parameters():
+            assert_close(p.grad, named_r[k].grad, tol=2e-5, what="twice-applied chain grad " + k)
+    # the optimiser still finds every gradient (sinks and fresh tensors alike) and a second window hands the sinks out again
+    fo.step({"m": mod}, opt)
+    mod.zero_grad()
+    (mod(xa) * ga).sum().backward()
+    views = {p.data_ptr(): v.data_ptr() for p, v in zip(fo.flats["m"].params, fo.flats["m"].grad_views())}
+    assert not ops().split_path() or all(p.grad.data_ptr() == views[p.data_ptr()] for p in mod.parameters()), "single use: every gradient lands in its bucket view"

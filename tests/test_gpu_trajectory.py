@@ -21,28 +21,40 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
+K_IMAGE, K_MANIF = 4.0, 6.0
+
+
+def _bands():
+    """profiles/r05_trajectory_spread.json (scripts/trajectory_spread.py): how far THREE exact-fp32 runs whose initial weights
+    differ by one unit in the last place end up from the unperturbed fp32 run, per loss and statistic -- the recipe's own
+    sensitivity to a single rounding.  Band = K x the largest of the three (4 for the image losses and the validation error,
+    6 for the manifold terms: values of 1e-4 that are differences of nearly equal features, with the heavier tail), floors
+    where the measured spread is too small to be a band (2e-3 per step early on, 1 % late)."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r05_trajectory_spread.json")) as f:
+        d = json.load(f)
+    return d["spread"], d["validation_rel"]
+
+
 def test_default_mode_training_trajectory_tracks_exact_fp32():
-    """Same initial weights, the same 16 batches cycled for 200 graphed steps (12.5 passes: l_total halves), the same pairing keys,
-    three arithmetics: exact fp32, ``bf16x3`` and the default mode.  Measured on MI355X (profiles/r04_trajectory.txt): the three
-    curves agree to 1e-4 .. 4e-4 per step for the first ~50 steps; around step 55-100 the run leaves a plateau of l_diffuse and
-    each arithmetic leaves it a few steps apart (the curves part by up to 6 % for bf16x3 AND for the default mode, the fp32 run
-    being the late one); from step ~120 on they are back within 0.1-1 % and end there (means of the last 50 steps: bf16x3 within
-    0.2 %, the default mode within 1 % of the fp32 run -- 0.95 % for rmse with the final kernels of round 4, 0.4 % with the ones
-    before them: every change of a rounding anywhere re-rolls these chaotic curves); validation error 0.009511 (fp32), 0.009514
-    (bf16x3), 0.009578 (default).  Held here:
-      * steps 1-40, per step: the image losses of the reduced-precision run within 2e-3 of the fp32 run's (5 % for the
-        manifold terms: values of 1e-4 that are differences of nearly equal features);
-      * the last 50 steps: means of the image losses within 1 %, MEDIANS of the manifold terms within 10 % (a manifold term is
-        ~6e-5 with one-step spikes of several times that in every arithmetic: step 194 of the default-mode run shows 4.3e-4, and
-        scripts/diag_spike.py evaluates that step's weights in all three arithmetics, fused and unfused, eager and graphed --
-        4.30e-4 each: the spike belongs to the weights the run has reached, not to the kernels that evaluate them);
-      * no excursion of the default mode beyond twice the largest one of ``bf16x3`` plus 1 % (both are legitimate arithmetics of
-        the same recipe: the default mode must not be the outlier);
-      * validation RelativeMSE on a held-out batch after the run within 1 % of the fp32 run's; the run trains (l_total -30 %)."""
+    """Same initial weights (weight-normalised PathNets), the same 16 batches cycled for 200 graphed steps (12.5 passes: l_total
+    halves), the same pairing keys, three arithmetics: exact fp32, ``bf16x3`` and the default mode.
+
+    A training run is a chaotic map: around step 55-100 it leaves a plateau of l_diffuse and every arithmetic -- and every fp32
+    run that starts ONE ULP away -- leaves it a few steps apart; the curves part by 4-12 % for a while and come back.  The bands
+    are therefore not numbers that sat well on one draw (round 4's 1 %) but multiples of the recipe's measured fp32-vs-fp32 spread
+    (``_bands``; measured on MI355X, round 5: rmse of the last 50 steps 0.56 %, validation 0.69 %, manifold medians 9.7 %, manifold
+    terms within the first 40 steps 11 %).  Held, for ``bf16x3`` and the default mode against the fp32 run:
+      * steps 1-40, per step: within max(K x spread, 2e-3) for the image losses, K x spread for the manifold terms;
+      * the last 50 steps: means of the image losses within max(K x spread, 1 %), MEDIANS of the manifold terms within K x spread;
+      * the largest excursion anywhere after step 20: within K x the fp32 runs' own largest excursion (image losses);
+      * validation RelativeMSE on a held-out batch after the run within K x spread; the run trains (l_total -30 %).
+    Measured (profiles/r05_trajectory_bands.txt): default mode rmse 0.99 %, validation 0.33 %, manifold median 9.8 % / 27 % (bf16x3)."""
     import train_trajectory as tt
     from wcmc_amd.synthetic import make_batch
     dev = torch.device("cuda", 0)
     steps, nb = 200, 16
+    spread, vspread = _bands()
     batches = [make_batch(8, 8, 128, seed=500 + i, device=dev) for i in range(nb)]
     held = make_batch(8, 8, 128, seed=999, device=dev)
     res = {m: tt.run(m, steps, nb, batches=batches, held_out=held) for m in ("fp32", "bf16x3", ops_default())}
@@ -53,24 +65,33 @@ def test_default_mode_training_trajectory_tracks_exact_fp32():
         assert all(math.isfinite(v) for m in res for v in res[m][0][k]), k
     first, last = np.mean(ref["l_total"][:16]), np.mean(ref["l_total"][-16:])
     assert last < 0.7 * first, "the run must actually train (l_total %.4f -> %.4f)" % (first, last)
-    dev3 = tt.deviations(res["bf16x3"][0], ref)
     lines, fails = [], []
     for mode in ("bf16x3", ops_default()):
         cur, val = res[mode]
         d = tt.deviations(cur, ref)
         for k in tt.KEYS:
             early, overall, late_mean, late_median = d[k]
+            s_early, s_all, s_mean, s_median = spread[k]
             manif = k in tt.MANIF_KEYS
-            late = late_median if manif else late_mean
-            lines.append("%-10s %-18s steps 1-40 %.2e  all %.2e  last-50 mean %.2e median %.2e" % (mode, k, early, overall, late_mean, late_median))
-            if early > (5e-2 if manif else 2e-3):
-                fails.append("%s %s: %.2e from the fp32 curve within the first 40 steps" % (mode, k, early))
-            if late > (0.10 if manif else 0.01):
-                fails.append("%s %s: %s of the last 50 steps %.2e from the fp32 run's" % (mode, k, "median" if manif else "mean", late))
-            if not manif and mode != "bf16x3" and overall > 2 * dev3[k][1] + 0.01:
-                fails.append("%s %s: excursion %.2e, bf16x3's largest %.2e" % (mode, k, overall, dev3[k][1]))
-        lines.append("%-10s validation RelativeMSE %.6f (fp32 %.6f)" % (mode, val, vref))
-        if abs(val - vref) > 0.01 * vref:
+            kk = K_MANIF if manif else K_IMAGE
+            late, band_late = (late_median, kk * s_median) if manif else (late_mean, max(kk * s_mean, 0.01))
+            band_early = kk * s_early if manif else max(kk * s_early, 2e-3)
+            lines.append("%-10s %-18s steps 1-40 %.2e (band %.2e)  all %.2e  last-50 mean %.2e median %.2e (band %.2e)" %
+                         (mode, k, early, band_early, overall, late_mean, late_median, band_late))
+            if s_median == 0.0 and manif:
+                # (a P-buffer whose final ReLU has died -- this seed's specular PathNet, within ten steps, in EVERY arithmetic and in
+                # the oracle alike -- leaves a manifold term that no longer depends on the weights: the curves must then be equal)
+                if not (late_median == 0.0 or late_median != late_median):
+                    fails.append("%s %s: the fp32 runs agree exactly on this term, this mode is %.2e away" % (mode, k, late_median))
+                continue
+            if early > band_early:
+                fails.append("%s %s: %.2e from the fp32 curve within the first 40 steps (band %.2e)" % (mode, k, early, band_early))
+            if late > band_late:
+                fails.append("%s %s: %s of the last 50 steps %.2e from the fp32 run's (band %.2e)" % (mode, k, "median" if manif else "mean", late, band_late))
+            if not manif and overall > K_IMAGE * s_all:
+                fails.append("%s %s: excursion %.2e, the fp32 runs' largest %.2e" % (mode, k, overall, s_all))
+        lines.append("%-10s validation RelativeMSE %.6f (fp32 %.6f; band %.2e)" % (mode, val, vref, K_IMAGE * vspread))
+        if abs(val - vref) > K_IMAGE * vspread * vref:
             fails.append("%s validation error %.6f vs fp32 %.6f" % (mode, val, vref))
     with open(os.path.join(out, "trajectory_bands.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")

@@ -86,6 +86,8 @@ SIGNATURES = {
     "wcmc_embed3_mean_supported": (I, [I, L]),
     "wcmc_embed3_mean_fwd": (I, [P, L, I, P, P, P, P, P, P, P, P, I, L, P]),
     "wcmc_embed3_bwd": (I, [P, L, I, P, P, P, P, P, P, P, I, P, I, I, L, F, P, P, P, P, P, P, P, Z, P]),
+    "wcmc_weight_norm_fwd": (I, [I, P, P, P, P, P, P, P]),
+    "wcmc_weight_norm_bwd": (I, [I, P, P, P, P, P, P, P, P, P]),
     "wcmc_clip_adam": (I, [P, P, P, P, L, F, D, D, D, D, I, F, P, P]),
     "wcmc_clip_adam_hyper": (None, [D, D, D, D, I, P]),
     "wcmc_clip_adam_dev": (I, [P, P, P, P, L, F, F, P, P, P]),

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/wcmc_hip.h"
 
@@ -11,6 +12,15 @@ namespace wcmc {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+
+// A/B switches -- WCMC_* environment variables that select a non-default kernel, tiling or schedule, every one of them measured
+// and decided (scripts/sweep_switches.sh, profiles/) -- exist in the DEBUG build only (`make debug`, loaded with WCMC_DEBUG_LIB=1):
+// the release library reads no environment variable, its launch plans are the defaults.
+#ifdef WCMC_DEBUG_BUILD
+inline const char* ab_env(const char* name) { return getenv(name); }
+#else
+inline const char* ab_env(const char*) { return nullptr; }
+#endif
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

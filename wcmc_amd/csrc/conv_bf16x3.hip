@@ -353,8 +353,8 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, u16* __res
   wp[((int64_t)n * 2 + 1) * Kt + k] = lo;
 }
 
-static int x_env_on(const char* name) {           // switch is ON unless the variable starts with '0'
-  const char* e = getenv(name);
+static int x_env_on(const char* name) {           // switch is ON unless the variable starts with '0' (debug build only: ab_env)
+  const char* e = ab_env(name);
   return (e && e[0] == '0') ? 0 : 1;
 }
 struct XKPlan { bool halo; int Kp, CS, nslabs, Ks, Kt, PXS, CSl, Ksl, ap; };     // CSl / Ksl: the last (narrower) slab
@@ -364,7 +364,7 @@ static int x_pick_nt(int tiles);
 // kernel instance for it exists (rows = the GEMM's output channels pick the instance), else the three-term plan.  The K
 // order of the packed weights follows the plan, so packing and launch must ask with the same (kchan, ks, ap_req, rows).
 static XKPlan x_plan_k(int kchan, int ks, int ap_req = 2, int rows = 0) {
-  // (A/B switches are read per call -- a getenv per launch -- so that tests/test_gpu_models.py can flip them in one process)
+  // (debug build: A/B switches are read per call, so that a script can flip them in one process)
   const int enable = x_env_on("WCMC_IGEMM_HALO");
   XKPlan q;
   q.ap = 2;
@@ -2135,7 +2135,7 @@ static int launch_xpw2(const XIgemmParams& p, hipStream_t stream) {
 // 1x1, no padding, the channel counts of the PathNet chains; anything else stays on the tiled kernel
 static bool x_plan_pw(const XIgemmParams& p, int* ntw, int* u) {
   if (p.ks != 1 || p.pad != 0 || p.gate || p.PXS) return false;
-  const char* e = getenv("WCMC_IGEMM_PW");      // read per call: the parity tests switch kernels inside one process
+  const char* e = ab_env("WCMC_IGEMM_PW");      // read per call: the parity tests switch kernels inside one process
   if (e && e[0] == '0') return false;
   const int U = p.Cpi / 4;
   if (p.Np == 64 && (U == 16 || U == 10)) *ntw = 4;
@@ -3121,7 +3121,7 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
   // The eight-wave kernel for the two-plane (three-term) launches, the seven-wave one for the one-plane launches of the default
   // mode: there the seven waves are faster alone (0.311 against 0.295 of the bf16 peak in the eager profile) and beside the other
   // half of the step (+0.9 % per step, round 4).  WCMC_WGRAD_ROWS8=1 / 0: eight / seven waves for both.
-  const char* r8e = getenv("WCMC_WGRAD_ROWS8");
+  const char* r8e = ab_env("WCMC_WGRAD_ROWS8");
   const bool rows8 = r8e ? r8e[0] != '0' : PL == 2;
   if (KS == 5 && TM == 7 && NW == 7 && rows8) {
     // two stages of NI = 8 (PL = 1: 4) instructions x 8 waves x 1 KB (> the 52 KB staging tile of the slab write)
@@ -3134,7 +3134,7 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
     }
     static LdsAttr attr8_set, attr80_set;
 #ifdef WCMC_DEBUG_BUILD
-    { const char* e = getenv("WCMC_DEBUG_ABLATE");
+    { const char* e = ab_env("WCMC_DEBUG_ABLATE");
       const int ab = e ? atoi(e) : 0;
       auto kfn = ab == 16 ? &conv_wgrad_rows8_bf16x3_kernel<16> : ab == 1 ? &conv_wgrad_rows8_bf16x3_kernel<1> : ab == 2 ? &conv_wgrad_rows8_bf16x3_kernel<2>
                  : ab == 3 ? &conv_wgrad_rows8_bf16x3_kernel<3> : ab == 8 ? &conv_wgrad_rows8_bf16x3_kernel<8> : ab == 32 ? &conv_wgrad_rows8_bf16x3_kernel<32>
@@ -3154,7 +3154,7 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
 #ifdef WCMC_DEBUG_BUILD        // `make debug` only: timing-only instances that compute WRONG results are not in the release library
   if (KS == 5 && TM == 7 && NW == 7 && PL == 2) {
     int ab;                             // WCMC_DEBUG_ABLATE: timing-only builds (1 = no MFMA, 2 = no stage fills, 4 = clock probe)
-    { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    { const char* e = ab_env("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
     if (ab == 1 || ab == 2 || ab == 3 || ab == 4 || ab == 8 || ab == 16) {
       auto kfn = ab == 16 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 16> : ab == 1 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 1> : ab == 2 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 2>
                  : ab == 3 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 3> : ab == 4 ? &conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 4>
@@ -3490,7 +3490,7 @@ static int launch_xigemm2(const XIgemmParams& p, hipStream_t stream) {
 #ifdef WCMC_DEBUG_BUILD
   if (NT == 7 && !PADDED) {       // WCMC_DEBUG_ABLATE=<mask>: timing-only ablation builds of the 5x5 forward GEMM
     static int ab = -1;
-    if (ab < 0) { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    if (ab < 0) { const char* e = ab_env("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
     switch (ab) {
       case 1: return launch_xigemm_dbg<1>(p, stream);
       case 2: return launch_xigemm_dbg<2>(p, stream);
@@ -3559,7 +3559,7 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   const size_t out = p.ys ? (size_t)128 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)128 * (NT * 16 + 4) * sizeof(float);
 #ifdef WCMC_DEBUG_BUILD
   if (NT == 7 && !pt3 && p.PXS == 80 && p.ks == 5) {
-    const char* e = getenv("WCMC_DEBUG_ABLATE");
+    const char* e = ab_env("WCMC_DEBUG_ABLATE");
     const int ab = e ? atoi(e) : 0;
     if (ab) {
       auto kfn = ab == 1 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 1, 80> : ab == 2 ? &conv_halo64_bf16x3_kernel<7, 3, 4, 2, 80>
@@ -3575,7 +3575,7 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   }
 #endif
   // three weight stages where two workgroups still fit a CU (80 KB each), else two
-  const char* nbe = getenv("WCMC_HALO_NB");
+  const char* nbe = ab_env("WCMC_HALO_NB");
   const int nb = (p.ap == 1 || (!(nbe && nbe[0] == '2') && halo + 3 * bstage <= 80 * 1024)) ? 3 : 2;
   const size_t main_ = halo + nb * bstage;
   const size_t lds = main_ > out ? main_ : out;
@@ -3594,7 +3594,7 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   const size_t lds_out = p.ys ? (size_t)256 * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)32 * NT * 16 * sizeof(float)
                               : (size_t)256 * (NT * 16 + 4) * sizeof(float);
   // three weight stages (two stages of DMA latency cover) where LDS allows, else two
-  const char* nbe = getenv("WCMC_HALO_NB");
+  const char* nbe = ab_env("WCMC_HALO_NB");
   const int nbmax = (nbe && nbe[0] == '2') ? 2 : 3;
   const int nb = (nbmax >= 3 && halo + 3 * bstage <= 160 * 1024) ? 3 : 2;
   const size_t lds_main = halo + nb * bstage;
@@ -3603,7 +3603,7 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
 #ifdef WCMC_DEBUG_BUILD
   if (NT == 7 && p.PXS == 160 && p.ks == 5) {
     int ab;                             // (read per call: scripts interleave the modes inside one process)
-    { const char* e = getenv("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
+    { const char* e = ab_env("WCMC_DEBUG_ABLATE"); ab = e ? atoi(e) : 0; }
     if (ab == 1 || ab == 2 || ab == 4 || ab == 8 || ab == 16 || ab == 10 || ab == 26 || ab == 18 || ab == 27 || ab == 31 || ab == 59 || ab == 63 || ab == 32) {
       // timing only (WRONG results): 1 = no MFMA, 2 = no weight DMA in the stage loop, 8 = no fragment reads, 16 = no stage
       // barrier, 4 = one halo per tile (no slab reloads), 32 = no epilogue; sums combine (27 = empty stage loop)
@@ -3638,7 +3638,7 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
 #endif
 #ifdef WCMC_DEBUG_BUILD
   if (NT == 4 && p.ks == 3) {        // wall-clock stamps of the U-Net 3x3 launches, 8x16 tiling (scripts/timeline_halo.py --unet)
-    const char* e = getenv("WCMC_DEBUG_ABLATE");
+    const char* e = ab_env("WCMC_DEBUG_ABLATE");
     if (e && atoi(e) == 64) {
       constexpr int TH8 = 8;
       XIgemmParams q = p;
@@ -3754,7 +3754,7 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
 #ifdef WCMC_DEBUG_BUILD
   {  // timing-only experiments (guide section 7: zero-record descriptors drop one operand's traffic)
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("WCMC_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) { const char* e = ab_env("WCMC_DEBUG_DROP"); dbg = e ? atoi(e) : 0; }
     if (dbg & 1) p.x_bytes = 0;
     if (dbg & 2) p.wp_bytes = 0;
   }
@@ -3827,8 +3827,8 @@ extern "C" int wcmc_conv2d_out_f16(const void* x_f16, int N, int H, int W, int C
 }
 
 static bool x_pair_enabled() {
-  const char* e = getenv("WCMC_IGEMM_PW");
-  const char* t = getenv("WCMC_PW_TAIL");       // WCMC_PW_TAIL=0: A/B switch back to two launches
+  const char* e = ab_env("WCMC_IGEMM_PW");
+  const char* t = ab_env("WCMC_PW_TAIL");       // WCMC_PW_TAIL=0: A/B switch back to two launches
   return !(e && e[0] == '0') && !(t && t[0] == '0');
 }
 // fused instances: (input units, couts of the first layer, tail kind)
@@ -3950,7 +3950,7 @@ extern "C" int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W
     XWRowsParams q;
     q.x = p.x; q.N = N; q.H = H; q.W = W; q.Cpi = p.Cpi; q.dy = p.dy; q.Ho = Ho; q.Wo = Wo; q.Cpo = p.Cpo;
     q.dbg = (float*)workspace + pl.slab_elems;
-    { const char* e = getenv("WCMC_WGRAD_ROWS8_PRIO"); q.prio = e ? atoi(e) : 8; if (q.prio < 0 || q.prio > 13) q.prio = 0; }   // (scripts/time_wgrad_rows8.py: 6-8 of 14 best)
+    { const char* e = ab_env("WCMC_WGRAD_ROWS8_PRIO"); q.prio = e ? atoi(e) : 8; if (q.prio < 0 || q.prio > 13) q.prio = 0; }   // (scripts/time_wgrad_rows8.py: 6-8 of 14 best)
     q.pad = pad; q.slabs = p.slabs; q.S = pl.S; q.rps = pl.rps; q.R = pl.R; q.Np = pl.Np; q.Cq = pl.Cq;
     q.coBlocks = pl.coBlocks; q.ciBlocks = pl.ciBlocks; q.x_bytes = p.x_bytes; q.dy_bytes = p.dy_bytes;
     q.xps = p.xps; q.yps = p.yps;

@@ -570,7 +570,7 @@ template <bool BWD, int D, int MAXROWS>
 static int ks_launch2(const KSParams& ps, int nb, hipStream_t st) {
 #ifdef WCMC_DEBUG_BUILD
   {
-    const char* e = getenv("WCMC_DEBUG_ABLATE");
+    const char* e = ab_env("WCMC_DEBUG_ABLATE");
     const int ab = e ? atoi(e) : 0;
     if (!BWD && D == 2 && (ab == 1 || ab == 2)) {
       if (ab == 1) hipLaunchKernelGGL((kernel_apply_strip_kernel<false, 2, MAXROWS, 1>), dim3((unsigned)nb), dim3(256), 0, st, ps);
@@ -621,7 +621,7 @@ static bool ks_ok(const KAParams& a, bool bwd) {
 
 // WCMC_KA_TILE=1: A/B switch back to the tile kernel (read per call: the parity test compares the two in one process)
 static bool ka_force_tile() {
-  const char* e = getenv("WCMC_KA_TILE");
+  const char* e = ab_env("WCMC_KA_TILE");
   return e && e[0] == '1';
 }
 static int ka_fill(KAParams& p, int N, int C, int h, int w, int k) {

@@ -14,9 +14,9 @@ class KPCN(nn.Module):
         super().__init__()
         self.ksize = ksize
         self.diffuse = ConvChain(n_in, ksize * ksize, depth=depth, width=width, ksize=5, pad=False,
-                                 output_type="linear")
+                                 output_type="linear", weight_norm=False)
         self.specular = ConvChain(n_in, ksize * ksize, depth=depth, width=width, ksize=5, pad=False,
-                                  output_type="linear")
+                                  output_type="linear", weight_norm=False)
         self.kernel_apply = KernelApply(softmax=True, splat=False)
 
     @staticmethod

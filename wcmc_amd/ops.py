@@ -86,7 +86,7 @@ def out_layer_terms(ks, act):
         return "h"                                              # one fp16 MFMA where wcmc_conv2d_out_f16_supported (decided per shape)
     if not (PRECISION == "bf16x321o" and ks == 5 and act == "linear"):
         return 3
-    return int(os.environ.get("WCMC_OUT_TERMS", "1"))          # (A/B switch: 2 = x_hi x (W_hi + W_lo), 3 = the "bf16x321" forward)
+    return 1
 
 # Optional per-launch timing (bench.py): HIP events recorded on the launch stream around an op.
 _PROFILER = None
@@ -418,7 +418,10 @@ class _ConvChain(torch.autograd.Function):
 # parameter's gradient to it as whatever tensor the backward returns -- so the weight-gradient kernels write their result
 # STRAIGHT INTO the parameter's slice of the bucket and return that view: AccumulateGrad adopts it (p.grad was None) and the
 # optimiser's gather (three multi-tensor copies, 60 us per step) has nothing left to move.  A parameter whose .grad is already
-# set (a second backward without zero_grad) gets a fresh tensor instead, which autograd accumulates as usual.
+# set (a second backward without zero_grad) gets a fresh tensor instead, which autograd accumulates as usual -- and so does the
+# SECOND producer of a parameter's gradient inside one engine run (a chain applied to two inputs: AccumulateGrad runs after
+# both, so a second hand-out of the same view would have the later node overwrite the earlier one's result and the engine sum
+# two aliases): a sink is handed out once per accumulation window, which ``release_grad_sinks`` (the optimiser's gather) ends.
 import weakref
 
 _GRAD_SINK = {}
@@ -426,7 +429,15 @@ _GRAD_SINK = {}
 
 def register_grad_sinks(params, views):
     for p, v in zip(params, views):
-        _GRAD_SINK[p.data_ptr()] = (weakref.ref(p), weakref.ref(v))
+        _GRAD_SINK[p.data_ptr()] = [weakref.ref(p), weakref.ref(v), False]
+
+
+def release_grad_sinks(params):
+    """End of an accumulation window: the gradients of `params` have been consumed (or dropped); their sinks may be handed out again."""
+    for p in params:
+        e = _GRAD_SINK.get(p.data_ptr())
+        if e is not None:
+            e[2] = False
 
 
 def _sink(param_ptr, shape, device):
@@ -436,9 +447,94 @@ def _sink(param_ptr, shape, device):
         p, v = e[0](), e[1]()
         if p is None or v is None or p.data_ptr() != param_ptr:
             del _GRAD_SINK[param_ptr]
-        elif p.grad is None and tuple(v.shape) == tuple(shape) and v.device == device:
+        elif p.grad is None and not e[2] and tuple(v.shape) == tuple(shape) and v.device == device:
+            e[2] = True
             return v.detach()                   # (a new tensor object on the same memory: AccumulateGrad may adopt it)
     return torch.empty(shape, device=device, dtype=torch.float32)
+
+
+def _param_ptr(t):
+    return t.data_ptr() if isinstance(t, torch.nn.Parameter) else 0
+
+
+# ---- weight normalisation ------------------------------------------------------------------
+class _WeightNormMulti(torch.autograd.Function):
+    """``w_l = g_l * v_l / ||v_l||`` for ALL weight-normalised layers of a model as one node: one launch forms every effective
+    weight before the model's first chain (``wcmc_weight_norm_fwd``), one launch turns every chain's weight gradient into
+    (dg, dv) once the last of them has arrived (``wcmc_weight_norm_bwd``), written straight into the optimiser's bucket.
+    Arguments g0, v0, g1, v1, ...; returns (w0, w1, ...)."""
+
+    @staticmethod
+    def forward(ctx, *gv):
+        n = len(gv) // 2
+        gs, vs = gv[0::2], gv[1::2]
+        _need_cuda(*gv)
+        ctx.set_materialize_grads(False)            # (a layer no chain used arrives as None, not as a tensor of zeros)
+        dev = vs[0].device
+        rows = [v.shape[0] for v in vs]
+        lens = [v[0].numel() for v in vs]
+        vc = [v.detach() if v.is_contiguous() else v.detach().contiguous() for v in vs]
+        gc = [g.detach().reshape(-1) if g.is_contiguous() else g.detach().contiguous().reshape(-1) for g in gs]
+        # one block for all effective weights (each on a 256-byte boundary) and one for the norms
+        offs, off = [], 0
+        for v in vc:
+            offs.append(off)
+            off += (v.numel() + 63) // 64 * 64
+        flat = torch.empty(off, device=dev, dtype=torch.float32)
+        ws = [flat[o:o + v.numel()].view(v.shape) for o, v in zip(offs, vc)]
+        noffs = [sum(rows[:i]) for i in range(n)]
+        norms = torch.empty(sum(rows), device=dev, dtype=torch.float32)
+        nv = [norms[o:o + r] for o, r in zip(noffs, rows)]
+        ap, ai = ctypes.c_void_p * n, ctypes.c_int * n
+        check(lib().wcmc_weight_norm_fwd(n, ap(*[t.data_ptr() for t in vc]), ap(*[t.data_ptr() for t in gc]),
+                                         ap(*[t.data_ptr() for t in ws]), ap(*[t.data_ptr() for t in nv]),
+                                         ai(*rows), ai(*lens), _stream()), "weight_norm_fwd")
+        ctx.geom = (rows, lens, noffs)
+        ctx.sinks = [(_param_ptr(g), _param_ptr(v)) for g, v in zip(gs, vs)]
+        ctx.save_for_backward(norms, *gc, *vc)
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *dws):
+        rows, lens, noffs = ctx.geom
+        n = len(rows)
+        saved = ctx.saved_tensors
+        norms, gc, vc = saved[0], saved[1:1 + n], saved[1 + n:]
+        dev = norms.device
+        live = [l for l in range(n) if dws[l] is not None]      # (a layer no chain used this step has no gradient: None, as torch)
+        grads = [None] * (2 * n)
+        if not live:
+            return tuple(grads)
+        dw, dv, dg = [], [], []
+        for l in live:
+            d = dws[l]
+            dw.append(d if d.is_contiguous() else d.contiguous())
+            gp, vp = ctx.sinks[l]
+            dg.append(_sink(gp, (rows[l], 1, 1, 1), dev))
+            dv.append(_sink(vp, vc[l].shape, dev))
+            grads[2 * l], grads[2 * l + 1] = dg[-1], dv[-1]
+        m = len(live)
+        ap, ai = ctypes.c_void_p * m, ctypes.c_int * m
+        check(lib().wcmc_weight_norm_bwd(m, ap(*[t.data_ptr() for t in dw]), ap(*[vc[l].data_ptr() for l in live]),
+                                         ap(*[gc[l].data_ptr() for l in live]),
+                                         ap(*[norms[noffs[l]:].data_ptr() for l in live]), ap(*[t.data_ptr() for t in dv]),
+                                         ap(*[t.data_ptr() for t in dg]), ai(*[rows[l] for l in live]),
+                                         ai(*[lens[l] for l in live]), _stream()), "weight_norm_bwd")
+        return tuple(grads)
+
+
+WEIGHT_NORM_MAX_LAYERS = 32
+
+
+def weight_norm_multi(gs, vs):
+    """[w_l] of ``torch.nn.utils.weight_norm``'s parametrisation for the layers (g_l, v_l), <= 32 of them per launch."""
+    out = []
+    for i in range(0, len(gs), WEIGHT_NORM_MAX_LAYERS):
+        gv = []
+        for g, v in zip(gs[i:i + WEIGHT_NORM_MAX_LAYERS], vs[i:i + WEIGHT_NORM_MAX_LAYERS]):
+            gv += [g, v]
+        out += list(_WeightNormMulti.apply(*gv))
+    return out
 
 
 # ---- split-bf16 chain ----------------------------------------------------------------------
@@ -522,8 +618,7 @@ def _pack_x(weight, mode):
 
 
 # One packing launch per chain (all layers, both orientations: wcmc_conv2d_pack_chain_bf16x3) instead of two per layer:
-# 114 launches per step become 16.  WCMC_PACK_CHAIN=0: A/B switch back to per-layer packing (bit-identical either way).
-PACK_CHAIN = os.environ.get("WCMC_PACK_CHAIN", "1") != "0"
+# 114 launches per step become 16 (bit-identical to per-layer packing, which chains of more than 10 layers still take).
 
 
 def _fwd_pack_mode(out_terms):
@@ -567,22 +662,21 @@ def _igemm_class(cin, cout, ks, dims=None, terms=3):
     tiles = (cout + 15) // 16
     nt = min((7, 4, 2, 1), key=lambda t: (-(-tiles // t)) * (t + 2))
     halo = 3 <= ks <= 5 and (cin + 7) // 8 * 8 >= 32
-    if ks == 1 and ((cin + 7) // 8 * 8, cout) in ((64, 64), (40, 64), (128, 128), (8, 128)) \
-            and os.environ.get("WCMC_IGEMM_PW", "1") != "0":
+    if ks == 1 and ((cin + 7) // 8 * 8, cout) in ((64, 64), (40, 64), (128, 128), (8, 128)):
         return "conv_pw"                    # x_plan_pw: the persistent pointwise kernel (HBM-bound class)
     if not (halo and nt == 7 and ks == 5):
         return "conv_igemm"
-    if dims is None or os.environ.get("WCMC_HALO64", "1") == "0" or os.environ.get("WCMC_IGEMM_HALO", "1") == "0":
-        return "conv_halo7"                 # conv_halo_bf16x3_kernel<7, 8, 16, 0, 2> (and the fp32 path's 5x5 class)
+    if dims is None:
+        return "conv_halo7"                 # (the fp32 path's 5x5 class)
     n, ho, wo = dims                        # conv_halo64_bf16x3_kernel<7, NB, PT>: 16x16 tiles (PT = 4) or 12x16 (PT = 3)
     kp = (cin + 7) // 8 * 8
-    x2 = terms <= 2 and kp % 32 != 24 and os.environ.get("WCMC_DGRAD_AP1", "1") != "0"     # x_plan_k grants ap = 1 (32-channel slabs, 80 B)
+    x2 = terms <= 2 and kp % 32 != 24      # x_plan_k grants ap = 1 (32-channel slabs, 80 B)
     x1 = x2 and terms == 1              # ... and the one-plane weight path: <7, 3, PT, 0, 80, 1, 1>, suffix "_x1"
-    if not x2 and kp >= 256 and kp % 32 == 0 and os.environ.get("WCMC_HALO64_CS32", "1") != "0":
+    if not x2 and kp >= 256 and kp % 32 == 0:
         return "conv_halo64_cs32"           # 32-channel slabs: <7, 2, 3> (two weight stages, 12x16 tiles)
     gy = -(-tiles // nt)
     rounds = lambda th: -(-(n * (-(-wo // 16)) * (-(-ho // th)) * gy) // 512) * th
-    pt3 = os.environ.get("WCMC_HALO64_PT3", "1") != "0" and rounds(12) < rounds(16)
+    pt3 = rounds(12) < rounds(16)
     return ("conv_halo64_pt3" if pt3 else "conv_halo64_pt4") + ("_x1" if x1 else "_x2" if x2 else "")
 
 
@@ -695,15 +789,12 @@ def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=Tr
     return dw, db
 
 
-# The data gradient's activation gate from the 1-bit mask the forward launch left (1/16 of the bytes of re-reading
-# the activation's hi plane; the predicate is the same, so results are bit-identical).  WCMC_GATE_MASK=0: A/B switch.
-USE_GATE_MASK = os.environ.get("WCMC_GATE_MASK", "1") != "0"
-
-
+# The data gradient's activation gate comes from the 1-bit mask the forward launch left (1/16 of the bytes of re-reading the
+# activation's hi plane; the predicate is the same, so results are bit-identical to gating on the activation).
+#
 # The bias gradient of a layer is the column sum of its dy.  The data-gradient GEMM that produces dy leaves per-tile column
 # sums; the slab-reduction launch of the layer's weight gradient finishes them (wcmc_conv2d_wgrad_bf16x3, dy_colsum_partial)
-# instead of a wcmc_colsum_finish launch per layer: ~55 launches less per step, bit-identical (WCMC_FUSE_BIAS_GRAD=0: A/B).
-FUSE_BIAS_GRAD = os.environ.get("WCMC_FUSE_BIAS_GRAD", "1") != "0"
+# instead of a wcmc_colsum_finish launch per layer: ~55 launches less per step.
 
 
 def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
@@ -730,7 +821,7 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
     oterms = 3 if pair else out_layer_terms(ks, acts[-1])      # MFMAs per product of the output layer's forward ("h": one, fp16)
     if oterms == "h" and not lib().wcmc_conv2d_out_f16_supported(params[2 * nl - 2].shape[1], params[2 * nl - 2].shape[0], ks):
         oterms = 3
-    packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks, oterms) if PACK_CHAIN and 2 * nl <= 20 else None
+    packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks, oterms) if 2 * nl <= 20 else None
     ctx.wp1 = [pk[1] for pk in packs] if packs is not None else None      # the data-gradient orientation, for the backward
     pack0 = (lambda l: packs[l][0]) if packs is not None else (lambda l: _pack_x(params[2 * l], _fwd_pack_mode(oterms) if l == nl - 1 else 0))
     for l in range(nl):
@@ -788,12 +879,8 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
     if dys is None:
         dy = _as_nhwc_nograd(dy)
         gated = acts[-1] != "linear"
-        if FUSE_BIAS_GRAD:          # split + the last layer's bias-gradient partials in one pass over dy
-            dys, part = split_dy_colsum_raw(dims[nl], dy=dy, post=saved[off] if gated else None, act=acts[-1])
-        elif gated:
-            dys = split_gated_raw(dy, saved[off], acts[-1])       # output-activation backward folded into the split
-        else:
-            dys = split_raw(dy)
+        # split (output-activation backward folded in) + the last layer's bias-gradient partials in one pass over dy
+        dys, part = split_dy_colsum_raw(dims[nl], dy=dy, post=saved[off] if gated else None, act=acts[-1])
         off += 1 if gated else 0
     else:
         assert acts[-1] == "linear"
@@ -816,20 +903,16 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None,
-                                            colsum_part=part if FUSE_BIAS_GRAD else None, terms=wterms, sinks=sink_of(l))
-                if part is not None and not FUSE_BIAS_GRAD:
-                    db = colsum_finish_raw(part, dims[l + 1])
+                                            colsum_part=part, terms=wterms, sinks=sink_of(l))
             dw.record_stream(main)
             db.record_stream(main)
             keep.append(dys)
             keep.append(part)
         else:
             dw, db = conv2d_wgrad_x_raw(xs[l], dims[l], dys, cout, ks, pad, wt.shape, want_bias=part is None,
-                                        colsum_part=part if FUSE_BIAS_GRAD else None, terms=wterms, sinks=sink_of(l))
-            if part is not None and not FUSE_BIAS_GRAD:
-                db = colsum_finish_raw(part, dims[l + 1])
+                                        colsum_part=part, terms=wterms, sinks=sink_of(l))
         grads[2 * l], grads[2 * l + 1] = dw, db
-        if (l == 1 and need_dx and ks == 1 and pad == 0 and USE_GATE_MASK and
+        if (l == 1 and need_dx and ks == 1 and pad == 0 and
                 lib().wcmc_conv1x1_pair_supported(cout, wt.shape[1], ws[0].shape[1])):
             # the data gradients of layers 1 and 0 in one launch (PathNet.final: 3 -> 128 -> 128): the 128-channel
             # gradient of the hidden activation is written once (the weight gradient of layer 0 reads it) and feeds
@@ -839,12 +922,11 @@ def _chainx_backward(ctx, dy, need_dx, dys=None, part=None):
                                                   gate_mask=masks[0], gate_act=acts[0], colsum=True, mask_out=False)
         elif l > 0:
             wpt = pack1(l)
-            g = dict(gate_mask=masks[l - 1]) if USE_GATE_MASK else dict(gate=xs[l])
             dys, part = conv2d_x_raw(dys, dims[l + 1], wpt, None, wt.shape[1], ks, ks - 1 - pad, "linear",
-                                     out_split=True, gate_act=acts[l - 1], colsum=True, terms=dterms, **g)
+                                     out_split=True, gate_act=acts[l - 1], colsum=True, terms=dterms, gate_mask=masks[l - 1])
         elif need_dx and dx is None:
             sub = getattr(ctx, "dx_channels", None)
-            if sub is not None and DX_SLICE and (sub[1] + 7) // 8 * 8 - sub[0] // 8 * 8 <= wt.shape[1] // 2:
+            if sub is not None and (sub[1] + 7) // 8 * 8 - sub[0] // 8 * 8 <= wt.shape[1] // 2:
                 # the consumer reads channels [c0, c1) only: a GEMM over the 8-aligned rows round them (KPCN's first layer: 16 of
                 # 48 padded rows, one cout tile instead of four); the rest of dx is zero, never read
                 a0, a1 = sub[0] // 8 * 8, min((sub[1] + 7) // 8 * 8, wt.shape[1])
@@ -918,13 +1000,7 @@ class _ChainSppMeanX(torch.autograd.Function):
         gy = _as_nhwc_nograd(gy) if gy is not None else None
         gm = _as_nhwc_nograd(gm) if gm is not None else None
         dev = (gy if gy is not None else gm).device
-        if FUSE_BIAS_GRAD:
-            dys, part = split_dy_colsum_raw((bs, c, h, w), dy=gy, gm=gm, s=s, scale=1.0 / s)
-        else:
-            dys, part = _split_empty(bs, c, h, w, dev), None
-            z = (_ptr(None), 0, 0, 0)
-            check(lib().wcmc_add_broadcast_split(*(_v(gy) if gy is not None else z), *(_v(gm) if gm is not None else z),
-                                                 1.0 / s, _ptr(dys), bs // s, s, h, w, c, _stream()), "add_broadcast_split")
+        dys, part = split_dy_colsum_raw((bs, c, h, w), dy=gy, gm=gm, s=s, scale=1.0 / s)
         dx, grads = _chainx_backward(ctx, None, ctx.needs_input_grad[0], dys=dys, part=part)
         return (dx, None, None, *grads)
 
@@ -943,11 +1019,6 @@ def _dense_pixel_stride(g):
     return None
 
 
-# The spp mean of the embedding inside the fused forward launch (round 4; WCMC_FUSE_EMBED_MEAN=0: A/B switch back to the
-# separate wcmc_spp_reduce pass over y)
-FUSE_EMBED_MEAN = os.environ.get("WCMC_FUSE_EMBED_MEAN", "1") != "0"
-
-
 class _EmbedSppMeanFusedX(torch.autograd.Function):
     """``y = chain3(x); m = y.view(B,S,...).mean(1)`` (networks.py:33-36) with the three 1x1 layers in ONE launch
     (``wcmc_embed3_fwd``) and a backward that recomputes the hidden activations (``wcmc_embed3_bwd``): nothing but x, y and
@@ -964,7 +1035,7 @@ class _EmbedSppMeanFusedX(torch.autograd.Function):
         m = nhwc_empty(n // s, 64, h, w, y.device)
         wb = (_ptr(packs[0][0]), _ptr(params[1].detach()), _ptr(packs[1][0]), _ptr(params[3].detach()), _ptr(packs[2][0]),
               _ptr(params[5].detach()))
-        if FUSE_EMBED_MEAN and lib().wcmc_embed3_mean_supported(s, h * w):
+        if lib().wcmc_embed3_mean_supported(s, h * w):
             # the mean leaves with y (the kernel walks the S samples of a pixel tile and keeps their sum in registers)
             with _Timed("embed3_fwd", 4.0 * n * h * w * ((cin + 7) // 8 * 8 + 64 + 64 // s), "byte"):
                 check(lib().wcmc_embed3_mean_fwd(_ptr(xs), n * h * w, cin, *wb, _ptr(y), _ptr(m), s, h * w, _stream()), "embed3_mean_fwd")
@@ -1118,13 +1189,9 @@ class _CatUpsampleChainX(torch.autograd.Function):
 
 def cat_upsample_chain(deep, skip, ksize, pad, acts, params):
     """``conv_chain(cat([upsample2(deep), skip], 1), ...)``; one autograd node on the split-bf16 path."""
-    if FUSE_CHAIN_GLUE and split_path() and deep.shape[1] % 8 == 0:
+    if split_path() and deep.shape[1] % 8 == 0:
         return _CatUpsampleChainX.apply(as_nhwc(deep), as_nhwc(skip), (ksize, pad, tuple(acts)), *params)
     return cat_broadcast_chain(upsample2(deep), skip, 1, ksize, pad, acts, params)
-
-
-# The first layer's data gradient restricted to the input channels its consumer reads (round 4; WCMC_DX_SLICE=0: A/B switch)
-DX_SLICE = os.environ.get("WCMC_DX_SLICE", "1") != "0"
 
 
 def conv_chain(x, ksize, pad, acts, params):
@@ -1135,19 +1202,15 @@ def conv_chain(x, ksize, pad, acts, params):
     return _ConvChainX.apply(as_nhwc(x), spec, *params)
 
 
-# A/B switch for the two PathNet glue fusions below (WCMC_FUSE_CHAIN_GLUE=0: separate spp-mean / concat nodes)
-FUSE_CHAIN_GLUE = os.environ.get("WCMC_FUSE_CHAIN_GLUE", "1") != "0"
-
-
 def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
     """``y = conv_chain(x, ...); return y, spp_mean(y, s)``; one autograd node on the split-bf16 path."""
     # (DEBUG_ACTS: the parity tests' hook wants the hidden activations, which the fused chain never materialises)
-    if (FUSE_EMBED and DEBUG_ACTS is None and FUSE_CHAIN_GLUE and reduced_backward() and ksize == 1 and pad == 0 and len(acts) == 3 and
+    if (FUSE_EMBED and DEBUG_ACTS is None and reduced_backward() and ksize == 1 and pad == 0 and len(acts) == 3 and
             tuple(acts) == ("relu", "relu", "linear") and not x.requires_grad and
             lib().wcmc_embed3_supported(params[0].shape[1], params[0].shape[0], params[2].shape[0], params[4].shape[0]) and
             (getattr(x, "_wcmc_split", None) is not None or is_nhwc_view(x))):
         return _EmbedSppMeanFusedX.apply(x, s, *params)
-    if FUSE_CHAIN_GLUE and split_path() and acts[-1] == "linear":
+    if split_path() and acts[-1] == "linear":
         pre = getattr(x, "_wcmc_split", None)
         if pre is not None and pre[0] == (x._version, None) and not x.requires_grad:
             return _ChainSppMeanX.apply(x, s, (ksize, pad, tuple(acts)), *params)      # channel-first x, split attached
@@ -1158,14 +1221,14 @@ def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
 
 def cat_broadcast_chain(flat, prop, s, ksize, pad, acts, params):
     """``conv_chain(cat_broadcast(flat, prop, s), ...)``; fused into one autograd node on the split-bf16 path."""
-    if (FUSE_FINAL and DEBUG_ACTS is None and FUSE_CHAIN_GLUE and reduced_backward() and ksize == 1 and pad == 0 and
+    if (FUSE_FINAL and DEBUG_ACTS is None and reduced_backward() and ksize == 1 and pad == 0 and
             tuple(acts) == ("relu", "relu") and flat.is_cuda and prop.shape[0] * s == flat.shape[0] and
             lib().wcmc_final2_supported(flat.shape[1], prop.shape[1], params[0].shape[0], params[2].shape[0], flat.shape[2] * flat.shape[3])
             and params[0].shape[1] == 128):
         fl, pr = as_nhwc(flat), as_nhwc(prop)
         if _dense_pixel_stride(fl) is not None and _dense_pixel_stride(pr) is not None:
             return _FinalFusedX.apply(fl, pr, s, *params)
-    if FUSE_CHAIN_GLUE and split_path() and flat.shape[1] % 8 == 0:
+    if split_path() and flat.shape[1] % 8 == 0:
         return _CatBroadcastChainX.apply(as_nhwc(flat), as_nhwc(prop), s, (ksize, pad, tuple(acts)), *params)
     return conv_chain(cat_broadcast(flat, prop, s), ksize, pad, acts, params)
 
@@ -1343,9 +1406,6 @@ class _MaxPool2Skip(torch.autograd.Function):
             g_skip = _as_nhwc_nograd(g_skip)
             check(lib().wcmc_maxpool2_bwd_add(*_v(x), *_v(g_pool), *_v(g_skip), *_v(dx), n, h, w, c, _stream()), "maxpool2_bwd_add")
         return dx
-
-
-POOL_SKIP = os.environ.get("WCMC_POOL_SKIP", "1") != "0"
 
 
 def maxpool2_skip(x):

@@ -81,6 +81,7 @@ class _Flat:
     def gather(self, have):
         """Copy the gradients that are NOT already in the bucket (a gradient a sink received IS its bucket view)."""
         gv = self.grad_views()
+        ops.release_grad_sinks(self.params)                 # (the accumulation window of these gradients ends here)
         idx = [j for j, h in enumerate(have) if h and self.params[j].grad.data_ptr() != gv[j].data_ptr()]
         if idx:
             torch._foreach_copy_([gv[j] for j in idx], [self.params[j].grad for j in idx])

@@ -7,14 +7,16 @@ tensor is a strided view of an NHWC buffer; slicing/cropping it stays free.
 import torch.nn as nn
 
 from .. import ops
-from ..modules import Autoencoder, ConvChain
+from ..modules import Autoencoder, ConvChain, weight_norm_scope
 
 
 class PathNet(nn.Module):
     """Path embedding network"""
 
-    def __init__(self, ic, intermc=64, outc=3, weight_norm=False):
-        """weight_norm (not a reference argument; default = this build's specification): see ``modules.ConvChain``."""
+    def __init__(self, ic, intermc=64, outc=3, weight_norm=True):
+        """weight_norm is not a reference argument: ``support/networks.py:18-24`` passes none to its chains, so upstream
+        ``sbmc.modules.ConvChain``'s default applies -- weight-normalised layers (see ``modules.ConvChain``).  False selects
+        plain ``nn.Conv2d`` weights (rounds 1-4 of this build; ``checkpoint.py`` restores either layout)."""
         super(PathNet, self).__init__()
         self.ic = ic
         self.intermc = intermc
@@ -40,7 +42,7 @@ class PathNet(nn.Module):
             return cached[1]
         bs, spp, nf, h, w = paths.shape
         flat = paths.reshape(bs * spp, nf, h, w)
-        if (ops.FUSE_CHAIN_GLUE and ops.split_path() and not paths.requires_grad and nf <= 64 and paths.is_cuda
+        if (ops.split_path() and not paths.requires_grad and nf <= 64 and paths.is_cuda
                 and bs * spp * h <= 65535):
             # the embedding chain is the only reader: transpose + split in one pass, once for both backbones
             flat = ops.presplit_shared(flat.detach())
@@ -52,7 +54,8 @@ class PathNet(nn.Module):
 
     def forward(self, samples):
         bs, spp, nf, h, w = samples["paths"].shape
-        flat, reduced = self.embedding.forward_spp_mean(self._paths_nhwc(samples), spp)   # networks.py:33-36
-        propagated = self.propagation(reduced)
-        out = self.final.forward_cat_broadcast(flat, propagated, spp)   # networks.py:39-42, (B*S, outc, H, W)
+        with weight_norm_scope(self):           # the 20 layers' g * v / ||v|| in one launch (and one for their gradients)
+            flat, reduced = self.embedding.forward_spp_mean(self._paths_nhwc(samples), spp)   # networks.py:33-36
+            propagated = self.propagation(reduced)
+            out = self.final.forward_cat_broadcast(flat, propagated, spp)   # networks.py:39-42, (B*S, outc, H, W)
         return out.unflatten(0, (bs, spp))

@@ -176,12 +176,16 @@ def init_model(sizes, args, device, group=None):
         ck = ckpt.load_checkpoint(model_fn) if is_pretrained else None
         if ck is not None:
             ckpt.precision_note(ck)
-        # upstream sbmc's ConvChain is believed to default to weight normalisation (which sbmc.KPCN switches off and PathNet,
-        # support/networks.py:18-24, does not): a checkpoint trained there carries `weight_g` / `weight_v` per PathNet layer
-        wn = bool(getattr(args, 'pathnet_weight_norm', False))
-        if ck is not None and any(k.endswith('weight_g') for k in ck.get('state_dict_backbone_diffuse', {})):
-            wn = True
-            print('The checkpoint holds weight-normalised PathNets (weight_g / weight_v): building them that way.')
+        # upstream sbmc's ConvChain defaults to weight normalisation (which sbmc.KPCN switches off and PathNet,
+        # support/networks.py:18-24, does not): PathNets are built that way (`weight_g` / `weight_v` per layer) unless
+        # --no_pathnet_weight_norm is given; on a resume the checkpoint's own layout decides
+        wn = bool(getattr(args, 'pathnet_weight_norm', True))
+        if ck is not None and 'state_dict_backbone_diffuse' in ck:
+            ck_wn = any(k.endswith('weight_g') for k in ck['state_dict_backbone_diffuse'])
+            if ck_wn != wn:
+                print('The checkpoint holds %s PathNets: building them that way.'
+                      % ('weight-normalised (weight_g / weight_v)' if ck_wn else 'plain-weight (weight_norm=False)'))
+            wn = ck_wn
         if args.use_llpm_buf:
             half = args.disentangle in ('m10r01', 'm11r01')
             n_in = sizes['dncnn_in_size'] - sizes['pnet_out_size'] + (pnet_out_size // 2 if half else pnet_out_size)
@@ -293,9 +297,11 @@ def build_parser():
                         "on a multi-GPU node yet, hence off by default)")
     p.add_argument('--pairing_rng', choices=('cpu', 'device'), default='cpu',
                    help="FeatureMSE pairings: the reference's CPU randperm stream, or a keyed permutation on the GPU")
-    p.add_argument('--pathnet_weight_norm', action='store_true',
+    p.add_argument('--pathnet_weight_norm', dest='pathnet_weight_norm', action='store_true', default=True,
                    help="weight-normalised PathNet layers (w = g * v / ||v||: upstream sbmc's ConvChain default, which "
-                        "support/networks.py:18-24 does not switch off); detected automatically when a checkpoint is restored")
+                        "support/networks.py:18-24 does not switch off).  The default; a restored checkpoint's layout wins")
+    p.add_argument('--no_pathnet_weight_norm', dest='pathnet_weight_norm', action='store_false',
+                   help="plain nn.Conv2d weights in the PathNets (the parametrisation of this build's rounds 1-4)")
     p.add_argument('--pairing', choices=('local', 'global'), default='local',
                    help="FeatureMSE intra-batch pairing under several ranks: inside a rank's patches (default), or over the "
                         "all-gathered GLOBAL batch as nn.DataParallel's gathered loss does (train_kpcn.py:266-269; not with --graph)")
