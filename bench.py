@@ -64,6 +64,7 @@ def rocprof_names(wgrad_terms):
 def mfma_terms(cls, wgrad_terms):
     return 1.0 if cls.endswith(("_x1", "_h1")) else 2.0 if cls.endswith("_x2") else float(wgrad_terms) if cls.startswith("conv_wgrad") else 3.0
 B_PER_GPU, SPP, PATCH = 8, 8, 128
+TWO_STREAM = True                 # the default form of the captured step (GraphedTrainStep(two_stream=...)); --one-graph: the other
 
 
 class EventProfiler:
@@ -251,7 +252,7 @@ def c2_leg(device, steps, warmup):
     itf.iters = 1
     itf.to_train_mode()
     batch = make_batch(B_PER_GPU, SPP, PATCH, seed=0, device=device, use_llpm=False)
-    graphed = GraphedTrainStep(itf, batch)
+    graphed = GraphedTrainStep(itf, batch, two_stream=TWO_STREAM)
     for _ in range(warmup):
         graphed(batch)
     torch.cuda.synchronize()
@@ -271,7 +272,7 @@ def c2_leg(device, steps, warmup):
             "losses_last_step": last}
 
 
-def extra_leg(device, steps, warmup, precision=None, group=None, force_collective=False, overlap=False, weight_norm=True):
+def extra_leg(device, steps, warmup, precision=None, group=None, force_collective=False, overlap=False, weight_norm=True, two_stream=TWO_STREAM):
     """The benchmarked step once more in another configuration, graphed, same weights (seed 0) and batch: another arithmetic
     (`other_precisions`), or the default one with the MULTI-RANK tail on a one-rank RCCL group (`multi_rank_path`)."""
     from wcmc_amd import ops
@@ -288,7 +289,7 @@ def extra_leg(device, steps, warmup, precision=None, group=None, force_collectiv
                                             order=("dncnn", "backbone_diffuse", "backbone_specular") if overlap else None)
         batch = make_batch(B_PER_GPU, SPP, PATCH, seed=0, device=device)
         torch.manual_seed(1234)
-        graphed = GraphedTrainStep(itf, batch, overlap_allreduce=overlap)
+        graphed = GraphedTrainStep(itf, batch, overlap_allreduce=overlap, two_stream=two_stream and not overlap)
         for _ in range(warmup):
             graphed(batch)
         if force_collective:
@@ -408,6 +409,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="smoke test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL refuses two ranks "
                          "on one device); the printed throughput is then meaningless")
+    ap.add_argument("--one-graph", action="store_true",
+                    help="the step as ONE forked hipGraph (rounds 2-4) instead of two half-step graphs on two streams + a tail graph")
     ap.add_argument("--no-pathnet-weight-norm", action="store_true",
                     help="plain nn.Conv2d weights in the PathNets instead of upstream sbmc's weight-normalised layers (the default)")
     ap.add_argument("--precision", choices=("bf16x321h", "bf16x321o", "bf16x321", "bf16x3", "fp32"), default=None,
@@ -464,8 +467,10 @@ def main():
         ops.USE_BRANCH_STREAM = False
         step = eager_profiled_step         # averages of `bench.py --eager` are then single-stream durations too)
     else:
-        from wcmc_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(itf, batch)
+        from wcmc_amd.graph import capture_validated
+        # every capture is timed (10 replays behind the device guard: nothing is updated) and re-made when it is more than 5 %
+        # slower than the fastest capture of this configuration the process has seen; at least two are compared
+        graphed = capture_validated(itf, batch, two_stream=TWO_STREAM and not args.one_graph)
         step = lambda: graphed(batch)
 
     for _ in range(args.warmup):
@@ -512,7 +517,7 @@ def main():
             # kernel the same launches measured 2-3x longer) instead of a GPU waiting for Python.
             prof.next_step()
             for _ in range(3):
-                graphed.graph.replay()
+                graphed._replay()
             pe0.record()
             eager_step()
             pe1.record()
@@ -590,6 +595,9 @@ def main():
                            else 1 if world == 1 and args.backend == "nccl" else 0),
             "collective_backend": ("rccl" if args.backend == "nccl" else args.backend + (" (smoke test, shared GPU)" if args.share_gpu else "")),
             "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
+            # capture validation (wcmc_amd.graph.capture_validated), this rank: ms per replay of every capture that was made; the last one is the step that ran
+            "capture_attempts": None if args.eager else graphed.capture_attempts,
+            "capture_ms": None if args.eager else graphed.capture_ms,
             "allreduce": comm,
             # loss_dict of the last timed step on rank 0 (seeded weights, inputs and pairings: reproducible run to run
             # with the same binary; a stream-ordering race in the captured step would show here)
@@ -598,6 +606,8 @@ def main():
                                    "FeatureMSE w=0.1 m11r11, train_branches), 128x128, S=8 spp, "
                                    "%d patches/GPU, global batch %d" % (B_PER_GPU, global_batch),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "graph_form": None if args.eager else ("two half-step hipGraphs on two streams + tail graph" if graphed.two_stream
+                                                               else "one forked hipGraph"),
                        "launch": ("eager" if args.eager else
                                   "one hipGraph replay per step, optimiser tail (finite check, loss sums, gradient gather, clip + Adam) captured in it"
                                   if graphed.tail_captured else

@@ -21,16 +21,18 @@ torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    modes = sys.argv[3].split(",") if len(sys.argv) > 3 else None
     import test_gpu_bench_config as t
     from wcmc_amd import ops
     t.GRAD_L2, t.GRAD_COS = 1.0, 1.0                  # (report only)
     print("# worst parameter-gradient tensor of the benchmarked step against the fp32 CPU oracle, two steps, weight-normalised PathNets")
     print("# %-10s %-5s %-10s %-10s %s" % ("arithmetic", "seed", "rel L2", "1 - cos", "tensor"))
     worst = {}
-    for mode in (ops.MODES[0], "fp32"):
+    for mode in (modes or (ops.MODES[0], "fp32")):
         ops.set_precision(mode)
         os.environ["WCMC_PRECISION"] = mode           # (the test asserts the mode it was started in)
-        for seed in range(n):
+        for seed in range(first, first + n):
             report, _ = t.parity_report("device", True, seed=seed)
             grads = [r for r in report if " grad " in r[0]]
             e = max(grads, key=lambda r: r[1])
@@ -38,6 +40,10 @@ if __name__ == "__main__":
             print("  %-10s %-5d %.3e  %.3e  %s   (worst 1 - cos: %.3e %s)" % (mode, seed, e[1], e[2], e[0], c[2], c[0]))
             sys.stdout.flush()
             worst[mode] = max(worst.get(mode, (0.0, 0.0)), (e[1], c[2]))
+            for r in sorted(grads, key=lambda r: -r[1])[1:6]:
+                print("      next: %.3e  %.3e  %s" % (r[1], r[2], r[0]))
+            nf = [f for f in _ if "delta" in f]
+            print("      parameter-delta failures: %d %s" % (len(nf), nf[:2]))
             outs = [r for r in report if " out " in r[0]]
             print("  %-10s %-5d denoised patches, worst max-norm error %.3e" % (mode, seed, max(r[1] for r in outs)))
     for mode, (e, c) in worst.items():

@@ -32,12 +32,17 @@ from oracle.models import KPCN as OKPCN                      # noqa: E402
 from oracle.networks import PathNet as OPathNet              # noqa: E402
 
 DEV = "cuda"
-# Per-tensor gradient bar, no fallback: relative L2 and 1 - cosine.  Measured on MI355X at this shape (gpurun_out/
-# bench_config_parity.txt): 2e-6 (output layers) .. 1.0e-3 (KPCN layer 0: the error grows with the depth
-# the gradient has travelled through ReLU gates), 1 - cosine <= 5e-7.  scripts/diag_grad_floor.py (same step, fp64 CPU run as
-# the yardstick): the fp32 CPU oracle is up to 4.7e-4 from fp64, the HIP path up to 1.0e-3 (medians 1.5e-5 / 8.5e-5);
-# exact-fp32 MFMA against the fp32 oracle at ONE patch: 3.9e-3, i.e. 1.4e-3 at eight -- the bar is twice the measured value.
-GRAD_L2, GRAD_COS = 2e-3, 2e-6
+# Per-tensor gradient bar, no fallback: relative L2 and 1 - cosine, on more than one draw (profiles/r05_grad_bar_calibration.txt,
+# scripts/calibrate_grad_bar.py: the test's own comparison for several seeds -- weights, biases, weight_g, batches and pairing keys
+# all move -- in the default arithmetic and in exact fp32 MFMA).  The worst tensor is the draw's, not the arithmetic's: seed 0 (the
+# one held here) 1.96e-3 / 1 - cos 1.8e-6 in the default mode and 0.98e-3 in exact fp32, on the same tensor (KPCN specular layer 0: the
+# error grows with the depth the gradient has travelled through ReLU gates and 8 x 92 x 92 L1 sign ties); seed 1: 1.36e-3 / 0.28e-3;
+# round 4's weights: 1.20e-3.  Seed 2 shows what a badly conditioned draw looks like: in its SECOND step all tensors of one PathNet
+# sit at 0.7-1.9e-2 in both split-bf16 arithmetics (bf16x3: 0.95e-2 at worst) and 0.17e-2 in exact fp32, the 3-entry weight_g of the
+# output layer at 4e-2 -- dg = <dW, v> / ||v|| is a projection, its relative error is dW's divided by the cosine between dW and v.
+# scripts/diag_grad_floor.py (round 2, fp64 CPU run as the yardstick): the fp32 CPU oracle itself is up to 4.7e-4 from fp64.
+# The bar is 2x the measured value of the draw the test holds.
+GRAD_L2, GRAD_COS = 4e-3, 4e-6
 
 
 def _max_rel(a, b):

@@ -1262,4 +1262,10 @@ def test_chain_applied_twice_in_one_backward_accumulates_both_weight_gradients(w
     mod.zero_grad()
     (mod(xa) * ga).sum().backward()
     views = {p.data_ptr(): v.data_ptr() for p, v in zip(fo.flats["m"].params, fo.flats["m"].grad_views())}
-    assert not ops().split_path() or all(p.grad.data_ptr() == views[p.data_ptr()] for p in mod.parameters()), "single use: every gradient lands in its bucket view"
+    in_views = lambda: all(p.grad.data_ptr() == views[p.data_ptr()] for p in mod.parameters())
+    assert not o.split_path() or in_views(), "single use: every gradient lands in its bucket view"
+    # ... and again after a zero_grad() WITHOUT an optimiser step in between (a graphed step's warm-up passes do exactly that):
+    # the tensor that was handed out is gone, so the sink is free
+    mod.zero_grad()
+    (mod(xb) * gb).sum().backward()
+    assert not o.split_path() or in_views(), "zero_grad() frees the sinks"

@@ -18,8 +18,16 @@ class GraphedTrainStep:
     """``step = GraphedTrainStep(itf, example_batch); step(batch)`` == ``itf.preprocess(batch); itf.train_batch(batch)``."""
 
     def __init__(self, itf, batch, warmup=2, side_stream=True, capture_optimizer=True, defer_check=False, overlap_allreduce=False,
-                 cut_backward=False):
-        """``defer_check`` (captured optimiser only): the non-finite-loss check of step t -- the step's one host sync -- is made
+                 cut_backward=False, two_stream=False):
+        """``two_stream`` (``train_branches`` steps): the diffuse and the specular half of the step -- PathNet, the branch's conv
+        stack, kernel apply, losses, the whole backward: ``KPCNInterface._half_forward_backward`` -- are captured as TWO hipGraphs
+        and replayed on two explicit streams, followed by a third graph with the recombined radiance's metrics and the optimiser
+        tail.  The single forked graph leaves the overlap of the halves to the stream assignment hipGraphInstantiate makes for
+        its parallel branches, which differs from capture to capture (round 4: 602-624 patches/s in two of four processes
+        against 690); two linear graphs on two streams overlap by construction.  Results are bit-identical (same kernels, same
+        order inside each half).
+
+        ``defer_check`` (captured optimiser only): the non-finite-loss check of step t -- the step's one host sync -- is made
         after step t + 1 has been enqueued, so the host prepares the next batch while the GPU runs (a loader-fed loop gains
         what the sync-then-prepare gap cost).  The device guard still skips the update of a non-finite step at once; the
         reference's error (``interfaces.py:254-257``) is raised one call later, or by ``flush()``, which the epoch loop calls
@@ -81,6 +89,9 @@ class GraphedTrainStep:
         if self.overlap:
             assert next(iter(fo.flats)) == 'dncnn', "overlap_allreduce: build FusedClipAdam(order=('dncnn', ...)) -- its bucket goes first"
         self.cut = self.overlap or bool(cut_backward)
+        self.two_stream = bool(two_stream)
+        if self.two_stream:
+            assert itf.halves_supported() and not self.cut, "two_stream: a train_branches step of sbmc.KPCN, no backward cut"
         self.defer_check = bool(defer_check) and self.tail_captured
         self._pending, self._flag_bufs, self._n_calls = None, None, 0
         if self.tail_captured or self.tail_split:
@@ -94,11 +105,16 @@ class GraphedTrainStep:
             self._sum_views = [self.sums[i] for i in range(self.sums.numel())]
         self.graph = torch.cuda.CUDAGraph()
         try:
+            pool = self._capture_halves(dev) if self.two_stream else None
             # thread_local: a loader thread (support/loader.py: pinned staging buffers, device allocations, H2D copies on its own
             # stream) may allocate while this thread captures -- in the default 'global' mode a hipHostMalloc / hipMalloc from
             # ANY thread invalidates the capture
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.losses = itf._forward_backward(self.static, cut=self.cut)
+            with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
+                if self.two_stream:     # (the halves are graphs of their own: what is left is the radiance, its metrics and the tail)
+                    self.losses = itf._finish_halves(self.static, self._half_out[0][0], self._half_out[1][0],
+                                                     self._half_out[0][1], self._half_out[1][1])
+                else:
+                    self.losses = itf._forward_backward(self.static, cut=self.cut)
                 if self.cut and not self.overlap:
                     itf._backward_stage2()                            # (same graph: the PathNets' backward as one more engine run)
                 if self.tail_captured:
@@ -157,6 +173,62 @@ class GraphedTrainStep:
         if fo is not None:
             fo.leave_grads = False                        # .grad must keep pointing at the captured buffers
 
+    def _capture_halves(self, dev):
+        """Graphs of the two-stream step: ``graph_h`` (the shared split of ``paths``, on the launch stream), ``graph_d`` /
+        ``graph_s`` (the halves, each on a stream and in a memory pool of its own: they run concurrently).  Returns the pool the
+        tail graph shares (it runs after both halves, on the launch stream)."""
+        itf = self.itf
+        self.half_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        branch = ops.USE_BRANCH_STREAM
+        ops.USE_BRANCH_STREAM = False                      # a half is linear: nothing forks inside it
+        try:
+            self.graph_h = None
+            pre = getattr(itf.models.get('backbone_diffuse'), '_paths_nhwc', None) if itf.use_llpm_buf else None
+            if pre is not None:
+                self.graph_h = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_h, capture_error_mode="thread_local"):
+                    pre(self.static)                       # NHWC / split copy of `paths`, read by both halves
+            self._half_out, self.half_graphs = [], []
+            for br, st in zip(('diffuse', 'specular'), self.half_streams):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+                    self._half_out.append(itf._half_forward_backward(self.static, br))
+                self.half_graphs.append(g)
+        finally:
+            ops.USE_BRANCH_STREAM = branch
+        return self.half_graphs[0].pool()
+
+    def _replay(self):
+        """One replay of the captured step up to (and including) ``self.graph``."""
+        if self.two_stream:
+            main = torch.cuda.current_stream()
+            if self.graph_h is not None:
+                self.graph_h.replay()
+            for g, st in zip(self.half_graphs, self.half_streams):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    g.replay()
+            for st in self.half_streams:
+                main.wait_stream(st)
+        self.graph.replay()
+
+    def time_replays(self, n=10):
+        """Milliseconds per replay of the captured step, measured with the optimiser held back by the device guard (``ok`` = 0:
+        parameters, moments, step counters and running sums stay as they are), so that a fresh capture can be judged before it
+        is used (``capture_validated``).  Captured single-rank tail only; returns None otherwise."""
+        if not self.tail_captured:
+            return None
+        self.ok.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self._replay()                                     # (first replay: uploads the executable graph)
+        e0.record()
+        for _ in range(n):
+            self._replay()
+        e1.record()
+        e1.synchronize()
+        self.ok.fill_(1.0)
+        return e0.elapsed_time(e1) / n
+
     def _draw(self):
         """Fresh pairings, in the reference's call order (diffuse: patch, batch; specular: patch, batch)."""
         if self.fm.rng == 'device':                       # written in place: no sort, no copy; the keys of the step's
@@ -188,7 +260,7 @@ class GraphedTrainStep:
             self._draw()
             self.fm._static_i = 0
         if not (self.tail_captured or self.tail_split):
-            self.graph.replay()
+            self._replay()
             itf._logging(self.losses)
             itf._optimization()
             return
@@ -199,7 +271,7 @@ class GraphedTrainStep:
                 self.sums[i].copy_(cur) if cur is not None else self.sums[i].zero_()
                 itf.m_losses['m_' + k] = self._sum_views[i]
         fo.refresh_hyper(itf.optims)
-        self.graph.replay()
+        self._replay()
         if self.tail_split:
             ev = getattr(self, 'tail_events', None)       # (bench.py: a list that receives (start, end) events of the tail)
             if ev is not None:
@@ -266,11 +338,16 @@ class GraphedTrainStep:
         last reference to this object goes: a process that builds one graphed step after another (a test session, a sweep over
         configurations) keeps at most one alive.  The object cannot be called afterwards."""
         torch.cuda.synchronize()
-        for name in ("graph_b", "graph_a2", "graph"):
-            g = self.__dict__.pop(name, None)
+        fo = getattr(self.itf, "fused_optim", None) if self.itf is not None else None
+        if fo is not None and getattr(fo, "last_guard", None) is self.__dict__.get("guard"):
+            fo.last_guard = None                          # (a tensor of the pool that is about to go)
+        graphs = [self.__dict__.pop(name, None) for name in ("graph_b", "graph_a2", "graph")]
+        graphs += list(reversed(self.__dict__.pop("half_graphs", []) or [])) + [self.__dict__.pop("graph_h", None)]
+        for g in graphs:                                  # (last captured first)
             if g is not None:
                 g.reset()
-        for name in ("losses", "static", "flags", "guard", "sums", "_sum_views", "perms", "_loss_refs", "_flag_bufs", "_pending"):
+        for name in ("losses", "static", "flags", "guard", "sums", "_sum_views", "perms", "_loss_refs", "_flag_bufs", "_pending", "ok",
+                     "after_enqueue", "tail_events", "_half_out", "half_streams"):
             self.__dict__.pop(name, None)
         if self.fm is not None and getattr(self.fm, "static_perms", None) is not None:
             self.fm.static_perms, self.fm.check_finite = None, True       # (the eager loss draws and checks for itself again)
@@ -284,3 +361,36 @@ class GraphedTrainStep:
         prev, self._pending = self._pending, None
         if prev is not None:
             self._check(prev)
+
+
+# ---- capture validation ------------------------------------------------------------------------------------------------------
+# The speed of a captured step is decided at capture / instantiate time (hipGraphInstantiate maps the graph's parallel branches
+# onto streams of its own choosing) and stays what it is for the life of the graph: a capture whose halves ended up in series
+# costs 9-12 % for a whole run.  ``capture_validated`` times every fresh capture and re-captures the slow ones.
+_BEST_MS = {}
+
+
+def capture_validated(itf, batch, attempts=3, min_attempts=2, tol=0.05, replays=10, **kw):
+    """``GraphedTrainStep(itf, batch, **kw)`` whose replay time is within ``tol`` of the best this process has seen for the same
+    configuration: a capture that is slower is closed (never two live steps) and made again, at most ``attempts`` times; the
+    first time a configuration is captured in a process, at least ``min_attempts`` captures are compared (there is no earlier
+    time to judge the first one by).  The accepted step carries ``capture_attempts`` and ``capture_ms`` (every attempt's time)."""
+    key = (ops.PRECISION, bool(kw.get("two_stream")), bool(ops.USE_BRANCH_STREAM), bool(ops.USE_SIDE_STREAM),
+           tuple(sorted((k, tuple(v.shape)) for k, v in batch.items() if isinstance(v, torch.Tensor))),
+           tuple(sorted((n, sum(p.numel() for p in m.parameters())) for n, m in itf.models.items())))
+    tried = []
+    for a in range(max(1, attempts)):
+        step = GraphedTrainStep(itf, batch, **kw)
+        t = step.time_replays(replays)
+        if t is None:                                      # (nothing to validate by: multi-rank tail, eager optimiser)
+            step.capture_attempts, step.capture_ms = 1, []
+            return step
+        tried.append(round(t, 4))
+        seen = key in _BEST_MS
+        best = min(_BEST_MS.get(key, t), t)
+        _BEST_MS[key] = best
+        last = a == max(1, attempts) - 1
+        if last or (t <= best * (1.0 + tol) and (seen or len(tried) >= min_attempts)):
+            step.capture_attempts, step.capture_ms = len(tried), tried
+            return step
+        step.close()

@@ -421,7 +421,8 @@ class _ConvChain(torch.autograd.Function):
 # set (a second backward without zero_grad) gets a fresh tensor instead, which autograd accumulates as usual -- and so does the
 # SECOND producer of a parameter's gradient inside one engine run (a chain applied to two inputs: AccumulateGrad runs after
 # both, so a second hand-out of the same view would have the later node overwrite the earlier one's result and the engine sum
-# two aliases): a sink is handed out once per accumulation window, which ``release_grad_sinks`` (the optimiser's gather) ends.
+# two aliases): a sink is out while the tensor that was handed out is alive -- in the engine's buffers until AccumulateGrad
+# has run, in ``p.grad`` afterwards, gone after ``zero_grad()`` -- or until ``release_grad_sinks`` (the optimiser's gather).
 import weakref
 
 _GRAD_SINK = {}
@@ -429,7 +430,7 @@ _GRAD_SINK = {}
 
 def register_grad_sinks(params, views):
     for p, v in zip(params, views):
-        _GRAD_SINK[p.data_ptr()] = [weakref.ref(p), weakref.ref(v), False]
+        _GRAD_SINK[p.data_ptr()] = [weakref.ref(p), weakref.ref(v), None]
 
 
 def release_grad_sinks(params):
@@ -437,7 +438,7 @@ def release_grad_sinks(params):
     for p in params:
         e = _GRAD_SINK.get(p.data_ptr())
         if e is not None:
-            e[2] = False
+            e[2] = None
 
 
 def _sink(param_ptr, shape, device):
@@ -447,9 +448,10 @@ def _sink(param_ptr, shape, device):
         p, v = e[0](), e[1]()
         if p is None or v is None or p.data_ptr() != param_ptr:
             del _GRAD_SINK[param_ptr]
-        elif p.grad is None and not e[2] and tuple(v.shape) == tuple(shape) and v.device == device:
-            e[2] = True
-            return v.detach()                   # (a new tensor object on the same memory: AccumulateGrad may adopt it)
+        elif p.grad is None and (e[2] is None or e[2]() is None) and tuple(v.shape) == tuple(shape) and v.device == device:
+            out = v.detach()                    # (a new tensor object on the same memory: AccumulateGrad may adopt it)
+            e[2] = weakref.ref(out)
+            return out
     return torch.empty(shape, device=device, dtype=torch.float32)
 
 

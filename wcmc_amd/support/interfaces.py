@@ -177,6 +177,60 @@ class KPCNInterface(BaseInterface):
         _ops.join_all_streams(dev)
         return loss_dict
 
+    # ---- the step as two independent halves (``GraphedTrainStep(two_stream=True)``) ----------------------------------
+    # With ``train_branches`` the diffuse and the specular half of the step -- PathNet, input assembly, the branch's nine
+    # convolutions, kernel apply, L1 (+ manifold) loss and the whole backward -- share no parameter, no activation and no
+    # autograd node (``interfaces.py:122-238``: two models' worth of PathNet, two ConvChains of ``sbmc.KPCN``, two
+    # ``backward()`` calls); only the logged metrics of the recombined radiance (``:240-249``) see both.  Each half can
+    # therefore be captured as a hipGraph of its own and replayed on a stream of its own.
+    def halves_supported(self):
+        return bool(self.train_branches) and hasattr(self.models['dncnn'], '_branch') and self.grad_sync is None
+
+    def _half_forward_backward(self, batch, br):
+        """One half (``br`` = 'diffuse' | 'specular') of ``_forward_backward``; returns (denoised branch output, its loss scalars)."""
+        losses, out_manif = {}, None
+        x = batch['kpcn_%s_in' % br]
+        if self.use_llpm_buf:
+            net = self.models['backbone_' + br]
+            net.zero_grad()
+            p = net(batch)
+            out_manif, p_regress = self._split({br: p}, train=True)
+            x = _ops.pbuffer_cat(x, p_regress[br])
+        kpcn = self.models['dncnn']
+        chain = getattr(kpcn, br)
+        for q in chain.parameters():
+            q.grad = None
+        r = kpcn._branch(chain, x, batch['kpcn_%s_buffer' % br])
+        tgt = crop_like(batch['target_' + br], r)
+        loss = _l1(self.loss_funcs['l_' + br], r, tgt)
+        if self.manif_learn:
+            l_manif = self.loss_funcs['l_manif'](crop_like(out_manif[br], r), tgt)
+            loss = loss + l_manif * self.w_manif
+            losses['l_manif_' + br] = l_manif.detach()
+        losses['l_' + br] = loss.detach()             # (L1 + w * manifold: the reference's aliasing quirk, see _backward)
+        torch.autograd.backward([loss])
+        return r.detach(), losses
+
+    def _finish_halves(self, batch, r_diffuse, r_specular, l_diffuse, l_specular):
+        """What is left of the step's forward once both halves are done: the recombined radiance and its two logged metrics
+        (``sbmc.KPCN.forward``'s last line, ``interfaces.py:240-249``); returns ``loss_dict`` in the reference's key order."""
+        with torch.no_grad():
+            albedo = crop_like(batch['kpcn_albedo'], r_diffuse)
+            total = _ops.recombine(albedo, r_diffuse, r_specular)
+            self.last_out = dict(radiance=total, diffuse=r_diffuse, specular=r_specular)
+            tgt_total = crop_like(batch['target_total'], total)
+            loss_dict = {}
+            for k in ('l_manif_diffuse', 'l_manif_specular', 'l_diffuse', 'l_specular'):
+                src = l_diffuse if k.endswith('diffuse') else l_specular
+                if k in src:
+                    loss_dict[k] = src[k]
+            if self._fused_metrics(total, tgt_total):
+                loss_dict['l_total'], loss_dict['rmse'] = _ops.image_metrics(total, tgt_total, self.loss_funcs['l_test'].eps)
+            else:
+                loss_dict['l_total'] = self.loss_funcs['l_recon'](total, tgt_total).detach()
+                loss_dict['rmse'] = self.loss_funcs['l_test'](total, tgt_total).detach()
+        return loss_dict
+
     def train_batch(self, batch, grad_hook_mode=False):
         loss_dict = self._forward_backward(batch)
 
