@@ -252,13 +252,15 @@ def c2_leg(device, steps, warmup):
     itf.iters = 1
     itf.to_train_mode()
     batch = make_batch(B_PER_GPU, SPP, PATCH, seed=0, device=device, use_llpm=False)
-    graphed = GraphedTrainStep(itf, batch, two_stream=TWO_STREAM)
+    graphed = GraphedTrainStep(itf, batch, two_stream=TWO_STREAM, defer_check=True)
+    batch = graphed.static
     for _ in range(warmup):
         graphed(batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         graphed(batch)
+    graphed.flush()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     last = {k: round(float(v), 6) for k, v in itf.last_loss_dict.items()}
@@ -289,7 +291,8 @@ def extra_leg(device, steps, warmup, precision=None, group=None, force_collectiv
                                             order=("dncnn", "backbone_diffuse", "backbone_specular") if overlap else None)
         batch = make_batch(B_PER_GPU, SPP, PATCH, seed=0, device=device)
         torch.manual_seed(1234)
-        graphed = GraphedTrainStep(itf, batch, overlap_allreduce=overlap, two_stream=two_stream and not overlap)
+        graphed = GraphedTrainStep(itf, batch, overlap_allreduce=overlap, two_stream=two_stream and not overlap, defer_check=True)
+        batch = graphed.static
         for _ in range(warmup):
             graphed(batch)
         if force_collective:
@@ -298,6 +301,7 @@ def extra_leg(device, steps, warmup, precision=None, group=None, force_collectiv
         t0 = time.perf_counter()
         for _ in range(steps):
             graphed(batch)
+        graphed.flush()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         out = {"value": round(B_PER_GPU * steps / el, 3), "unit": "patches/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
@@ -409,6 +413,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="smoke test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL refuses two ranks "
                          "on one device); the printed throughput is then meaningless")
+    ap.add_argument("--sync-check", action="store_true",
+                    help="read the non-finite-loss flags of every step before the next one is enqueued (one host sync per step) instead of one step later")
     ap.add_argument("--one-graph", action="store_true",
                     help="the step as ONE forked hipGraph (rounds 2-4) instead of two half-step graphs on two streams + a tail graph")
     ap.add_argument("--no-pathnet-weight-norm", action="store_true",
@@ -470,7 +476,11 @@ def main():
         from wcmc_amd.graph import capture_validated
         # every capture is timed (10 replays behind the device guard: nothing is updated) and re-made when it is more than 5 %
         # slower than the fastest capture of this configuration the process has seen; at least two are compared
-        graphed = capture_validated(itf, batch, two_stream=TWO_STREAM and not args.one_graph)
+        graphed = capture_validated(itf, batch, two_stream=TWO_STREAM and not args.one_graph, defer_check=not args.sync_check)
+        # the synthetic batch lives IN the step's static buffers (inputs resident in HBM: a loader assembles the next batch into them
+        # at the step boundary, support/loader.py) -- no hand-over copy; the pairings are drawn inside the graph (device keys); the
+        # non-finite flags of step t are read after step t + 1 has been enqueued (--sync_check: before)
+        batch = graphed.static
         step = lambda: graphed(batch)
 
     for _ in range(args.warmup):
@@ -485,6 +495,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if not args.eager:
+        graphed.flush()                    # (the deferred non-finite check of the last step)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -598,6 +610,9 @@ def main():
             # capture validation (wcmc_amd.graph.capture_validated), this rank: ms per replay of every capture that was made; the last one is the step that ran
             "capture_attempts": None if args.eager else graphed.capture_attempts,
             "capture_ms": None if args.eager else graphed.capture_ms,
+            # the two streams the halves replay on: picked once per process by a spin-kernel probe so that they sit on different
+            # hardware queues (wcmc_amd.ops.concurrent_stream_pair)
+            "stream_pair": (getattr(graphed.half_streams[0], "probe", None) if (not args.eager and graphed.two_stream) else None),
             "allreduce": comm,
             # loss_dict of the last timed step on rank 0 (seeded weights, inputs and pairings: reproducible run to run
             # with the same binary; a stream-ordering race in the captured step would show here)
@@ -659,6 +674,7 @@ def main():
             t0 = time.perf_counter()
             for _ in range(nlong):
                 graphed(batch)
+            graphed.flush()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             line["value_long"] = {"value": round(B_PER_GPU * nlong / el, 3), "unit": "patches/s", "steps": nlong,

@@ -431,6 +431,14 @@ int wcmc_grs_bwd(const float* p, int64_t psb, int64_t pss, int64_t psc, int64_t 
  * the `rng='device'` source of the FeatureMSE / GRS pairings instead of the sort behind torch.randperm.  The
  * reference draws its pairings with torch.randperm on the CPU generator (support/losses.py:35,50). */
 int wcmc_random_permutation(int64_t* out, int64_t n, uint64_t seed, void* stream);
+/* The same bijection keyed from DEVICE memory, for a launch captured into the step's hipGraph (a by-value seed is frozen at capture):
+ * state = {seed, step counter} (two uint64), key = wcmc_permutation_key(seed, counter, slot) (host mirror of the device arithmetic:
+ * wcmc_random_permutation_dev(out, n, state, slot) == wcmc_random_permutation(out, n, wcmc_permutation_key(state[0], state[1], slot))).
+ * wcmc_step_counter_advance: state[1] += 1, once per step, ahead of the step's draws (losses.py:35,50 draws fresh pairings per call).
+ * slot in [0, 8): the step's draws (diffuse patch / batch, specular patch / batch). */
+uint64_t wcmc_permutation_key(uint64_t seed, uint64_t counter, int slot);
+int wcmc_random_permutation_dev(int64_t* out, int64_t n, const uint64_t* state, int slot, void* stream);
+int wcmc_step_counter_advance(uint64_t* state, void* stream);
 
 /* ---------------------------------------------------------------- weight normalisation
  * sbmc.modules.ConvChain wraps every nn.Conv2d in torch.nn.utils.weight_norm unless its caller passes weight_norm=False;

@@ -885,7 +885,7 @@ def test_launcher_flag_surface_and_argument_errors():
     for k, v in want.items():
         assert getattr(a, k) == v, k
     # this build's own switches are off unless asked for
-    assert not a.graph and not a.defer_check and not a.overlap_allreduce and a.pairing_rng == "cpu"
+    assert not a.graph and a.defer_check and not a.one_graph and not a.overlap_allreduce and a.pairing_rng == "cpu"
     assert p.parse_args(["--desc", "d", "--graph", "--overlap_allreduce"]).overlap_allreduce
     with pytest.raises(SystemExit):
         p.parse_args([])                                                     # --desc is required

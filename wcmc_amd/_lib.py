@@ -76,6 +76,9 @@ SIGNATURES = {
     "wcmc_grs_fwd": (I, [P, L, L, L, L, L, P, L, L, L, L, P, P, F, P, P, Z, I, I, I, I, I, P]),
     "wcmc_grs_bwd": (I, [P, L, L, L, L, L, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "wcmc_random_permutation": (I, [P, L, ctypes.c_uint64, P]),
+    "wcmc_permutation_key": (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_uint64, I]),
+    "wcmc_random_permutation_dev": (I, [P, L, P, I, P]),
+    "wcmc_step_counter_advance": (I, [P, P]),
     "wcmc_final2_supported": (I, [I, I, I, I, L]),
     "wcmc_final2_bwd_workspace_bytes": (Z, []),
     "wcmc_final2_fwd": (I, [P, I, P, I, I, I, L, P, P, P, P, I, P, P]),

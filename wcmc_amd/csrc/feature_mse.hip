@@ -354,7 +354,64 @@ __global__ __launch_bounds__(256) void random_permutation_kernel(int64_t* __rest
     out[i] = (int64_t)x;
   }
 }
+// The same bijection with its key formed on the device from state = {seed, step counter} and a slot number: a launch captured
+// into the step's hipGraph draws another permutation at every replay (the by-value key of wcmc_random_permutation is frozen at
+// capture).  key = splitmix64(seed + GOLDEN * (8 * counter + slot + 1)); wcmc_permutation_key is the same arithmetic on the host.
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t permutation_key(uint64_t seed, uint64_t counter, int slot) {
+  return splitmix64(seed + 0x632be59bd9b4e019ull * (8ull * counter + (uint64_t)slot + 1ull));
+}
+__global__ __launch_bounds__(256) void random_permutation_dev_kernel(int64_t* __restrict__ out, int64_t n, int h,
+                                                                    const uint64_t* __restrict__ state, int slot) {
+  const uint64_t key = permutation_key(state[0], state[1], slot);
+  const unsigned k0 = (unsigned)(key & 0xffffffffu), k1 = (unsigned)(key >> 32);
+  const unsigned mask = (1u << h) - 1u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t x = (uint64_t)i;
+    do {
+      unsigned l = (unsigned)(x >> h) & mask, r = (unsigned)x & mask;
+#pragma unroll
+      for (int rd = 0; rd < 6; ++rd) {
+        const unsigned f = perm_mix(r ^ (rd & 1 ? k1 : k0) ^ (0x9e3779b9u * (unsigned)(rd + 1))) & mask;
+        const unsigned t = l ^ f;
+        l = r; r = t;
+      }
+      x = ((uint64_t)l << h) | r;
+    } while (x >= (uint64_t)n);
+    out[i] = (int64_t)x;
+  }
+}
+__global__ void step_counter_advance_kernel(uint64_t* state) { state[1] += 1ull; }
 }  // namespace wcmc
+
+static int perm_half_bits(int64_t n) {
+  int bits = 1;
+  while (((int64_t)1 << bits) < n) ++bits;
+  return (bits + 1) / 2 < 1 ? 1 : (bits + 1) / 2;
+}
+
+extern "C" uint64_t wcmc_permutation_key(uint64_t seed, uint64_t counter, int slot) { return wcmc::permutation_key(seed, counter, slot); }
+
+extern "C" int wcmc_random_permutation_dev(int64_t* out, int64_t n, const uint64_t* state, int slot, void* stream) {
+  WCMC_REQUIRE(out && state && n > 0 && n < ((int64_t)1 << 62) && slot >= 0 && slot < 8, WCMC_ERR_BAD_ARG, "random_permutation_dev: bad argument");
+  const int h = perm_half_bits(n);
+  WCMC_REQUIRE(h <= 31, WCMC_ERR_BAD_ARG, "random_permutation_dev: n too large");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(wcmc::random_permutation_dev_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, out, n, h, state, slot);
+  return wcmc::check_launch("random_permutation_dev");
+}
+
+extern "C" int wcmc_step_counter_advance(uint64_t* state, void* stream) {
+  WCMC_REQUIRE(state, WCMC_ERR_BAD_ARG, "step_counter_advance: null state");
+  hipLaunchKernelGGL(wcmc::step_counter_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  return wcmc::check_launch("step_counter_advance");
+}
 
 extern "C" int wcmc_random_permutation(int64_t* out, int64_t n, uint64_t seed, void* stream) {
   WCMC_REQUIRE(out && n > 0 && n < ((int64_t)1 << 62), WCMC_ERR_BAD_ARG, "random_permutation: bad argument");

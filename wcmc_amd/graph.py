@@ -66,6 +66,11 @@ class GraphedTrainStep:
                           for _ in range(2)]
             self._draw()
             self.fm.static_perms, self.fm._static_i, self.fm.check_finite = self.perms, 0, False
+            # rng='device': the draws are PART of the captured step -- [seed, step counter] on the device, the counter advanced by the
+            # graph's first node, every permutation keyed with (seed, counter, slot): no host draw, no eager launch between replays
+            self.dev_keys = self.fm.rng == 'device'
+            self.key_state = torch.zeros(2, dtype=torch.int64, device=dev)
+            self._seeded = False
         side = ops.USE_SIDE_STREAM
         ops.USE_SIDE_STREAM = side and side_stream        # forked capture: wgrad branches run beside dgrad in the graph
         self.static.pop('_wcmc_paths_nhwc', None)
@@ -92,7 +97,7 @@ class GraphedTrainStep:
         self.two_stream = bool(two_stream)
         if self.two_stream:
             assert itf.halves_supported() and not self.cut, "two_stream: a train_branches step of sbmc.KPCN, no backward cut"
-        self.defer_check = bool(defer_check) and self.tail_captured
+        self.defer_check = bool(defer_check) and (self.tail_captured or self.tail_split)
         self._pending, self._flag_bufs, self._n_calls = None, None, 0
         if self.tail_captured or self.tail_split:
             assert warmup >= 1
@@ -110,6 +115,10 @@ class GraphedTrainStep:
             # stream) may allocate while this thread captures -- in the default 'global' mode a hipHostMalloc / hipMalloc from
             # ANY thread invalidates the capture
             with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
+                if not self.two_stream and self.fm is not None and self.dev_keys:
+                    ops.step_counter_advance(self.key_state)
+                    self._draw_captured(0)
+                    self._draw_captured(1)
                 if self.two_stream:     # (the halves are graphs of their own: what is left is the radiance, its metrics and the tail)
                     self.losses = itf._finish_halves(self.static, self._half_out[0][0], self._half_out[1][0],
                                                      self._half_out[0][1], self._half_out[1][1])
@@ -178,20 +187,26 @@ class GraphedTrainStep:
         ``graph_s`` (the halves, each on a stream and in a memory pool of its own: they run concurrently).  Returns the pool the
         tail graph shares (it runs after both halves, on the launch stream)."""
         itf = self.itf
-        self.half_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        self.half_streams = ops.concurrent_stream_pair(dev)      # two streams on different hardware queues, probed once per process
         branch = ops.USE_BRANCH_STREAM
         ops.USE_BRANCH_STREAM = False                      # a half is linear: nothing forks inside it
         try:
             self.graph_h = None
             pre = getattr(itf.models.get('backbone_diffuse'), '_paths_nhwc', None) if itf.use_llpm_buf else None
-            if pre is not None:
+            keys = self.fm is not None and self.dev_keys
+            if pre is not None or keys:
                 self.graph_h = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_h, capture_error_mode="thread_local"):
-                    pre(self.static)                       # NHWC / split copy of `paths`, read by both halves
+                    if keys:
+                        ops.step_counter_advance(self.key_state)
+                    if pre is not None:
+                        pre(self.static)                   # NHWC / split copy of `paths`, read by both halves
             self._half_out, self.half_graphs = [], []
-            for br, st in zip(('diffuse', 'specular'), self.half_streams):
+            for i, (br, st) in enumerate(zip(('diffuse', 'specular'), self.half_streams)):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+                    if keys:
+                        self._draw_captured(i)             # this half's pairings (FeatureMSE reads perms[i])
                     self._half_out.append(itf._half_forward_backward(self.static, br))
                 self.half_graphs.append(g)
         finally:
@@ -229,6 +244,21 @@ class GraphedTrainStep:
         self.ok.fill_(1.0)
         return e0.elapsed_time(e1) / n
 
+    def _draw_captured(self, half):
+        """Under capture: the two permutations of one half (slot 2 * half: patch, 2 * half + 1: batch), keyed from ``key_state``."""
+        ip, ib = self.perms[half]
+        ops.random_permutation_dev(ip, self.key_state, 2 * half)
+        if ib is not None:
+            ops.random_permutation_dev(ib, self.key_state, 2 * half + 1)
+
+    def reseed(self, seed=None):
+        """Key the captured draws: seed (default: one draw from torch's CPU generator, so ``torch.manual_seed`` fixes the whole
+        sequence of pairings) and counter 0.  Done by the first call of the step if nobody did it before."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.key_state.copy_(torch.tensor([int(seed), 0], dtype=torch.int64), non_blocking=False)
+        self._seeded = True
+
     def _draw(self):
         """Fresh pairings, in the reference's call order (diffuse: patch, batch; specular: patch, batch)."""
         if self.fm.rng == 'device':                       # written in place: no sort, no copy; the keys of the step's
@@ -257,7 +287,11 @@ class GraphedTrainStep:
                 for v, b in zip(dst, src):
                     v.copy_(b, non_blocking=True)
         if self.fm is not None:
-            self._draw()
+            if self.dev_keys:
+                if not self._seeded:
+                    self.reseed()
+            else:
+                self._draw()
             self.fm._static_i = 0
         if not (self.tail_captured or self.tail_split):
             self._replay()
@@ -347,7 +381,7 @@ class GraphedTrainStep:
             if g is not None:
                 g.reset()
         for name in ("losses", "static", "flags", "guard", "sums", "_sum_views", "perms", "_loss_refs", "_flag_bufs", "_pending", "ok",
-                     "after_enqueue", "tail_events", "_half_out", "half_streams"):
+                     "after_enqueue", "tail_events", "_half_out", "half_streams", "key_state"):
             self.__dict__.pop(name, None)
         if self.fm is not None and getattr(self.fm, "static_perms", None) is not None:
             self.fm.static_perms, self.fm.check_finite = None, True       # (the eager loss draws and checks for itself again)
@@ -379,7 +413,9 @@ def capture_validated(itf, batch, attempts=3, min_attempts=2, tol=0.05, replays=
            tuple(sorted((k, tuple(v.shape)) for k, v in batch.items() if isinstance(v, torch.Tensor))),
            tuple(sorted((n, sum(p.numel() for p in m.parameters())) for n, m in itf.models.items())))
     tried = []
-    for a in range(max(1, attempts)):
+    rng0 = torch.get_rng_state()          # (every attempt's warm-up draws pairings from the CPU generator: all attempts start from the
+    for a in range(max(1, attempts)):     # same state, so the generator ends up where ONE capture would have left it)
+        torch.set_rng_state(rng0)
         step = GraphedTrainStep(itf, batch, **kw)
         t = step.time_replays(replays)
         if t is None:                                      # (nothing to validate by: multi-rank tail, eager optimiser)

@@ -314,6 +314,63 @@ def join_all_streams(device):
         cur.wait_stream(s)
 
 
+# Two streams overlap on the GPU only when the HIP runtime has mapped them onto DIFFERENT hardware queues; it deals its (few) queues
+# out to streams as they are created, so two freshly made streams may share one and then run strictly one after the other -- the
+# "lottery" of rounds 3-4 (a captured step whose halves ran in series: 13.4 instead of 11.7 ms, decided at stream creation and stable
+# for the life of the streams).  ``concurrent_stream_pair`` makes streams until two of them demonstrably run a pair of spin kernels
+# side by side, once per device and process; the two-stream step replays its halves on that pair.
+_STREAM_PAIRS = {}
+
+
+def _spin_ms(streams, cycles):
+    cur = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for s in streams:
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(cycles)
+    for s in streams:
+        cur.wait_stream(s)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def concurrent_stream_pair(device, tries=8):
+    """Two side streams of `device` that run concurrently (probed with spin kernels), cached per device; ``.probe`` on the returned
+    tuple's first stream holds what was measured (ms of one spin kernel, of the accepted pair, streams tried)."""
+    device = torch.device(device)
+    key = (device.type, device.index)
+    if key in _STREAM_PAIRS:
+        return _STREAM_PAIRS[key]
+    with torch.cuda.device(device):
+        first = torch.cuda.Stream(device=device)
+        cycles = 200000
+        one = _spin_ms([first], cycles)
+        one = _spin_ms([first], cycles)                      # (second run: without first-launch costs)
+        if one < 0.2:                                        # aim at ~0.3 ms per spin: long against launch latencies
+            cycles = int(cycles * 0.3 / max(one, 1e-3))
+            one = _spin_ms([first], cycles)
+        pool, best = [first], None
+        for _ in range(tries):
+            cand = torch.cuda.Stream(device=device)
+            for other in pool:
+                t = min(_spin_ms([other, cand], cycles), _spin_ms([other, cand], cycles))
+                if best is None or t < best[0]:
+                    best = (t, other, cand)
+                if t < 1.4 * one:
+                    break
+            pool.append(cand)
+            if best[0] < 1.4 * one:
+                break
+    pair = (best[1], best[2])
+    pair[0].probe = {"spin_ms": round(one, 4), "pair_ms": round(best[0], 4), "streams_tried": len(pool), "concurrent": bool(best[0] < 1.4 * one)}
+    _STREAM_PAIRS[key] = pair
+    return pair
+
+
 class on_branch:
     """``with on_branch(device) as br: y = f(x)`` runs f on the branch stream after everything enqueued
     so far on the current stream; ``br.join(y, ...)`` makes the current stream wait for it."""
@@ -1790,3 +1847,21 @@ def random_permutation(n, device, out=None, seed=None):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     check(lib().wcmc_random_permutation(_ptr(out), n, int(seed), _stream()), "random_permutation")
     return out
+
+
+def random_permutation_dev(out, state, slot):
+    """``random_permutation`` keyed from the device tensor ``state`` = [seed, step counter] (int64) and ``slot``: the form a hipGraph
+    can replay with another key every step (``wcmc_random_permutation_dev``)."""
+    assert out.is_cuda and out.dtype == torch.int64 and out.is_contiguous() and state.is_cuda and state.dtype == torch.int64 and state.numel() >= 2
+    check(lib().wcmc_random_permutation_dev(_ptr(out), out.numel(), _ptr(state), int(slot), _stream()), "random_permutation_dev")
+    return out
+
+
+def step_counter_advance(state):
+    """state[1] += 1 on the device (``wcmc_step_counter_advance``)."""
+    check(lib().wcmc_step_counter_advance(_ptr(state), _stream()), "step_counter_advance")
+
+
+def permutation_key(seed, counter, slot):
+    """Host mirror of the key ``random_permutation_dev`` forms (``wcmc_permutation_key``; no GPU call)."""
+    return int(lib().wcmc_permutation_key(int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1), int(slot)))

@@ -64,9 +64,12 @@ def train_epoch_kpcn(epoch, interfaces, dataloaders, params, args):
         for i, itf in enumerate(interfaces):
             if getattr(args, 'graph', False):
                 if i not in steps:
-                    from .graph import GraphedTrainStep
-                    steps[i] = GraphedTrainStep(itf, batch, defer_check=getattr(args, 'defer_check', False),
-                                                overlap_allreduce=getattr(args, 'overlap_allreduce', False))
+                    from .graph import capture_validated
+                    overlap = getattr(args, 'overlap_allreduce', False)
+                    two = bool(getattr(itf, 'halves_supported', lambda: False)()) and not overlap and not getattr(args, 'one_graph', False)
+                    # (each capture is timed and re-made if it is more than 5 % slower than the best this process has seen)
+                    steps[i] = capture_validated(itf, batch, defer_check=getattr(args, 'defer_check', True),
+                                                 overlap_allreduce=overlap, two_stream=two)
                     kick = getattr(dataloaders['train'], 'kick', None)      # support/loader.py: pace the producer thread
                     if kick is not None and i == len(interfaces) - 1:
                         steps[i].after_enqueue = kick
@@ -287,10 +290,14 @@ def build_parser():
     p.add_argument('--synthetic', type=int, default=16, help='synthetic batches per epoch (the dataset reader is out of scope)')
     p.add_argument('--patch_size', type=int, default=128)
     p.add_argument('--graph', action='store_true', help='one hipGraph replay per training step')
-    p.add_argument('--defer_check', action='store_true',
-                   help="with --graph: check a step's losses for non-finite values after the NEXT step has been enqueued (the "
-                        "device guard still skips the update at once; the error is raised one step later) -- the host prepares "
-                        "the next batch while the GPU runs")
+    p.add_argument('--defer_check', dest='defer_check', action='store_true', default=True,
+                   help="with --graph (the default there): check a step's losses for non-finite values after the NEXT step has "
+                        "been enqueued (the device guard still skips the update at once; the error is raised one step later) -- "
+                        "the host prepares the next batch while the GPU runs")
+    p.add_argument('--sync_check', dest='defer_check', action='store_false',
+                   help="with --graph: read the non-finite flags of every step before the next one is enqueued (one host sync per step)")
+    p.add_argument('--one_graph', action='store_true',
+                   help="with --graph: the step as ONE forked hipGraph instead of two half-step graphs on two streams + a tail graph")
     p.add_argument('--overlap_allreduce', action='store_true',
                    help="with --graph on several ranks and --use_llpm_buf: cut the backward at the P-buffers and put the dncnn "
                         "gradient bucket on the wire while the PathNets' backward runs (three graphs; bit-identical; not measured "
