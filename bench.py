@@ -685,7 +685,7 @@ def main():
             if args.precision is None:
                 # the other arithmetics the library ships, same box, same process
                 line["other_precisions"] = {m: extra_leg(device, n, 3, precision=m)
-                                            for m, n in (("bf16x321h", args.steps), ("bf16x321o", args.steps), ("bf16x3", args.steps),
+                                            for m, n in (("bf16x321", args.steps), ("bf16x321o", args.steps), ("bf16x3", args.steps),
                                                          ("fp32", max(3, args.steps // 4)))}
                 # ... and the other PathNet parametrisation (plain weights when the headline is weight-normalised, and vice versa)
                 line["other_parametrisation"] = dict(extra_leg(device, args.steps, 3, weight_norm=bool(args.no_pathnet_weight_norm)),

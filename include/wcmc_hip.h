@@ -269,6 +269,13 @@ size_t wcmc_conv2d_wgrad_bf16x3_workspace_bytes(int N, int Ho, int Wo, int Cout,
  * terms: bf16 MFMAs per product -- 3 = dy_lo*x_hi + dy_hi*x_lo + dy_hi*x_hi; 1 = dy_hi*x_hi only (the lo planes are not
  * read: half the operand bytes).  The reference's counterpart is cuDNN's weight gradient under
  * `torch.backends.cudnn.allow_tf32` (train_kpcn.py:349 leaves the default, TF32 = 10 mantissa bits per operand). */
+/* Phase 2 of up to 32 wcmc_conv2d_wgrad_bf16x3 calls in ONE launch: layer i's split-K slabs (workspace[i], filled by a phase-1
+ * call with the same N, Ho, Wo, Cout, Cin, ks and terms) are summed into dw[i], and db[i] (optional) is finished from
+ * dy_colsum_partial[i] (required with db[i]).  Bit-identical to the per-layer phase 2.  The U-Net's fifteen weight gradients per
+ * PathNet and backward pass are reduced by one launch at the end of the chain walk instead of fifteen between its GEMMs. */
+int wcmc_conv2d_wgrad_reduce_multi(int n, void* const* workspace, float* const* dw, float* const* db,
+                                   const float* const* dy_colsum_partial, const int* N, const int* Ho, const int* Wo,
+                                   const int* Cout, const int* Cin, const int* ks, int terms, void* stream);
 int wcmc_conv2d_wgrad_bf16x3(const void* x_split, int N, int H, int W, int Cin,
                              const void* dy_split, int Cout, int ks, int pad, float* dw, float* db,
                              void* workspace, size_t workspace_bytes, int phase, const float* dy_colsum_partial,

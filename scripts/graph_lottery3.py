@@ -15,6 +15,10 @@ import torch
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+    if len(sys.argv) > 2:                                   # A/B of ops.DEFER_MAX_BYTES (MiB): which slab reductions wait for the multi launch
+        from wcmc_amd import ops as _o
+        _o.DEFER_MAX_BYTES = int(float(sys.argv[2]) * (1 << 20))
+        print("# DEFER_MAX_BYTES = %d" % _o.DEFER_MAX_BYTES)
     import bench
     from wcmc_amd.graph import GraphedTrainStep
     from wcmc_amd.synthetic import make_batch

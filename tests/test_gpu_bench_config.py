@@ -41,8 +41,9 @@ DEV = "cuda"
 # sit at 0.7-1.9e-2 in both split-bf16 arithmetics (bf16x3: 0.95e-2 at worst) and 0.17e-2 in exact fp32, the 3-entry weight_g of the
 # output layer at 4e-2 -- dg = <dW, v> / ||v|| is a projection, its relative error is dW's divided by the cosine between dW and v.
 # scripts/diag_grad_floor.py (round 2, fp64 CPU run as the yardstick): the fp32 CPU oracle itself is up to 4.7e-4 from fp64.
-# The bar is 2x the measured value of the draw the test holds.
-GRAD_L2, GRAD_COS = 4e-3, 4e-6
+# The default mode ("bf16x321h": one fp16 MFMA per product in the KPCN output layers' forward) sits at 2.00e-3 / 2.0e-6 on seed 0.
+# The bar is 2.5x the measured value of the draw the test holds.
+GRAD_L2, GRAD_COS = 5e-3, 5e-6
 
 
 def _max_rel(a, b):

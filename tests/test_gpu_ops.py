@@ -1269,3 +1269,40 @@ def test_chain_applied_twice_in_one_backward_accumulates_both_weight_gradients(w
     mod.zero_grad()
     (mod(xb) * gb).sum().backward()
     assert not o.split_path() or in_views(), "zero_grad() frees the sinks"
+
+
+def test_deferred_multi_layer_slab_reduction_is_bit_identical(three_term_mode):
+    """``ops.deferred_wgrad_reduce()``: the slab reductions of a chain's small layers collected and run as ONE launch
+    (``wcmc_conv2d_wgrad_reduce_multi``) give the weight AND bias gradients of the per-layer reductions bit for bit -- a U-Net chain
+    (3x3, padded), a 1x1 chain and a chain whose last layer has three outputs; a layer above ``DEFER_MAX_BYTES`` is not deferred."""
+    from wcmc_amd.modules import ConvChain
+    o = ops()
+    for (cin, cout, ks, width, depth, hw) in ((64, 64, 3, 64, 3, (40, 36)), (384, 128, 3, 128, 3, (24, 24)), (36, 3, 1, 64, 3, (32, 64))):
+        torch.manual_seed(7)
+        mod = ConvChain(cin, cout, ksize=ks, width=width, depth=depth, pad=True, output_type="relu", weight_norm=False).to(DEV)
+        x = gen(4, cin, *hw, seed=70).to(DEV)
+        g = gen(4, cout, *hw, seed=71).to(DEV)
+        res = []
+        for defer in (False, True):
+            mod.zero_grad()
+            y = mod(x)
+            if defer:
+                with o.deferred_wgrad_reduce():
+                    y.backward(g)
+                    pend = sum(len(v[1]) for v in o._DEFERRED.values())
+                assert 2 <= pend <= depth, "the chain's small layers should have been deferred: %d of %d were" % (pend, depth)
+                assert o._DEFERRED is None
+            else:
+                y.backward(g)
+            res.append([p.grad.clone() for p in mod.parameters()])
+        for a, b, (k, _) in zip(res[0], res[1], mod.named_parameters()):
+            assert torch.equal(a, b), "deferred reduction changes %s" % k
+    old = o.DEFER_MAX_BYTES
+    o.DEFER_MAX_BYTES = 1
+    try:
+        with o.deferred_wgrad_reduce():
+            mod.zero_grad()
+            mod(x).backward(g)
+            assert not o._DEFERRED
+    finally:
+        o.DEFER_MAX_BYTES = old

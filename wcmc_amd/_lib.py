@@ -50,6 +50,7 @@ SIGNATURES = {
     "wcmc_conv2d_igemm_colsum_elems": (Z, [I, I, I, I]),
     "wcmc_colsum_finish": (I, [P, I, I, I, I, P, P]),
     "wcmc_conv2d_wgrad_bf16x3_workspace_bytes": (Z, [I, I, I, I, I, I]),
+    "wcmc_conv2d_wgrad_reduce_multi": (I, [I, P, P, P, P, P, P, P, P, P, P, I, P]),
     "wcmc_conv2d_wgrad_bf16x3": (I, [P, I, I, I, I, P, I, I, I, P, P, P, Z, I, P, I, P]),
     "wcmc_act_backward": (I, [P, L, L, L, P, L, L, L, P, L, L, L, I, I, I, I, I, F, P]),
     "wcmc_kernel_apply_fwd": (I, [P, L, L, L, P, L, L, L, L, P, L, L, L, L, P, I, I, I, I, I, P]),

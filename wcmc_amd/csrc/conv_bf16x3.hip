@@ -3462,6 +3462,37 @@ extern "C" int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* 
   return check_launch("conv2d_pack_chain_bf16x3");
 }
 
+extern "C" int wcmc_conv2d_wgrad_reduce_multi(int n, void* const* workspace, float* const* dw, float* const* db,
+                                              const float* const* dy_colsum_partial, const int* N, const int* Ho, const int* Wo,
+                                              const int* Cout, const int* Cin, const int* ks, int terms, void* stream) {
+  WCMC_REQUIRE(n > 0 && n <= WRM_MAX && workspace && dw && db && dy_colsum_partial && N && Ho && Wo && Cout && Cin && ks &&
+               (terms == 1 || terms == 3), WCMC_ERR_BAD_ARG, "conv2d_wgrad_reduce_multi: bad argument (1..%d layers)", WRM_MAX);
+  WRMTable t;
+  t.n = n;
+  unsigned blocks = 0;
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    WCMC_REQUIRE(workspace[i] && dw[i] && N[i] > 0 && Ho[i] > 0 && Wo[i] > 0 && Cout[i] > 0 && Cin[i] > 0 && ks[i] > 0 && ks[i] <= 7,
+                 WCMC_ERR_BAD_ARG, "conv2d_wgrad_reduce_multi: bad layer %d", i);
+    WCMC_REQUIRE(!db[i] || dy_colsum_partial[i], WCMC_ERR_BAD_ARG,
+                 "conv2d_wgrad_reduce_multi: layer %d wants a bias gradient without the column sums of dy", i);
+    const XWgradPlan pl = x_plan_wgrad(N[i], Ho[i], Wo[i], Cout[i], Cin[i], ks[i], terms);
+    WRMEntry& e = t.e[i];
+    const bool fuse_db = db[i] != nullptr;
+    e.slabs = (const float*)workspace[i]; e.dw = dw[i]; e.cs_partial = fuse_db ? dy_colsum_partial[i] : nullptr; e.db = db[i];
+    e.S = pl.S; e.taps = ks[i] * ks[i]; e.Cout = Cout[i]; e.Cin = Cin[i]; e.Np = pl.Np; e.Cq = pl.Cq;
+    e.cs_gmax = x_colsum_rows(N[i], Ho[i], Wo[i]); e.cs_ld = round_up(Cout[i], 16);
+    e.gx = (Cin[i] + WR_CI - 1) / WR_CI;
+    e.block0 = blocks;
+    blocks += (unsigned)e.gx * (unsigned)(Cout[i] + (fuse_db ? (Cout[i] + 63) / 64 : 0));
+    size_t l = (size_t)WR_CI * (e.taps + 1) * sizeof(float) + 256 * sizeof(float);
+    if (fuse_db && l < (size_t)16 * 64 * sizeof(float)) l = (size_t)16 * 64 * sizeof(float);
+    if (l > lds) lds = l;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, t);
+  return check_launch("conv2d_wgrad_reduce_multi");
+}
+
 static int g_xigemm_dbuf = -1;      // WCMC_IGEMM_DBUF=0/1 (A/B switch); default: double buffer
 template <int NT, bool PADDED, bool DBUF>
 static int launch_xigemm3(const XIgemmParams& p, hipStream_t stream) {

@@ -14,16 +14,17 @@ constexpr int WR_CI = 32;
 // from the per-tile column sums of dy that the launch producing dy left: 64 channels per block, the 16 row groups of
 // colsum_final_strided_kernel (four per quarter of the block), same order of additions -- the bias gradient costs no
 // launch of its own.
-static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                                  int S, int taps, int Cout, int Cin, int Np, int Cq,
-                                                                  const float* __restrict__ cs_partial, int cs_gmax,
-                                                                  int cs_ld, float* __restrict__ db) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [WR_CI][taps + 1] (>= 16 x 64 floats with cs_partial)
-  if ((int)blockIdx.y >= Cout) {
-    if (blockIdx.x != 0) return;
+// (bx, by) = the block's position in the launch's (Cin / 32, Cout + bias rows) grid: wgrad_reduce_kernel passes blockIdx,
+// wgrad_reduce_multi_kernel -- the reductions of several layers in one launch -- a position inside its entry's share of a flat grid.
+static __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                         int S, int taps, int Cout, int Cin, int Np, int Cq,
+                                                         const float* __restrict__ cs_partial, int cs_gmax,
+                                                         int cs_ld, float* __restrict__ db, int bx, int by, float* smem) {
+  if (by >= Cout) {
+    if (bx != 0) return;
     float (*red)[64] = reinterpret_cast<float (*)[64]>(smem);
     const int cl = threadIdx.x & 63, q4 = threadIdx.x >> 6;
-    const int c = ((int)blockIdx.y - Cout) * 64 + cl;
+    const int c = (by - Cout) * 64 + cl;
     const int G = min(cs_gmax, reinterpret_cast<const int*>(cs_partial)[(int64_t)cs_gmax * cs_ld]);
     for (int gg = q4; gg < 16; gg += 4) {
       float acc = 0.f;
@@ -48,7 +49,7 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
     }
     return;
   }
-  const int co = blockIdx.y, ci0 = blockIdx.x * WR_CI;
+  const int co = by, ci0 = bx * WR_CI;
   const int LD = taps + 1;
   const int64_t sstride = (int64_t)taps * Np * Cq;
   if (taps * WR_CI * 2 <= 256) {
@@ -119,6 +120,33 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* _
     const int cl = e / taps, tap = e - cl * taps;
     out[e] = smem[cl * LD + tap];
   }
+}
+
+static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                  int S, int taps, int Cout, int Cin, int Np, int Cq,
+                                                                  const float* __restrict__ cs_partial, int cs_gmax,
+                                                                  int cs_ld, float* __restrict__ db) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [WR_CI][taps + 1] (>= 16 x 64 floats with cs_partial)
+  wgrad_reduce_body(slabs, dw, S, taps, Cout, Cin, Np, Cq, cs_partial, cs_gmax, cs_ld, db, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+
+// The slab reductions (and bias-gradient finishes) of up to WRM_MAX layers in ONE launch: a U-Net level's layers have a few
+// hundred reduction blocks of 5-15 us each -- fifteen launches per PathNet whose kernels do not fill the chip and whose
+// boundaries cost as much as they do.  Same arithmetic per block as wgrad_reduce_kernel (bit-identical results).
+constexpr int WRM_MAX = 32;
+struct WRMEntry { const float* slabs; float* dw; const float* cs_partial; float* db;
+                  int S, taps, Cout, Cin, Np, Cq, cs_gmax, cs_ld, gx; unsigned block0; };
+struct WRMTable { WRMEntry e[WRM_MAX]; int n; };
+static __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WRMTable t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < t.n; ++i)
+    if (blockIdx.x >= t.e[i].block0) k = i;
+  const WRMEntry& q = t.e[k];
+  const int local = (int)(blockIdx.x - q.block0);
+  wgrad_reduce_body(q.slabs, q.dw, q.S, q.taps, q.Cout, q.Cin, q.Np, q.Cq, q.cs_partial, q.cs_gmax, q.cs_ld, q.db,
+                    local % q.gx, local / q.gx, smem);
 }
 
 // out[c] = sum_g partial[g][c]; 16 g-groups x 64 channels per 1024-thread block, fixed order.

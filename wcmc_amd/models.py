@@ -10,6 +10,8 @@ from .support.utils import crop_like
 
 
 class KPCN(nn.Module):
+    single_use_parameters = True        # every parameter feeds one autograd node per step (support/interfaces.py: _defer_scope)
+
     def __init__(self, n_in, ksize=21, depth=9, width=100):
         super().__init__()
         self.ksize = ksize

@@ -208,7 +208,8 @@ class KPCNInterface(BaseInterface):
             loss = loss + l_manif * self.w_manif
             losses['l_manif_' + br] = l_manif.detach()
         losses['l_' + br] = loss.detach()             # (L1 + w * manifold: the reference's aliasing quirk, see _backward)
-        torch.autograd.backward([loss])
+        with self._defer_scope():                     # (the small layers' slab reductions: one launch at the end)
+            torch.autograd.backward([loss])
         return r.detach(), losses
 
     def _finish_halves(self, batch, r_diffuse, r_specular, l_diffuse, l_specular):
@@ -320,17 +321,27 @@ class KPCNInterface(BaseInterface):
 
         return loss_dict
 
+    def _defer_scope(self):
+        """``ops.deferred_wgrad_reduce()`` when every model declares that each of its parameters feeds exactly ONE autograd node per
+        step (``single_use_parameters``: this package's KPCN and PathNet) -- a weight gradient whose reduction is deferred must not be
+        summed with another producer's by the engine before the reduction has run; any other model keeps the reduction behind its GEMM."""
+        import contextlib
+        if all(getattr(m, 'single_use_parameters', False) for m in self.models.values()):
+            return _ops.deferred_wgrad_reduce()
+        return contextlib.nullcontext()
+
     def _run_backward(self, *losses):
         """``loss.backward()`` of every given loss in one engine run (interfaces.py:237-238, 246), or -- with the P-buffer cut of
         ``_forward_backward(cut=True)`` -- its first stage: down to the parameters of ``dncnn`` and to the PathNets' outputs,
         whose gradients stay in their ``.grad``."""
         raw = getattr(self, '_p_raw', None)
         if raw is None:
-            if os.environ.get('WCMC_JOINT_BACKWARD', '1') == '0':      # A/B switch: the reference's one engine run per loss
-                for loss in losses:
-                    loss.backward()
-                return
-            torch.autograd.backward(list(losses))
+            with self._defer_scope():                   # (the small layers' slab reductions: one launch per stream at the end)
+                if os.environ.get('WCMC_JOINT_BACKWARD', '1') == '0':      # A/B switch: the reference's one engine run per loss
+                    for loss in losses:
+                        loss.backward()
+                else:
+                    torch.autograd.backward(list(losses))
             return
         ins = [p for p in self.models['dncnn'].parameters() if p.requires_grad] + [t for t in raw.values() if t.requires_grad]
         # (no retain_graph: the engine frees what it walks, and with `inputs` it walks only the nodes above the P-buffers -- the

@@ -12,6 +12,7 @@ from ..modules import Autoencoder, ConvChain, weight_norm_scope
 
 class PathNet(nn.Module):
     """Path embedding network"""
+    single_use_parameters = True        # every parameter feeds one autograd node per step (support/interfaces.py: _defer_scope)
 
     def __init__(self, ic, intermc=64, outc=3, weight_norm=True):
         """weight_norm is not a reference argument: ``support/networks.py:18-24`` passes none to its chains, so upstream
