@@ -447,6 +447,27 @@ uint64_t wcmc_permutation_key(uint64_t seed, uint64_t counter, int slot);
 int wcmc_random_permutation_dev(int64_t* out, int64_t n, const uint64_t* state, int slot, void* stream);
 int wcmc_step_counter_advance(uint64_t* state, void* stream);
 
+/* ---------------------------------------------------------------- image losses of the sample-based interfaces
+ * support/losses.py:267-320, built at train_lbmc.py:164-170 / train_sbmc.py (SMAPE: LBMC; Tonemapped*: SBMC).  Strided (N,C,H,W)
+ * operands like wcmc_image_loss_fwd; one pass + a one-block finish in a fixed order (bitwise reproducible); workspace of
+ * wcmc_image_loss_workspace_bytes().  T = Reinhard tone map of the clamped image (losses.py:234-242).
+ *   kind 0  SMAPE                  mean |x - ref| / (eps + |x| + |ref|)   (the denominator carries no gradient, losses.py:279-282)
+ *   kind 1  TonemappedMSE          0.5 * mean (T(x) - T(ref))^2
+ *   kind 2  TonemappedRelativeMSE  0.5 * mean (T(x) - T(ref))^2 / (T(ref)^2 + eps)
+ * bwd: dx (contiguous (N,C,H,W)) = *grad_loss * d loss / d x. */
+int wcmc_image_loss2_fwd(int kind, const float* x, int64_t xsn, int64_t xsc, int64_t xsh, int64_t xsw, const float* ref,
+                         int64_t rsn, int64_t rsc, int64_t rsh, int64_t rsw, float eps, float* loss, void* workspace,
+                         size_t workspace_bytes, int N, int C, int H, int W, void* stream);
+int wcmc_image_loss2_bwd(int kind, const float* x, int64_t xsn, int64_t xsc, int64_t xsh, int64_t xsw, const float* ref,
+                         int64_t rsn, int64_t rsc, int64_t rsh, int64_t rsw, float eps, const float* grad_loss, float* dx,
+                         int N, int C, int H, int W, void* stream);
+/* torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) (support/interfaces.py:454-458, 826-833: 1000 for SBMC, 250 for LBMC)
+ * over up to 96 gradient tensors in three launches: norm_and_coef[0] = the total 2-norm BEFORE clipping (what the reference prints),
+ * norm_and_coef[1] = min(1, max_norm / (norm + 1e-6)); the gradients are scaled in place when the factor is below one. */
+size_t wcmc_grad_norm_clip_workspace_bytes(int n_tensors, const int64_t* numel);
+int wcmc_grad_norm_clip(int n_tensors, float* const* grads, const int64_t* numel, float max_norm, float* norm_and_coef,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- weight normalisation
  * sbmc.modules.ConvChain wraps every nn.Conv2d in torch.nn.utils.weight_norm unless its caller passes weight_norm=False;
  * support/networks.py:18-24 (PathNet's embedding / propagation / final chains) does not, sbmc.KPCN does.  Parameters per

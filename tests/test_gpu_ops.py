@@ -365,7 +365,12 @@ TWO_TERM_FALLBACKS = ((2, 100, 30, 29, 39, 4, 5), (2, 120, 24, 24, 100, 4, 5), (
                                   # the U-Net's 3x3 layers (conv_halo_bf16x3_kernel<4 | 7, .., AP = 1>): one 64- / 128-channel slab, two of 96,
                                   # three of 128, 12 cout tiles (NT = 7), a 40-channel slab, the 16x16 and the 8x16 tiling
                                   (2, 64, 40, 37, 64, 1, 3), (1, 128, 37, 21, 128, 1, 3), (2, 192, 24, 24, 64, 1, 3), (1, 384, 33, 18, 128, 1, 3),
-                                  (1, 256, 20, 36, 192, 1, 3), (1, 40, 20, 20, 64, 1, 3), (8, 64, 128, 128, 64, 1, 3)) + TWO_TERM_FALLBACKS)
+                                  (1, 256, 20, 36, 192, 1, 3), (1, 40, 20, 20, 64, 1, 3), (8, 64, 128, 128, 64, 1, 3),
+                                  # the ONE-cout-tile 5x5 instance (conv_halo64<1, 3, PT, 0, 80, 1>: x_plan_k grants it to every two-term 5x5
+                                  # launch with at most 16 output rows, not only to the sliced first-layer gradient of KPCN): 3 / 8 / 16
+                                  # rows, 32 / 40 / 100 channels (Kp % 32 = 0 and 8), odd sizes with partial tiles
+                                  (2, 32, 21, 23, 3, 4, 5), (1, 40, 19, 27, 8, 4, 5), (2, 100, 25, 21, 16, 4, 5), (1, 100, 17, 33, 3, 4, 5),
+                                  (3, 32, 13, 40, 16, 4, 5)) + TWO_TERM_FALLBACKS)
 def test_two_term_data_gradient_against_fp64(case):
     """terms = 2 of wcmc_conv2d_igemm_bf16x3: x (= dy in the data gradient) rounded to its hi plane, W exact to 16 bits,
     weights packed with mode 2 (32-channel slabs in the hi-plane-only halo).  Against fp64 on the rounded x at the kernel's
@@ -1306,3 +1311,43 @@ def test_deferred_multi_layer_slab_reduction_is_bit_identical(three_term_mode):
             assert not o._DEFERRED
     finally:
         o.DEFER_MAX_BYTES = old
+
+
+@pytest.mark.parametrize("kind,cls", [("smape", "SMAPE"), ("tonemapped_mse", "TonemappedMSE"), ("tonemapped_relative_mse", "TonemappedRelativeMSE")])
+def test_sample_interface_losses_match_the_oracle(kind, cls):
+    """SMAPE / TonemappedMSE / TonemappedRelativeMSE (support/losses.py:267-320) as HIP passes: value and dL/dx against the oracle's
+    torch expressions in fp64 -- negative pixels (the tone map clamps them: zero gradient), a strided (cropped) operand, and through
+    the ``support.losses`` classes the interfaces build."""
+    from wcmc_amd.support import losses as hl
+    o = ops()
+    x = gen(2, 3, 37, 45, seed=80, scale=2.0) + 0.3
+    ref = gen(2, 3, 37, 45, seed=81, scale=2.0).abs()
+    big = gen(2, 3, 41, 49, seed=82, scale=2.0)
+    for xin in (x, big[:, :, 2:39, 3:48] + 0.3):
+        xr = xin.double().requires_grad_(True)
+        want = getattr(ol, cls)()(xr, ref.double())
+        want.backward()
+        src = (big.to(DEV)[:, :, 2:39, 3:48] + 0.3 if xin is not x else x.to(DEV)).requires_grad_(True)
+        got = getattr(hl, cls)()(src, ref.to(DEV))
+        got.backward()
+        assert_close(got.reshape(1), want.reshape(1), tol=2e-6, what=cls)
+        assert_close(src.grad, xr.grad, tol=2e-6, what=cls + " gradient")
+    assert torch.equal(o.image_loss2(x.to(DEV), ref.to(DEV), kind), o.image_loss2(x.to(DEV), ref.to(DEV), kind))
+
+
+def test_clip_grad_norm_matches_torch():
+    o = ops()
+    shapes = [(64, 36, 1, 1), (64,), (128, 128, 3, 3), (3,), (5000,), (1,)]
+    for scale, max_norm in ((1.0, 1000.0), (300.0, 250.0)):
+        ps, pr = [], []
+        for i, shp in enumerate(shapes):
+            g = gen(*shp, seed=300 + i) * scale
+            p = torch.nn.Parameter(torch.zeros(shp, device=DEV)); p.grad = g.to(DEV)
+            q = torch.nn.Parameter(torch.zeros(shp, dtype=torch.float64)); q.grad = g.double()
+            ps.append(p); pr.append(q)
+        want = torch.nn.utils.clip_grad_norm_(pr, max_norm)
+        got = o.clip_grad_norm_(ps, max_norm)
+        assert_close(got.reshape(1), want.reshape(1), tol=2e-6, what="total norm")
+        for p, q in zip(ps, pr):
+            assert_close(p.grad, q.grad, tol=2e-6, what="clipped gradient")
+        assert (float(want) > max_norm) == (scale > 1.0)

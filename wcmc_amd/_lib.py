@@ -90,6 +90,10 @@ SIGNATURES = {
     "wcmc_embed3_mean_supported": (I, [I, L]),
     "wcmc_embed3_mean_fwd": (I, [P, L, I, P, P, P, P, P, P, P, P, I, L, P]),
     "wcmc_embed3_bwd": (I, [P, L, I, P, P, P, P, P, P, P, I, P, I, I, L, F, P, P, P, P, P, P, P, Z, P]),
+    "wcmc_image_loss2_fwd": (I, [I, P, L, L, L, L, P, L, L, L, L, F, P, P, Z, I, I, I, I, P]),
+    "wcmc_image_loss2_bwd": (I, [I, P, L, L, L, L, P, L, L, L, L, F, P, P, I, I, I, I, P]),
+    "wcmc_grad_norm_clip_workspace_bytes": (Z, [I, P]),
+    "wcmc_grad_norm_clip": (I, [I, P, P, F, P, P, Z, P]),
     "wcmc_weight_norm_fwd": (I, [I, P, P, P, P, P, P, P]),
     "wcmc_weight_norm_bwd": (I, [I, P, P, P, P, P, P, P, P, P]),
     "wcmc_clip_adam": (I, [P, P, P, P, L, F, D, D, D, D, I, F, P, P]),

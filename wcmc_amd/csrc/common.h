@@ -1,6 +1,7 @@
 // Shared helpers for libwcmc_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -75,15 +76,24 @@ __device__ __forceinline__ float wave_sum(float v) {
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, DEVICE): a process-wide "already set" flag leaves the kernel at
 // the 64 KB default on every other GPU of the process.  One LdsAttr per launch site remembers the largest value set
 // per device ordinal; ordinals beyond the table set the attribute on every launch.
-struct LdsAttr { size_t v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
-static inline void set_max_lds(const void* fn, size_t lds, LdsAttr& a) {
+struct LdsAttr { std::atomic<size_t> v[16]; LdsAttr() { for (auto& x : v) x.store(0); } };
+// Returns hipSuccess, or the error of hipFuncSetAttribute (the launch that follows would fail with a less telling one).  The table
+// entry is published only AFTER the attribute has been set: a second host thread that sees it may launch with that much dynamic LDS.
+static inline hipError_t set_max_lds(const void* fn, size_t lds, LdsAttr& a) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16) {
-    if (lds <= a.v[dev]) return;
-    a.v[dev] = lds;
+  const bool tracked = dev >= 0 && dev < 16;
+  if (tracked && lds <= a.v[dev].load(std::memory_order_acquire)) return hipSuccess;
+  const hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (rc != hipSuccess) {
+    set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed: %s", lds, hipGetErrorString(rc));
+    return rc;
   }
-  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (tracked) {
+    size_t cur = a.v[dev].load(std::memory_order_relaxed);
+    while (cur < lds && !a.v[dev].compare_exchange_weak(cur, lds, std::memory_order_release, std::memory_order_relaxed)) {}
+  }
+  return hipSuccess;
 }
 
 }  // namespace wcmc

@@ -547,7 +547,7 @@ template <int NT>
 static int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   const size_t lds = (size_t)2 * (BM + NT * 16) * LDK * sizeof(float);
   static LdsAttr attr_set;
-  set_max_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<NT>), (size_t)lds, attr_set);
+  if (set_max_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<NT>), (size_t)lds, attr_set) != hipSuccess) return WCMC_ERR_LAUNCH;
   const dim3 grid((unsigned)ceil_div64(p.M, BM), (unsigned)((p.Np / 16 + NT - 1) / NT));
   hipLaunchKernelGGL(conv_igemm_kernel<NT>, grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm");

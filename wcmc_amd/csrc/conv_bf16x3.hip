@@ -2118,7 +2118,7 @@ static int launch_xpw2(const XIgemmParams& p, hipStream_t stream) {
   static_assert(lds <= 160 * 1024, "LDS");
   static int cus = 0;
   static LdsAttr attr_set;
-  set_max_lds(reinterpret_cast<const void*>(&conv_pw_bf16x3_kernel<NTW, U, SPLIT, TAIL>), lds, attr_set);
+  if (set_max_lds(reinterpret_cast<const void*>(&conv_pw_bf16x3_kernel<NTW, U, SPLIT, TAIL>), lds, attr_set) != hipSuccess) return WCMC_ERR_LAUNCH;
   if (cus == 0) {                     // (one node holds one kind of GPU: the CU count is read once)
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -3128,7 +3128,7 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
     constexpr size_t lds8 = (size_t)2 * ((PL * (64 * 14 + 68 * 14) + 511) / 512) * 512 * 16;
     if (PL == 1) {
       static LdsAttr attr81_set;
-      set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>), (size_t)lds8, attr81_set);
+      if (set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>), (size_t)lds8, attr81_set) != hipSuccess) return WCMC_ERR_LAUNCH;
       hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>), grid, dim3(512), lds8, st, q);
       return check_launch("conv2d_wgrad_bf16x3(rows8, one plane)");
     }
@@ -3145,8 +3145,8 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
         return check_launch("conv2d_wgrad_bf16x3(rows8 ablation / stamps)");
       } }
 #endif
-    set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1>), (size_t)lds8, attr8_set);
-    set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 0>), (size_t)lds8, attr80_set);
+    if (set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 1>), (size_t)lds8, attr8_set) != hipSuccess) return WCMC_ERR_LAUNCH;
+    if (set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows8_bf16x3_kernel<0, 0>), (size_t)lds8, attr80_set) != hipSuccess) return WCMC_ERR_LAUNCH;
     if (x_env_on("WCMC_WGRAD_ROWS8_XE")) hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0, 1>), grid, dim3(512), lds8, st, q);
     else hipLaunchKernelGGL((conv_wgrad_rows8_bf16x3_kernel<0, 0>), grid, dim3(512), lds8, st, q);
     return check_launch("conv2d_wgrad_bf16x3(rows8)");
@@ -3166,7 +3166,7 @@ static int launch_xwgrad_rows(const XWRowsParams& q, hipStream_t st) {
   }
 #endif
   static LdsAttr attr_set;
-  set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<KS, TM, NW, 0, PL>), (size_t)lds, attr_set);
+  if (set_max_lds(reinterpret_cast<const void*>(&conv_wgrad_rows_bf16x3_kernel<KS, TM, NW, 0, PL>), (size_t)lds, attr_set) != hipSuccess) return WCMC_ERR_LAUNCH;
   hipLaunchKernelGGL((conv_wgrad_rows_bf16x3_kernel<KS, TM, NW, 0, PL>), grid, dim3(NW * 64), lds, st, q);
   return check_launch("conv2d_wgrad_bf16x3(rows)");
 }
@@ -3500,7 +3500,7 @@ static int launch_xigemm3(const XIgemmParams& p, hipStream_t stream) {
   const size_t lds_out = (size_t)XBM * (2 * NT * 16 + 8) * sizeof(u16) + (size_t)16 * NT * 16 * sizeof(float);   // epilogue staging tile + column-sum partials
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   static LdsAttr attr_set;
-  set_max_lds(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>), (size_t)lds, attr_set);
+  if (set_max_lds(reinterpret_cast<const void*>(&conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>), (size_t)lds, attr_set) != hipSuccess) return WCMC_ERR_LAUNCH;
   const dim3 grid((unsigned)ceil_div64(p.M, XBM), (unsigned)((p.Np / 16 + NT - 1) / NT));
   hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<NT, PADDED, DBUF>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3");
@@ -3545,7 +3545,7 @@ template <int NT, int NB, int AP = 2>
 static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   constexpr int TH = 16, TW = 16;
   static LdsAttr attr;
-  set_max_lds(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>), lds, attr);
+  if (set_max_lds(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>), lds, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
   hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH, TW, 0, NB, AP>), grid, dim3(512), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo)");
@@ -3553,7 +3553,7 @@ static int launch_xhalo2(const XIgemmParams& p, size_t lds, hipStream_t stream) 
 template <int NT, int NB, int PT, int PXST, int AP = 2, int WP = 2, int F16 = 0>
 static int launch_xhalo64c(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   static LdsAttr attr;
-  set_max_lds(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>), lds, attr);
+  if (set_max_lds(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>), lds, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
   const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
   hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
@@ -3709,13 +3709,13 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
     if constexpr (NT == 4 || NT == 7) {
       if (p.ap == 1) {                           // (x_plan_k grants ap = 1 to this kernel for ks = 3 and NT = 4 or 7 only)
         static LdsAttr attr81;
-        set_max_lds(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2, 1>), lds8, attr81);
+        if (set_max_lds(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2, 1>), lds8, attr81) != hipSuccess) return WCMC_ERR_LAUNCH;
         hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2, 1>), grid, dim3(TH8 * TW * 2), lds8, stream, q);
         return check_launch("conv2d_igemm_bf16x3(halo, 8x16, x hi plane)");
       }
     }
     static LdsAttr attr8;
-    set_max_lds(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>), lds8, attr8);
+    if (set_max_lds(reinterpret_cast<const void*>(&conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>), lds8, attr8) != hipSuccess) return WCMC_ERR_LAUNCH;
     hipLaunchKernelGGL((conv_halo_bf16x3_kernel<NT, TH8, TW, 0, 2>), grid, dim3(TH8 * TW * 2), lds8, stream, q);
     return check_launch("conv2d_igemm_bf16x3(halo, 8x16)");
   }

@@ -349,6 +349,115 @@ __global__ void l1_mean_bwd_kernel(const float* __restrict__ x, S4 sx, const flo
   }
 }
 
+// ---- the sample-based interfaces' image losses (support/losses.py:267-320): SMAPE (LBMC), TonemappedMSE, TonemappedRelativeMSE
+// (SBMC), forward in one pass + the one-block finish of image_loss_finish_kernel's kind, backward in one pass.
+//   T(v) = max(v, 0) / (1 + max(v, 0))   (Reinhard, losses.py:234-242);  T'(v) = 1 / (1 + v)^2 for v >= 0 (torch.clamp passes the
+//   gradient at the bound), 0 below.
+//   kind 0  SMAPE:                 mean |x - r| / (eps + |x| + |r|), the denominator carries no gradient (losses.py:279-282)
+//   kind 1  TonemappedMSE:         0.5 * mean (T(x) - T(r))^2
+//   kind 2  TonemappedRelativeMSE: 0.5 * mean (T(x) - T(r))^2 / (T(r)^2 + eps)
+__device__ __forceinline__ float reinhard(float v) { v = fmaxf(v, 0.f); return v / (1.f + v); }
+template <int KIND>
+__device__ __forceinline__ float loss2_term(float v, float q, float eps) {
+  if (KIND == 0) return fabsf(v - q) / (eps + fabsf(v) + fabsf(q));
+  const float tv = reinhard(v), tq = reinhard(q), d = tv - tq;
+  return KIND == 1 ? d * d : (d * d) / (tq * tq + eps);
+}
+template <int KIND>
+__device__ __forceinline__ float loss2_grad(float v, float q, float eps) {
+  if (KIND == 0) {
+    const float d = v - q, den = eps + fabsf(v) + fabsf(q);
+    return d > 0.f ? 1.f / den : (d < 0.f ? -1.f / den : (d == 0.f ? 0.f : d));
+  }
+  const float tv = reinhard(v), tq = reinhard(q), d = tv - tq;
+  const float dt = v >= 0.f ? 1.f / ((1.f + v) * (1.f + v)) : (v < 0.f ? 0.f : v);      // (NaN stays NaN)
+  return KIND == 1 ? d * dt : d * dt / (tq * tq + eps);                                  // (the 0.5 and the 2 of the square cancel)
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void image_loss2_partial_kernel(const float* __restrict__ x, S4 sx, const float* __restrict__ r,
+                                                                  S4 sr, float eps, float* __restrict__ partial, int C, int H,
+                                                                  int W, int64_t total) {
+  float a = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W); int64_t t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C); const int n = (int)(t / C);
+    a += loss2_term<KIND>(x[n * sx.n + c * sx.c + y * sx.h + xx * sx.w], r[n * sr.n + c * sr.c + y * sr.h + xx * sr.w], eps);
+  }
+  a = wave_sum(a);
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(64) void image_loss2_finish_kernel(const float* __restrict__ partial, int nblocks, float scale,
+                                                                float* __restrict__ loss) {
+  if (threadIdx.x != 0) return;
+  float a = 0.f;
+  for (int g = 0; g < nblocks; ++g) a += partial[g];
+  loss[0] = a * scale;
+}
+template <int KIND>
+__global__ void image_loss2_bwd_kernel(const float* __restrict__ x, S4 sx, const float* __restrict__ r, S4 sr, float eps,
+                                       const float* __restrict__ g, float inv_total, float* __restrict__ dx, int C, int H, int W,
+                                       int64_t total) {
+  const float gs = g[0] * inv_total;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W); int64_t t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C); const int n = (int)(t / C);
+    dx[i] = gs * loss2_grad<KIND>(x[n * sx.n + c * sx.c + y * sx.h + xx * sx.w], r[n * sr.n + c * sr.c + y * sr.h + xx * sr.w], eps);
+  }
+}
+
+// ---- clip_grad_norm_ over a model's gradient tensors (interfaces.py:454-458, 826-833): sums of squares per tensor chunk, the total
+// norm and the clip factor by one block, then one scaling pass -- three launches for any number of tensors (<= GN_MAX per call group).
+constexpr int GN_MAX = 96, GN_CHUNK = 256 * 16;
+struct GNEntry { float* g; int64_t n; unsigned block0; };
+struct GNTable { GNEntry e[GN_MAX]; int n; };
+__device__ __forceinline__ const GNEntry& gn_find(const GNTable& t, unsigned b) {
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < t.n; ++i)
+    if (b >= t.e[i].block0) k = i;
+  return t.e[k];
+}
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(GNTable t, float* __restrict__ partial) {
+  const GNEntry& q = gn_find(t, blockIdx.x);
+  const int64_t i0 = (int64_t)(blockIdx.x - q.block0) * GN_CHUNK;
+  float a = 0.f;
+  for (int64_t i = i0 + threadIdx.x; i < q.n && i < i0 + GN_CHUNK; i += 256) a += q.g[i] * q.g[i];
+  a = wave_sum(a);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+// out[0] = total norm, out[1] = min(1, max_norm / (norm + 1e-6))  (torch.nn.utils.clip_grad_norm_'s clamped coefficient)
+__global__ __launch_bounds__(256) void grad_norm_finish_kernel(const float* __restrict__ partial, int nblocks, float max_norm,
+                                                               float* __restrict__ out) {
+  float a = 0.f;
+  for (int g = threadIdx.x; g < nblocks; g += 256) a += partial[g];
+  a = wave_sum(a);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf(((red[0] + red[1]) + red[2]) + red[3]);
+    const float coef = max_norm / (nrm + 1e-6f);
+    out[0] = nrm;
+    out[1] = coef < 1.f ? coef : 1.f;
+  }
+}
+__global__ __launch_bounds__(256) void grad_scale_kernel(GNTable t, const float* __restrict__ coef) {
+  const float c = coef[1];
+  if (c >= 1.f) return;
+  const GNEntry& q = gn_find(t, blockIdx.x);
+  const int64_t i0 = (int64_t)(blockIdx.x - q.block0) * GN_CHUNK;
+  for (int64_t i = i0 + threadIdx.x; i < q.n && i < i0 + GN_CHUNK; i += 256) q.g[i] *= c;
+}
+
 static unsigned grid_for(int64_t total) {
   const int64_t g = ceil_div64(total, 256);
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -595,4 +704,64 @@ extern "C" int wcmc_recombine_bwd(const float* grad_out, const float* albedo, in
   hipLaunchKernelGGL(recombine_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, grad_out, albedo,
                      S4{asn, asc, ash, asw}, r_specular, S4{ssn, ssc, ssh, ssw}, d_diffuse, d_specular, C, H, W, total);
   return check_launch("recombine_bwd");
+}
+
+extern "C" int wcmc_image_loss2_fwd(int kind, const float* x, int64_t xsn, int64_t xsc, int64_t xsh, int64_t xsw, const float* ref,
+                                    int64_t rsn, int64_t rsc, int64_t rsh, int64_t rsw, float eps, float* loss, void* workspace,
+                                    size_t workspace_bytes, int N, int C, int H, int W, void* stream) {
+  WCMC_REQUIRE(kind >= 0 && kind <= 2 && x && ref && loss && workspace && N > 0 && C > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG,
+               "image_loss2_fwd: bad argument");
+  WCMC_REQUIRE(workspace_bytes >= wcmc_image_loss_workspace_bytes(), WCMC_ERR_WORKSPACE, "image_loss2_fwd: workspace too small");
+  const int64_t total = (int64_t)N * C * H * W;
+  const int64_t want = ceil_div64(total, 256);
+  const int blocks = (int)(want < IL_BLOCKS ? want : IL_BLOCKS);
+  const S4 sx{xsn, xsc, xsh, xsw}, sr{rsn, rsc, rsh, rsw};
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 0) hipLaunchKernelGGL(image_loss2_partial_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, x, sx, ref, sr, eps, (float*)workspace, C, H, W, total);
+  else if (kind == 1) hipLaunchKernelGGL(image_loss2_partial_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, sx, ref, sr, eps, (float*)workspace, C, H, W, total);
+  else hipLaunchKernelGGL(image_loss2_partial_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, sx, ref, sr, eps, (float*)workspace, C, H, W, total);
+  hipLaunchKernelGGL(image_loss2_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, blocks,
+                     (float)((kind == 0 ? 1.0 : 0.5) / (double)total), loss);
+  return check_launch("image_loss2_fwd");
+}
+
+extern "C" int wcmc_image_loss2_bwd(int kind, const float* x, int64_t xsn, int64_t xsc, int64_t xsh, int64_t xsw, const float* ref,
+                                    int64_t rsn, int64_t rsc, int64_t rsh, int64_t rsw, float eps, const float* grad_loss, float* dx,
+                                    int N, int C, int H, int W, void* stream) {
+  WCMC_REQUIRE(kind >= 0 && kind <= 2 && x && ref && grad_loss && dx && N > 0 && C > 0 && H > 0 && W > 0, WCMC_ERR_BAD_ARG,
+               "image_loss2_bwd: bad argument");
+  const int64_t total = (int64_t)N * C * H * W;
+  const S4 sx{xsn, xsc, xsh, xsw}, sr{rsn, rsc, rsh, rsw};
+  hipStream_t st = (hipStream_t)stream;
+  const float inv = (float)(1.0 / (double)total);
+  if (kind == 0) hipLaunchKernelGGL(image_loss2_bwd_kernel<0>, dim3(grid_for(total)), dim3(256), 0, st, x, sx, ref, sr, eps, grad_loss, inv, dx, C, H, W, total);
+  else if (kind == 1) hipLaunchKernelGGL(image_loss2_bwd_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, sx, ref, sr, eps, grad_loss, inv, dx, C, H, W, total);
+  else hipLaunchKernelGGL(image_loss2_bwd_kernel<2>, dim3(grid_for(total)), dim3(256), 0, st, x, sx, ref, sr, eps, grad_loss, inv, dx, C, H, W, total);
+  return check_launch("image_loss2_bwd");
+}
+
+extern "C" size_t wcmc_grad_norm_clip_workspace_bytes(int n_tensors, const int64_t* numel) {
+  size_t blocks = 0;
+  for (int i = 0; i < n_tensors; ++i) blocks += (size_t)ceil_div64(numel[i] > 0 ? numel[i] : 1, GN_CHUNK);
+  return (blocks + 4) * sizeof(float);
+}
+
+extern "C" int wcmc_grad_norm_clip(int n_tensors, float* const* grads, const int64_t* numel, float max_norm, float* norm_and_coef,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  WCMC_REQUIRE(n_tensors > 0 && n_tensors <= GN_MAX && grads && numel && norm_and_coef && workspace && max_norm > 0.f, WCMC_ERR_BAD_ARG,
+               "grad_norm_clip: bad argument (1..%d tensors)", GN_MAX);
+  WCMC_REQUIRE(workspace_bytes >= wcmc_grad_norm_clip_workspace_bytes(n_tensors, numel), WCMC_ERR_WORKSPACE, "grad_norm_clip: workspace too small");
+  GNTable t;
+  t.n = n_tensors;
+  unsigned blocks = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    WCMC_REQUIRE(grads[i] && numel[i] > 0, WCMC_ERR_BAD_ARG, "grad_norm_clip: bad tensor %d", i);
+    t.e[i].g = grads[i]; t.e[i].n = numel[i]; t.e[i].block0 = blocks;
+    blocks += (unsigned)ceil_div64(numel[i], GN_CHUNK);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, st, t, (float*)workspace);
+  hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)blocks, max_norm, norm_and_coef);
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(blocks), dim3(256), 0, st, t, (const float*)norm_and_coef);
+  return check_launch("grad_norm_clip");
 }

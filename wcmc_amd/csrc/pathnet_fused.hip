@@ -920,7 +920,7 @@ extern "C" int wcmc_final2_fwd(const float* y, int y_pixel_stride, const float* 
   WCMC_REQUIRE(out && aligned16(out), WCMC_ERR_BAD_ARG, "final2_fwd: bad output");
   p.out = out;
   static LdsAttr attr;
-  set_max_lds(reinterpret_cast<const void*>(&final2_kernel<false>), (size_t)F2_LDS_FWD, attr);
+  if (set_max_lds(reinterpret_cast<const void*>(&final2_kernel<false>), (size_t)F2_LDS_FWD, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
   const int64_t nsuper = (int64_t)B * (HW / 64);
   hipLaunchKernelGGL(final2_kernel<false>, dim3((unsigned)(nsuper < f2_grid() ? nsuper : f2_grid())), dim3(512), F2_LDS_FWD, (hipStream_t)stream, p);
   return check_launch("final2_fwd");
@@ -940,7 +940,7 @@ extern "C" int wcmc_final2_bwd(const float* y, int y_pixel_stride, const float* 
   const int64_t M = (int64_t)B * S * HW;
   p.dy_bytes = (unsigned)(M * 256); p.dp_bytes = (unsigned)((int64_t)B * HW * 256);
   static LdsAttr attr;
-  set_max_lds(reinterpret_cast<const void*>(&final2_kernel<true>), (size_t)F2_LDS_BWD, attr);
+  if (set_max_lds(reinterpret_cast<const void*>(&final2_kernel<true>), (size_t)F2_LDS_BWD, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
   const int nblk = f2_grid();
   hipLaunchKernelGGL(final2_kernel<true>, dim3((unsigned)nblk), dim3(512), F2_LDS_BWD, (hipStream_t)stream, p);
   if (int rc = check_launch("final2_bwd")) return rc;

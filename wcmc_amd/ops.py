@@ -1483,6 +1483,65 @@ def relative_mse(x, ref, eps=1e-2):
     return _image_loss_raw(x.detach(), ref.detach(), eps, False, True)[1]
 
 
+LOSS2_KINDS = {"smape": 0, "tonemapped_mse": 1, "tonemapped_relative_mse": 2}
+
+
+class _ImageLoss2(torch.autograd.Function):
+    """SMAPE / TonemappedMSE / TonemappedRelativeMSE (support/losses.py:267-320) of an (N,C,H,W) pair: one HIP pass + a one-block
+    finish forward (``wcmc_image_loss2_fwd``), one pass backward (``wcmc_image_loss2_bwd``); ref carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, ref, kind, eps):
+        _need_cuda(x, ref)
+        assert x.shape == ref.shape and x.dim() == 4, (x.shape, ref.shape)
+        n, c, h, w = x.shape
+        ws = torch.empty(lib().wcmc_image_loss_workspace_bytes() // 4, device=x.device, dtype=torch.float32)
+        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        check(lib().wcmc_image_loss2_fwd(kind, _ptr(x), *x.stride(), _ptr(ref), *ref.stride(), float(eps), _ptr(loss), _ptr(ws),
+                                         ws.numel() * 4, n, c, h, w, _stream()), "image_loss2_fwd")
+        ctx.save_for_backward(x, ref)
+        ctx.kind, ctx.eps = kind, float(eps)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ref = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+        g = g.contiguous()
+        check(lib().wcmc_image_loss2_bwd(ctx.kind, _ptr(x), *x.stride(), _ptr(ref), *ref.stride(), ctx.eps, _ptr(g), _ptr(dx),
+                                         n, c, h, w, _stream()), "image_loss2_bwd")
+        return dx, None, None, None
+
+
+def image_loss2(x, ref, kind, eps=1e-2):
+    """kind: 'smape' | 'tonemapped_mse' | 'tonemapped_relative_mse'; differentiable in x."""
+    return _ImageLoss2.apply(x, ref.detach(), LOSS2_KINDS[kind], eps)
+
+
+def clip_grad_norm_(parameters, max_norm):
+    """``torch.nn.utils.clip_grad_norm_(parameters, max_norm)`` (interfaces.py:454-458, 826-833) as three HIP launches per 96
+    gradient tensors (``wcmc_grad_norm_clip``); returns the total norm before clipping as a 0-d device tensor."""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    _need_cuda(*grads)
+    grads = [g if g.is_contiguous() else None for g in grads]
+    if any(g is None for g in grads):
+        raise RuntimeError("clip_grad_norm_: gradients must be contiguous")
+    if len(grads) > 96:
+        # (more tensors than one table holds: norms of the groups first, then one common factor -- not needed by any model here)
+        raise NotImplementedError("clip_grad_norm_: more than 96 gradient tensors")
+    m = len(grads)
+    numel = (ctypes.c_int64 * m)(*[g.numel() for g in grads])
+    nbytes = lib().wcmc_grad_norm_clip_workspace_bytes(m, numel)
+    ws = torch.empty((nbytes + 3) // 4, device=grads[0].device, dtype=torch.float32)
+    out = torch.empty(2, device=grads[0].device, dtype=torch.float32)
+    check(lib().wcmc_grad_norm_clip(m, (ctypes.c_void_p * m)(*[g.data_ptr() for g in grads]), numel, float(max_norm), _ptr(out),
+                                    _ptr(ws), ws.numel() * 4, _stream()), "grad_norm_clip")
+    return out[0]
+
+
 # ------------------------------------------------------------------------ U-Net glue
 class _MaxPool2(torch.autograd.Function):
     @staticmethod

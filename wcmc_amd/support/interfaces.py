@@ -715,7 +715,11 @@ class SBMCInterface(BaseInterface):
             if not torch.isfinite(loss_dict[key]).all():
                 raise RuntimeError("%s: Non-finite loss at train time." % (key))
         for name, model in self.models.items():
-            actual = nn.utils.clip_grad_norm_(model.parameters(), max_norm=self.GRAD_NORM_CLIP)
+            params = [p for p in model.parameters() if p.grad is not None]
+            if params and all(p.grad.is_cuda and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params) and len(params) <= 96:
+                actual = _ops.clip_grad_norm_(params, self.GRAD_NORM_CLIP)          # three HIP launches (wcmc_grad_norm_clip)
+            else:
+                actual = nn.utils.clip_grad_norm_(model.parameters(), max_norm=self.GRAD_NORM_CLIP)
             if actual > self.GRAD_NORM_CLIP:
                 print("Clipped %s gradients %f -> %f" % (name, self.GRAD_NORM_CLIP, actual))
         for key in loss_dict:

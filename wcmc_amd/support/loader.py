@@ -248,8 +248,8 @@ class PatchLoader:
                 with torch.cuda.stream(side):
                     origins_dev = torch.as_tensor(origins, dtype=torch.int32).to(dev)      # one copy per image
                     for k in range(0, len(origins), self.batch_size):
-                        if self._paced:
-                            self._tick.acquire(timeout=self.pace_timeout)                  # (see ``kick``)
+                        if self._paced and not self._tick.acquire(timeout=self.pace_timeout):
+                            self._paced = False           # no kick within the timeout: this consumer does not pace -- stop waiting for it
                         if stop.is_set():
                             return
                         batch = self.batcher.batch(kpcn, llpm, gt, origins_dev[k:k + self.batch_size], check=False)
@@ -272,6 +272,11 @@ class PatchLoader:
         ``scripts/time_loader.py``).  ``numpy.random`` is drawn from on the producer thread, in image order."""
         dev = self.stager.device
         out_q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
+        # every pass starts un-paced, with no permits left over from the last one: pacing belongs to the consumer of THIS pass
+        # (a loader used with --graph and then eagerly would otherwise wait 50 ms per batch for kicks that never come)
+        self._paced = False
+        while self._tick.acquire(blocking=False):
+            pass
         worker = threading.Thread(target=self._produce, args=(out_q, stop), daemon=True)
         worker.start()
         try:
