@@ -1,4 +1,4 @@
-"""Smallest stand-alone form of the crash DESIGN.md section 5 records (ROCm 7.0 / PyTorch 2.10 on gfx950): with TWO captured training
+"""Smallest stand-alone form of the crash profiles/HISTORY.md section 5 records (ROCm 7.0 / PyTorch 2.10 on gfx950): with TWO captured training
 steps alive in one process -- two sets of hipGraphExec objects with private memory pools, built one after the other -- a later
 hipGraphLaunch of either can segfault inside the HIP runtime.  The product therefore keeps at most one captured step alive
 (``GraphedTrainStep.close()``, ``capture_validated`` closes a rejected capture before it makes the next one).

@@ -1,4 +1,4 @@
-"""What this MI355X sustains on plain streams (context for the roofline fractions in DESIGN.md section 6).
+"""What this MI355X sustains on plain streams (context for the roofline fractions in DESIGN.md section 4).
    python3 scripts/hbm_probe.py"""
 import torch
 def timeit(fn, n=20):

@@ -2817,7 +2817,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
   // consecutive cout tiles -- pair 32: waves 0-2 (cout tiles {0,1}, {2,3}, {4,5,6}), pair 33: waves 3-5 alike, pair 34: waves
   // 6, 7 ({0,1,2}, {3,4,5,6}); 4 / 5 / 6 / 6 extra tiles per SIMD (waves w, w + 4) -- so that a wave reads ONE extra x
   // fragment per k-step instead of three (48 instead of 56 transposing reads per 90-96 MFMAs; the kernel is bound by the
-  // issue of its non-MFMA instructions: DESIGN.md 6.1).  The extras sit in loop slots 0 .. nex-1 (slots 2, 3 behind a
+  // issue of its non-MFMA instructions: profiles/HISTORY.md 6.1).  The extras sit in loop slots 0 .. nex-1 (slots 2, 3 behind a
   // wave-uniform test); XE = 0: three pairs x cout tile `wave` in slot 0, wave 7 multiplies wave 0's again and drops them.
   const int er = wave % 3;
   const int epair = XE ? (wave < 6 ? wave / 3 : 2) : 0;
@@ -2871,7 +2871,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rows8_bf16x3_kernel(XWRowsP
   // The stage loop is unrolled by two so that the buffer of a stage is a compile-time choice: this lane's fragment
   // addresses in either buffer (7 dy cout tiles, 4 + 1 x slots) are worked out ONCE and every transposing read is an
   // address register plus an immediate -- the loop had ~30 address additions per stage and wave, and it is bound by the
-  // issue of exactly such instructions.
+  // issue of exactly such instructions (profiles/HISTORY.md 6.1).
   unsigned ayv[2][TM], axv[2][NS], aEv[2], aXv[2];
   {
     const int prow0 = 4 * g + tq;

@@ -8,7 +8,7 @@ Mirrors, on device tensors, what the reference does around ``validate_batch``:
   * valid crop + has-hit composite ``test_models.py:217-232``       drop the outer (128 - 72) / 2 pixels and keep
     the noisy input where no surface was hit.
 ``test_models.py`` is not importable as shipped (``from train_kpcn import weights_init`` does not exist there), so
-these are restatements checked by known-answer tests, not by a golden (parity unpinned, DESIGN.md 2).
+these are restatements checked by known-answer tests, not by a golden (parity unpinned, DESIGN.md section 2).
 """
 import torch
 import torch.nn.functional as F

@@ -18,7 +18,7 @@ What differs, on purpose:
     its own shard, gradients are summed inside the fused clip + Adam (``wcmc_amd.optim.FusedClipAdam``), rank 0 saves;
   * ``--graph`` replays one hipGraph per step (``wcmc_amd.graph.GraphedTrainStep``) when the loader keeps its shapes;
   * the reading of the authors' dataset files (``support/datasets.py:MSDenoiseDataset``) is out of scope (SURVEY.md 8,
-    DESIGN.md section 0): ``init_data`` feeds ``--synthetic N`` batches per epoch with the dataset's schema
+    DESIGN.md section 1): ``init_data`` feeds ``--synthetic N`` batches per epoch with the dataset's schema
     (``wcmc_amd.synthetic``), or any iterable of batch dictionaries handed to ``train`` by the caller;
   * no visdom (``--visual`` is accepted and ignored), no tqdm.
 """
