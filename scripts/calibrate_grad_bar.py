@@ -30,8 +30,13 @@ if __name__ == "__main__":
     print("# %-10s %-5s %-10s %-10s %s" % ("arithmetic", "seed", "rel L2", "1 - cos", "tensor"))
     worst = {}
     for mode in (modes or (ops.MODES[0], "fp32")):
-        ops.set_precision(mode)
-        os.environ["WCMC_PRECISION"] = mode           # (the test asserts the mode it was started in)
+        emulate = mode.endswith("+F")                 # rung F: hidden KPCN activations rounded to fp16 (scripts/arith_trajectories.py)
+        if emulate:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from arith_trajectories import round_hidden_to_f16
+        ops.EMULATE_HIDDEN = round_hidden_to_f16 if emulate else None
+        ops.set_precision(mode[:-2] if emulate else mode)
+        os.environ["WCMC_PRECISION"] = mode[:-2] if emulate else mode           # (the test asserts the mode it was started in)
         for seed in range(first, first + n):
             report, _ = t.parity_report("device", True, seed=seed)
             grads = [r for r in report if " grad " in r[0]]

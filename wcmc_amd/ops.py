@@ -244,6 +244,11 @@ def act_backward_raw(dy, y, act):
     return dx
 
 
+# Emulation hook (scripts/arith_trajectories.py only; None in the product): a callable (split tensor, dims, ksize) -> split tensor applied
+# to every HIDDEN activation a split-bf16 chain has just written -- "what if this layer's output were rounded to fp16?" measured on
+# training trajectories before any kernel is written.
+EMULATE_HIDDEN = None
+
 # Test hook: when a list, every chain forward appends its post-activation layer outputs (used by the
 # parity tests to count ReLU sign flips against the oracle; a flipped unit changes gradients by ~1e-3).
 DEBUG_ACTS = None
@@ -973,7 +978,7 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
         hh, ww = dims[l][2] + 2 * pad - ks + 1, dims[l][3] + 2 * pad - ks + 1
         dims.append((n, cout, hh, ww))
         if hidden:
-            xs.append(out[0])
+            xs.append(out[0] if EMULATE_HIDDEN is None else EMULATE_HIDDEN(out[0], dims[-1], ks))
             masks.append(out[1])       # (hi > 0) bits of the hidden activation: the data gradient's ReLU gate
         else:
             y = out
