@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
 _ROWS8_ENV = os.environ.get("WCMC_WGRAD_ROWS8")                 # which filter-row weight-gradient kernel the library launches:
 _rows8 = lambda terms: (_ROWS8_ENV[:1] != "0") if _ROWS8_ENV else terms == 3      # eight waves for three-term launches, seven for one-term ones
 _ROWS8_XE = 0 if os.environ.get("WCMC_WGRAD_ROWS8_XE", "1")[:1] == "0" else 1
-PROFILE_ROUND = "r04"              # profiles/<round>_pmc_summary.json, <round>_bench_kernel_stats.csv: the evidence of THIS binary
+PROFILE_ROUND = "r05"              # profiles/<round>_pmc_summary.json, <round>_bench_kernel_stats.csv: the evidence of THIS binary
 
 
 def rocprof_names(wgrad_terms):

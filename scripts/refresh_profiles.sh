@@ -1,7 +1,7 @@
 # Evidence behind profiles/: the bench lines, the two rocprofv3 kernel-stats runs (graphed, eager) and the PMC passes.
-#   gpurun -- 'bash scripts/refresh_profiles.sh r04'      (then copy the summaries from gpurun_out/<tag>/ into profiles/)
+#   gpurun -- 'bash scripts/refresh_profiles.sh r05'      (then copy the summaries from gpurun_out/<tag>/ into profiles/)
 set -x
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O/pmc

@@ -889,8 +889,10 @@ def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path(rccl
         assert dist.get_backend() == "nccl"
         results = {}
         for coll in (False, True):
-            for graphed in (False, True, "overlap"):
-                if graphed == "overlap" and not coll:
+            # (False: eager | True: one forked graph A | "overlap": the cut backward | "halves": what the launcher builds on several ranks --
+            # the two half-step graphs + gather graph in front of the all-reduces, graph B behind them, the flags read one step late)
+            for graphed in (False, True, "overlap", "halves"):
+                if graphed in ("overlap", "halves") and not coll:
                     continue
                 torch.manual_seed(21)
                 kw = dict(ksize=21, depth=3, width=24)
@@ -913,8 +915,10 @@ def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path(rccl
                 itf.to_train_mode()
                 batches = [make_batch(2, 4, 48, seed=30 + i, device=DEV) for i in range(3)]
                 if graphed:
-                    step = GraphedTrainStep(itf, batches[0], overlap_allreduce=(graphed == "overlap"))
+                    step = GraphedTrainStep(itf, batches[0], overlap_allreduce=(graphed == "overlap"), two_stream=(graphed == "halves"),
+                                            defer_check=(graphed == "halves"))
                     assert step.tail_split == coll and step.tail_captured == (not coll) and step.overlap == (graphed == "overlap")
+                    assert step.defer_check == (graphed == "halves")
                 else:
                     def step(b):
                         itf.preprocess(b)
@@ -922,6 +926,8 @@ def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path(rccl
                 torch.manual_seed(22)
                 for b in batches:
                     step(b)
+                if graphed:
+                    step.flush()
                 state = lambda: torch.cat([torch.cat([fo.flats[n].flat, fo.flats[n].m, fo.flats[n].v]) for n in sorted(fo.flats)]).clone()
                 results[(coll, graphed)] = (state(), {k: v.item() for k, v in itf.m_losses.items()}, [fl.steps for fl in fo.flats.values()])
                 if coll:
@@ -931,10 +937,14 @@ def test_collective_branch_on_a_one_rank_rccl_group_equals_the_world_1_path(rccl
                     bad["target_total"][0, 0, 20, 20] = float("inf")        # (enters l_total and rmse only: FeatureMSE has its own check)
                     with pytest.raises(RuntimeError, match="Non-finite loss at train time"):
                         step(bad)
+                        if graphed:
+                            step.flush()                                # (deferred check: the error is raised by the flush)
                     torch.cuda.synchronize()
                     assert torch.equal(state(), before) and [fl.steps for fl in fo.flats.values()] == [3, 3, 3]
                     assert {k: v.item() for k, v in itf.m_losses.items()} == sums
                     step(batches[1])
+                    if graphed:
+                        step.flush()
                     assert [fl.steps for fl in fo.flats.values()] == [4, 4, 4] and not torch.equal(state(), before)
                 if graphed:
                     step.close()                                        # one graphed step alive at a time
