@@ -18,7 +18,8 @@ torch.set_num_threads(min(16, os.cpu_count() or 1))
 # Kernel A/B switches (WCMC_* variables that select a non-default kernel, tiling or schedule) exist in the DEBUG build of the library
 # only (csrc/common.h: ab_env; `make -C wcmc_amd/csrc debug`, loaded with WCMC_DEBUG_LIB=1).  The tests that hold a shipped kernel
 # bit for bit against the kernel it replaced need that build; against the release library they are skipped (and their variant
-# legs collapse to the shipped plan):   WCMC_DEBUG_LIB=1 python -m pytest tests -m gpu -k "variant or switch_matrix or strip_equals or eight_wave"
+# legs collapse to the shipped plan); tests/test_gpu_ops.py::test_kernel_cross_checks_run_against_the_debug_build_in_a_subprocess runs
+# them in a child process that loads the debug library:   WCMC_DEBUG_LIB=1 python -m pytest tests -m gpu -k "variant or switch_matrix or ..."
 DEBUG_LIB = os.environ.get("WCMC_DEBUG_LIB") == "1"
 needs_debug_lib = pytest.mark.skipif(not DEBUG_LIB, reason="kernel A/B switches exist in the debug build only (make -C wcmc_amd/csrc debug; WCMC_DEBUG_LIB=1)")
 

@@ -1351,3 +1351,30 @@ def test_clip_grad_norm_matches_torch():
         for p, q in zip(ps, pr):
             assert_close(p.grad, q.grad, tol=2e-6, what="clipped gradient")
         assert (float(want) > max_norm) == (scale > 1.0)
+
+
+VARIANT_EXPR = "variant or switch_matrix or strip_equals or eight_wave or many_slabs or one_term_weight or three_term_forward"
+
+
+def test_kernel_cross_checks_run_against_the_debug_build_in_a_subprocess():
+    """The kernel A/B switches exist in the DEBUG build of the library only (csrc/common.h: ab_env), so the tests that hold a shipped
+    kernel bit for bit against the kernel it replaced (`needs_debug_lib`; skipped in this process) are run here in a child process
+    that loads ``libwcmc_hip_debug.so`` (``__graft_entry__.build()`` makes it beside the release library): the filter-row weight
+    gradient against the one-tap kernel, eight against seven waves, the strip kernel-apply against the tile kernel, every entry of the
+    switch matrix, ...  (A child process, never an exec: this one has initialised the GPU.)"""
+    import subprocess
+    import sys
+    if DEBUG_LIB:
+        pytest.skip("this process already runs against the debug library")
+    from wcmc_amd._lib import LIB_PATH
+    dbg = os.path.join(os.path.dirname(LIB_PATH), "libwcmc_hip_debug.so")
+    if not os.path.isfile(dbg):
+        pytest.skip("libwcmc_hip_debug.so has not been built (make -C wcmc_amd/csrc debug)")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, WCMC_DEBUG_LIB="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider", "-k", VARIANT_EXPR],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    tail = (r.stdout or "")[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
+    print(tail.strip().splitlines()[-1])
