@@ -38,7 +38,12 @@ class HostReaderPool:
     training thread never touches a file.  No GPU call in here (``tests/test_cpu_host.py`` runs eight of these side by side).
 
     Iterating yields ``(slot, prob, nbytes)``: ``slot['raw']`` / ``slot['gt']`` hold the staged arrays; give the slot back with
-    ``release(slot)`` once its contents have been consumed (after the host -> device copy's event, for a pinned slot)."""
+    ``release(slot)`` once its contents have been consumed (after the host -> device copy's event, for a pinned slot).
+
+    Pinned host memory: ``depth + workers`` slots stay allocated for the life of the pool, each the size of the largest image
+    read so far -- 0.9 GB for a 512 x 512 x 8 spp frame of 104 raw channels, i.e. 3.6 GB per rank with the defaults (two workers,
+    depth two), eight times that on a node with eight ranks.  ``workers=1, depth=1`` halves it; ``pin=False`` stages in pageable
+    memory (the copy stream then waits for the driver's own staging)."""
 
     def __init__(self, reader, indices, workers=2, depth=2, pin=None):
         assert workers >= 1 and depth >= 1
