@@ -1,13 +1,20 @@
-"""One hipGraph per training step.
+"""The training step as captured hipGraphs.
 
 ``KPCNInterface._forward_backward`` (two PathNet forwards, input assembly, KPCN forward, losses, both
 backward passes) is ~2,400 kernel launches whose shapes never change during training
 (``train_kpcn.py:45`` feeds fixed-size batches).  Eagerly the host needs ~40 ms to enqueue them from
-Python -- as long as the MI355X needs to run them -- so the step is captured once with
-``torch.cuda.graph`` (HIP stream capture) and replayed with one launch.  What stays eager is what
-talks to the host or other ranks: drawing the FeatureMSE pairings, reading the non-finite-loss flags
-(``interfaces.py:254-257``) and the RCCL gradient all-reduce; the optimiser tail is captured too -- into the same graph
-on one rank, into a second graph behind the all-reduces with several.
+Python -- four times as long as the MI355X needs to run them -- so the step is captured once with
+``torch.cuda.graph`` (HIP stream capture) and replayed.  Two forms:
+
+* ``two_stream=True`` (what ``capture_validated`` builds for the launcher and the benchmark): the diffuse and the specular
+  half of the step as two linear graphs replayed on two streams that ``ops.concurrent_stream_pair`` has shown to sit on
+  different hardware queues, between a head graph (step counter, the shared split of ``paths``) and a tail graph (radiance
+  metrics, guard, clip + Adam).  The pairings of ``FeatureMSE(rng='device')`` are drawn inside the graphs.
+* ``two_stream=False``: one forked graph (rounds 2-4); the overlap of its halves is up to hipGraphInstantiate.
+
+What stays eager is what talks to the host or other ranks: reading the non-finite-loss flags (``interfaces.py:254-257``; one
+step late with ``defer_check``), CPU-generator pairings (``rng='cpu'``) and the RCCL gradient all-reduces, around which the
+multi-rank step is split into graph(s) A and graph B.
 """
 import torch
 
