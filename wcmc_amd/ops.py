@@ -356,6 +356,11 @@ def concurrent_stream_pair(device, tries=8):
         return _STREAM_PAIRS[key]
     with torch.cuda.device(device):
         first = torch.cuda.Stream(device=device)
+        if not hasattr(torch.cuda, "_sleep"):                # (no spin kernel to probe with: two fresh streams, unprobed)
+            pair = (first, torch.cuda.Stream(device=device))
+            pair[0].probe = {"spin_ms": None, "pair_ms": None, "streams_tried": 2, "concurrent": None}
+            _STREAM_PAIRS[key] = pair
+            return pair
         cycles = 200000
         one = _spin_ms([first], cycles)
         one = _spin_ms([first], cycles)                      # (second run: without first-launch costs)
