@@ -1348,6 +1348,332 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 }
 
 
+// ------------------------------------------------------------------ implicit GEMM, halo-resident, 3x3, K split over two wave groups
+// The PathNet U-Net's 3x3 layers (64 .. 384 channels, 128^2 .. 32^2 pixels; support/networks.py:20-22).  In the kernel above one
+// wave walks a 32-k stage in ~1,000-1,500 cycles of which 384 are its 24 MFMAs: an in-order wave pays the stage barrier, its two
+// weight-DMA instructions, the LDS latency of its last fragment reads and the tap arithmetic one after the other, and with LDS
+// for two 128-pixel workgroups per CU only two waves share a SIMD to cover them (profiles/r02_halo_unet_timeline.txt: 15 us in the
+// stage loop for 7 us of MFMAs; one wave per SIMD on the 64^2 / 32^2 levels).  Here a workgroup is EIGHT waves on the same 8x16
+// tile: wave (pg, grp) owns the 32 pixels of tile rows 2 pg, 2 pg + 1 as before, and the two groups grp = 0 / 1 multiply the even
+// / odd 32-k stages of the tile -- half the stages, barriers and DMA issues per wave, FOUR waves per SIMD at two workgroups per CU
+// (<= 128 VGPRs), the same weight stream per workgroup.  The two groups' partial sums meet in LDS after the loop (grp 0 + grp 1,
+// a fixed order) and each group finishes half of the cout tiles, so the epilogue per wave halves too.
+//   * One barrier per PAIR of stages; four weight buffers (pair being read, pair landing).  They fit beside the second workgroup
+//     because a halo pixel is a 256-byte record without pad (AP = 2: 64 channels hi | lo; AP = 1: 128 channels of the hi plane):
+//     the 16-byte unit q of pixel p sits at slot q ^ (p & 15), MFMA row r of a pixel tile is pixel column {1,3,5,7, 0,2,..,14,
+//     9,11,13,15}[r] and k-group kg reads unit swap01(kg) + 4 h: the two 8-lane halves of a ds_read_b128 lane group then hold
+//     pixels of opposite parity and units that differ in bit 1, i.e. sixteen different slots for every filter tap (the 288-byte
+//     stride of the kernel above buys the same with 32 bytes of pad per pixel, which is what did not fit).
+//   * ks = 3 and the slab width are template constants and a slab's iterations are unrolled: a tap's halo offset is an immediate
+//     addition on the lane's pixel index, the k-half inside a tap an XOR constant; no tap counters, no wraps.
+// Stage s of a slab = tap s / SPT, 32-channel quarter s % SPT of the slab's CS = 32 SPT / AP ... channels (pack order k = tap CS + c,
+// as x_plan_k and pack_weight_split_multi_kernel lay it out: the packs are those of the kernel above).
+template <int AP, int SPT, int KG = 2>
+__global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmParams p) {
+  static_assert(KG == 2, "two K groups (h = hc | grp below)");
+  constexpr int NT = 4, BN = NT * 16, TH = 8, TW = 16, KS = 3, HWd = TW + KS - 1, HHt = TH + KS - 1, HP = HWd * HHt;   // 18 x 10 halo
+  constexpr int NTHR = 256 * KG, NWV = 4 * KG, TPX = TH * TW, PXB = 256;
+  constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
+  constexpr int ITS = KS * KS * SPT / KG;                 // iterations (stage pairs) per slab: 9 or 18
+  static_assert((KS * KS * SPT) % KG == 0, "a slab is a whole number of stage pairs");
+  constexpr int CSU = AP == 2 ? 8 : 4 * SPT, CS = CSU * 8;    // 16-byte units / channels of one plane of a slab
+  static_assert(AP == 1 || SPT == 2, "two planes: 64-channel slabs");
+  extern __shared__ __attribute__((aligned(16))) u16 smem16[];
+  char* const halo = reinterpret_cast<char*>(smem16);
+  u16* const bsm = smem16 + HP * PXB / 2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pg = wave & 3, grp = wave >> 2;               // pixel group (tile rows 2 pg, 2 pg + 1), K group
+  int tile;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tpi = p.tilesX * p.tilesY;
+  const int img = tile / tpi, trem = tile - img * tpi;
+  const int oy0 = (trem / p.tilesX) * TH, ox0 = (trem % p.tilesX) * TW;
+  const int n0 = blockIdx.y * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  const int pixb = 4 * p.Cpi;
+
+  // ---- halo: 180 records of 16 units, filled by LDS-DMA as 45 linear kilobytes; wave instruction ii covers pixels 4 ii .. 4 ii + 3,
+  // the per-lane SOURCE picks the unit that belongs into the lane's slot.  The source offsets of slab 0 are worked out once; a
+  // slab's fill is one addition per instruction.
+  constexpr int NHI = (HP * 16 / 64 + NWV - 1) / NWV;      // 45 instructions over 8 waves: up to 6 each
+  static_assert(HP * 16 % 64 == 0, "no tail instruction");
+  unsigned hoff[NHI];
+#pragma unroll
+  for (int kq = 0; kq < NHI; ++kq) {
+    const int ii = wave + NWV * kq;
+    const int px = ii * 4 + (lane >> 4), slot = lane & 15;
+    const int q = slot ^ (px & 15);
+    const int w = (q & 12) | ((q & 1) << 1) | ((q >> 1) & 1);          // source unit: bits 0 and 1 swapped
+    const int hy = (px * 3641) >> 16, hx = px - hy * HWd;               // px / 18, exact below 180
+    const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+    const int plane = AP == 2 ? (w >> 3) : 0, chunk = AP == 2 ? (w & 7) : w;
+    hoff[kq] = XOOB;
+    if (ii * 64 < HP * 16 && chunk < CSU && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      hoff[kq] = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb + plane * 2 * p.Cpi + chunk * 16);
+  }
+  auto dma_halo = [&](int slab) {
+    const unsigned so = (unsigned)(slab * CS * 2);
+#pragma unroll
+    for (int kq = 0; kq < NHI; ++kq) {
+      const int ii = wave + NWV * kq;
+      if (ii * 64 < HP * 16)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(halo + ii * 1024), 16, hoff[kq] + so, 0, 0, 0);
+    }
+  };
+
+  // ---- weights: LDS-DMA, 2 KG stage buffers.  A pair of stages is sixteen 1-KB pieces (stage, row group, plane); wave (pg, grp)
+  // fetches both planes of row group pg of ITS group's stage.
+  const int nstages = p.Kt / XKC;
+  const int drow = 16 * pg + (lane >> 2);
+  const int dvq = (lane & 3) ^ ((drow >> 1) & 3);
+  const unsigned dbase = n0 + drow < p.Np ? (unsigned)(((n0 + drow) * 2 * p.Kt + dvq * 8) * 2) : XOOB;
+  const unsigned dbase2 = dbase >= XOOB ? XOOB : dbase + (unsigned)(p.Kt * 2);
+  auto dma_b = [&](int g, int buf) {                        // global stage g -> buffer buf (stages past the end: out of range, zeros)
+    const unsigned sg = g < nstages ? (unsigned)(g * XKC * 2) : 0x40000000u;
+    u16* d = bsm + buf * B_ELEMS + 16 * pg * XROW;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, dbase + sg, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, dbase2 + sg, 0, 0, 0);
+  };
+
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // ---- fragments
+  const int frow = lane & 15, kg = lane >> 4;
+  const int col = frow < 4 ? 2 * frow + 1 : frow < 12 ? 2 * (frow - 4) : 2 * (frow - 12) + 9;   // pixel column of MFMA row frow
+  const int qsel = ((kg & 1) << 1) | (kg >> 1) | (grp << 2);        // unit of this lane's k-group in quarter h = hc | grp (hc below)
+  int pl0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) pl0[i] = (2 * pg + i) * HWd + col;
+  bf16x8 ah[2], al[2], wh[NT], wl[NT];
+  // local iteration l of a slab: this group's stage s = KG l + grp -> tap s / SPT, quarter s % SPT = hc | grp
+  auto read_a1 = [&](int i, int l) {
+    const int tap = SPT == 2 ? l : (l >> 1), hc = SPT == 2 ? 0 : 2 * (l & 1);
+    // (opaque copy: the five vector instructions of a tap's address are recomputed where they are used -- hoisted out of the slab
+    // loop, the 36 addresses of a slab spilled to scratch memory, whose loads share the wave's vmcnt with the LDS-DMA)
+    int pb = pl0[i];
+    asm volatile("" : "+v"(pb));
+    const int P = pb + (tap / KS) * HWd + (tap % KS);
+    const int a = ((P << 8) | (((qsel ^ P) & 15) << 4)) ^ (hc << 6);
+    ah[i] = *reinterpret_cast<const bf16x8*>(halo + a);
+    if (AP == 2) al[i] = *reinterpret_cast<const bf16x8*>(halo + (a ^ 128));
+  };
+  const int fslot = (kg ^ ((frow >> 1) & 3)) * 8;
+  const u16* bfr_c = bsm + frow * XROW + fslot + grp * B_ELEMS;           // this group's buffer of the pair being multiplied next ...
+  const u16* bfr_n = bfr_c + KG * B_ELEMS;                                // ... and of the pair after it
+  auto read_b = [&](const u16* b, int j) {
+    wh[j] = *reinterpret_cast<const bf16x8*>(b + j * 16 * XROW);
+    wl[j] = *reinterpret_cast<const bf16x8*>(b + B_LO + j * 16 * XROW);
+  };
+
+  dma_b(grp, grp);
+  dma_b(KG + grp, KG + grp);
+  dma_halo(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) read_a1(i, 0);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) read_b(bfr_c, j);
+  { const u16* t = bfr_c; bfr_c = bfr_n; bfr_n = t; }     // bfr_c: what is read DURING the iteration (the next pair)
+  int gi = 0, dset = 0;                                    // global iteration; buffer set whose fragments are in registers
+  for (int slab = 0; slab < p.nslabs; ++slab) {
+#pragma unroll
+    for (int l = 0; l < ITS; ++l) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the next pair (requested one iteration ago)
+      pw_barrier();                                        // ... everyone's; everyone has read the fragments of this pair
+      dma_b(KG * (gi + 2) + grp, dset * KG + grp);
+      const bool last = l == ITS - 1;
+      if (last && slab + 1 < p.nslabs) dma_halo(slab + 1); // (every fragment of this slab is in registers)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
+          if (AP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
+          if (j == NT - 1 && !last) read_a1(i, l + 1);      // the pixel tile's next fragments replace it at once
+        }
+        read_b(bfr_c, j);                                   // next pair, same cout tile, into the registers just consumed
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      { const u16* t = bfr_c; bfr_c = bfr_n; bfr_n = t; }
+      dset ^= 1;
+      ++gi;
+      if (last && slab + 1 < p.nslabs) {                    // slab boundary: the next A fragments come from the next halo
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) read_a1(i, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: group grp finishes cout tiles 2 grp, 2 grp + 1 of its pixels
+  const int fq = kg * 4;
+  float bv[2][4];
+  {
+    const __amdgpu_buffer_rsrc_t brs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.wp), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        bv[jl][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, (n0 + (2 * grp + jl) * 16 + fq + e) * 4, 0, 0));
+  }
+  const bool use_gate = p.ys && p.gate, use_mask = p.ys && !p.gate && p.gate_mask && p.gate_act != WCMC_ACT_LINEAR;
+  u32x2 gv[2][2];
+  bool okp[2]; int64_t mp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = oy0 + 2 * pg + i, ox = ox0 + col;
+    okp[i] = oy < p.Ho && ox < p.Wo;
+    mp[i] = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+  }
+  if (use_gate) {
+    const int64_t gbytes = (int64_t)p.N * p.Ho * p.Wo * 4 * p.Cpo;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gate, 0, (int)(gbytes < 0x7fffffff ? gbytes : 0x7fffffff), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        const int co = n0 + (2 * grp + jl) * 16 + fq;
+        gv[i][jl] = __builtin_amdgcn_raw_buffer_load_b64(grs, (okp[i] && co < p.Cpo) ? (unsigned)((mp[i] * 2 * p.Cpo + co) * 2) : XOOB, 0, 0);
+      }
+  } else if (use_mask) {
+    const int64_t mbytes = (int64_t)p.N * p.Ho * p.Wo * (p.Cpo >> 3);
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gate_mask, 0, (int)mbytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        const int co = n0 + (2 * grp + jl) * 16 + fq;
+        gv[i][jl].x = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(mrs, (okp[i] && co < p.Cpo) ? (unsigned)(mp[i] * (p.Cpo >> 3) + (co >> 3)) : XOOB, 0, 0);
+      }
+  }
+  const XAct ak = x_act(p.act, p.slope);
+  const float gate_off = p.gate_act == WCMC_ACT_RELU ? 0.f : p.gate_act == WCMC_ACT_LEAKY_RELU ? p.gate_slope : 1.f;
+  const int gkind = use_gate ? 1 : use_mask ? 2 : 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (zero) weight stages past the end have landed:
+  __syncthreads();                                     // LDS is free
+  // exchange: a wave parks the two cout tiles its partner (same pixels, other group) finishes, then adds the partner's to its own --
+  // always (group 0) + (group 1)
+  constexpr int XOFF = 36864;                          // behind the staging tile (34,816 B) and its column-sum partials
+  f32x4* const xch = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem16) + XOFF);
+  f32x4 fin[2][2];
+  if (grp == 0) {
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xch[(wave * 4 + jl * 2 + i) * 64 + lane] = acc[2 + jl][i];
+  } else {
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xch[(wave * 4 + jl * 2 + i) * 64 + lane] = acc[jl][i];
+  }
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fin[jl][i] = acc[jl][i] + xch[((wave ^ 4) * 4 + jl * 2 + i) * 64 + lane];
+  } else {
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fin[jl][i] = xch[((wave ^ 4) * 4 + jl * 2 + i) * 64 + lane] + acc[2 + jl][i];
+  }
+
+  auto pix_of = [&](int pr, int& oy, int& ox) {
+    oy = oy0 + (pr >> 4); ox = ox0 + (pr & 15);
+    return oy < p.Ho && ox < p.Wo;
+  };
+  if (p.ys) {
+    constexpr int OLD = 2 * BN + 8;
+    u16* so = smem16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pr = (2 * pg + i) * 16 + col;
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        const int j = 2 * grp + jl;
+        const int co = n0 + j * 16 + fq;
+        float v[4];
+        x_epi_quad(fin[jl][i], bv[jl], okp[i], ak, gkind, gv[i][jl], co, gate_off, v);
+        unsigned h01, l01, h23, l23;
+        x_split2(v[0], v[1], h01, l01);
+        x_split2(v[2], v[3], h23, l23);
+        *reinterpret_cast<uint2*>(so + pr * OLD + j * 16 + fq) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(so + pr * OLD + BN + j * 16 + fq) = make_uint2(l01, l23);
+      }
+    }
+    __syncthreads();
+    constexpr int VPP = BN / 8;
+    for (int v = tid; v < TPX * 2 * VPP; v += NTHR) {
+      const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
+      const int plane = q >= VPP, vec = q - plane * VPP;
+      const int co = n0 + vec * 8;
+      int oy, ox;
+      if (pix_of(pr, oy, ox) && co < p.Cpo) {
+        const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+        *reinterpret_cast<u32x4*>(p.ys + m * 2 * p.Cpo + plane * p.Cpo + co) = hv;
+        if (p.mask_out && plane == 0) p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
+      }
+    }
+    if (p.colsum) {
+      constexpr int CW = 64, RG = NTHR / CW;
+      float* red = reinterpret_cast<float*>(so + TPX * OLD);
+      const int c = tid % CW, rg = tid / CW;
+      float a = 0.f;
+      for (int r = rg; r < TPX; r += RG) a += bf2f(so[r * OLD + c]) + bf2f(so[r * OLD + BN + c]);
+      if (rg > 0) red[(rg - 1) * BN + c] = a;
+      __syncthreads();
+      if (rg == 0 && n0 + c < p.Np) {
+        for (int q = 0; q < RG - 1; ++q) a += red[q * BN + c];
+        p.colsum[(int64_t)tile * p.Np + n0 + c] = a;
+        // trailer: the number of rows this launch wrote (the finish kernel reads no further)
+        if (tile == 0 && n0 + c == 0) reinterpret_cast<int*>(p.colsum)[(int64_t)p.G * p.Np] = (int)gridDim.x;
+      }
+    }
+  } else {
+    constexpr int OLD = BN + 4;
+    float* so = reinterpret_cast<float*>(smem16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pr = (2 * pg + i) * 16 + col;
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        const int j = 2 * grp + jl;
+        const int co = n0 + j * 16 + fq;
+        float v[4];
+        x_epi_quad(fin[jl][i], bv[jl], true, ak, 0, u32x2{0u, 0u}, co, 1.f, v);
+        *reinterpret_cast<float4*>(so + pr * OLD + j * 16 + fq) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();
+    constexpr int VPP = BN / 4;
+    for (int v = tid; v < TPX * VPP; v += NTHR) {
+      const int pr = v / VPP, vec = v - pr * VPP;
+      const int co = n0 + vec * 4;
+      int oy, ox;
+      if (pix_of(pr, oy, ox) && co < p.Cpo)
+        *reinterpret_cast<float4*>(p.yf + (int64_t)img * p.ysn + (int64_t)oy * p.ysh + (int64_t)ox * p.ysw + co) =
+            *reinterpret_cast<const float4*>(so + pr * OLD + vec * 4);
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------ implicit GEMM, halo-resident, 64 pixels per wave
 // Interleaved timing ablations of the kernel above (scripts/time_halo_abl.py, 175 us): without the weight stream of the
 // stage loop 156, without fragment reads 160, without both 135 -- per 32-k stage a workgroup of 128 pixels moves 86 KB
@@ -3724,6 +4050,30 @@ static int launch_xhalo(const XIgemmParams& p, hipStream_t stream) {
   }
   return nb == 3 ? launch_xhalo2<NT, 3>(p, lds, stream) : launch_xhalo2<NT, 2>(p, lds, stream);
 }
+// conv_halo3_bf16x3_kernel (3x3, K split over two wave groups): 64-cout blocks, slabs of exactly 64 channels (two planes) or
+// 64 / 128 channels (hi plane only) -- every U-Net layer of support/networks.py:20-22 in both directions
+static bool x_halo3_ok(const XIgemmParams& p) {
+  if (p.ks != 3 || !p.PXS || p.Np % 64 != 0 || !x_env_on("WCMC_HALO3")) return false;
+  if (p.ap == 2) return p.CS == 64 && p.CSl == 64 && p.SPS == 18 && p.SPSl == 18;
+  return (p.CS == 64 && p.nslabs == 1 && p.SPSl == 18) || (p.CS == 128 && p.CSl == 128 && p.SPS == 36 && p.SPSl == 36);
+}
+template <int AP, int SPT>
+static int launch_xhalo3b(const XIgemmParams& q, hipStream_t stream) {
+  constexpr int KG = 2;
+  const size_t lds = (size_t)180 * 256 + (size_t)2 * KG * (2 * 64 * XROW + 64) * sizeof(u16);      // 79,360 B: two workgroups per CU
+  static LdsAttr attr;
+  if (set_max_lds(reinterpret_cast<const void*>(&conv_halo3_bf16x3_kernel<AP, SPT, KG>), lds, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
+  const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)(q.Np / 64));
+  hipLaunchKernelGGL((conv_halo3_bf16x3_kernel<AP, SPT, KG>), grid, dim3(256 * KG), lds, stream, q);
+  return check_launch("conv2d_igemm_bf16x3(halo 3x3, K groups)");
+}
+static int launch_xhalo3(const XIgemmParams& p, hipStream_t stream) {
+  XIgemmParams q = p;
+  q.tilesY = (p.Ho + 7) / 8;
+  q.PXS = 256;
+  if (p.ap == 2) return launch_xhalo3b<2, 2>(q, stream);
+  return p.CS == 128 ? launch_xhalo3b<1, 4>(q, stream) : launch_xhalo3b<1, 2>(q, stream);
+}
 template <int NT>
 static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
   if (p.PXS) return launch_xhalo<NT>(p, stream);
@@ -3798,6 +4148,7 @@ extern "C" int wcmc_conv2d_igemm_bf16x3(const void* x_split, int N, int H, int W
     int ntw = 0, u = 0;
     if (x_plan_pw(p, &ntw, &u)) return launch_xpw(p, ntw, u, st);
   }
+  if (x_halo3_ok(p)) return launch_xhalo3(p, st);
   switch (x_pick_nt(p.Np / 16)) {
     case 7: return launch_xigemm<7>(p, st);
     case 4: return launch_xigemm<4>(p, st);
