@@ -1403,7 +1403,8 @@ __global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmPa
   // slab's fill is one addition per instruction.
   constexpr int NHI = (HP * 16 / 64 + NWV - 1) / NWV;      // 45 instructions over 8 waves: up to 6 each
   static_assert(HP * 16 % 64 == 0, "no tail instruction");
-  unsigned hoff[NHI];
+  static_assert(NHI == 6, "hoff");                        // (a literal bound: an array of dependent size captured by the lambda below loses the kernel's host stub, clang 22)
+  unsigned hoff[6];
 #pragma unroll
   for (int kq = 0; kq < NHI; ++kq) {
     const int ii = wave + NWV * kq;
