@@ -1368,7 +1368,8 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 //     addition on the lane's pixel index, the k-half inside a tap an XOR constant; no tap counters, no wraps.
 // Stage s of a slab = tap s / SPT, 32-channel quarter s % SPT of the slab's CS = 32 SPT / AP ... channels (pack order k = tap CS + c,
 // as x_plan_k and pack_weight_split_multi_kernel lay it out: the packs are those of the kernel above).
-template <int AP, int SPT, int KG = 2>
+// DBG (debug library, timing only, WRONG results): 1 no MFMA, 2 no weight DMA in the loop, 8 no fragment reads, 16 no loop barrier, 32 no epilogue
+template <int AP, int SPT, int KG = 2, int DBG = 0>
 __global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmParams p) {
   static_assert(KG == 2, "two K groups (h = hc | grp below)");
   constexpr int NT = 4, BN = NT * 16, TH = 8, TW = 16, KS = 3, HWd = TW + KS - 1, HHt = TH + KS - 1, HP = HWd * HHt;   // 18 x 10 halo
@@ -1489,8 +1490,8 @@ __global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmPa
 #pragma unroll
     for (int l = 0; l < ITS; ++l) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the next pair (requested one iteration ago)
-      pw_barrier();                                        // ... everyone's; everyone has read the fragments of this pair
-      dma_b(KG * (gi + 2) + grp, dset * KG + grp);
+      if (!(DBG & 16)) pw_barrier();                       // ... everyone's; everyone has read the fragments of this pair
+      if (!(DBG & 2)) dma_b(KG * (gi + 2) + grp, dset * KG + grp);
       const bool last = l == ITS - 1;
       if (last && slab + 1 < p.nslabs) dma_halo(slab + 1); // (every fragment of this slab is in registers)
       __builtin_amdgcn_sched_barrier(0);
@@ -1498,12 +1499,14 @@ __global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmPa
       for (int j = 0; j < NT; ++j) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
-          if (AP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
-          if (j == NT - 1 && !last) read_a1(i, l + 1);      // the pixel tile's next fragments replace it at once
+          if (!(DBG & 1)) {
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
+            if (AP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
+          }
+          if (j == NT - 1 && !last && !(DBG & 8)) read_a1(i, l + 1);      // the pixel tile's next fragments replace it at once
         }
-        read_b(bfr_c, j);                                   // next pair, same cout tile, into the registers just consumed
+        if (!(DBG & 8)) read_b(bfr_c, j);                   // next pair, same cout tile, into the registers just consumed
         __builtin_amdgcn_sched_barrier(0);
       }
       { const u16* t = bfr_c; bfr_c = bfr_n; bfr_n = t; }
@@ -1518,6 +1521,14 @@ __global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmPa
     }
   }
 
+  if (DBG & 32) {                                      // timing only: no epilogue (one store keeps the accumulators alive)
+    float keep = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) keep += (acc[j][0][0] + acc[j][0][1] + acc[j][0][2] + acc[j][0][3]) +
+                                         (acc[j][1][0] + acc[j][1][1] + acc[j][1][2] + acc[j][1][3]);
+    if (keep == 12345.678f && p.ys) p.ys[0] = 1;
+    return;
+  }
   // ---- epilogue: group grp finishes cout tiles 2 grp, 2 grp + 1 of its pixels
   const int fq = kg * 4;
   float bv[2][4];
@@ -4065,6 +4076,21 @@ static int launch_xhalo3b(const XIgemmParams& q, hipStream_t stream) {
   static LdsAttr attr;
   if (set_max_lds(reinterpret_cast<const void*>(&conv_halo3_bf16x3_kernel<AP, SPT, KG>), lds, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
   const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)(q.Np / 64));
+#ifdef WCMC_DEBUG_BUILD
+  if (AP == 2) {                          // WCMC_DEBUG_ABLATE=<mask>: timing-only ablations of the forward instance (scripts/time_unet_abl.py)
+    const char* e = ab_env("WCMC_DEBUG_ABLATE");
+    const int ab = e ? atoi(e) : 0;
+    if (ab) {
+      auto kfn = ab == 1 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 1> : ab == 2 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 2> : ab == 8 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 8>
+                 : ab == 16 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 16> : ab == 32 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 32> : ab == 10 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 10>
+                 : ab == 26 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 26> : ab == 27 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 27> : ab == 59 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 59>
+                 : ab == 33 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 33> : ab == 18 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 18> : &conv_halo3_bf16x3_kernel<2, 2, 2, 9>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, grid, dim3(256 * KG), lds, stream, q);
+      return check_launch("conv2d_igemm_bf16x3(halo 3x3, ablation)");
+    }
+  }
+#endif
   hipLaunchKernelGGL((conv_halo3_bf16x3_kernel<AP, SPT, KG>), grid, dim3(256 * KG), lds, stream, q);
   return check_launch("conv2d_igemm_bf16x3(halo 3x3, K groups)");
 }
