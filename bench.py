@@ -54,6 +54,10 @@ def rocprof_names(wgrad_terms):
             "conv_halo64_pt3_h1": "wcmc::conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 1>",
             "conv_wgrad_rows": ("wcmc::conv_wgrad_rows8_bf16x3_kernel<0, %d, %d>" % (_ROWS8_XE if wgrad_terms == 3 else 1, 1 if wgrad_terms == 1 else 2)) if _rows8(wgrad_terms)
                                else "wcmc::conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, %d>" % (1 if wgrad_terms == 1 else 2),
+            # the U-Net's 3x3 layers: <planes of x multiplied, stages per tap, K groups, debug>; the two-term class runs two instances
+            # (64- and 128-channel slabs of the hi plane)
+            "conv_halo3": "wcmc::conv_halo3_bf16x3_kernel<2, 2, 2, 0>",
+            "conv_halo3_x2": "wcmc::conv_halo3_bf16x3_kernel<1, 4, 2, 0> and <1, 2, 2, 0>",
             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)",
             # the fused PathNet chains (csrc/pathnet_fused.hip); the backward brackets include their small finish kernels
             "embed3_fwd": "wcmc::embed3_fwd_kernel", "embed3_bwd": "wcmc::embed3_bwd_kernel",
@@ -573,12 +577,24 @@ def main():
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "share_of_profiled_region": round(d["ms"] / (prof_elapsed * 1e3), 4)}
 
+        def family(label, keys):
+            keys = [k for k in keys if k in summ and summ[k]["ms"] > 0]
+            if not keys:
+                return None
+            work, ms = sum(summ[k]["work"] for k in keys), sum(summ[k]["ms"] for k in keys)
+            ach = work / (ms * 1e-3) / 1e12
+            peak = PEAK_BF16_MFMA_TFLOPS if ops.split_path() else PEAK_FP32_MFMA_TFLOPS
+            return {"family": label, "classes": keys, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "launches": sum(summ[k]["launches"] for k in keys),
+                    "ms_per_profiled_step": round(ms / max(1, prof.step), 4),
+                    "share_of_profiled_region": round(ms / (prof_elapsed * 1e3), 4)}
+
         # classes = kernels: conv_halo64_pt4 / _pt3 / _cs32 are the instances of conv_halo64_bf16x3_kernel<7,NB,PT> (KPCN 5x5 fwd +
         # dgrad: 16x16 tiles, 12x16 tiles, 12x16 with 32-channel slabs for the 441-channel data gradient; conv_halo7 = the 8x16
         # kernel they replace, WCMC_HALO64=0), conv_wgrad_rows is conv_wgrad_rows_bf16x3_kernel<5,7,7> for one-term launches, conv_wgrad_rows8_bf16x3_kernel for three-term ones (WCMC_WGRAD_ROWS8=0|1: one of them for both);
         # conv_igemm / conv_wgrad collect the other GEMM kernels
         conv_keys = [k for k in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_pt3_x2", "conv_halo64_pt4_x2", "conv_halo64_pt3_x1", "conv_halo64_pt4_x1", "conv_halo64_pt3_h1", "conv_halo64_pt4_h1", "conv_halo64_cs32", "conv_halo7",
-                                 "conv_wgrad_rows", "conv_igemm", "conv_wgrad")
+                                 "conv_halo3", "conv_halo3_x2", "conv_wgrad_rows", "conv_igemm", "conv_wgrad")
                      if k in summ]
         # the roofline kernel: the single kernel (one rocprof name) with the most time per step; the two catch-all classes
         # collect several kernels and are reported under roofline_other_conv (exact-fp32 mode: one kernel per class anyway)
@@ -610,6 +626,7 @@ def main():
             # capture validation (wcmc_amd.graph.capture_validated), this rank: ms per replay of every capture that was made; the last one is the step that ran
             "capture_attempts": None if args.eager else graphed.capture_attempts,
             "capture_ms": None if args.eager else graphed.capture_ms,
+            "capture_validated": None if args.eager else getattr(graphed, "capture_validated", None),
             # the two streams the halves replay on: picked once per process by a spin-kernel probe so that they sit on different
             # hardware queues (wcmc_amd.ops.concurrent_stream_pair)
             "stream_pair": (getattr(graphed.half_streams[0], "probe", None) if (not args.eager and graphed.two_stream) else None),
@@ -656,6 +673,15 @@ def main():
                                                       (PEAK_BF16_MFMA_TFLOPS if ops.split_path() else PEAK_FP32_MFMA_TFLOPS), 4)},
             "roofline": dict(roof(dominant, "mfma"), traffic=traffic.get(dominant)) if dominant else None,
             "roofline_other_conv": [dict(roof(k, "mfma"), traffic=traffic.get(k)) for k in conv_keys if k != dominant],
+            # families: every instance of one kernel template (and, for the U-Net, what is left of it in the catch-all class) summed --
+            # algorithmic FLOPs of all their launches / their HIP-event time -- so that the figure does not depend on how the template
+            # arguments split the time
+            "roofline_family": [f for f in (family("conv_halo64 (KPCN 5x5 forward + data gradient, every instance)",
+                                                   [k for k in conv_keys if k.startswith("conv_halo64")]),
+                                            family("U-Net 3x3 forward + data gradient (conv_halo3 instances + class conv_igemm)",
+                                                   [k for k in conv_keys if k.startswith("conv_halo3") or k == "conv_igemm"]),
+                                            family("weight gradients (conv_wgrad_rows + class conv_wgrad)",
+                                                   [k for k in conv_keys if k.startswith("conv_wgrad")])) if f],
             "roofline_pointwise": (dict(roof("conv_pw", "hbm"), traffic=traffic.get("conv_pw")) if roof("conv_pw", "hbm") else None),
             # PathNet.embedding / PathNet.final as one launch per direction (hidden activations never leave the CU): HBM-bound by
             # construction, algorithmic bytes = input + output (+ gradients) once

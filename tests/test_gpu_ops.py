@@ -1281,15 +1281,20 @@ def test_deferred_multi_layer_slab_reduction_is_bit_identical(three_term_mode):
     (``wcmc_conv2d_wgrad_reduce_multi``) give the weight AND bias gradients of the per-layer reductions bit for bit -- a U-Net chain
     (3x3, padded), a 1x1 chain and a chain whose last layer has three outputs; a layer above ``DEFER_MAX_BYTES`` is not deferred."""
     from wcmc_amd.modules import ConvChain
+    from wcmc_amd.optim import FusedClipAdam
     o = ops()
     for (cin, cout, ks, width, depth, hw) in ((64, 64, 3, 64, 3, (40, 36)), (384, 128, 3, 128, 3, (24, 24)), (36, 3, 1, 64, 3, (32, 64))):
         torch.manual_seed(7)
         mod = ConvChain(cin, cout, ksize=ks, width=width, depth=depth, pad=True, output_type="relu", weight_norm=False).to(DEV)
+        # (gradient sinks registered, as in the product's step: a reduction is deferred only into memory that is certain to be the
+        # gradient's when it runs -- a bucket view, or a weight-normalised layer's effective weight)
+        fo = FusedClipAdam({"m": mod}, {"optim_m": torch.optim.Adam(mod.parameters(), lr=1e-3)})
         x = gen(4, cin, *hw, seed=70).to(DEV)
         g = gen(4, cout, *hw, seed=71).to(DEV)
         res = []
         for defer in (False, True):
             mod.zero_grad()
+            o.release_grad_sinks(list(mod.parameters()))
             y = mod(x)
             if defer:
                 with o.deferred_wgrad_reduce():
@@ -1307,10 +1312,70 @@ def test_deferred_multi_layer_slab_reduction_is_bit_identical(three_term_mode):
     try:
         with o.deferred_wgrad_reduce():
             mod.zero_grad()
+            o.release_grad_sinks(list(mod.parameters()))
             mod(x).backward(g)
             assert not o._DEFERRED
     finally:
         o.DEFER_MAX_BYTES = old
+    del fo
+
+
+@pytest.mark.parametrize("weight_norm", [False, True])
+def test_deferred_reduction_never_writes_into_memory_that_is_not_the_gradients(weight_norm):
+    """a deferred slab reduction writes dw / db long after the weight-gradient GEMM returned.  It may do so only into
+    memory that is certain to be the gradient's by then: (i) parameters WITHOUT a registered bucket view, (ii) parameters that already
+    hold a .grad (accumulation: autograd adds the returned tensor into .grad and frees it at once) and (iii) parameters that need no
+    gradient are reduced inline; (iv) the weight-gradient side stream (``USE_SIDE_STREAM``) never queues an entry the weight-norm
+    node's flush on the main stream would miss.  Every case: gradients equal to the un-deferred run bit for bit."""
+    from wcmc_amd.modules import ConvChain
+    from wcmc_amd.optim import FusedClipAdam
+    o = ops()
+    torch.manual_seed(9)
+    mod = ConvChain(64, 64, ksize=3, width=64, depth=3, pad=True, output_type="relu", weight_norm=weight_norm).to(DEV)
+    x = gen(4, 64, 40, 36, seed=72).to(DEV)
+    g = gen(4, 64, 40, 36, seed=73).to(DEV)
+
+    def grads(defer, passes=1, side=False):
+        mod.zero_grad()
+        o.release_grad_sinks(list(mod.parameters()))
+        old = o.USE_SIDE_STREAM
+        o.USE_SIDE_STREAM = side
+        try:
+            for _ in range(passes):
+                y = mod(x)
+                if defer:
+                    with o.deferred_wgrad_reduce():
+                        y.backward(g)
+                else:
+                    y.backward(g)
+        finally:
+            o.USE_SIDE_STREAM = old
+        torch.cuda.synchronize()
+        return [None if p.grad is None else p.grad.clone() for p in mod.parameters()]
+
+    def same(a, b, what):
+        for u, v, (k, _) in zip(a, b, mod.named_parameters()):
+            assert (u is None) == (v is None) and (u is None or torch.equal(u, v)), "%s: %s differs" % (what, k)
+
+    # (i) no sinks registered at all
+    same(grads(False), grads(True), "no bucket views")
+    # (ii) accumulation over two backward passes, without and with bucket views
+    same(grads(False, passes=2), grads(True, passes=2), "accumulation, no bucket views")
+    fo = FusedClipAdam({"m": mod}, {"optim_m": torch.optim.Adam(mod.parameters(), lr=1e-3)})
+    same(grads(False, passes=2), grads(True, passes=2), "accumulation, bucket views")
+    # (iii) a frozen layer
+    frozen = [list(mod.parameters())[2]]
+    for p in frozen:
+        p.requires_grad_(False)
+    try:
+        same(grads(False), grads(True), "frozen parameter")
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
+    # (iv) weight gradients on the side stream
+    same(grads(False, side=True), grads(True, side=True), "side stream")
+    same(grads(False), grads(True, side=True), "side stream vs main stream")
+    del fo
 
 
 @pytest.mark.parametrize("kind,cls", [("smape", "SMAPE"), ("tonemapped_mse", "TonemappedMSE"), ("tonemapped_relative_mse", "TonemappedRelativeMSE")])
@@ -1351,6 +1416,13 @@ def test_clip_grad_norm_matches_torch():
         for p, q in zip(ps, pr):
             assert_close(p.grad, q.grad, tol=2e-6, what="clipped gradient")
         assert (float(want) > max_norm) == (scale > 1.0)
+    # a non-finite gradient poisons every gradient, as torch's clamp(NaN) = NaN does
+    ps = [torch.nn.Parameter(torch.zeros(shp, device=DEV)) for shp in shapes]
+    for i, p in enumerate(ps):
+        p.grad = gen(*shapes[i], seed=310 + i).to(DEV)
+    ps[2].grad[5, 7, 1, 1] = float("nan")
+    got = o.clip_grad_norm_(ps, 1000.0)
+    assert torch.isnan(got).all() and all(torch.isnan(p.grad).all() for p in ps)
 
 
 VARIANT_EXPR = "variant or switch_matrix or strip_equals or eight_wave or many_slabs or one_term_weight or three_term_forward"

@@ -447,12 +447,13 @@ __global__ __launch_bounds__(256) void grad_norm_finish_kernel(const float* __re
     const float nrm = sqrtf(((red[0] + red[1]) + red[2]) + red[3]);
     const float coef = max_norm / (nrm + 1e-6f);
     out[0] = nrm;
-    out[1] = coef < 1.f ? coef : 1.f;
+    // torch.clamp(coef, max=1.0) keeps a NaN a NaN (a NaN norm poisons every gradient visibly, interfaces.py:826-833): so here
+    out[1] = (coef < 1.f || coef != coef) ? coef : 1.f;
   }
 }
 __global__ __launch_bounds__(256) void grad_scale_kernel(GNTable t, const float* __restrict__ coef) {
   const float c = coef[1];
-  if (c >= 1.f) return;
+  if (c >= 1.f) return;                                      // (false for a NaN coefficient: the gradients are multiplied by it)
   const GNEntry& q = gn_find(t, blockIdx.x);
   const int64_t i0 = (int64_t)(blockIdx.x - q.block0) * GN_CHUNK;
   for (int64_t i = i0 + threadIdx.x; i < q.n && i < i0 + GN_CHUNK; i += 256) q.g[i] *= c;

@@ -241,14 +241,18 @@ class GraphedTrainStep:
         if not self.tail_captured:
             return None
         self.ok.zero_()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self._replay()                                     # (first replay: uploads the executable graph)
+        keys = getattr(self, "key_state", None)
+        keys0 = keys.clone() if keys is not None else None      # (the replays advance the pairing counter: put it back, so that a
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)     # seed set BEFORE this call keeps
+        self._replay()                                     # (first replay: uploads the executable graph)     its sequence)
         e0.record()
         for _ in range(n):
             self._replay()
         e1.record()
         e1.synchronize()
         self.ok.fill_(1.0)
+        if keys0 is not None:
+            keys.copy_(keys0)
         return e0.elapsed_time(e1) / n
 
     def _draw_captured(self, half):
@@ -426,8 +430,9 @@ def capture_validated(itf, batch, attempts=3, min_attempts=2, tol=0.05, replays=
         step = GraphedTrainStep(itf, batch, **kw)
         t = step.time_replays(replays)
         if t is None:                                      # (nothing to validate by: multi-rank tail, eager optimiser)
-            step.capture_attempts, step.capture_ms = 1, []
+            step.capture_attempts, step.capture_ms, step.capture_validated = 1, [], False
             return step
+        step.capture_validated = True
         tried.append(round(t, 4))
         seen = key in _BEST_MS
         best = min(_BEST_MS.get(key, t), t)

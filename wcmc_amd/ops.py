@@ -512,18 +512,25 @@ def release_grad_sinks(params):
             e[2] = None
 
 
-def _sink(param_ptr, shape, device):
-    """The bucket view a gradient of `shape` for the parameter at `param_ptr` may be written into, or a fresh tensor."""
+def _sink_ex(param_ptr, shape, device):
+    """(tensor, is_bucket_view): the bucket view a gradient of `shape` for the parameter at `param_ptr` may be written into, or a
+    fresh tensor.  A bucket view is handed out only for a parameter that requires a gradient and has none yet (AccumulateGrad will
+    adopt the tensor), and its memory belongs to the optimiser: it outlives the step."""
     e = _GRAD_SINK.get(param_ptr)
     if e is not None:
         p, v = e[0](), e[1]()
         if p is None or v is None or p.data_ptr() != param_ptr:
             del _GRAD_SINK[param_ptr]
-        elif p.grad is None and (e[2] is None or e[2]() is None) and tuple(v.shape) == tuple(shape) and v.device == device:
+        elif (p.grad is None and p.requires_grad and (e[2] is None or e[2]() is None) and tuple(v.shape) == tuple(shape)
+              and v.device == device):
             out = v.detach()                    # (a new tensor object on the same memory: AccumulateGrad may adopt it)
             e[2] = weakref.ref(out)
-            return out
-    return torch.empty(shape, device=device, dtype=torch.float32)
+            return out, True
+    return torch.empty(shape, device=device, dtype=torch.float32), False
+
+
+def _sink(param_ptr, shape, device):
+    return _sink_ex(param_ptr, shape, device)[0]
 
 
 def _param_ptr(t):
@@ -738,6 +745,14 @@ def _igemm_class(cin, cout, ks, dims=None, terms=3):
     halo = 3 <= ks <= 5 and (cin + 7) // 8 * 8 >= 32
     if ks == 1 and ((cin + 7) // 8 * 8, cout) in ((64, 64), (40, 64), (128, 128), (8, 128)):
         return "conv_pw"                    # x_plan_pw: the persistent pointwise kernel (HBM-bound class)
+    if halo and ks == 3 and (cout + 15) // 16 * 16 % 64 == 0:
+        # conv_halo3_bf16x3_kernel (x_halo3_ok): the U-Net's 3x3 layers -- slabs of exactly 64 channels (three terms) or of 64 / 128
+        # channels of the hi plane (two terms: "_x2")
+        kp3 = (cin + 7) // 8 * 8
+        if terms >= 3 and kp3 % 64 == 0:
+            return "conv_halo3"
+        if terms <= 2 and (kp3 == 64 or kp3 % 128 == 0):
+            return "conv_halo3_x2"
     if not (halo and nt == 7 and ks == 5):
         return "conv_igemm"
     if dims is None:
@@ -872,12 +887,19 @@ class deferred_wgrad_reduce:
 
 
 def flush_wgrad_reduce():
-    """Run the reductions collected so far on the CURRENT stream (their results are about to be read)."""
+    """Run the reductions collected so far on the CURRENT stream (their results are about to be read).  Entries are only ever
+    queued under the stream their GEMM ran on and never under a weight-gradient side stream (conv2d_wgrad_x_raw reduces inline
+    there), so the reader's stream is where they all are."""
     if _DEFERRED:
         st = torch.cuda.current_stream()
         hit = _DEFERRED.pop(st.cuda_stream, None)
         if hit is not None:
             _reduce_multi(hit[1])
+
+
+def _on_side_stream():
+    cur = torch.cuda.current_stream().cuda_stream
+    return any(s.cuda_stream == cur for s in _SIDE_STREAMS.values())
 
 
 def _reduce_multi(entries):
@@ -902,17 +924,25 @@ def conv2d_wgrad_x_raw(xs, xdims, dys, cout, ks, pad, weight_shape, want_bias=Tr
     ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
     nbytes = lib().wcmc_conv2d_wgrad_bf16x3_workspace_bytes(n, ho, wo, cout, cin, ks)
     ws = torch.empty((nbytes + 3) // 4, device=xs.device, dtype=torch.float32)
-    dw = _sink(sinks[0], weight_shape, xs.device)
-    db = _sink(sinks[1], (cout,), xs.device) if (want_bias or colsum_part is not None) else None
+    dw, dw_view = _sink_ex(sinks[0], weight_shape, xs.device)
+    db, db_view = _sink_ex(sinks[1], (cout,), xs.device) if (want_bias or colsum_part is not None) else (None, True)
     args = (_ptr(xs), n, h, w, cin, _ptr(dys), cout, ks, pad, _ptr(dw), _ptr(db), _ptr(ws), ws.numel() * 4)
     cs = _ptr(colsum_part)
     terms = wgrad_terms() if terms is None else terms
-    if (_PROFILER is None and _DEFERRED is not None and nbytes <= DEFER_MAX_BYTES and (db is None or colsum_part is not None)):
+    # A reduction may be deferred only where the memory it will write is certain to be the gradient's when it runs:
+    # a bucket view (the optimiser's memory; AccumulateGrad adopts the tensor -- a parameter that already has a .grad, or needs
+    # none, gets a fresh tensor from _sink_ex, which autograd adds into .grad or drops at once), or the weight gradient of a
+    # NON-leaf weight (sinks[0] == 0: the effective weight of a weight-normalised layer, consumed by the weight-norm node, which
+    # flushes first; the entry then holds the tensor itself).  A fresh tensor for a leaf is reduced inline.  And never on a
+    # weight-gradient side stream: the reader flushes ITS stream's entries.
+    safe = (dw_view or sinks[0] == 0) and db_view
+    if (_PROFILER is None and _DEFERRED is not None and safe and nbytes <= DEFER_MAX_BYTES and (db is None or colsum_part is not None)
+            and not _on_side_stream()):
         check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 1, cs, terms, _stream()), "conv2d_wgrad_bf16x3")      # the GEMM now,
         st = torch.cuda.current_stream()                                                                 # the reduction later
-        # (dw / db by ADDRESS: a reference held here would keep AccumulateGrad from adopting the tensor -- it would clone it, unreduced)
-        _DEFERRED.setdefault(st.cuda_stream, (st, []))[1].append((ws, dw.data_ptr(), db.data_ptr() if db is not None else 0, colsum_part,
-                                                                  n, ho, wo, cout, cin, ks, terms))
+        # (bucket views by ADDRESS: a reference held here would keep AccumulateGrad from adopting the tensor -- it would clone it, unreduced)
+        _DEFERRED.setdefault(st.cuda_stream, (st, []))[1].append((ws, dw.data_ptr() if dw_view else dw, db.data_ptr() if db is not None else 0,
+                                                                  colsum_part, n, ho, wo, cout, cin, ks, terms))
     elif _PROFILER is None:
         check(lib().wcmc_conv2d_wgrad_bf16x3(*args, 0, cs, terms, _stream()), "conv2d_wgrad_bf16x3")
     else:       # bracket the split-K GEMM launch alone; the slab reduce + bias gradient is its own class
