@@ -83,6 +83,16 @@ def dgrad_terms():
     return 2 if reduced_backward() else 3
 
 
+# (weight-gradient, data-gradient) MFMAs per product of the chains with a given filter size, where they differ from the mode's:
+# the rung table of the backward GEMMs (profiles/r06_grad_rungs.txt; empty = the mode's rungs everywhere)
+TERMS_BY_KS = {}
+
+
+def chain_terms(ks, cin=None):
+    """cin: input channels of the chain's first layer -- a key (ks, cin) singles out one chain (PathNet.embedding: (1, 36), final: (1, 128))."""
+    return TERMS_BY_KS.get((ks, cin), TERMS_BY_KS.get(ks, (wgrad_terms(), dgrad_terms())))
+
+
 def out_layer_terms(ks, act):
     """bf16 MFMAs per product in the FORWARD of a chain's output layer: 1 in the "bf16x321o" mode for a linear (un-gated) 5x5
     output layer -- the shape the library's one-term instance and the measurement behind it cover -- else 3."""
@@ -721,7 +731,7 @@ def _pack_chain_x(weights, ks, out_terms=3):
         keep.append(w)
         cout, cin = w.shape[0], w.shape[1]
         pair = []
-        for mode in (_fwd_pack_mode(out_terms) if li == n - 1 else 0, _dgrad_mode()):
+        for mode in (_fwd_pack_mode(out_terms) if li == n - 1 else 0, _dgrad_mode(chain_terms(ks, weights[0].shape[1])[1])):
             rows, kch = (cout, cin) if mode in (0, 3, 4) else (cin, cout)
             wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks, mode), device=dev, dtype=torch.int16)
             ws.append(w.data_ptr()); outs.append(wp.data_ptr()); couts.append(cout); cins.append(cin); modes.append(mode)
@@ -981,7 +991,7 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
     pair = (ks == 1 and pad == 0 and nl >= 2 and
             lib().wcmc_conv1x1_pair_supported(params[2 * nl - 4].shape[1], params[2 * nl - 4].shape[0],
                                               params[2 * nl - 2].shape[0]))
-    ctx.terms = (wgrad_terms(), dgrad_terms())     # the backward multiplies as the mode of ITS forward says
+    ctx.terms = chain_terms(ks, dims0[1])          # the backward multiplies as the mode of ITS forward says
     oterms = 3 if pair else out_layer_terms(ks, acts[-1])      # MFMAs per product of the output layer's forward ("h": one, fp16)
     if oterms == "h" and not lib().wcmc_conv2d_out_f16_supported(params[2 * nl - 2].shape[1], params[2 * nl - 2].shape[0], ks):
         oterms = 3
