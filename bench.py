@@ -508,6 +508,12 @@ def main():
     elapsed = wd.max_over_ranks(my_elapsed, device)
     rank_ms = wd.gather_floats(my_elapsed / args.steps * 1e3, device)        # every rank's own ms per step (rank 0 reports min / max)
     comm = wd.time_allreduce(itf.fused_optim, group, device) if world > 1 else None
+    # every rank's parameters after the timed steps, as an exact integer checksum (sum of the fp32 bit patterns): data-parallel
+    # replicas that saw the same summed gradients must hold the same bits
+    with torch.no_grad():
+        digest = sum(int(p.detach().contiguous().view(torch.int32).to(torch.int64).sum().item())
+                     for m in itf.models.values() for p in m.parameters())
+    digests = wd.gather_ints(digest, device)
     last_losses = {k: float(v) for k, v in itf.last_loss_dict.items()}       # of step warmup + steps, this rank
     ops.set_profiler(None)
     prof_elapsed = elapsed
@@ -623,6 +629,7 @@ def main():
                            else 1 if world == 1 and args.backend == "nccl" else 0),
             "collective_backend": ("rccl" if args.backend == "nccl" else args.backend + (" (smoke test, shared GPU)" if args.share_gpu else "")),
             "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
+            "params_identical_across_ranks": (len(set(digests)) == 1) if world > 1 else None,
             # capture validation (wcmc_amd.graph.capture_validated), this rank: ms per replay of every capture that was made; the last one is the step that ran
             "capture_attempts": None if args.eager else graphed.capture_attempts,
             "capture_ms": None if args.eager else graphed.capture_ms,

@@ -77,6 +77,17 @@ def gather_floats(value, device):
     return [float(x.item()) for x in out]
 
 
+def gather_ints(value, device):
+    """One python int (64 bits, two's complement) per rank, on every rank (world 1: [value])."""
+    value = ((int(value) + (1 << 63)) % (1 << 64)) - (1 << 63)
+    if not dist.is_initialized():
+        return [value]
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [int(x.item()) for x in out]
+
+
 def time_allreduce(fused_optim, group, device, iters=10):
     """The step's gradient exchange alone: the per-model buckets of ``FusedClipAdam`` (46.8 MB in 3 messages) all-reduced
     back to back ``iters`` times, HIP events on the launch stream around them (a synchronous collective runs on the

@@ -1376,14 +1376,30 @@ def conv_chain(x, ksize, pad, acts, params):
     return _ConvChainX.apply(as_nhwc(x), spec, *params)
 
 
+_UNFUSED_NOTED = set()
+
+
+def _note_unfused(what, why):
+    """A fused PathNet chain exists for the reference's shapes (support/networks.py:18-24) in the reduced-backward modes; another
+    shape or mode runs the same arithmetic layer by layer in HIP -- correct, slower -- and says so once."""
+    if (what, why) not in _UNFUSED_NOTED:
+        _UNFUSED_NOTED.add((what, why))
+        import warnings
+        warnings.warn("wcmc_amd: %s runs layer by layer (no fused kernel for %s)" % (what, why), RuntimeWarning, stacklevel=3)
+
+
 def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
     """``y = conv_chain(x, ...); return y, spp_mean(y, s)``; one autograd node on the split-bf16 path."""
     # (DEBUG_ACTS: the parity tests' hook wants the hidden activations, which the fused chain never materialises)
-    if (FUSE_EMBED and DEBUG_ACTS is None and reduced_backward() and ksize == 1 and pad == 0 and len(acts) == 3 and
-            tuple(acts) == ("relu", "relu", "linear") and not x.requires_grad and
-            lib().wcmc_embed3_supported(params[0].shape[1], params[0].shape[0], params[2].shape[0], params[4].shape[0]) and
-            (getattr(x, "_wcmc_split", None) is not None or is_nhwc_view(x))):
-        return _EmbedSppMeanFusedX.apply(x, s, *params)
+    if (FUSE_EMBED and DEBUG_ACTS is None and ksize == 1 and pad == 0 and len(acts) == 3 and
+            tuple(acts) == ("relu", "relu", "linear") and not x.requires_grad and x.is_cuda):
+        if not reduced_backward():
+            _note_unfused("PathNet.embedding", "precision mode %s" % PRECISION)
+        elif not lib().wcmc_embed3_supported(params[0].shape[1], params[0].shape[0], params[2].shape[0], params[4].shape[0]):
+            _note_unfused("PathNet.embedding", "channels %d -> %d -> %d -> %d" % (params[0].shape[1], params[0].shape[0],
+                                                                                 params[2].shape[0], params[4].shape[0]))
+        elif getattr(x, "_wcmc_split", None) is not None or is_nhwc_view(x):
+            return _EmbedSppMeanFusedX.apply(x, s, *params)
     if split_path() and acts[-1] == "linear":
         pre = getattr(x, "_wcmc_split", None)
         if pre is not None and pre[0] == (x._version, None) and not x.requires_grad:
@@ -1395,13 +1411,18 @@ def conv_chain_spp_mean(x, s, ksize, pad, acts, params):
 
 def cat_broadcast_chain(flat, prop, s, ksize, pad, acts, params):
     """``conv_chain(cat_broadcast(flat, prop, s), ...)``; fused into one autograd node on the split-bf16 path."""
-    if (FUSE_FINAL and DEBUG_ACTS is None and reduced_backward() and ksize == 1 and pad == 0 and
-            tuple(acts) == ("relu", "relu") and flat.is_cuda and prop.shape[0] * s == flat.shape[0] and
-            lib().wcmc_final2_supported(flat.shape[1], prop.shape[1], params[0].shape[0], params[2].shape[0], flat.shape[2] * flat.shape[3])
-            and params[0].shape[1] == 128):
-        fl, pr = as_nhwc(flat), as_nhwc(prop)
-        if _dense_pixel_stride(fl) is not None and _dense_pixel_stride(pr) is not None:
-            return _FinalFusedX.apply(fl, pr, s, *params)
+    if (FUSE_FINAL and DEBUG_ACTS is None and ksize == 1 and pad == 0 and
+            tuple(acts) == ("relu", "relu") and flat.is_cuda and prop.shape[0] * s == flat.shape[0]):
+        if not reduced_backward():
+            _note_unfused("PathNet.final", "precision mode %s" % PRECISION)
+        elif not (lib().wcmc_final2_supported(flat.shape[1], prop.shape[1], params[0].shape[0], params[2].shape[0],
+                                             flat.shape[2] * flat.shape[3]) and params[0].shape[1] == 128):
+            _note_unfused("PathNet.final", "channels %d + %d -> %d -> %d at %d pixels per image" %
+                          (flat.shape[1], prop.shape[1], params[0].shape[0], params[2].shape[0], flat.shape[2] * flat.shape[3]))
+        else:
+            fl, pr = as_nhwc(flat), as_nhwc(prop)
+            if _dense_pixel_stride(fl) is not None and _dense_pixel_stride(pr) is not None:
+                return _FinalFusedX.apply(fl, pr, s, *params)
     if split_path() and flat.shape[1] % 8 == 0:
         return _CatBroadcastChainX.apply(as_nhwc(flat), as_nhwc(prop), s, (ksize, pad, tuple(acts)), *params)
     return conv_chain(cat_broadcast(flat, prop, s), ksize, pad, acts, params)

@@ -177,11 +177,27 @@ class RelativeMSE(torch.nn.Module):
         return 0.5 * torch.mean(mse / (torch.pow(ref, 2) + self.eps))
 
 
-def _hip_image(im, ref):
+_REFUSED = set()
+
+
+def _hip_image(im, ref, who="image loss"):
     """The HIP loss kernels take fp32 (N,C,H,W) CUDA images whose reference carries no gradient (every call site of the reference:
-    ``interfaces.py:418-421, 815-818``); anything else -- the CPU host-logic tests -- takes the torch expression."""
-    return (im.is_cuda and im.dim() == 4 and im.dtype == torch.float32 and ref.shape == im.shape and ref.dtype == torch.float32
-            and not ref.requires_grad)
+    ``interfaces.py:418-421, 815-818``).  CPU tensors (the host-logic tests) take the torch expression; a CUDA tensor the kernels
+    refuse takes it too, but not silently: one warning per class and reason."""
+    if not im.is_cuda:
+        return False
+    why = ("a %d-D image" % im.dim() if im.dim() != 4 else
+           "dtype %s / %s" % (im.dtype, ref.dtype) if im.dtype != torch.float32 or ref.dtype != torch.float32 else
+           "shapes %s vs %s" % (tuple(im.shape), tuple(ref.shape)) if ref.shape != im.shape else
+           "a reference that requires a gradient" if ref.requires_grad else None)
+    if why is None:
+        return True
+    if (who, why) not in _REFUSED:
+        _REFUSED.add((who, why))
+        import warnings
+        warnings.warn("wcmc_amd.support.losses.%s: %s is outside what the HIP pass takes (fp32 (N,C,H,W) images, gradient-free "
+                      "reference); this call runs the torch expression instead" % (who, why), RuntimeWarning, stacklevel=3)
+    return False
 
 
 def _reinhard(im):
@@ -198,7 +214,7 @@ class SMAPE(torch.nn.Module):
         self.eps = eps
 
     def forward(self, im, ref):
-        if _hip_image(im, ref):
+        if _hip_image(im, ref, "SMAPE"):
             return ops.image_loss2(im, ref, "smape", self.eps)
         scale = self.eps + im.detach().abs() + ref.detach().abs()
         return torch.mean((im - ref).abs() / scale)
@@ -212,7 +228,7 @@ class TonemappedMSE(torch.nn.Module):
         self.eps = eps
 
     def forward(self, im, ref):
-        if _hip_image(im, ref):
+        if _hip_image(im, ref, "TonemappedMSE"):
             return ops.image_loss2(im, ref, "tonemapped_mse", self.eps)
         return 0.5 * torch.mean(torch.pow(_reinhard(im) - _reinhard(ref), 2))
 
@@ -225,7 +241,7 @@ class TonemappedRelativeMSE(torch.nn.Module):
         self.eps = eps
 
     def forward(self, im, ref):
-        if _hip_image(im, ref):
+        if _hip_image(im, ref, "TonemappedRelativeMSE"):
             return ops.image_loss2(im, ref, "tonemapped_relative_mse", self.eps)
         im, ref = _reinhard(im), _reinhard(ref)
         return 0.5 * torch.mean(torch.pow(im - ref, 2) / (torch.pow(ref, 2) + self.eps))
