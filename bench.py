@@ -103,15 +103,24 @@ class EventProfiler:
         return out
 
 
-def build_interface(device, group, rng="device", weight_norm=True, seed=0):
+# Seed of the initial weights.  PathNet.final ends in a ReLU on top of ReLU activations (support/networks.py:23-24): at
+# initialisation every output channel of a P-buffer is positive almost everywhere or almost nowhere, a coin per channel, and a
+# channel that starts dead gets no gradient.  Seed 0 draws a specular PathNet with NO live channel (3 % of its entries positive)
+# and a diffuse one with one of three; seed 1 draws live channels in both, and on the round-6 synthetic scenes
+# (wcmc_amd/synthetic.py: ``scene=True``) both manifold terms then keep moving for 200 steps (profiles/r06_pbuffer_death.txt).
+WEIGHT_SEED = 1
+
+
+def build_interface(device, group, rng="device", weight_norm=True, seed=None):
     """weight_norm: the PathNets' parametrisation -- True = upstream sbmc's ConvChain default, which
     ``support/networks.py:18-24`` does not switch off (w = g * v / ||v|| per layer); False = plain weights (rounds 1-4)."""
+    seed = WEIGHT_SEED if seed is None else seed
     from wcmc_amd import KPCN
     from wcmc_amd.optim import FusedClipAdam
     from wcmc_amd.support.interfaces import KPCNInterface
     from wcmc_amd.support.losses import FeatureMSE, RelativeMSE
     from wcmc_amd.support.networks import PathNet
-    torch.manual_seed(seed)                                         # train_kpcn.py:346-348 (seed 0)
+    torch.manual_seed(seed)                                         # train_kpcn.py:346-348 seeds the generator the same way (with 0)
     models = {"dncnn": KPCN(39), "backbone_diffuse": PathNet(ic=36, outc=3, weight_norm=weight_norm),
               "backbone_specular": PathNet(ic=36, outc=3, weight_norm=weight_norm)}
     for k in models:
@@ -655,6 +664,9 @@ def main():
                                   if graphed.tail_split else
                                   "one hipGraph replay per step (forward + backward) + eager all-reduce of three buckets + eager clip + Adam"),
                        "feature_mse_rng": "cpu (reference stream)" if args.cpu_rng else "device",
+                       # initial weights and synthetic patches: the seed that draws live output channels in BOTH P-buffers, scenes with
+                       # object-scale contrast whose path descriptors carry the radiance (both manifold terms stay alive)
+                       "weights_seed": WEIGHT_SEED, "synthetic_patches": "scene (wcmc_amd/synthetic.py, round 6)",
                        # PathNet layers as sbmc.modules.ConvChain builds them when support/networks.py:18-24 passes no weight_norm
                        # argument: w = g * v / ||v|| (wcmc_weight_norm_fwd / _bwd, one launch per PathNet and direction)
                        "pathnet_weight_norm": not args.no_pathnet_weight_norm,

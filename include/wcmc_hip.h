@@ -161,7 +161,7 @@ int wcmc_split_dy_colsum_bf16(const float* dy, int64_t dsn, int64_t dsh, int64_t
 size_t wcmc_conv2d_packed_elems_bf16x3(int rows, int kchan, int ks, int mode);
 int wcmc_conv2d_pack_weight_bf16x3(const float* w_oihw, void* wp, int Cout, int Cin, int ks, int mode,
                                    void* stream);
-/* The same for up to 20 (layer, mode) pairs of one chain in ONE launch: w[i] OIHW (Cout[i], Cin[i], ks, ks) ->
+/* The same for up to 32 (layer, mode) pairs (one chain, or the chains of one U-Net) in ONE launch: w[i] OIHW (Cout[i], Cin[i], ks, ks) ->
  * wp[i] (wcmc_conv2d_packed_elems_bf16x3(rows, kchan, ks, mode) u16 each), mode[i] as above; host arrays of n_entries items. */
 int wcmc_conv2d_pack_chain_bf16x3(int n_entries, const float* const* w, void* const* wp, const int* Cout,
                                   const int* Cin, const int* mode, int ks, void* stream);

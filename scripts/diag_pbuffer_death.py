@@ -12,17 +12,17 @@ from wcmc_amd.synthetic import make_batch
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seeds = [int(s) for s in (sys.argv[2] if len(sys.argv) > 2 else "0,1").split(",")]
 dev = torch.device("cuda", 0)
-for variant in (os.environ.get("VARIANTS", "recipe").split(",")):
+for variant in (os.environ.get("VARIANTS", "recipe_r5,scene").split(",")):
     for seed in seeds:
         itf = bench.build_interface(dev, None, rng="device", seed=seed)
         torch.manual_seed(1234 + seed)
-        batches = [make_batch(bench.B_PER_GPU, bench.SPP, bench.PATCH, seed=100 * seed + i, device=dev) for i in range(4)]
+        batches = [make_batch(bench.B_PER_GPU, bench.SPP, bench.PATCH, seed=100 * seed + i, device=dev, scene=(variant != "recipe_r5")) for i in range(4)]
         rows = []
         for st in range(steps):
             b = batches[st % len(batches)]
             itf.preprocess(b)
             itf.train_batch(b)
-            if st < 12 or st % 10 == 9:
+            if st < 6 or st % 20 == 19:
                 with torch.no_grad():
                     ps = itf.models["backbone_specular"](b)
                     pd = itf.models["backbone_diffuse"](b)

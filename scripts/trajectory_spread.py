@@ -7,7 +7,7 @@ one unit in the last place (`train_trajectory.run(ulp_seed=...)`) -- the size of
 batches and the same pairing keys, and records how far the perturbed runs end up from the unperturbed one in every statistic
 the test holds.  The test's bands are K x the largest of them (and never below a floor that keeps the band meaningful).
 
-    python3 scripts/trajectory_spread.py [STEPS] [NB] [N]      -> profiles/r05_trajectory_spread.json (+ a table on stdout)
+    python3 scripts/trajectory_spread.py [STEPS] [NB] [N]      -> profiles/r06_trajectory_spread.json (+ a table on stdout)
 """
 import json
 import os
@@ -42,8 +42,8 @@ if __name__ == "__main__":
            "columns": ["steps 1-40 max", "steps 20.. max", "last-50 mean", "last-50 median"],
            "spread": spread, "validation_rel": max(vals), "validation_fp32": vref,
            "pathnet_weight_norm": True}
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_trajectory_spread.json")
-    for pth in (path, os.path.join(os.path.dirname(os.path.dirname(path)), "gpurun_out", "r05_trajectory_spread.json")):
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_trajectory_spread.json")
+    for pth in (path, os.path.join(os.path.dirname(os.path.dirname(path)), "gpurun_out", "r06_trajectory_spread.json")):
         if os.path.isdir(os.path.dirname(pth)):       # (gpurun_out/ is what travels back from the GPU box)
             with open(pth, "w") as f:
                 json.dump(out, f, indent=1)

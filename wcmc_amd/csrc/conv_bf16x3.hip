@@ -458,7 +458,7 @@ static XKPlan x_plan_k(int kchan, int ks, int ap_req = 2, int rows = 0) {
 // All weights of a chain, both orientations, in ONE launch: a table of up to 20 (layer, mode) entries by value; a block
 // finds its entry by its block range and runs pack_weight_split_kernel's body on it.  (114 packing launches of ~4 us per
 // step become 16.)
-constexpr int XPACK_MAX = 20;
+constexpr int XPACK_MAX = 32;      // (2.3 KB of kernel arguments: the fifteen U-Net layers of a PathNet, both orientations, in one launch)
 struct XPackEntry { const float* w; u16* wp; int Cout, Cin, mode, rows, Np, CS, Ks, Kt, nslabs, CSl; unsigned block0; int f16; };
 struct XPackTable { XPackEntry e[XPACK_MAX]; int n, ks; };
 __global__ __launch_bounds__(256) void pack_weight_split_multi_kernel(XPackTable t) {

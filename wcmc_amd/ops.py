@@ -717,31 +717,92 @@ def _fwd_pack_mode(out_terms):
     return 4 if out_terms == "h" else 0 if out_terms == 3 else 3
 
 
-def _pack_chain_x(weights, ks, out_terms=3):
-    """[(wp_mode0, wp_mode1)] of the OIHW weights of one chain, packed by ONE launch.  out_terms < 3: the LAST layer's forward
-    pack is made in the K order of a hi-plane launch (mode 3)."""
-    n = len(weights)
-    assert 2 * n <= 20
-    dev = weights[0].device
-    ws, outs, couts, cins, modes, keep = [], [], [], [], [], []
-    for li, wt in enumerate(weights):
-        w = wt.detach()
-        if not w.is_contiguous():
-            w = w.contiguous()
-        keep.append(w)
-        cout, cin = w.shape[0], w.shape[1]
-        pair = []
-        for mode in (_fwd_pack_mode(out_terms) if li == n - 1 else 0, _dgrad_mode(chain_terms(ks, weights[0].shape[1])[1])):
-            rows, kch = (cout, cin) if mode in (0, 3, 4) else (cin, cout)
-            wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks, mode), device=dev, dtype=torch.int16)
-            ws.append(w.data_ptr()); outs.append(wp.data_ptr()); couts.append(cout); cins.append(cin); modes.append(mode)
-            pair.append(wp)
-        keep.append(pair)
+PACK_MAX_ENTRIES = 32       # (layer, orientation) pairs per wcmc_conv2d_pack_chain_bf16x3 launch
+
+
+def _pack_chains_x(chains, ks):
+    """chains: [(weights, out_terms)] of filter size ks -> per chain [(wp_mode0, wp_mode1, (mode0, mode1))] per layer, ALL packed by
+    ONE launch.  out_terms < 3: that chain's LAST layer's forward pack is made in the K order of a hi-plane launch (mode 3 / 4)."""
+    assert sum(2 * len(w) for w, _ in chains) <= PACK_MAX_ENTRIES
+    dev = chains[0][0][0].device
+    ws, outs, couts, cins, modes, keep, res = [], [], [], [], [], [], []
+    for weights, out_terms in chains:
+        n = len(weights)
+        dmode = _dgrad_mode(chain_terms(ks, weights[0].shape[1])[1])
+        per = []
+        for li, wt in enumerate(weights):
+            w = wt.detach()
+            if not w.is_contiguous():
+                w = w.contiguous()
+            keep.append(w)
+            cout, cin = w.shape[0], w.shape[1]
+            pair = []
+            for mode in (_fwd_pack_mode(out_terms) if li == n - 1 else 0, dmode):
+                rows, kch = (cout, cin) if mode in (0, 3, 4) else (cin, cout)
+                wp = torch.empty(lib().wcmc_conv2d_packed_elems_bf16x3(rows, kch, ks, mode), device=dev, dtype=torch.int16)
+                ws.append(w.data_ptr()); outs.append(wp.data_ptr()); couts.append(cout); cins.append(cin); modes.append(mode)
+                pair.append(wp)
+            per.append((pair[0], pair[1], (_fwd_pack_mode(out_terms) if li == n - 1 else 0, dmode)))
+        res.append(per)
     m = len(ws)
     arr_p, arr_i = ctypes.c_void_p * m, ctypes.c_int * m
     check(lib().wcmc_conv2d_pack_chain_bf16x3(m, arr_p(*ws), arr_p(*outs), arr_i(*couts), arr_i(*cins), arr_i(*modes), ks,
                                               _stream()), "conv2d_pack_chain_bf16x3")
-    return [keep[2 * i + 1] for i in range(n)]
+    return res
+
+
+def _pack_chain_x(weights, ks, out_terms=3):
+    """[(wp_mode0, wp_mode1)] of the OIHW weights of one chain, packed by ONE launch."""
+    return [(a, b) for a, b, _ in _pack_chains_x([(weights, out_terms)], ks)[0]]
+
+
+# Packs made AHEAD of the chains that use them.  A chain packs its weights in front of its first GEMM: one 12-us launch per chain,
+# 16 per step, each a dependency edge at the head of a chain of GEMMs -- worth 0.69 ms of the 10.75 ms step when removed
+# (profiles/r06_marginal_step_value.txt), 3.6 x their kernel time.  The weights do not change inside a step, so a model packs the
+# chains of a whole sub-network at its entry in one launch (PathNet: the U-Net's five chains, 30 (layer, orientation) pairs; the
+# interface: a KPCN branch's chain before its PathNet runs) and the chains find their packs here: weight.data_ptr() -> (weight,
+# wp_mode0, wp_mode1, (mode0, mode1), version).  Entries hold the weight alive (so the address stays its own) and are dropped by whoever made them.
+_PREPACK = {}
+
+
+def prepack_chains(chains, ks):
+    """chains: [(weights, output activation)] of the split-bf16 chains with filter size ks that are about to run, in this
+    arithmetic; returns a token for ``prepack_release``.  A no-op (None) off the split-bf16 path."""
+    if not split_path() or not chains or not chains[0][0][0].is_cuda:
+        return None
+    req, token = [], []
+    for weights, act in chains:
+        oterms = _chain_out_terms(ks, act, weights[-1].shape[1], weights[-1].shape[0], False)
+        req.append((list(weights), oterms))
+    # (as many launches as PACK_MAX_ENTRIES asks for: one for a U-Net or a KPCN chain)
+    batch, count = [], 0
+    def flush():
+        if batch:
+            for (weights, _), per in zip(batch, _pack_chains_x(batch, ks)):
+                for w, (a, b, modes) in zip(weights, per):
+                    _PREPACK[w.data_ptr()] = (w, a, b, modes, w._version)
+                    token.append(w.data_ptr())
+    for weights, oterms in req:
+        if count + 2 * len(weights) > PACK_MAX_ENTRIES:
+            flush()
+            batch, count = [], 0
+        batch.append((weights, oterms))
+        count += 2 * len(weights)
+    flush()
+    return token
+
+
+def prepack_release(token):
+    for k in token or ():
+        _PREPACK.pop(k, None)
+
+
+def _chain_out_terms(ks, act_last, cin_last, cout_last, pair):
+    """MFMAs per product of a chain's output layer's forward (3, 1, or "h": one fp16 MFMA), as _chainx_forward decides it."""
+    oterms = 3 if pair else out_layer_terms(ks, act_last)
+    if oterms == "h" and not lib().wcmc_conv2d_out_f16_supported(cin_last, cout_last, ks):
+        oterms = 3
+    return oterms
 
 
 def _igemm_class(cin, cout, ks, dims=None, terms=3):
@@ -992,10 +1053,15 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
             lib().wcmc_conv1x1_pair_supported(params[2 * nl - 4].shape[1], params[2 * nl - 4].shape[0],
                                               params[2 * nl - 2].shape[0]))
     ctx.terms = chain_terms(ks, dims0[1])          # the backward multiplies as the mode of ITS forward says
-    oterms = 3 if pair else out_layer_terms(ks, acts[-1])      # MFMAs per product of the output layer's forward ("h": one, fp16)
-    if oterms == "h" and not lib().wcmc_conv2d_out_f16_supported(params[2 * nl - 2].shape[1], params[2 * nl - 2].shape[0], ks):
-        oterms = 3
-    packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks, oterms) if 2 * nl <= 20 else None
+    oterms = _chain_out_terms(ks, acts[-1], params[2 * nl - 2].shape[1], params[2 * nl - 2].shape[0], pair)     # ("h": one fp16 MFMA)
+    # the packs: made ahead by the enclosing model (prepack_chains) where that holds for THIS arithmetic, else here in one launch
+    want = [(_fwd_pack_mode(oterms) if l == nl - 1 else 0, _dgrad_mode(chain_terms(ks, dims0[1])[1])) for l in range(nl)]
+    pre = [_PREPACK.get(params[2 * l].data_ptr()) for l in range(nl)]
+    if all(e is not None and e[0].shape == params[2 * l].shape and e[4] == params[2 * l]._version and e[3] == want[l]
+           for l, e in enumerate(pre)):
+        packs = [(e[1], e[2]) for e in pre]
+    else:
+        packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks, oterms) if 2 * nl <= PACK_MAX_ENTRIES else None
     ctx.wp1 = [pk[1] for pk in packs] if packs is not None else None      # the data-gradient orientation, for the backward
     pack0 = (lambda l: packs[l][0]) if packs is not None else (lambda l: _pack_x(params[2 * l], _fwd_pack_mode(oterms) if l == nl - 1 else 0))
     for l in range(nl):

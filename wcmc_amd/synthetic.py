@@ -26,8 +26,21 @@ def _grads(x):
     return dx, dy
 
 
-def make_batch(b, s, h, seed=0, device="cpu", use_llpm=True):
-    """One batch dict of fp32 tensors on ``device`` (keys of SURVEY.md Appendix B)."""
+def _objects(randn, b, h, cell=16):
+    """A smooth field with structure at the scale of `cell` pixels: coarse Gaussian noise, bilinearly upsampled."""
+    n = max(2, h // cell + 1)
+    return F.interpolate(randn(b, 3, n, n), size=(h, h), mode="bilinear", align_corners=True)
+
+
+def make_batch(b, s, h, seed=0, device="cpu", use_llpm=True, scene=True):
+    """One batch dict of fp32 tensors on ``device`` (keys of SURVEY.md Appendix B).
+
+    scene (round 6): radiance with object-scale contrast (a coarse lognormal field under the per-pixel one) and path descriptors whose
+    first two bounces CARRY the sample's radiance, as a renderer's throughputs do.  Without it (rounds 1-5) the targets were
+    box-blurred white noise (spatial std 0.05 / 0.16 after the blur) and `paths` pure noise, independent of the image: the
+    path-disentangling loss (losses.py:82-113) then has its optimum at a CONSTANT P-buffer and both PathNets' final ReLUs died
+    within 10 - 40 steps of the benchmark recipe, in every arithmetic and in the oracle (scripts/diag_pbuffer_death.py,
+    profiles/r06_pbuffer_death.txt).  Shapes, keys, ranges and the sparsity of the descriptors are unchanged."""
     dev = torch.device(device)
     g = torch.Generator(device=dev).manual_seed(seed)
     rand = lambda *sh: torch.rand(*sh, generator=g, device=dev)
@@ -37,6 +50,9 @@ def make_batch(b, s, h, seed=0, device="cpu", use_llpm=True):
     albedo = (albedo_gt + 0.05 * randn(b, 3, h, h)).clamp(0, 1)
     rad_d_gt = _blur(torch.exp(randn(b, 3, h, h) - 1.0)) * albedo_gt
     rad_s_gt = _blur(torch.exp(randn(b, 3, h, h) - 2.0))
+    if scene:
+        rad_d_gt = rad_d_gt * torch.exp(1.0 * _objects(randn, b, h))
+        rad_s_gt = rad_s_gt * torch.exp(1.5 * _objects(randn, b, h) + 0.5)
     noise = lambda: torch.exp(0.5 * randn(b, 3, h, h))
     diffuse = rad_d_gt * noise() / (albedo + eps)                 # albedo-factored (datasets.py:546)
     specular = torch.log1p(rad_s_gt * noise())                    # log(1+x)       (datasets.py:550)
@@ -76,6 +92,13 @@ def make_batch(b, s, h, seed=0, device="cpu", use_llpm=True):
         p[:, :, 6:24] = torch.log(rand(b, s, 18, h, h) * alive3 + 1e-6) / 30.0    # floor -0.4605 past the end
         p[:, :, 24:30] = torch.randint(0, 20, (b, s, 6, h, h), generator=g, device=dev).float() / 19.0 * alive
         p[:, :, 30:36] = torch.sqrt(rand(b, s, 6, h, h)) * alive
+        if scene:
+            # the throughputs of the first two bounces carry the sample's radiance (sample noise: lognormal, sigma 1): bounce 0 the
+            # diffuse part, bounce 1 the specular part (where the path is that long; else the floor stays)
+            sd = (rad_d_gt / (albedo_gt + eps)).unsqueeze(1) * torch.exp(randn(b, s, 3, h, h))
+            ss = rad_s_gt.unsqueeze(1) * torch.exp(randn(b, s, 3, h, h))
+            p[:, :, 6:9] = torch.log(sd * alive3[:, :, 0:3] + 1e-6) / 30.0
+            p[:, :, 9:12] = torch.log(ss * alive3[:, :, 3:6] + 1e-6) / 30.0
         batch["paths"] = p
     return {k: v.contiguous().float() for k, v in batch.items()}
 
