@@ -763,13 +763,12 @@ def _pack_chain_x(weights, ks, out_terms=3):
 # interface: a KPCN branch's chain before its PathNet runs) and the chains find their packs here: weight.data_ptr() -> (weight,
 # wp_mode0, wp_mode1, (mode0, mode1), version).  Entries hold the weight alive (so the address stays its own) and are dropped by whoever made them.
 _PREPACK = {}
-PREPACK = os.environ.get("WCMC_PREPACK", "1") != "0"       # A/B switch (scripts/ab_step_switch.py)
 
 
 def prepack_chains(chains, ks):
     """chains: [(weights, output activation)] of the split-bf16 chains with filter size ks that are about to run, in this
     arithmetic; returns a token for ``prepack_release``.  A no-op (None) off the split-bf16 path."""
-    if not PREPACK or not split_path() or not chains or not chains[0][0][0].is_cuda:
+    if not split_path() or not chains or not chains[0][0][0].is_cuda:
         return None
     req, token = [], []
     for weights, act in chains:
