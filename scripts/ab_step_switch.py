@@ -1,0 +1,39 @@
+"""Same-box A/B of a Python-level switch of the captured step: alternating captures with ops.<NAME> = 0 / 1, best of 3 timings each.
+    python3 scripts/ab_step_switch.py PREPACK [rounds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from wcmc_amd import ops
+from wcmc_amd.graph import GraphedTrainStep
+from wcmc_amd.synthetic import make_batch
+
+name = sys.argv[1]
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda", 0)
+res = {False: [], True: []}
+for r in range(rounds):
+    for val in (False, True):
+        setattr(ops, name, val)
+        itf = bench.build_interface(dev, None, rng="device")
+        batch = make_batch(bench.B_PER_GPU, bench.SPP, bench.PATCH, seed=0, device=dev)
+        torch.manual_seed(1234)
+        step = GraphedTrainStep(itf, batch, two_stream=True, defer_check=True)
+        b = step.static
+        ts = []
+        for rep in range(3):
+            for _ in range(5):
+                step(b)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(40):
+                step(b)
+            step.flush()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 40 * 1e3)
+        res[val].append(min(ts))
+        print("round %d  ops.%s = %-5s  %.3f ms per step" % (r, name, val, min(ts)), flush=True)
+        step.close()
+        del step, itf
+print("ops.%s: off %.3f ms (median of %d), on %.3f ms" % (name, sorted(res[False])[len(res[False]) // 2], rounds, sorted(res[True])[len(res[True]) // 2]))

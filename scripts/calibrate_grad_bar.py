@@ -7,7 +7,7 @@ This script runs the test's own comparison (``parity_report``) for several seeds
 keys all move) in the default arithmetic AND in exact fp32 MFMA, and prints the worst tensor of every run: the bar is 2 x the
 largest value seen in the default mode, and the exact-fp32 column shows that the distance is not the split-bf16 arithmetic's.
 
-    python3 scripts/calibrate_grad_bar.py [NSEEDS] > profiles/r05_grad_bar_calibration.txt
+    python3 scripts/calibrate_grad_bar.py [NSEEDS] > profiles/r06_grad_bar_calibration.txt
 """
 import os
 import sys
@@ -25,7 +25,7 @@ if __name__ == "__main__":
     modes = sys.argv[3].split(",") if len(sys.argv) > 3 else None
     import test_gpu_bench_config as t
     from wcmc_amd import ops
-    t.GRAD_L2, t.GRAD_COS = 1.0, 1.0                  # (report only)
+    REPORT_ONLY = (1.0, 1.0)
     print("# worst parameter-gradient tensor of the benchmarked step against the fp32 CPU oracle, two steps, weight-normalised PathNets")
     print("# %-10s %-5s %-10s %-10s %s" % ("arithmetic", "seed", "rel L2", "1 - cos", "tensor"))
     worst = {}
@@ -38,7 +38,7 @@ if __name__ == "__main__":
         ops.set_precision(mode[:-2] if emulate else mode)
         os.environ["WCMC_PRECISION"] = mode[:-2] if emulate else mode           # (the test asserts the mode it was started in)
         for seed in range(first, first + n):
-            report, _ = t.parity_report("device", True, seed=seed)
+            report, _ = t.parity_report("device", True, seed=seed, bars=REPORT_ONLY)
             grads = [r for r in report if " grad " in r[0]]
             e = max(grads, key=lambda r: r[1])
             c = max(grads, key=lambda r: r[2])

@@ -21,7 +21,6 @@ if __name__ == "__main__":
     seeds = [int(s) for s in (sys.argv[1] if len(sys.argv) > 1 else "2,0").split(",")]
     import test_gpu_bench_config as t
     from wcmc_amd import ops
-    t.GRAD_L2, t.GRAD_COS = 1.0, 1.0                  # (report only)
     default = ops.MODES[0]
     fine = len(sys.argv) > 2 and sys.argv[2] == "fine"
     variants = [("1x1 chains layer by layer", default, {}, False),
@@ -53,7 +52,7 @@ if __name__ == "__main__":
             ops.FUSE_EMBED, ops.FUSE_FINAL = (fe and fuse), (ff and fuse)
             try:
                 # (parity_report asserts the default switches; the fused-chain switches are part of what is varied here)
-                report, _ = t.parity_report("device", True, seed=seed, pin_defaults=False)
+                report, _ = t.parity_report("device", True, seed=seed, pin_defaults=False, bars=(1.0, 1.0))
             finally:
                 ops.FUSE_EMBED, ops.FUSE_FINAL = fe, ff
                 ops.TERMS_BY_KS = {}

@@ -756,47 +756,6 @@ def _pack_chain_x(weights, ks, out_terms=3):
     return [(a, b) for a, b, _ in _pack_chains_x([(weights, out_terms)], ks)[0]]
 
 
-# Packs made AHEAD of the chains that use them.  A chain packs its weights in front of its first GEMM: one 12-us launch per chain,
-# 16 per step, each a dependency edge at the head of a chain of GEMMs -- worth 0.69 ms of the 10.75 ms step when removed
-# (profiles/r06_marginal_step_value.txt), 3.6 x their kernel time.  The weights do not change inside a step, so a model packs the
-# chains of a whole sub-network at its entry in one launch (PathNet: the U-Net's five chains, 30 (layer, orientation) pairs; the
-# interface: a KPCN branch's chain before its PathNet runs) and the chains find their packs here: weight.data_ptr() -> (weight,
-# wp_mode0, wp_mode1, (mode0, mode1), version).  Entries hold the weight alive (so the address stays its own) and are dropped by whoever made them.
-_PREPACK = {}
-
-
-def prepack_chains(chains, ks):
-    """chains: [(weights, output activation)] of the split-bf16 chains with filter size ks that are about to run, in this
-    arithmetic; returns a token for ``prepack_release``.  A no-op (None) off the split-bf16 path."""
-    if not split_path() or not chains or not chains[0][0][0].is_cuda:
-        return None
-    req, token = [], []
-    for weights, act in chains:
-        oterms = _chain_out_terms(ks, act, weights[-1].shape[1], weights[-1].shape[0], False)
-        req.append((list(weights), oterms))
-    # (as many launches as PACK_MAX_ENTRIES asks for: one for a U-Net or a KPCN chain)
-    batch, count = [], 0
-    def flush():
-        if batch:
-            for (weights, _), per in zip(batch, _pack_chains_x(batch, ks)):
-                for w, (a, b, modes) in zip(weights, per):
-                    _PREPACK[w.data_ptr()] = (w, a, b, modes, w._version)
-                    token.append(w.data_ptr())
-    for weights, oterms in req:
-        if count + 2 * len(weights) > PACK_MAX_ENTRIES:
-            flush()
-            batch, count = [], 0
-        batch.append((weights, oterms))
-        count += 2 * len(weights)
-    flush()
-    return token
-
-
-def prepack_release(token):
-    for k in token or ():
-        _PREPACK.pop(k, None)
-
-
 def _chain_out_terms(ks, act_last, cin_last, cout_last, pair):
     """MFMAs per product of a chain's output layer's forward (3, 1, or "h": one fp16 MFMA), as _chainx_forward decides it."""
     oterms = 3 if pair else out_layer_terms(ks, act_last)
@@ -1054,14 +1013,9 @@ def _chainx_forward(ctx, xs0, dims0, spec, params, extra_saved=None):
                                               params[2 * nl - 2].shape[0]))
     ctx.terms = chain_terms(ks, dims0[1])          # the backward multiplies as the mode of ITS forward says
     oterms = _chain_out_terms(ks, acts[-1], params[2 * nl - 2].shape[1], params[2 * nl - 2].shape[0], pair)     # ("h": one fp16 MFMA)
-    # the packs: made ahead by the enclosing model (prepack_chains) where that holds for THIS arithmetic, else here in one launch
-    want = [(_fwd_pack_mode(oterms) if l == nl - 1 else 0, _dgrad_mode(chain_terms(ks, dims0[1])[1])) for l in range(nl)]
-    pre = [_PREPACK.get(params[2 * l].data_ptr()) for l in range(nl)]
-    if all(e is not None and e[0].shape == params[2 * l].shape and e[4] == params[2 * l]._version and e[3] == want[l]
-           for l, e in enumerate(pre)):
-        packs = [(e[1], e[2]) for e in pre]
-    else:
-        packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks, oterms) if 2 * nl <= PACK_MAX_ENTRIES else None
+    # (packing every chain of a sub-network AHEAD in one launch -- five U-Net chains, a KPCN branch before its PathNet runs -- was
+    # built and measured in round 6: 10.93 -> 10.96 ms per step, same box, three alternations: the 16 pack launches of a step cost nothing)
+    packs = _pack_chain_x([params[2 * l] for l in range(nl)], ks, oterms) if 2 * nl <= PACK_MAX_ENTRIES else None
     ctx.wp1 = [pk[1] for pk in packs] if packs is not None else None      # the data-gradient orientation, for the backward
     pack0 = (lambda l: packs[l][0]) if packs is not None else (lambda l: _pack_x(params[2 * l], _fwd_pack_mode(oterms) if l == nl - 1 else 0))
     for l in range(nl):

@@ -190,22 +190,17 @@ class KPCNInterface(BaseInterface):
         """One half (``br`` = 'diffuse' | 'specular') of ``_forward_backward``; returns (denoised branch output, its loss scalars)."""
         losses, out_manif = {}, None
         x = batch['kpcn_%s_in' % br]
+        if self.use_llpm_buf:
+            net = self.models['backbone_' + br]
+            net.zero_grad()
+            p = net(batch)
+            out_manif, p_regress = self._split({br: p}, train=True)
+            x = _ops.pbuffer_cat(x, p_regress[br])
         kpcn = self.models['dncnn']
         chain = getattr(kpcn, br)
-        # the KPCN branch's weights are packed (one launch) BEFORE its PathNet runs: nothing in front of the chain's first GEMM
-        token = _ops.prepack_chains([([conv.weight for conv in chain.layers], chain.output_type)], chain.ksize) if x.is_cuda else None
-        try:
-            if self.use_llpm_buf:
-                net = self.models['backbone_' + br]
-                net.zero_grad()
-                p = net(batch)
-                out_manif, p_regress = self._split({br: p}, train=True)
-                x = _ops.pbuffer_cat(x, p_regress[br])
-            for q in chain.parameters():
-                q.grad = None
-            r = kpcn._branch(chain, x, batch['kpcn_%s_buffer' % br])
-        finally:
-            _ops.prepack_release(token)
+        for q in chain.parameters():
+            q.grad = None
+        r = kpcn._branch(chain, x, batch['kpcn_%s_buffer' % br])
         tgt = crop_like(batch['target_' + br], r)
         loss = _l1(self.loss_funcs['l_' + br], r, tgt)
         if self.manif_learn:

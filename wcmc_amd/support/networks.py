@@ -56,18 +56,7 @@ class PathNet(nn.Module):
     def forward(self, samples):
         bs, spp, nf, h, w = samples["paths"].shape
         with weight_norm_scope(self):           # the 20 layers' g * v / ||v|| in one launch (and one for their gradients)
-            # the U-Net's five chains pack their weights (both orientations) in ONE launch here, ahead of everything, instead of one
-            # launch in front of each chain's first GEMM (ops.prepack_chains)
-            chains = getattr(self, "_unet_chains", None)
-            if chains is None:
-                chains = [m for m in self.propagation.modules() if isinstance(m, ConvChain)]
-                object.__setattr__(self, "_unet_chains", chains)
-            token = ops.prepack_chains([([conv.weight for conv in c.layers], c.output_type) for c in chains], 3) \
-                if samples["paths"].is_cuda else None
-            try:
-                flat, reduced = self.embedding.forward_spp_mean(self._paths_nhwc(samples), spp)   # networks.py:33-36
-                propagated = self.propagation(reduced)
-                out = self.final.forward_cat_broadcast(flat, propagated, spp)   # networks.py:39-42, (B*S, outc, H, W)
-            finally:
-                ops.prepack_release(token)
+            flat, reduced = self.embedding.forward_spp_mean(self._paths_nhwc(samples), spp)   # networks.py:33-36
+            propagated = self.propagation(reduced)
+            out = self.final.forward_cat_broadcast(flat, propagated, spp)   # networks.py:39-42, (B*S, outc, H, W)
         return out.unflatten(0, (bs, spp))
