@@ -158,7 +158,10 @@ def test_three_unrestarted_steps_against_the_oracle(precision):
             # Adam's first steps are -lr * sign(g): an entry whose gradient is within rounding of zero may go the other way in two
             # correct implementations (2 lr apart per step); everything else must sit within a fraction of lr
             assert float(d.max()) <= 6.5 * lr, (mn, k, float(d.max()) / lr)
-            assert float((d > 0.5 * lr).float().mean()) <= 0.02 or d.numel() < 50, (mn, k, float((d > 0.5 * lr).float().mean()))
+            # (at most 2 % of a tensor's entries, or five of them: after three sign steps on the round-6 scene patches a 128-entry
+            # bias of the U-Net holds three or four such ties in every split-bf16 mode, none in exact fp32)
+            ties = int((d > 0.5 * lr).sum())
+            assert ties <= max(5, 0.02 * d.numel()), (mn, k, ties, d.numel())
 
 
 def _fixed_points(perm):
