@@ -14,8 +14,7 @@ def timeit(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 n, ks = 8, 3
-VARS = {"old": ("0", "0"), "th8": ("1", "0"), "th16": ("1", "1")}        # WCMC_HALO3, WCMC_HALO3_TH16
-tot = {k: 0.0 for k in VARS}
+tot = {"0": 0.0, "1": 0.0}
 for (cin, cout, h, cnt) in ((64, 64, 128, 10), (128, 128, 64, 8), (256, 256, 32, 4), (192, 64, 128, 1), (384, 128, 64, 1), (64, 128, 64, 1),
                             (128, 256, 32, 1)):
     x = o.to_nhwc_raw(torch.randn(n, cin, h, h, device=dev))
@@ -30,9 +29,8 @@ for (cin, cout, h, cnt) in ((64, 64, 128, 10), (128, 128, 64, 8), (256, 256, 32,
     d3 = lambda: o.conv2d_x_raw(dy, (n, cout, h, h), wp1, None, cin, ks, 1, "linear", out_split=True, gate_mask=mask, gate_act="relu",
                                 colsum=True)
     res = {}
-    for sw, (h3, t16) in VARS.items():
-        os.environ["WCMC_HALO3"] = h3
-        os.environ["WCMC_HALO3_TH16"] = t16
+    for sw in ("0", "1"):
+        os.environ["WCMC_HALO3"] = sw
         yf, mf = f(); y2, c2 = d2(); y3, c3 = d3()
         G = c2.numel() // ((cin + 15) // 16 * 16) if False else None
         res[sw] = dict(tf=timeit(f), t2=timeit(d2), t3=timeit(d3), yf=o.unsplit_debug(yf, n, cout, h, h).clone(), mf=mf.clone(),
@@ -40,11 +38,11 @@ for (cin, cout, h, cnt) in ((64, 64, 128, 10), (128, 128, 64, 8), (256, 256, 32,
                        c2=o.colsum_finish_raw(c2, (n, cin, h, h)).clone() if hasattr(o, "colsum_finish_raw") else None)
         tot[sw] += cnt * (res[sw]["tf"] + res[sw]["t2"])
     rel = lambda a, b: ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
-    a, b_, c_ = res["old"], res["th8"], res["th16"]
+    a, b_ = res["0"], res["1"]
     extra = ""
     if a["c2"] is not None:
-        extra = " colsum %.1e %.1e" % (rel(a["c2"], b_["c2"]), rel(a["c2"], c_["c2"]))
-    print("%3d -> %3d at %3d^2 (x%d): fwd %6.1f | %6.1f | %6.1f us   dgrad(2) %6.1f | %6.1f | %6.1f us   dgrad(3) %6.1f | %6.1f | %6.1f   (old | 8-row tiles | 16-row tiles)  rel diff of the 16-row kernel vs old: fwd %.1e mask %.1e d2 %.1e d3 %.1e%s" % (
-        cin, cout, h, cnt, a["tf"], b_["tf"], c_["tf"], a["t2"], b_["t2"], c_["t2"], a["t3"], b_["t3"], c_["t3"], rel(a["yf"], c_["yf"]),
-        (a["mf"] != c_["mf"]).float().mean().item(), rel(a["y2"], c_["y2"]), rel(a["y3"], c_["y3"]), extra), flush=True)
-print("weighted sum per backbone (fwd + two-term dgrad): old %.3f, 8-row %.3f, 16-row %.3f ms" % (tot["old"] / 1e3, tot["th8"] / 1e3, tot["th16"] / 1e3))
+        extra = " colsum %.1e" % rel(a["c2"], b_["c2"])
+    print("%3d -> %3d at %3d^2 (x%d): fwd %6.1f -> %6.1f us   dgrad(2) %6.1f -> %6.1f us   dgrad(3) %6.1f -> %6.1f   | rel diff fwd %.1e mask %.1e d2 %.1e d3 %.1e%s" % (
+        cin, cout, h, cnt, a["tf"], b_["tf"], a["t2"], b_["t2"], a["t3"], b_["t3"], rel(a["yf"], b_["yf"]),
+        (a["mf"] != b_["mf"]).float().mean().item(), rel(a["y2"], b_["y2"]), rel(a["y3"], b_["y3"]), extra), flush=True)
+print("weighted sum per backbone (fwd + two-term dgrad): %.3f -> %.3f ms" % (tot["0"] / 1e3, tot["1"] / 1e3))

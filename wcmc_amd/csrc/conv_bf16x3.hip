@@ -1369,15 +1369,11 @@ __global__ __launch_bounds__(TH * TW * 2, (TH * TW <= 128 ? 2 : 1)) void conv_ha
 // Stage s of a slab = tap s / SPT, 32-channel quarter s % SPT of the slab's CS = 32 SPT / AP ... channels (pack order k = tap CS + c,
 // as x_plan_k and pack_weight_split_multi_kernel lay it out: the packs are those of the kernel above).
 // DBG (debug library, timing only, WRONG results): 1 no MFMA, 2 no weight DMA in the loop, 8 no fragment reads, 16 no loop barrier, 32 no epilogue
-// TH: tile height -- 8 (two workgroups of 4 KG waves per CU) or 16 (ONE workgroup of 8 KG waves: the same four waves per SIMD, half the
-// weight stream per pixel; where a launch is 256 such tiles, i.e. the U-Net's 64^2 level, whose 18- and 36-iteration loops wait for
-// their weight DMA rather than for the matrix pipe)
-template <int AP, int SPT, int KG = 2, int DBG = 0, int TH = 8>
-__global__ __launch_bounds__(32 * TH * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmParams p) {
+template <int AP, int SPT, int KG = 2, int DBG = 0>
+__global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmParams p) {
   static_assert(KG == 2, "two K groups (h = hc | grp below)");
-  static_assert(TH == 8 || TH == 16, "tile height");
-  constexpr int NT = 4, BN = NT * 16, TW = 16, KS = 3, HWd = TW + KS - 1, HHt = TH + KS - 1, HP = HWd * HHt;   // 18 x 10 (18 x 18) halo
-  constexpr int PG = TH / 2, NTHR = 64 * PG * KG, NWV = PG * KG, TPX = TH * TW, PXB = 256;     // PG pixel groups of two tile rows
+  constexpr int NT = 4, BN = NT * 16, TH = 8, TW = 16, KS = 3, HWd = TW + KS - 1, HHt = TH + KS - 1, HP = HWd * HHt;   // 18 x 10 halo
+  constexpr int NTHR = 256 * KG, NWV = 4 * KG, TPX = TH * TW, PXB = 256;
   constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
   constexpr int ITS = KS * KS * SPT / KG;                 // iterations (stage pairs) per slab: 9 or 18
   static_assert((KS * KS * SPT) % KG == 0, "a slab is a whole number of stage pairs");
@@ -1388,7 +1384,7 @@ __global__ __launch_bounds__(32 * TH * KG, 4) void conv_halo3_bf16x3_kernel(XIge
   u16* const bsm = smem16 + HP * PXB / 2;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pg = wave % PG, grp = wave / PG;              // pixel group (tile rows 2 pg, 2 pg + 1), K group
+  const int pg = wave & 3, grp = wave >> 2;               // pixel group (tile rows 2 pg, 2 pg + 1), K group
   int tile;
   {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -1406,7 +1402,7 @@ __global__ __launch_bounds__(32 * TH * KG, 4) void conv_halo3_bf16x3_kernel(XIge
   // ---- halo: 180 records of 16 units, filled by LDS-DMA as 45 linear kilobytes; wave instruction ii covers pixels 4 ii .. 4 ii + 3,
   // the per-lane SOURCE picks the unit that belongs into the lane's slot.  The source offsets of slab 0 are worked out once; a
   // slab's fill is one addition per instruction.
-  constexpr int NHI = (HP * 16 / 64 + NWV - 1) / NWV;      // 45 instructions over 8 waves (81 over 16): up to 6 each
+  constexpr int NHI = (HP * 16 / 64 + NWV - 1) / NWV;      // 45 instructions over 8 waves: up to 6 each
   static_assert(HP * 16 % 64 == 0, "no tail instruction");
   static_assert(NHI == 6, "hoff");                        // (a literal bound: an array of dependent size captured by the lambda below loses the kernel's host stub, clang 22)
   unsigned hoff[6];
@@ -1433,19 +1429,18 @@ __global__ __launch_bounds__(32 * TH * KG, 4) void conv_halo3_bf16x3_kernel(XIge
     }
   };
 
-  // ---- weights: LDS-DMA, 2 KG stage buffers.  A pair of stages is sixteen 1-KB pieces (stage, row group, plane); with four pixel
-  // groups wave (pg, grp) fetches both planes of row group pg of ITS group's stage, with eight one plane (pg & 1) of row group pg >> 1.
+  // ---- weights: LDS-DMA, 2 KG stage buffers.  A pair of stages is sixteen 1-KB pieces (stage, row group, plane); wave (pg, grp)
+  // fetches both planes of row group pg of ITS group's stage.
   const int nstages = p.Kt / XKC;
-  const int rgp = PG == 4 ? pg : (pg >> 1);
-  const int drow = 16 * rgp + (lane >> 2);
+  const int drow = 16 * pg + (lane >> 2);
   const int dvq = (lane & 3) ^ ((drow >> 1) & 3);
   const unsigned dbase = n0 + drow < p.Np ? (unsigned)(((n0 + drow) * 2 * p.Kt + dvq * 8) * 2) : XOOB;
   const unsigned dbase2 = dbase >= XOOB ? XOOB : dbase + (unsigned)(p.Kt * 2);
   auto dma_b = [&](int g, int buf) {                        // global stage g -> buffer buf (stages past the end: out of range, zeros)
     const unsigned sg = g < nstages ? (unsigned)(g * XKC * 2) : 0x40000000u;
-    u16* d = bsm + buf * B_ELEMS + 16 * rgp * XROW;
-    if (PG == 4 || !(pg & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, dbase + sg, 0, 0, 0);
-    if (PG == 4 || (pg & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, dbase2 + sg, 0, 0, 0);
+    u16* d = bsm + buf * B_ELEMS + 16 * pg * XROW;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)d, 16, dbase + sg, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(d + B_LO), 16, dbase2 + sg, 0, 0, 0);
   };
 
   f32x4 acc[NT][2];
@@ -1583,7 +1578,7 @@ __global__ __launch_bounds__(32 * TH * KG, 4) void conv_halo3_bf16x3_kernel(XIge
   __syncthreads();                                     // LDS is free
   // exchange: a wave parks the two cout tiles its partner (same pixels, other group) finishes, then adds the partner's to its own --
   // always (group 0) + (group 1)
-  constexpr int XOFF = TH == 8 ? 36864 : 73728;        // behind the staging tile (34,816 / 69,632 B) and its column-sum partials
+  constexpr int XOFF = 36864;                          // behind the staging tile (34,816 B) and its column-sum partials
   f32x4* const xch = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem16) + XOFF);
   f32x4 fin[2][2];
   if (grp == 0) {
@@ -1602,12 +1597,12 @@ __global__ __launch_bounds__(32 * TH * KG, 4) void conv_halo3_bf16x3_kernel(XIge
 #pragma unroll
     for (int jl = 0; jl < 2; ++jl)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fin[jl][i] = acc[jl][i] + xch[((wave + PG) * 4 + jl * 2 + i) * 64 + lane];
+      for (int i = 0; i < 2; ++i) fin[jl][i] = acc[jl][i] + xch[((wave ^ 4) * 4 + jl * 2 + i) * 64 + lane];
   } else {
 #pragma unroll
     for (int jl = 0; jl < 2; ++jl)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fin[jl][i] = xch[((wave - PG) * 4 + jl * 2 + i) * 64 + lane] + acc[2 + jl][i];
+      for (int i = 0; i < 2; ++i) fin[jl][i] = xch[((wave ^ 4) * 4 + jl * 2 + i) * 64 + lane] + acc[2 + jl][i];
   }
 
   auto pix_of = [&](int pr, int& oy, int& ox) {
@@ -4074,19 +4069,15 @@ static bool x_halo3_ok(const XIgemmParams& p) {
   if (p.ap == 2) return p.CS == 64 && p.CSl == 64 && p.SPS == 18 && p.SPSl == 18;
   return (p.CS == 64 && p.nslabs == 1 && p.SPSl == 18) || (p.CS == 128 && p.CSl == 128 && p.SPS == 36 && p.SPSl == 36);
 }
-template <int AP, int SPT, int TH>
+template <int AP, int SPT>
 static int launch_xhalo3b(const XIgemmParams& q, hipStream_t stream) {
   constexpr int KG = 2;
-  // 8-row tiles: 79,360 B, two workgroups per CU; 16-row tiles: one (the exchange of the two K groups' sums and the staging tile
-  // of the epilogue are what its size is)
-  const size_t lds_main = (size_t)(TH + 2) * 18 * 256 + (size_t)2 * KG * (2 * 64 * XROW + 64) * sizeof(u16);
-  const size_t lds_epi = (size_t)(TH == 8 ? 36864 : 73728) + (size_t)(TH / 2) * KG * 4 * 64 * 16;
-  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  const size_t lds = (size_t)180 * 256 + (size_t)2 * KG * (2 * 64 * XROW + 64) * sizeof(u16);      // 79,360 B: two workgroups per CU
   static LdsAttr attr;
-  if (set_max_lds(reinterpret_cast<const void*>(&conv_halo3_bf16x3_kernel<AP, SPT, KG, 0, TH>), lds, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
+  if (set_max_lds(reinterpret_cast<const void*>(&conv_halo3_bf16x3_kernel<AP, SPT, KG>), lds, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
   const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)(q.Np / 64));
 #ifdef WCMC_DEBUG_BUILD
-  if (AP == 2 && TH == 8) {               // WCMC_DEBUG_ABLATE=<mask>: timing-only ablations of the forward instance (scripts/time_unet_abl.py)
+  if (AP == 2) {                          // WCMC_DEBUG_ABLATE=<mask>: timing-only ablations of the forward instance (scripts/time_unet_abl.py)
     const char* e = ab_env("WCMC_DEBUG_ABLATE");
     const int ab = e ? atoi(e) : 0;
     if (ab) {
@@ -4100,23 +4091,15 @@ static int launch_xhalo3b(const XIgemmParams& q, hipStream_t stream) {
     }
   }
 #endif
-  hipLaunchKernelGGL((conv_halo3_bf16x3_kernel<AP, SPT, KG, 0, TH>), grid, dim3(32 * TH * KG), lds, stream, q);
+  hipLaunchKernelGGL((conv_halo3_bf16x3_kernel<AP, SPT, KG>), grid, dim3(256 * KG), lds, stream, q);
   return check_launch("conv2d_igemm_bf16x3(halo 3x3, K groups)");
 }
-template <int TH>
-static int launch_xhalo3t(const XIgemmParams& p, hipStream_t stream) {
-  XIgemmParams q = p;
-  q.tilesY = (p.Ho + TH - 1) / TH;
-  q.PXS = 256;
-  if (p.ap == 2) return launch_xhalo3b<2, 2, TH>(q, stream);
-  return p.CS == 128 ? launch_xhalo3b<1, 4, TH>(q, stream) : launch_xhalo3b<1, 2, TH>(q, stream);
-}
 static int launch_xhalo3(const XIgemmParams& p, hipStream_t stream) {
-  // 16-row tiles where the launch is a whole number of rounds of 256 of them (one workgroup per CU): the 64^2 level of the U-Net
-  const int64_t blocks16 = (int64_t)p.N * p.tilesX * ((p.Ho + 15) / 16) * (p.Np / 64);
-  const char* e = ab_env("WCMC_HALO3_TH16");          // (debug build) 0 / 1: never / always
-  const bool th16 = e ? e[0] == '1' : (blocks16 % 256 == 0 && blocks16 <= 768 && p.Ho % 16 == 0);
-  return th16 ? launch_xhalo3t<16>(p, stream) : launch_xhalo3t<8>(p, stream);
+  XIgemmParams q = p;
+  q.tilesY = (p.Ho + 7) / 8;
+  q.PXS = 256;
+  if (p.ap == 2) return launch_xhalo3b<2, 2>(q, stream);
+  return p.CS == 128 ? launch_xhalo3b<1, 4>(q, stream) : launch_xhalo3b<1, 2>(q, stream);
 }
 template <int NT>
 static int launch_xigemm(const XIgemmParams& p, hipStream_t stream) {
