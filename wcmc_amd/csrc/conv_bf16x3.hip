@@ -513,16 +513,20 @@ constexpr unsigned XOOB = 0x80000000u;   // byte offset beyond any buffer (num_r
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// bit e = (bf16 number e of the vector is > 0): the activation-derivative predicate of act_gate on a hi plane
+// bit e = (bf16 number e of the vector is > 0): the activation-derivative predicate of act_gate on a hi plane.
+// A bf16 is positive iff it is positive as an int16; per dword (two of them): max(., 0) of both halves in one packed instruction,
+// "half != 0" as bit 15 of half + 0x7fff (no carry between the halves: a clamped half is at most 0x7fff) -- four vector
+// instructions per pair where the test half by half took ten (the gate masks cost 3 of a U-Net layer's 37 us, profiles/r06_unet_halo3.txt).
+typedef short xs16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned positive_pair(unsigned w) {          // bit 0: low half > 0, bit 16: high half > 0
+  const xs16x2 z = {0, 0};
+  const xs16x2 c = __builtin_elementwise_max(__builtin_bit_cast(xs16x2, w), z);
+  return ((__builtin_bit_cast(unsigned, c) + 0x7fff7fffu) >> 15) & 0x00010001u;
+}
 __device__ __forceinline__ unsigned char positive_mask8(const u32x4 v) {
-  unsigned m = 0;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned lo = v[e] & 0xffffu, hi = v[e] >> 16;
-    m |= (unsigned)((lo & 0x8000u) == 0 && (lo & 0x7fffu) != 0) << (2 * e);
-    m |= (unsigned)((hi & 0x8000u) == 0 && (hi & 0x7fffu) != 0) << (2 * e + 1);
-  }
-  return (unsigned char)m;
+  // pairs e = 0..3 -> bits 2e (low half) and 2e + 1 (high half)
+  const unsigned x = positive_pair(v[0]) | (positive_pair(v[1]) << 2) | (positive_pair(v[2]) << 4) | (positive_pair(v[3]) << 6);
+  return (unsigned char)((x | (x >> 15)) & 0xffu);
 }
 
 // Epilogue of one accumulator quad (4 consecutive couts of one pixel): bias, activation, pixel validity, gate, split --
@@ -1630,16 +1634,27 @@ __global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmPa
     }
     __syncthreads();
     constexpr int VPP = BN / 8;
+    static_assert(TPX * 2 * VPP % NTHR == 0, "every thread takes part in every pass (the mask bytes meet by DPP below)");
+    // (a pixel's eight hi-plane vectors sit in lanes 16 n .. 16 n + 7: four neighbouring lanes put their mask bytes into one word
+    // by two quad permutations and one of them stores it -- 256 four-byte stores per tile instead of 1,024 one-byte ones; the
+    // byte-per-lane form stays for channel counts whose mask rows are not whole words)
+    const bool mask_words = p.mask_out && (p.Cpo & 31) == 0 && !(DBG & 128);
     for (int v = tid; v < TPX * 2 * VPP; v += NTHR) {
       const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
       const int plane = q >= VPP, vec = q - plane * VPP;
       const int co = n0 + vec * 8;
       int oy, ox;
-      if (pix_of(pr, oy, ox) && co < p.Cpo) {
-        const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
-        const u32x4 hv = *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
-        *reinterpret_cast<u32x4*>(p.ys + m * 2 * p.Cpo + plane * p.Cpo + co) = hv;
-        if (p.mask_out && plane == 0) p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
+      const bool ok = pix_of(pr, oy, ox) && co < p.Cpo;
+      const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+      const u32x4 hv = *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
+      if (ok && !(DBG & 64)) *reinterpret_cast<u32x4*>(p.ys + m * 2 * p.Cpo + plane * p.Cpo + co) = hv;      // (DBG & 64 / 128, timing only: no result stores / no gate mask)
+      if (mask_words) {
+        unsigned w = (unsigned)positive_mask8(hv) << (8 * (vec & 3));
+        w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
+        w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xf, 0xf, false);      // quad_perm [2, 3, 0, 1]
+        if (ok && plane == 0 && (vec & 3) == 0) *reinterpret_cast<unsigned*>(p.mask_out + m * (p.Cpo >> 3) + (co >> 3)) = w;
+      } else if (ok && p.mask_out && plane == 0 && !(DBG & 128)) {
+        p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
       }
     }
     if (p.colsum) {
@@ -4084,7 +4099,8 @@ static int launch_xhalo3b(const XIgemmParams& q, hipStream_t stream) {
       auto kfn = ab == 1 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 1> : ab == 2 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 2> : ab == 8 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 8>
                  : ab == 16 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 16> : ab == 32 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 32> : ab == 10 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 10>
                  : ab == 26 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 26> : ab == 27 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 27> : ab == 59 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 59>
-                 : ab == 33 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 33> : ab == 18 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 18> : &conv_halo3_bf16x3_kernel<2, 2, 2, 9>;
+                 : ab == 33 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 33> : ab == 18 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 18> : ab == 64 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 64>
+                 : ab == 128 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 128> : ab == 192 ? &conv_halo3_bf16x3_kernel<2, 2, 2, 192> : &conv_halo3_bf16x3_kernel<2, 2, 2, 9>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kfn, grid, dim3(256 * KG), lds, stream, q);
       return check_launch("conv2d_igemm_bf16x3(halo 3x3, ablation)");
