@@ -1635,10 +1635,14 @@ __global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmPa
     __syncthreads();
     constexpr int VPP = BN / 8;
     static_assert(TPX * 2 * VPP % NTHR == 0, "every thread takes part in every pass (the mask bytes meet by DPP below)");
-    // (a pixel's eight hi-plane vectors sit in lanes 16 n .. 16 n + 7: four neighbouring lanes put their mask bytes into one word
-    // by two quad permutations and one of them stores it -- 256 four-byte stores per tile instead of 1,024 one-byte ones; the
-    // byte-per-lane form stays for channel counts whose mask rows are not whole words)
-    const bool mask_words = p.mask_out && (p.Cpo & 31) == 0 && !(DBG & 128);
+    // The gate mask of the tile (128 pixels x 8 bytes) leaves through LDS as ONE 8-byte store per pixel: a pixel's eight hi-plane
+    // vectors sit in lanes 16 n .. 16 n + 7, four neighbouring lanes put their mask bytes into one word by two quad permutations
+    // and park it; two wave instructions then store the tile's kilobyte.  (Byte stores from the lanes that hold the vectors
+    // were 1,024 per tile in four more store instructions per wave -- and it is the store INSTRUCTIONS the epilogue waits
+    // for: the masks cost 3 of a 64 -> 64 layer's 37 us, profiles/r06_unet_halo3.txt.)  Mask rows that are not whole 8-byte
+    // groups (channel counts off a multiple of 64) keep the byte stores.
+    const bool mask_lds = p.mask_out && (p.Cpo & 63) == 0 && !(DBG & 128);
+    unsigned* const mstage = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(smem16) + XOFF);      // (the exchange area is free again)
     for (int v = tid; v < TPX * 2 * VPP; v += NTHR) {
       const int pr = v / (2 * VPP), q = v - pr * (2 * VPP);
       const int plane = q >= VPP, vec = q - plane * VPP;
@@ -1648,13 +1652,21 @@ __global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmPa
       const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
       const u32x4 hv = *reinterpret_cast<const u32x4*>(so + pr * OLD + plane * BN + vec * 8);
       if (ok && !(DBG & 64)) *reinterpret_cast<u32x4*>(p.ys + m * 2 * p.Cpo + plane * p.Cpo + co) = hv;      // (DBG & 64 / 128, timing only: no result stores / no gate mask)
-      if (mask_words) {
+      if (mask_lds) {
         unsigned w = (unsigned)positive_mask8(hv) << (8 * (vec & 3));
         w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
         w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xf, 0xf, false);      // quad_perm [2, 3, 0, 1]
-        if (ok && plane == 0 && (vec & 3) == 0) *reinterpret_cast<unsigned*>(p.mask_out + m * (p.Cpo >> 3) + (co >> 3)) = w;
+        if (plane == 0 && (vec & 3) == 0) mstage[pr * 2 + (vec >> 2)] = w;
       } else if (ok && p.mask_out && plane == 0 && !(DBG & 128)) {
         p.mask_out[m * (p.Cpo >> 3) + (co >> 3)] = positive_mask8(hv);
+      }
+    }
+    if (mask_lds) {
+      __syncthreads();
+      int oy, ox;
+      if (tid < TPX && pix_of(tid, oy, ox)) {
+        const int64_t m = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
+        *reinterpret_cast<uint2*>(p.mask_out + m * (p.Cpo >> 3) + (n0 >> 3)) = *reinterpret_cast<const uint2*>(mstage + tid * 2);
       }
     }
     if (p.colsum) {
