@@ -3616,7 +3616,8 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks,
       // 64^2 57 -> 36 us, 128 -> 256 at 32^2 32 -> 26; the 64-channel layers are even; WCMC_WGRAD_ROWS_3X3=0: A/B switch back
       // to >= 256 input channels only -- scripts/time_wgrad_unet.py)
       const int wide = x_env_on("WCMC_WGRAD_ROWS_3X3");
-      if (coT % 8 == 0 && ciT % 8 == 0 && (ciT >= 16 || wide)) { tm = 8; nw = 8; }
+      const char* e44 = ab_env("WCMC_WGRAD_44");          // (debug build) 1: 4 x 4 channel tiles per block everywhere
+      if (coT % 8 == 0 && ciT % 8 == 0 && (ciT >= 16 || wide) && !(e44 && e44[0] == '1')) { tm = 8; nw = 8; }
       else if (wide && coT % 4 == 0 && ciT % 4 == 0) { tm = 4; nw = 4; }
     }
     if (tm && nw) {
@@ -3626,10 +3627,13 @@ static XWgradPlan x_plan_wgrad(int N, int Ho, int Wo, int Cout, int Cin, int ks,
       // per CU): at most that many per XCD keeps the launch to one round
       const size_t lds = xwr_lds_bytes_rt(ks, tm, nw, terms == 1 ? 1 : 2);
       int wpc = (int)((160 * 1024) / lds);
-      const int wcap = nw <= 4 ? 2 : 1;               // as the kernel's __launch_bounds__
+      int wcap = nw <= 4 ? 2 : 1;                     // as the kernel's __launch_bounds__
+      { const char* e = ab_env("WCMC_WGRAD_WCAP"); if (e && nw <= 4) wcap = atoi(e); }      // (debug build: scripts/time_wgrad_unet.py)
+      int sdiv = 1;
+      { const char* e = ab_env("WCMC_WGRAD_SDIV"); if (e) sdiv = atoi(e); }                 // (debug build: fewer, longer splits)
       if (wpc > wcap) wpc = wcap;
       if (wpc < 1) wpc = 1;
-      int S = 8 * ((32 * wpc) / ks) / (pl.coBlocks * pl.ciBlocks);
+      int S = 8 * ((32 * wpc) / ks) / (pl.coBlocks * pl.ciBlocks) / sdiv;
       if (S > pl.R / 4) S = pl.R / 4;                 // at least 4 rows per block
       if (S < 1) S = 1;
       pl.rps = (pl.R + S - 1) / S;
