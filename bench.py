@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable)
 _ROWS8_ENV = os.environ.get("WCMC_WGRAD_ROWS8")                 # which filter-row weight-gradient kernel the library launches:
 _rows8 = lambda terms: (_ROWS8_ENV[:1] != "0") if _ROWS8_ENV else terms == 3      # eight waves for three-term launches, seven for one-term ones
 _ROWS8_XE = 0 if os.environ.get("WCMC_WGRAD_ROWS8_XE", "1")[:1] == "0" else 1
-PROFILE_ROUND = "r05"              # profiles/<round>_pmc_summary.json, <round>_bench_kernel_stats.csv: the evidence of THIS binary
+PROFILE_ROUND = "r06"              # profiles/<round>_pmc_summary.json, <round>_bench_kernel_stats.csv: the evidence of THIS binary
 
 
 def rocprof_names(wgrad_terms):
@@ -61,7 +61,7 @@ def rocprof_names(wgrad_terms):
             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)",
             # the fused PathNet chains (csrc/pathnet_fused.hip); the backward brackets include their small finish kernels
             "embed3_fwd": "wcmc::embed3_fwd_kernel", "embed3_bwd": "wcmc::embed3_bwd_kernel",
-            "final2_fwd": "wcmc::final2_kernel<false>", "final2_bwd": "wcmc::final2_kernel<true>"}
+            "final2_fwd": "wcmc::final2w_fwd_kernel", "final2_bwd": "wcmc::final2_kernel<true>"}
 
 
 # bf16 MFMAs issued per algorithmic multiply-add, by profiler class (forward 3; "_x2" data gradients 2; weight gradient: the mode's)
@@ -231,7 +231,8 @@ def pmc_traffic():
                          ("conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>" if _rows8(1) else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, 1>", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("embed3_fwd_kernel", "embed3_fwd"), ("embed3_bwd_kernel", "embed3_bwd"),
-                         ("final2_kernel<false>", "final2_fwd"), ("final2_kernel<true>", "final2_bwd"),
+                         ("final2w_fwd_kernel", "final2_fwd"), ("final2_kernel<true>", "final2_bwd"),
+                         ("conv_halo3_bf16x3_kernel<2, 2, 2, 0>", "conv_halo3"), ("conv_halo3_bf16x3_kernel<1, 2, 2, 0>", "conv_halo3_x2"),
                          ("kernel_apply_strip_kernel<false", "kernel_apply_fwd"), ("kernel_apply_strip_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):
                 shape = ("64x128x128 64->64 1x1 hidden layer (PathNet embedding): 536.9 MB algorithmic" if key == "conv_pw" else
@@ -240,6 +241,7 @@ def pmc_traffic():
                          "8x96x96 100->441 5x5 (the KPCN output layer, 92x92 outputs)" if key.endswith(("_x1", "_h1")) else
                          "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles) and the 100->441 output layer" if key == "conv_halo64_pt3" else
                          "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles)" if key.startswith("conv_halo64_pt3") else
+                         "8x128x128 64->64 3x3, pad 1 (a U-Net layer of the 128^2 level)" if key.startswith("conv_halo3") else
                          "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else "logits (8,441,92,92)")
                 pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "shape": shape,
                              "source": "profiles/%s_pmc_summary.json" % PROFILE_ROUND}

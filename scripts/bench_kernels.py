@@ -36,11 +36,21 @@ for t in pe + pf: t.requires_grad_(True)
 gy = o.to_nhwc_raw(torch.randn(64, 64, 128, 128, device=dev)); gm = o.to_nhwc_raw(torch.randn(8, 64, 128, 128, device=dev))
 prop = o.to_nhwc_raw(torch.randn(8, 64, 128, 128, device=dev)).requires_grad_(True)
 gout = o.to_nhwc_raw(torch.randn(64, 3, 128, 128, device=dev))
+# the U-Net's 3x3 layers (conv_halo3_bf16x3_kernel): 64 -> 64 at 128^2, forward (three terms) and data gradient (two)
+xu = o.split_raw(o.to_nhwc_raw(torch.relu(torch.randn(8, 64, 128, 128, device=dev))))
+wu = torch.randn(64, 64, 3, 3, device=dev) * 0.05
+bu = torch.zeros(64, device=dev)
+wu0, wu2 = o._pack_x(wu, 0), o._pack_x(wu, 2)
+dyu = o.split_raw(o.to_nhwc_raw(torch.randn(8, 64, 128, 128, device=dev)))
+mu = (torch.rand(8 * 128 * 128 * 8, device=dev) * 255).to(torch.uint8)
 def run():
+    o.conv2d_x_raw(xu, (8, 64, 128, 128), wu0, bu, 64, 3, 1, "relu", out_split=True, mask_out=True)                     # conv_halo3<2, 2, 2>
+    o.conv2d_x_raw(dyu, (8, 64, 128, 128), wu2, None, 64, 3, 1, "linear", out_split=True, gate_mask=mu, gate_act="relu",
+                   colsum=True, terms=2)                                                                                 # conv_halo3<1, 2, 2>
     ye, me = o.conv_chain_spp_mean(xe, 8, 1, 0, ["relu", "relu", "linear"], pe)              # embed3_fwd / embed3_bwd
     torch.autograd.backward([ye, me], [gy, gm])
     yl = ye.detach().requires_grad_(True)
-    o.cat_broadcast_chain(yl, prop, 8, 1, 0, ["relu", "relu"], pf).backward(gout)             # final2_kernel<false> / <true>
+    o.cat_broadcast_chain(yl, prop, 8, 1, 0, ["relu", "relu"], pf).backward(gout)             # final2w_fwd_kernel / final2_kernel<true>
     y = o.conv2d_x_raw(xs, (n, c, h, h), wp, b, 100, 5, 0, "relu", out_split=True)          # bf16x3 fwd
     o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu")   # three-term dgrad (bf16x3 mode)
     o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt2, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu", terms=2)   # two-term dgrad, 16x16 tiles

@@ -1,7 +1,7 @@
 # Evidence behind profiles/: the bench lines, the two rocprofv3 kernel-stats runs (graphed, eager) and the PMC passes.
-#   gpurun -- 'bash scripts/refresh_profiles.sh r05'      (then copy the summaries from gpurun_out/<tag>/ into profiles/)
+#   gpurun -- 'bash scripts/refresh_profiles.sh r06'      (then copy the summaries from gpurun_out/<tag>/ into profiles/)
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O/pmc
@@ -29,7 +29,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_eager -- python3
 cd $R
 python3 scripts/trace_gaps.py $O/prof_graph > $O/step_trace_gaps.txt 2>&1
 python3 -m pytest tests/test_gpu_bench_config.py -q -m gpu > $O/bench_config_test.log 2>&1; tail -1 $O/bench_config_test.log
-cp gpurun_out/bench_config_parity_device.txt $O/bench_config_parity_device.txt
+cat gpurun_out/bench_config_parity_device_seed0.txt gpurun_out/bench_config_parity_device_seed1.txt gpurun_out/bench_config_parity_device_seed2.txt > $O/bench_config_parity_device.txt
 set +x
 for i in 1 2 3; do python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['dtype'], d['roofline']['class'], d['roofline']['frac'], 'long', d['value_long']['value'], 'c2', d['c2']['value'], {k: v['value'] for k, v in d['other_precisions'].items()}, 'multi_rank_path', d['multi_rank_path']['value'], d['multi_rank_path']['tail_ms'], 'overlap_allreduce', d['multi_rank_path']['overlap_allreduce']['value'])"; done > $O/bench_runs.txt 2>&1
 set -x
