@@ -653,18 +653,14 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
           a2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            // (the k-slot order of final2w_fwd_kernel's output layer -- slot (q, e) = hidden channel 32 c + 16 (e >> 2) + 4 q + (e & 3) --
-            // so that the out recomputed here, whose sign gates d_out, is the forward's bit for bit)
-            const int o = (16 * wave + fr) * F2_RS + c * 32 + q * 4;
-            const u32x2 ah0 = *reinterpret_cast<const u32x2*>(HH + o), ah1 = *reinterpret_cast<const u32x2*>(HH + o + 16);
-            const u32x2 al0 = *reinterpret_cast<const u32x2*>(HL + o), al1 = *reinterpret_cast<const u32x2*>(HL + o + 16);
-            const u16* wa = W1S + fr * F2_W1RS + c * 32 + q * 4;
-            const u32x2 wh0 = *reinterpret_cast<const u32x2*>(wa), wh1 = *reinterpret_cast<const u32x2*>(wa + 16);
-            const u32x2 wl0 = *reinterpret_cast<const u32x2*>(wa + F2_C), wl1 = *reinterpret_cast<const u32x2*>(wa + F2_C + 16);
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, u32x4{ah0[0], ah0[1], ah1[0], ah1[1]});
-            const bf16x8 al = __builtin_bit_cast(bf16x8, u32x4{al0[0], al0[1], al1[0], al1[1]});
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, u32x4{wh0[0], wh0[1], wh1[0], wh1[1]});
-            const bf16x8 wl = __builtin_bit_cast(bf16x8, u32x4{wl0[0], wl0[1], wl1[0], wl1[1]});
+            // (standard k-slot order: final2w_fwd_kernel's output layer sums the same 128 products per output in another slot
+            // order, so the out recomputed here can differ from the forward's in the last ulp -- its SIGN, which is all that is
+            // used, differs for outputs within an ulp of zero only; reading the tiles in the forward's order costs this kernel
+            // eight more LDS instructions per tile and 16 % of its time: measured, not kept)
+            const int o = (16 * wave + fr) * F2_RS + c * 32 + q * 8;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(HH + o), al = *reinterpret_cast<const bf16x8*>(HL + o);
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(W1S + fr * F2_W1RS + c * 32 + q * 8);
+            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(W1S + fr * F2_W1RS + F2_C + c * 32 + q * 8);
             a2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, a2[0], 0, 0, 0);
             a2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, a2[0], 0, 0, 0);
             a2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, a2[0], 0, 0, 0);
