@@ -1,21 +1,33 @@
-"""Same-box A/B of a Python-level switch of the captured step: alternating captures with ops.<NAME> = 0 / 1, best of 3 timings each.
-    python3 scripts/ab_step_switch.py PREPACK [rounds]"""
+"""Same-box A/B of a switch of the captured step: alternating captures with the switch off / on, best of 3 timings each.
+    python3 scripts/ab_step_switch.py FUSE_FINAL [rounds]          a Python-level switch: ops.<NAME> = False / True
+    python3 scripts/ab_step_switch.py ENV:WCMC_HALO3 [rounds]      a kernel switch of the DEBUG library (read per launch at capture time):
+                                                                   the environment variable = "0" / "1"; loads libwcmc_hip_debug.so"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+name_ = sys.argv[1]
+if name_.startswith("ENV:"):
+    os.environ["WCMC_DEBUG_LIB"] = "1"
 import bench
 from wcmc_amd import ops
 from wcmc_amd.graph import GraphedTrainStep
 from wcmc_amd.synthetic import make_batch
 
 name = sys.argv[1]
+ENV = name.startswith("ENV:")
+if ENV:
+    os.environ["WCMC_DEBUG_LIB"] = "1"
+    name = name[4:]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda", 0)
 res = {False: [], True: []}
 for r in range(rounds):
     for val in (False, True):
-        setattr(ops, name, val)
+        if ENV:
+            os.environ[name] = "1" if val else "0"
+        else:
+            setattr(ops, name, val)
         itf = bench.build_interface(dev, None, rng="device")
         batch = make_batch(bench.B_PER_GPU, bench.SPP, bench.PATCH, seed=0, device=dev)
         torch.manual_seed(1234)
@@ -33,7 +45,7 @@ for r in range(rounds):
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) / 40 * 1e3)
         res[val].append(min(ts))
-        print("round %d  ops.%s = %-5s  %.3f ms per step" % (r, name, val, min(ts)), flush=True)
+        print("round %d  %s = %-5s  %.3f ms per step" % (r, name, val, min(ts)), flush=True)
         step.close()
         del step, itf
-print("ops.%s: off %.3f ms (median of %d), on %.3f ms" % (name, sorted(res[False])[len(res[False]) // 2], rounds, sorted(res[True])[len(res[True]) // 2]))
+print("%s: off %.3f ms (median of %d), on %.3f ms" % (name, sorted(res[False])[len(res[False]) // 2], rounds, sorted(res[True])[len(res[True]) // 2]))
