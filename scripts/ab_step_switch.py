@@ -22,8 +22,10 @@ if ENV:
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda", 0)
 res = {False: [], True: []}
+# (order off-on-on-off per pair of rounds: the chip warms up over the first minute of a process and a fixed order would charge the
+# drift to whichever arm comes second)
 for r in range(rounds):
-    for val in (False, True):
+    for val in ((False, True) if r % 2 == 0 else (True, False)):
         if ENV:
             os.environ[name] = "1" if val else "0"
         else:
@@ -48,4 +50,4 @@ for r in range(rounds):
         print("round %d  %s = %-5s  %.3f ms per step" % (r, name, val, min(ts)), flush=True)
         step.close()
         del step, itf
-print("%s: off %.3f ms (median of %d), on %.3f ms" % (name, sorted(res[False])[len(res[False]) // 2], rounds, sorted(res[True])[len(res[True]) // 2]))
+print("%s: off %.3f ms (mean of %d), on %.3f ms" % (name, sum(res[False]) / len(res[False]), rounds, sum(res[True]) / len(res[True])))
