@@ -1,0 +1,1118 @@
+"""CPU-side checks (no GPU): the C-ABI library builds/loads and exports every declared symbol, the
+host logic of the drop-in interface against the reference goldens (with the device ops swapped for the
+oracle's by monkeypatching -- the product itself has no CPU path), the loud failure without a GPU,
+and the N>1 host path on gloo."""
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_golden as mg  # noqa: E402
+
+from oracle import losses as ol  # noqa: E402
+from oracle.step import assemble_input  # noqa: E402
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _free_port():
+    """A TCP port nobody listens on right now (the gloo rendezvous of the world-2 tests)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from wcmc_amd._lib import SIGNATURES, lib
+    header = open(os.path.join(ROOT, "include", "wcmc_hip.h")).read()
+    declared = set(re.findall(r"\b(wcmc_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(SIGNATURES), declared ^ set(SIGNATURES)
+    h = lib()
+    for name in declared:
+        assert getattr(h, name) is not None
+    assert h.wcmc_abi_version() == 2
+    # pure host-side size queries work without a GPU
+    assert h.wcmc_conv2d_packed_elems(100, 100, 5) == 112 * 2528
+    assert h.wcmc_conv2d_packed_elems(441, 100, 5) == 448 * 2528
+    assert h.wcmc_conv2d_wgrad_workspace_bytes(8, 92, 92, 441, 100, 5) > 0
+    assert h.wcmc_feature_mse_workspace_bytes(8, 8, 3, 92, 92) > 8 * 8 * 92 * 92 * 8
+
+
+def test_header_argument_counts_match_binding():
+    """Each ctypes signature has as many arguments as the prototype in include/wcmc_hip.h."""
+    from wcmc_amd._lib import SIGNATURES
+    header = open(os.path.join(ROOT, "include", "wcmc_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for name, (_, args) in SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, header, flags=re.S)
+        assert m, name
+        body = m.group(1).strip()
+        n = 0 if body in ("", "void") else len(body.split(","))
+        assert n == len(args), (name, n, len(args))
+
+
+def test_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Every entry point validates before it launches: negative status + a message in wcmc_last_error(), no abort,
+    no exception across the ABI (include/wcmc_hip.h contract).  Argument checks precede any HIP call, so this runs
+    on the CPU-only box."""
+    import ctypes
+    from wcmc_amd import _lib
+    L = _lib.lib()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)          # a non-null, 16-byte aligned address that is never dereferenced by the checks
+    cases = {
+        "wcmc_preprocess_llpm": (null, 10, 104, 5, one, null),
+        "wcmc_preprocess_kpcn": (one, 4, 4, 2, 50, 5, one, one, 1 << 20, null),          # too few raw channels
+        "wcmc_gradients": (one, 0, 4, 3, one, null),
+        "wcmc_cat_broadcast_split": (one, 64, 16, 4, one, 64, 16, 4, one, 1, 2, 4, 4, 12, 8, null),   # C1 % 8 != 0
+        "wcmc_add_broadcast_split": (null, 0, 0, 0, null, 0, 0, 0, 1.0, one, 1, 2, 4, 4, 8, null),   # both gradients null
+        "wcmc_conv2d_igemm_bf16x3": (one, 1, 8, 8, 8, one, null, null, 0, 0, 0, null, 8, 3, 1, 0, 0.0,
+                                     null, 0, 0.0, null, null, null, 3, null),            # neither y nor y_split
+        "wcmc_conv2d_wgrad_bf16x3": (one, 1, 8, 8, 8, one, 8, 3, 1, one, null, one, 1 << 20, 0, null, 2, null),   # terms must be 3 or 1
+        "wcmc_clip_adam": (null, one, one, one, 4, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, null, null),
+        # no fused instance for 100 -> 128 -> 3 channels
+        "wcmc_conv1x1_pair_bf16x3": (one, 1, 8, 8, 100, one, null, 128, 1, 0.0, one, null, null, 0, 0.0, null, one, null, 3,
+                                     1, 0.0, one, 256, 32, 4, null),
+        "wcmc_sample_cat_fwd": (one, 1, 1, 1, 1, 1, one, 1, 1, 1, 1, 1, one, 2, 1, 4, 3, 8, 8, null),     # S = 1: no variance
+        "wcmc_assemble_kpcn_patches": (one, null, one, one, 2, 16, 16, 0, 32, one, one, one, one, one, null, one, one, one,
+                                       null),                                                      # patch larger than the image
+    }
+    for name, args in cases.items():
+        rc = getattr(L, name)(*args)
+        assert rc < 0, name
+        msg = L.wcmc_last_error().decode()
+        assert msg and name.replace("wcmc_", "").split("_bf16x3")[0].split("_fwd")[0][:8] in msg.replace("conv2d_", "conv2d_"), (name, msg)
+    assert L.wcmc_preprocess_kpcn_workspace_bytes(0, 4) == 0 and L.wcmc_preprocess_kpcn_workspace_bytes(4, 4) == (2 * 16 + 4) * 4
+    assert L.wcmc_abi_version() >= 1
+    # which 1x1 layer pairs have a fused instance is a pure host-side question
+    assert L.wcmc_conv1x1_pair_supported(128, 128, 3) and L.wcmc_conv1x1_pair_supported(3, 128, 128)
+    assert L.wcmc_conv1x1_pair_supported(64, 64, 64) and not L.wcmc_conv1x1_pair_supported(36, 64, 64)
+    assert not L.wcmc_conv1x1_pair_supported(128, 128, 8)
+
+
+def test_ops_fail_loudly_without_gpu():
+    from wcmc_amd import KPCN, ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.conv_chain(torch.zeros(1, 4, 8, 8), 3, 1, ["relu"], [torch.zeros(4, 4, 3, 3), torch.zeros(4)])
+    m = KPCN(11, ksize=5, depth=2, width=8)
+    batch = {k: torch.zeros(1, c, 16, 16) for k, c in (("kpcn_diffuse_in", 11), ("kpcn_specular_in", 11),
+             ("kpcn_diffuse_buffer", 3), ("kpcn_specular_buffer", 3), ("kpcn_albedo", 3))}
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(batch)
+    from wcmc_amd.support.losses import FeatureMSE, GlobalRelativeSimilarityLoss
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FeatureMSE()(torch.zeros(1, 2, 3, 4, 4), torch.zeros(1, 3, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        GlobalRelativeSimilarityLoss()(torch.zeros(1, 2, 3, 4, 4), torch.zeros(1, 3, 4, 4))
+
+
+def test_product_never_imports_oracle():
+    import subprocess
+    out = subprocess.run(["grep", "-rn", "-E", r"^\s*(from|import)\s+oracle", os.path.join(ROOT, "wcmc_amd")],
+                         capture_output=True, text=True).stdout
+    assert out == "", out
+
+
+def test_crop_like_product_matches_golden(golden_dir):
+    from wcmc_amd.support.utils import crop_like
+    d = np.load(os.path.join(golden_dir, "crop_like.npz"))
+    for i in range(int(d["n"])):
+        ss, ts = tuple(d["src_shape_%d" % i]), tuple(d["tgt_shape_%d" % i])
+        src = torch.arange(int(np.prod(ss)), dtype=torch.float32).view(ss)
+        assert np.array_equal(crop_like(src, torch.zeros(ts)).numpy(), d["out_%d" % i])
+
+
+class _OracleOps:
+    """Stand-in for wcmc_amd.ops inside the interface (host-logic test only)."""
+
+    @staticmethod
+    def pbuffer_cat(base, p):
+        return assemble_input(base, p)
+
+    @staticmethod
+    def sample_features_cat(features, p):                     # interfaces.py:394-403 spelled out
+        s = p.shape[1]
+        p_var = p.var(1).mean(1, keepdims=True) / s
+        return torch.cat([features, p, torch.stack([p_var] * s, axis=1).detach()], 2)
+
+    @staticmethod
+    def join_all_streams(device):
+        pass
+
+    @staticmethod
+    def fork_all_streams(device):
+        pass
+
+    class on_branch:                     # stream fork/join is a no-op on the host
+        def __init__(self, device):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def join(self, *tensors):
+            pass
+
+
+class _OracleFeatureMSE(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.last_perms = None
+
+    def forward(self, p, ref):
+        b, s, c, h, w = p.shape
+        ip, ib = torch.randperm(s * h * w), torch.randperm(b * s * h * w)
+        self.last_perms = (ip, ib)
+        return ol.feature_mse(p, ref, ip, ib)
+
+
+@pytest.mark.parametrize("case", list(mg.INTERFACE_CASES))
+def test_interface_host_logic_against_reference_golden(golden_dir, case, monkeypatch):
+    """wcmc_amd.support.interfaces.KPCNInterface orchestration (splits, loss bookkeeping incl. the
+    in-place logging quirk, clip, Adam, validation, summaries) == the real reference interface."""
+    from wcmc_amd.support import interfaces as itf_mod
+    monkeypatch.setattr(itf_mod, "_ops", _OracleOps)
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    use_llpm, manif, tb, option, pout = mg.INTERFACE_CASES[case]
+    models = mg.build_models(case, 0)
+    for mn, m in models.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+          "l_test": ol.RelativeMSE()}
+    if manif:
+        lf["l_manif"] = _OracleFeatureMSE()
+    itf = itf_mod.KPCNInterface(models, optims, lf, types.SimpleNamespace(model_name="g"), use_llpm_buf=use_llpm,
+                                manif_learn=manif, w_manif=0.1, train_branches=tb, disentanglement_option=option)
+    assert str(itf) == "KPCNInterface" and itf.best_err == 1e10 and itf.iters == 0
+    itf.iters = 1
+    batch = {k[len("batch/"):]: T(d[k]) for k in d.files if k.startswith("batch/")}
+    itf.to_train_mode()
+    torch.manual_seed(int(d["seed"]))
+    itf.preprocess(batch)
+    assert itf.iters == 2
+    itf.train_batch(batch)
+    assert set("m_losses/" + k for k in itf.m_losses) == set(k for k in d.files if k.startswith("m_losses/")) - {"m_losses/m_val"}
+    for k, v in itf.m_losses.items():
+        np.testing.assert_allclose(v.item(), d["m_losses/" + k], rtol=2e-5, err_msg=k)
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            np.testing.assert_allclose(p.grad.numpy(), d["grad/%s/%s" % (mn, k)], rtol=1e-4, atol=1e-7)
+    itf.to_eval_mode()
+    with torch.no_grad():
+        rad, pb = itf.validate_batch(batch)
+    np.testing.assert_allclose(rad.numpy(), d["val/radiance"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(itf.get_epoch_summary("eval", 1), d["val/summary"], rtol=1e-5)
+    assert itf.get_epoch_summary("train", 1) == -1.0
+    assert all(float(v) == 0.0 for k, v in itf.m_losses.items() if k != "m_val")
+
+
+@pytest.mark.parametrize("case", list(mg.VARIANT_CASES))
+def test_ref_and_pre_interfaces_host_logic_against_reference_golden(golden_dir, case, monkeypatch):
+    """KPCNRefInterface / KPCNPreInterface == the real reference classes: which models
+    train, clip and step in each phase, batch assembly, loss keys, validation."""
+    from wcmc_amd.support import interfaces as itf_mod
+    monkeypatch.setattr(itf_mod, "_ops", _OracleOps)
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    kind, manif, tb = mg.VARIANT_CASES[case]
+    models = mg.build_variant_models(case, 0)
+    for mn, m in models.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    lf = {"l_diffuse": torch.nn.L1Loss(), "l_specular": torch.nn.L1Loss(), "l_recon": torch.nn.L1Loss(),
+          "l_test": ol.RelativeMSE()}
+    if manif:
+        lf["l_manif"] = _OracleFeatureMSE()
+    args = types.SimpleNamespace(model_name="g")
+    if kind == "KPCNRefInterface":
+        itf = itf_mod.KPCNRefInterface(models, optims, lf, args, train_branches=tb)
+        with pytest.raises(AssertionError):
+            itf_mod.KPCNRefInterface(models, optims, lf, args, use_llpm_buf=True)
+    else:
+        itf = itf_mod.KPCNPreInterface(models, optims, lf, args, manif_learn=manif, w_manif=0.1, train_branches=tb)
+        assert itf.use_llpm_buf
+    assert str(itf) == kind
+    itf.iters = 1
+    batch = {k[len("batch/"):]: T(d[k]) for k in d.files if k.startswith("batch/")}
+    itf.to_train_mode()
+    assert [int(m.training) for m in models.values()] == list(d["train_flags"])
+    torch.manual_seed(int(d["seed"]))
+    itf.preprocess(batch)
+    itf.train_batch(batch)
+    assert set("m_losses/" + k for k in itf.m_losses) == set(k for k in d.files if k.startswith("m_losses/")) - {"m_losses/m_val"}
+    for k, v in itf.m_losses.items():
+        np.testing.assert_allclose(v.item(), d["m_losses/" + k], rtol=2e-5, err_msg=k)
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            want = d["grad/%s/%s" % (mn, k)]
+            if want.size == 0:
+                assert p.grad is None, (mn, k)         # the pre-training phase never touches KPCN
+            else:
+                np.testing.assert_allclose(p.grad.numpy(), want, rtol=1e-4, atol=1e-7, err_msg="%s %s" % (mn, k))
+        for k, v in m.state_dict().items():
+            # (Adam's first step is lr * g / (|g| + 1e-8): ill-conditioned where |g| ~ eps, as in tests/test_oracle_golden.py)
+            g = np.abs(d["grad/%s/%s" % (mn, k)])
+            want, got = d["after/%s/%s" % (mn, k)], v.numpy()
+            big = g > 1e-5 if g.size else np.zeros(want.shape, bool)
+            np.testing.assert_allclose(got[big], want[big], rtol=1e-4, atol=2e-6, err_msg="after %s %s" % (mn, k))
+            np.testing.assert_allclose(got[~big], want[~big], atol=4.1e-3, err_msg="after %s %s" % (mn, k))
+    itf.to_eval_mode()
+    with torch.no_grad():
+        rad, pb = itf.validate_batch(batch)
+    np.testing.assert_allclose(rad.numpy(), d["val/radiance"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(itf.get_epoch_summary("eval", 1), d["val/summary"], rtol=1e-5)
+    assert (pb is None) == ("val/p_diffuse" not in d.files)
+
+
+@pytest.mark.parametrize("case", list(mg.SAMPLE_CASES))
+def test_sbmc_and_lbmc_interfaces_host_logic_against_reference_golden(golden_dir, case, monkeypatch):
+    """SBMCInterface / LBMCInterface == the real reference classes around a stand-in for the
+    external base denoiser: disentanglement slicing, per-sample feature assembly, loss keys (incl. the reference's
+    aliased l_recon == l_total), gradient-norm clamp 1000 / 250, Adam step, validation."""
+    from wcmc_amd.support import interfaces as itf_mod
+    monkeypatch.setattr(itf_mod, "_ops", _OracleOps)
+    d = np.load(os.path.join(golden_dir, "interface_%s.npz" % case))
+    kind, use_llpm, manif, option, pout, recon, nfeat = mg.SAMPLE_CASES[case]
+    models = mg.build_sample_models(case, 0)
+    for mn, m in models.items():
+        m.load_state_dict({k[len("init/%s/" % mn):]: T(d[k]) for k in d.files if k.startswith("init/%s/" % mn)})
+    optims = {"optim_" + mn: torch.optim.Adam(m.parameters(), lr=1e-3 if mn == "dncnn" else 2e-3)
+              for mn, m in models.items()}
+    lf = {"l_recon": torch.nn.L1Loss() if recon == "L1Loss" else getattr(ol, recon)(), "l_test": ol.RelativeMSE()}
+    if manif:
+        lf["l_manif"] = _OracleFeatureMSE()
+    args = types.SimpleNamespace(model_name="g")
+    cls = getattr(itf_mod, kind)
+    kw = dict(use_llpm_buf=use_llpm, manif_learn=manif, w_manif=0.1, disentangle=option)
+    itf = cls(models, optims, lf, args, **kw)
+    assert str(itf) == kind and itf.GRAD_NORM_CLIP == (1000.0 if kind == "SBMCInterface" else 250.0)
+    with pytest.raises(AssertionError):
+        cls(models, optims, lf, args, disentangle="m00r00")
+    with pytest.raises(AssertionError):
+        cls({k: v for k, v in models.items() if k != "dncnn"}, optims, lf, args)
+    itf.iters = 1
+    batch = {k[len("batch/"):]: T(d[k]) for k in d.files if k.startswith("batch/")}
+    with pytest.raises(AssertionError):
+        itf.preprocess({k: v for k, v in batch.items() if k != "radiance"})
+    itf.iters = 1
+    itf.to_train_mode()
+    torch.manual_seed(int(d["seed"]))
+    itf.preprocess(batch)
+    itf.train_batch(batch)
+    if manif:
+        assert np.array_equal(lf["l_manif"].last_perms[0].numpy(), d["perm/patch"])
+    assert set("m_losses/" + k for k in itf.m_losses) == set(k for k in d.files if k.startswith("m_losses/")) - {"m_losses/m_val"}
+    for k, v in itf.m_losses.items():
+        np.testing.assert_allclose(v.item(), d["m_losses/" + k], rtol=2e-5, err_msg=k)
+    for mn, m in models.items():
+        for k, p in m.named_parameters():
+            np.testing.assert_allclose(p.grad.numpy(), d["grad/%s/%s" % (mn, k)], rtol=2e-4, atol=1e-7, err_msg="%s %s" % (mn, k))
+        norm = float(torch.sqrt(sum((p.grad ** 2).sum() for p in m.parameters())))
+        np.testing.assert_allclose(norm, d["gradnorm/" + mn], rtol=1e-4)
+        for k, v in m.state_dict().items():
+            # (Adam's first step is lr * g / (|g| + 1e-8): ill-conditioned where |g| ~ eps, as in tests/test_oracle_golden.py)
+            g = np.abs(d["grad/%s/%s" % (mn, k)])
+            want, got = d["after/%s/%s" % (mn, k)], v.numpy()
+            big = g > 1e-5 if g.size else np.zeros(want.shape, bool)
+            np.testing.assert_allclose(got[big], want[big], rtol=1e-4, atol=2e-6, err_msg="after %s %s" % (mn, k))
+            np.testing.assert_allclose(got[~big], want[~big], atol=4.1e-3, err_msg="after %s %s" % (mn, k))
+    if case.endswith("clipped"):
+        np.testing.assert_allclose(float(d["gradnorm/dncnn"]), itf.GRAD_NORM_CLIP, rtol=1e-5)     # the clamp did bite
+    itf.to_eval_mode()
+    with torch.no_grad():
+        out, pb = itf.validate_batch(batch)
+    np.testing.assert_allclose(out.numpy(), d["val/out"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(itf.get_epoch_summary("eval", 1), d["val/summary"], rtol=1e-5)
+    assert (pb is None) == ("val/p_buffer" not in d.files)
+    if pb is not None:
+        np.testing.assert_allclose(pb.numpy(), d["val/p_buffer"], rtol=1e-4, atol=1e-6)
+    assert itf.get_epoch_summary("train", 1) == -1.0
+
+
+def test_checkpoint_format_round_trip_and_reference_layouts(tmp_path):
+    """SURVEY.md 8f rank 4, train_kpcn.py:106-124 (save) / :240-296 (load): the dict keys, the pickled optimiser
+    objects, the DataParallel prefix fallback, the older `params` location of the optimisers, the learning-rate
+    override."""
+    from wcmc_amd.support import checkpoint as ck_mod
+    from oracle.networks import PathNet
+
+    def build(seed):
+        torch.manual_seed(seed)
+        models = {"dncnn": torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.ReLU(), torch.nn.Conv2d(4, 3, 3)),
+                  "backbone_diffuse": PathNet(36, intermc=4, outc=3)}
+        optims = {"optim_" + n: torch.optim.Adam(m.parameters(), lr=1e-3 if n == "dncnn" else 2e-3) for n, m in models.items()}
+        return models, optims
+
+    models, optims = build(1)
+    for n, m in models.items():                                  # two Adam steps so that the moments are non-trivial
+        for _ in range(2):
+            optims["optim_" + n].zero_grad()
+            sum((p ** 2).sum() for p in m.parameters()).backward()
+            optims["optim_" + n].step()
+    itf = types.SimpleNamespace(models=models, optims=optims, best_err=0.125)
+    args = types.SimpleNamespace(desc="unit", model_name="m", lr_dncnn=1e-3)
+    path = str(tmp_path / "weights" / "latest_m.pth")
+    ck_mod.save_checkpoint(path, itf, epoch=4, args=args, params={"vis": object, "batch_size": 8})
+    ck = ck_mod.load_checkpoint(path)
+    assert set(ck) == {"description", "start_epoch", "model", "params", "optims", "args", "best_err",
+                       "state_dict_dncnn", "state_dict_backbone_diffuse",                    # train_kpcn.py:110-121
+                       "wcmc_precision"}                                                     # + this build's one extra key
+    assert ck["start_epoch"] == 5 and ck["model"] == str(models["dncnn"]) and ck["params"]["vis"] is None
+    assert ck["description"] == "unit" and ck["args"].model_name == "m" and ck["params"]["batch_size"] == 8
+
+    def same(a, b):
+        return all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))
+
+    m2, o2 = build(2)
+    assert not same(m2["dncnn"], models["dncnn"])
+    assert ck_mod.restore_models(ck, m2) == (5, 0.125)
+    assert all(same(m2[n], models[n]) for n in models)
+    logs = []
+    ck_mod.restore_optims(ck, o2, {"optim_dncnn": 5e-4, "optim_backbone_diffuse": 7e-4}, log=logs.append)
+    assert o2["optim_dncnn"].param_groups[0]["lr"] == 5e-4 and len(logs) == 2               # command line wins
+    for n in models:
+        a, b = optims["optim_" + n].state_dict()["state"], o2["optim_" + n].state_dict()["state"]
+        assert a.keys() == b.keys() and all(torch.equal(a[k]["exp_avg_sq"], b[k]["exp_avg_sq"]) and a[k]["step"] == b[k]["step"] for k in a)
+    ck_mod.restore_optims(ck, o2, {"optim_dncnn": 5e-4, "optim_backbone_diffuse": 7e-4}, lr_ckpt=True, log=logs.append)
+    assert o2["optim_dncnn"].param_groups[0]["lr"] == 1e-3                                  # --lr_ckpt keeps the stored one
+    # a file saved from inside nn.DataParallel ('module.' prefix) and with the optimisers under `params` (older layout)
+    old = {k: v for k, v in ck.items() if k != "optims"}
+    old["state_dict_dncnn"] = {"module." + k: v for k, v in ck["state_dict_dncnn"].items()}
+    old["params"] = dict(ck["params"], optim_dncnn=optims["optim_dncnn"])
+    m3, o3 = build(3)
+    ck_mod.restore_models(old, m3)
+    assert same(m3["dncnn"], models["dncnn"])
+    logs.clear()
+    ck_mod.restore_optims(old, o3, {"optim_dncnn": 1e-3, "optim_backbone_diffuse": 2e-3}, log=logs.append)
+    assert any("No state for the optimizer for backbone_diffuse" in l for l in logs)
+    assert len(o3["optim_dncnn"].state_dict()["state"]) > 0 and len(o3["optim_backbone_diffuse"].state_dict()["state"]) == 0
+    # the conv arithmetic of the run travels with the file; a resume under another one says so, a reference file is silent
+    from wcmc_amd import ops
+    assert ck["wcmc_precision"] == ops.PRECISION
+    logs.clear()
+    assert ck_mod.precision_note(ck, log=logs.append) == ops.PRECISION and not logs
+    assert ck_mod.precision_note(dict(ck, wcmc_precision="bf16x3" if ops.PRECISION != "bf16x3" else "fp32"), log=logs.append) is not None
+    assert len(logs) == 1 and "conv arithmetic" in logs[0]
+    logs.clear()
+    assert ck_mod.precision_note(old if "wcmc_precision" not in old else {}, log=logs.append) in (None, ops.PRECISION)
+
+
+def test_tiled_inference_stitches_every_pixel_once():
+    """Rank-4 host logic (test_models.py:49-101, datasets.py:1276-1299): with a network that returns the centre
+    crop of its input, the stitched image equals the input wherever tiles own pixels from their valid interior,
+    and replicate-padded values on the outer ring."""
+    from wcmc_amd.support import inference as inf
+    H, W, P, PAD = 192, 256, 128, 32
+    coords = inf.tile_coords(H, W, P, PAD)
+    assert len(coords) == ((H - 2 * PAD) // (P - 2 * PAD)) * ((W - 2 * PAD) // (P - 2 * PAD))
+    cover = torch.zeros(H, W)
+    for i0, j0, i1, j1, i, j in coords:
+        cover[i0:i1, j0:j1] += 1
+    assert torch.equal(cover, torch.ones(H, W))                 # a partition of the image
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(3, H, W, generator=g)
+    pbuf = torch.rand(2, 4, H, W, generator=g)
+
+    class FakeItf:
+        def to_eval_mode(self):
+            self.eval_called = True
+
+        def validate_batch(self, batch):
+            x = batch["kpcn_diffuse_buffer"]                    # (B,3,128,128) -> valid 5x5 x9 geometry: 92x92
+            return x[..., 18:110, 18:110], {"diffuse": batch["p"], "specular": batch["p"] * 2}
+
+    def loader():
+        for k in range(0, len(coords), 2):
+            cs = coords[k:k + 2]
+            batch = {"kpcn_diffuse_buffer": torch.stack([img[:, c[4]:c[4] + P, c[5]:c[5] + P] for c in cs]),
+                     "p": torch.stack([pbuf[:, :, c[4]:c[4] + P, c[5]:c[5] + P] for c in cs])}
+            yield (batch, *[torch.tensor([c[q] for c in cs]) for q in range(6)])
+
+    itf = FakeItf()
+    rad, path = inf.inference(itf, loader(), H, W, P)
+    assert itf.eval_called
+    inner = (slice(None), slice(18, H - 18), slice(18, W - 18))
+    assert torch.equal(rad[inner], img[inner])                  # interior pixels come straight from the network
+    assert torch.equal(rad[:, 0, 40], img[:, 18, 40])           # outer ring: replicate padding of the 92x92 output
+    assert torch.equal(path["diffuse"], pbuf) and torch.equal(path["specular"], pbuf * 2)
+    hit = (torch.rand(H, W, 1, generator=g) > 0.3).float()
+    noisy = torch.rand(H, W, 3, generator=g)
+    comp = inf.crop_and_composite(rad.permute(1, 2, 0), noisy, hit)
+    assert comp.shape == (H - 56, W - 56, 3)
+    want = torch.where(hit[28:-28, 28:-28] == 0, noisy[28:-28, 28:-28], rad.permute(1, 2, 0)[28:-28, 28:-28])
+    assert torch.equal(comp, want)
+
+
+def test_eight_host_reader_pools_share_one_hosts_cores():
+    """SURVEY 8f rank 3 / VERDICT r3 item 9: the reference reads through ``DataLoader`` workers (``train_kpcn.py:177-188``); here
+    every rank runs a ``HostReaderPool`` (``workers`` reader / staging threads, results in order).  Eight of them -- one per
+    rank of an 8-GPU node -- side by side on this host's cores: every image arrives once, in order, intact; reads overlap
+    (the wall time is well under the serial sum of the readers' I/O waits); a reader error surfaces in the consumer; an
+    abandoned iteration leaves no thread behind."""
+    import threading
+    import time
+    from wcmc_amd.support.loader import HostReaderPool
+    H, W, S, C, NIMG, WAIT = 16, 16, 2, 104, 6, 0.03
+
+    def make_reader(rank):
+        def reader(i):
+            time.sleep(WAIT)                                           # the file read (releases the interpreter lock, as I/O does)
+            raw = np.full((H, W, S, C), 1000.0 * rank + i, dtype=np.float32)
+            return {"raw": raw, "gt": np.full((H, W, 9), -float(i), dtype=np.float32), "prob": None}
+        return reader
+
+    results, errors = {}, []
+
+    def consume(rank):
+        try:
+            pool = HostReaderPool(make_reader(rank), range(NIMG), workers=2, depth=2, pin=False)
+            got = []
+            for slot, prob, nbytes in pool:
+                got.append((float(slot["raw"][0, 0, 0, 0]), float(slot["gt"][0, 0, 0]), nbytes))
+                pool.release(slot)
+            results[rank] = got
+        except BaseException as exc:
+            errors.append(exc)
+
+    before = threading.active_count()
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=consume, args=(r,)) for r in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    wall = time.perf_counter() - t0
+    assert not errors and sorted(results) == list(range(8))
+    for rank, got in results.items():
+        assert [g[0] for g in got] == [1000.0 * rank + i for i in range(NIMG)], (rank, got)      # once each, in order
+        assert [g[1] for g in got] == [-float(i) for i in range(NIMG)]
+        assert all(g[2] == (H * W * S * C + H * W * 9) * 4 for g in got)
+    assert wall < 0.6 * 8 * NIMG * WAIT, "the pools' reads did not overlap: %.2f s for %.2f s of I/O waits" % (wall, 8 * NIMG * WAIT)
+    assert wall < 1.2 * NIMG * WAIT, "two workers per pool should halve a pool's own I/O wait: %.2f s" % wall
+    # a reader error reaches the consumer
+    def bad(i):
+        if i == 2:
+            raise OSError("disk on fire")
+        return make_reader(0)(i)
+    pool = HostReaderPool(bad, range(5), workers=2, depth=2, pin=False)
+    seen = []
+    with pytest.raises(OSError, match="disk on fire"):
+        for slot, _, _ in pool:
+            seen.append(float(slot["raw"][0, 0, 0, 0]))
+            pool.release(slot)
+    assert seen == [0.0, 1.0]
+    # an abandoned iteration: the generator's close() stops the workers
+    pool = HostReaderPool(make_reader(0), range(50), workers=2, depth=2, pin=False)
+    it = iter(pool)
+    next(it)
+    it.close()
+    deadline = time.time() + 5
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() <= before, "reader threads left behind"
+
+
+def test_interface_asserts_like_reference():
+    from wcmc_amd.support.interfaces import KPCNInterface
+    lf = {"l_recon": None, "l_test": None}
+    with pytest.raises(AssertionError, match="dncnn"):
+        KPCNInterface({}, {}, lf, None, train_branches=False)
+    with pytest.raises(AssertionError, match="backbone_diffuse"):
+        KPCNInterface({"dncnn": None}, {}, dict(lf, l_manif=None), None, manif_learn=True, train_branches=False)
+    with pytest.raises(AssertionError):
+        KPCNInterface({"dncnn": None}, {}, lf, None, train_branches=False, disentanglement_option="m00r00")
+    itf = KPCNInterface({"dncnn": torch.nn.Linear(1, 1)}, {}, lf, None, train_branches=False)
+    with pytest.raises(AssertionError, match="optim_dncnn"):
+        itf.to_train_mode()
+    with pytest.raises(AssertionError):
+        itf.preprocess({"target_total": 0})
+
+
+def test_synthetic_batch_schema():
+    from wcmc_amd.synthetic import LOG_FLOOR, make_batch
+    b = make_batch(2, 4, 32, seed=3)
+    shapes = {"kpcn_diffuse_in": (2, 35, 32, 32), "kpcn_specular_in": (2, 35, 32, 32),
+              "kpcn_diffuse_buffer": (2, 3, 32, 32), "kpcn_specular_buffer": (2, 3, 32, 32),
+              "kpcn_albedo": (2, 3, 32, 32), "target_diffuse": (2, 3, 32, 32), "target_specular": (2, 3, 32, 32),
+              "target_total": (2, 3, 32, 32), "paths": (2, 4, 36, 32, 32)}
+    assert {k: tuple(v.shape) for k, v in b.items()} == shapes
+    assert all(v.dtype == torch.float32 and torch.isfinite(v).all() for v in b.values())
+    assert torch.equal(b["kpcn_diffuse_in"][:, :3], b["kpcn_diffuse_buffer"])          # datasets.py:1082
+    assert (b["kpcn_diffuse_in"][:, 4:7, :, 0] == 0).all()                             # zero first dx column
+    thr = b["paths"][:, :, 6:24]
+    assert (thr >= LOG_FLOOR - 1e-6).all() and (thr == thr.min()).float().mean() > 0.2  # sparse descriptors
+    assert torch.equal(make_batch(2, 4, 32, seed=3)["paths"], b["paths"])              # seeded
+    assert "paths" not in make_batch(1, 2, 16, use_llpm=False) and make_batch(1, 2, 16, use_llpm=False)["kpcn_diffuse_in"].shape[1] == 34
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from wcmc_amd import distributed as wd
+    r, w, _ = wd.init("gloo")
+    torch.manual_seed(100 + rank)
+    models = {"dncnn": torch.nn.Linear(4, 3), "backbone_diffuse": torch.nn.Linear(2, 2)}
+    wd.broadcast_parameters(models)
+    w0 = torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()]).clone()
+    for i, m in enumerate(models.values()):
+        for p in m.parameters():
+            p.grad = torch.full_like(p, float(rank + 1 + i))
+    wd.average_gradients(models)
+    g = torch.cat([p.grad.reshape(-1) for m in models.values() for p in m.parameters()])
+    t = wd.max_over_ranks(float(rank), torch.device("cpu"))
+    q.put((rank, w0.tolist(), g.tolist(), t, wd.shard_seed(7, rank)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_average_and_broadcast():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, w0, g0, t0, s0), (r1, w1, g1, t1, s1) = res
+    assert w0 == w1                                     # rank 0's weights everywhere
+    assert g0 == g1                                     # same averaged gradient on both ranks
+    assert set(g0) == {1.5, 2.5}                        # mean of (1,2) and of (2,3)
+    assert t0 == t1 == 1.0                              # MAX over ranks
+    assert (s0, s1) == (7, 8)                           # disjoint data shards
+
+
+def _emulated_clip_adam(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0,
+                        guard=None):
+    """torch emulation of the wcmc_clip_adam kernel's contract (csrc/optim.hip) for the host-logic test: scale, clip
+    (NaN-propagating), Adam; no-op when the device guard is 0."""
+    import math
+    if guard is not None and float(guard) == 0.0:
+        return
+    grad.mul_(grad_scale).clamp_(-clip, clip)
+    m.mul_(beta1).add_(grad, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    param.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+
+def _fused_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from wcmc_amd import distributed as wd
+    from wcmc_amd import ops, optim as wo
+    wd.init("gloo")
+    ops.clip_adam_ = _emulated_clip_adam
+
+    def build():
+        torch.manual_seed(5)                                  # same weights on both ranks
+        # parameter sizes that are not multiples of 4 floats (441-style biases): exercises the aligned flat layout
+        models = {"dncnn": torch.nn.Linear(7, 3), "backbone_diffuse": torch.nn.Linear(5, 2),
+                  "backbone_specular": torch.nn.Linear(3, 3)}
+        optims = {"optim_" + n: torch.optim.Adam(m.parameters(), lr=1e-2) for n, m in models.items()}
+        return models, optims
+
+    def grads_for(models, r, step):
+        g = torch.Generator().manual_seed(1000 * step + r)
+        return {n: [torch.randn(p.shape, generator=g) * 1.5 for p in m.parameters()] for n, m in models.items()}
+
+    models, optims = build()
+    fused = wo.FusedClipAdam(models, optims, process_group=dist.group.WORLD)
+    assert list(fused.flats) == ["backbone_diffuse", "dncnn", "backbone_specular"]      # backward order
+    ref_models, ref_optims = build()
+    log = {}
+    for step in (1, 2):
+        mine = grads_for(models, rank, step)
+        for n, m in models.items():
+            for p, g in zip(m.parameters(), mine[n]):
+                p.grad = g.clone()
+        gg = fused.step(models, optims, guard=torch.tensor(1.0))
+        assert float(gg) == 1.0
+        # reference: nn.DataParallel sums the replicas' gradients (train_kpcn.py:266-269) -> mean -> clip_grad_value_
+        # (interfaces.py:260-261) -> Adam
+        both = [grads_for(models, r, step) for r in range(world)]
+        for n, m in ref_models.items():
+            for i, p in enumerate(m.parameters()):
+                p.grad = sum(b[n][i] for b in both) / world
+            torch.nn.utils.clip_grad_value_(m.parameters(), 1.0)
+            ref_optims["optim_" + n].step()
+    log["params"] = max(float((p - q).abs().max()) for n in models
+                        for p, q in zip(models[n].parameters(), ref_models[n].parameters()))
+    log["grads_left"] = max(float((p.grad - q.grad).abs().max()) for n in models
+                            for p, q in zip(models[n].parameters(), ref_models[n].parameters()))
+    # clip-then-average would differ: make sure this test could tell
+    both = [grads_for(models, r, 2) for r in range(world)]
+    wrong = sum(b["dncnn"][0].clamp(-1, 1) for b in both) / world
+    log["order_matters"] = float((wrong - ref_models["dncnn"].weight.grad).abs().max())
+    log["state_step"] = float(optims["optim_dncnn"].state[models["dncnn"].weight]["step"])
+    # one rank sees a non-finite loss: EVERY rank skips the update, rolls the counters back
+    before = torch.cat([p.detach().reshape(-1).clone() for m in models.values() for p in m.parameters()])
+    for n, m in models.items():
+        for p in m.parameters():
+            p.grad = torch.ones_like(p)
+    gg = fused.step(models, optims, guard=torch.tensor(0.0 if rank == 1 else 1.0))
+    log["global_guard"] = float(gg)
+    if float(gg) == 0.0:
+        fused.rollback()
+    after = torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()])
+    log["skipped"] = bool(torch.equal(before, after))
+    log["steps_after_rollback"] = [fl.steps for fl in fused.flats.values()]
+    # a parameter without a gradient is skipped like torch.optim.Adam skips it (no moment decay, no update)
+    for n, m in models.items():
+        for p in m.parameters():
+            p.grad = torch.full_like(p, 0.25 * (rank + 1))
+    models["dncnn"].bias.grad = None
+    ref_b = models["dncnn"].bias.detach().clone()
+    ref_m = optims["optim_dncnn"].state[models["dncnn"].bias]["exp_avg"].clone()
+    fused.step(models, optims, guard=torch.tensor(1.0))
+    log["none_grad_skipped"] = bool(torch.equal(models["dncnn"].bias.detach(), ref_b) and
+                                    torch.equal(optims["optim_dncnn"].state[models["dncnn"].bias]["exp_avg"], ref_m))
+    log["weight_moved"] = float((models["dncnn"].weight.detach() - ref_models["dncnn"].weight.detach()).abs().max())
+    # ... and keeps its OWN Adam step count: when it rejoins, its bias correction is that of torch.optim.Adam,
+    # which counts per parameter -- checked against a torch Adam fed the same (rank-averaged, clipped) gradients
+    tw = torch.nn.Linear(7, 3)
+    with torch.no_grad():
+        tw.weight.copy_(models["dncnn"].weight); tw.bias.copy_(models["dncnn"].bias)
+    topt = torch.optim.Adam(tw.parameters(), lr=1e-2)
+    st = optims["optim_dncnn"].state
+    for p_t, p_f in ((tw.weight, models["dncnn"].weight), (tw.bias, models["dncnn"].bias)):
+        topt.state[p_t] = {"step": torch.tensor(float(st[p_f]["step"])), "exp_avg": st[p_f]["exp_avg"].clone(),
+                           "exp_avg_sq": st[p_f]["exp_avg_sq"].clone()}
+    log["steps_diverged"] = [float(st[models["dncnn"].weight]["step"]), float(st[models["dncnn"].bias]["step"])]
+    for n, m in models.items():
+        for p in m.parameters():
+            p.grad = torch.full_like(p, 0.125 * (rank + 1))
+    mean = sum(0.125 * (r + 1) for r in range(world)) / world
+    tw.weight.grad = torch.full_like(tw.weight, mean)
+    tw.bias.grad = torch.full_like(tw.bias, mean)
+    fused.step(models, optims, guard=torch.tensor(1.0))
+    topt.step()
+    log["rejoin"] = max(float((tw.weight.detach() - models["dncnn"].weight.detach()).abs().max()),
+                        float((tw.bias.detach() - models["dncnn"].bias.detach()).abs().max()))
+    q.put((rank, log))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_fused_clip_adam_reduce_then_scale_then_clip():
+    """The multi-rank path bench.py runs (FusedClipAdam(process_group=...)): per-bucket async all-reduce (sum),
+    grad_scale = 1/world inside the kernel, clip AFTER the mean, Adam; the non-finite guard reduced over the ranks;
+    parameters without a gradient skipped.  The kernel is replaced by a torch emulation of its contract (no GPU here)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        log = res[rank]
+        assert log["params"] <= 1e-6 and log["grads_left"] <= 1e-6, log
+        assert log["order_matters"] > 1e-2, log
+        assert log["state_step"] == 2.0
+        assert log["global_guard"] == 0.0 and log["skipped"] and log["steps_after_rollback"] == [2, 2, 2], log
+        assert log["none_grad_skipped"] and log["weight_moved"] > 1e-4, log
+        assert log["steps_diverged"] == [3.0, 2.0] and log["rejoin"] <= 1e-6, log
+
+
+def test_fused_clip_adam_adopts_an_optimizer_state_loaded_after_construction(monkeypatch):
+    """``optim.load_state_dict()`` AFTER ``FusedClipAdam`` was built brings fresh state dicts with 'step' tensors of
+    their own; the next step must adopt them (moments AND step counts) and keep ``optim.state_dict()`` current -- a checkpoint
+    written afterwards must carry step N + 1, and a rolled-back step N.  The kernel is emulated (no GPU here)."""
+    import copy
+    from wcmc_amd import ops, optim as wo
+    monkeypatch.setattr(ops, "clip_adam_", _emulated_clip_adam)
+
+    def build():
+        torch.manual_seed(5)
+        models = {"dncnn": torch.nn.Linear(7, 3), "backbone_diffuse": torch.nn.Linear(5, 2)}
+        optims = {"optim_" + n: torch.optim.Adam(m.parameters(), lr=1e-2) for n, m in models.items()}
+        return models, optims
+
+    def set_grads(models, step):
+        g = torch.Generator().manual_seed(step)
+        for m in models.values():
+            for p in m.parameters():
+                p.grad = torch.randn(p.shape, generator=g)
+
+    models, optims = build()
+    fused = wo.FusedClipAdam(models, optims)
+    for step in (1, 2):
+        set_grads(models, step)
+        fused.step(models, optims)
+    saved_w = {n: copy.deepcopy(m.state_dict()) for n, m in models.items()}
+    saved_o = {n: copy.deepcopy(o.state_dict()) for n, o in optims.items()}
+    assert all(float(st["step"]) == 2.0 for o in saved_o.values() for st in o["state"].values())
+
+    models2, optims2 = build()
+    for n, m in models2.items():
+        m.load_state_dict(saved_w[n])
+    fused2 = wo.FusedClipAdam(models2, optims2)              # built first (as init_model does) ...
+    for n, o in optims2.items():
+        o.load_state_dict(saved_o[n])                        # ... state loaded afterwards
+    for ms, os_, f in ((models, optims, fused), (models2, optims2, fused2)):
+        set_grads(ms, 3)
+        f.step(ms, os_)
+    for n in models:
+        for p, q in zip(models[n].parameters(), models2[n].parameters()):
+            assert torch.equal(p.detach(), q.detach()), n
+    for n, o in optims2.items():
+        sd = o.state_dict()
+        assert [float(st["step"]) for st in sd["state"].values()] == [3.0] * len(sd["state"]), (n, sd["state"])
+        for st, st_ref in zip(sd["state"].values(), optims[n].state_dict()["state"].values()):
+            assert torch.equal(st["exp_avg"], st_ref["exp_avg"]) and torch.equal(st["exp_avg_sq"], st_ref["exp_avg_sq"])
+    fused2.rollback()
+    assert all(float(st["step"]) == 2.0 for o in optims2.values() for st in o.state_dict()["state"].values())
+    # a model whose parameters do not share one step count: every 'step' tensor follows its own parameter
+    set_grads(models2, 4)
+    models2["dncnn"].bias.grad = None
+    fused2.step(models2, optims2)
+    st = optims2["optim_dncnn"].state
+    assert (float(st[models2["dncnn"].weight]["step"]), float(st[models2["dncnn"].bias]["step"])) == (3.0, 2.0)
+    fused2.rollback()
+    assert (float(st[models2["dncnn"].weight]["step"]), float(st[models2["dncnn"].bias]["step"])) == (2.0, 2.0)
+
+
+def _global_pairing_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from wcmc_amd import distributed as wd
+    from wcmc_amd import ops
+    from wcmc_amd.support.losses import FeatureMSE
+    wd.init("gloo")
+    ops.feature_mse = lambda p, ref, ip, ib: ol.feature_mse(p, ref, ip, ib)      # the HIP op's contract, on the CPU (no GPU here)
+    b, s, c, h, w = 2, 3, 4, 6, 5
+    g = torch.Generator().manual_seed(77)
+    p_all = torch.rand(world * b, s, c, h, w, generator=g)
+    ref_all = torch.rand(world * b, 3, h, w, generator=g) * 2
+    out = {}
+    for mode in ("cpu", "explicit"):
+        fm = FeatureMSE(non_local=True, rng="cpu", pairing="global", process_group=dist.group.WORLD)
+        mine = p_all[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        torch.manual_seed(100 + rank)               # DIFFERENT generators per rank: the pairing must still be one for all (rank 0's)
+        perms = None
+        if mode == "explicit":
+            gp = torch.Generator().manual_seed(5)
+            perms = (torch.randperm(s * h * w, generator=gp), torch.randperm(world * b * s * h * w, generator=gp))
+        loss = fm(mine, ref_all[rank * b:(rank + 1) * b], perms=perms)
+        loss.backward()
+        # what the ranks' gradient MEAN makes of it (FusedClipAdam / average_gradients divide the sum by world)
+        full = torch.zeros_like(p_all)
+        full[rank * b:(rank + 1) * b] = mine.grad
+        dist.all_reduce(full)
+        # (numpy: pickled by value -- a torch tensor travels through the queue as a shared-memory handle that dies with this process)
+        out[mode] = dict(loss=loss.item(), grad=(full / world).numpy().copy(), ip=fm.last_perms[0].numpy().copy(),
+                         ib=fm.last_perms[1].numpy().copy())
+    # local pairing (the default) never communicates and pairs inside the rank's rows
+    fl = FeatureMSE(non_local=True, rng="cpu")
+    torch.manual_seed(9)
+    out["local"] = fl(p_all[rank * b:(rank + 1) * b], ref_all[rank * b:(rank + 1) * b]).item()
+    out["local_rows"] = int(fl.last_perms[1].numel())
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_feature_mse_global_pairing_equals_the_single_process_loss_of_the_gathered_batch():
+    """SURVEY 8e option (b) / VERDICT round 2: ``FeatureMSE(pairing='global')`` evaluates the reference's DataParallel
+    semantics -- the intra-batch permutation spans the GATHERED global batch (``support/losses.py:48-61``;
+    ``train_kpcn.py:266-269``) -- across one process per GPU: loss value = the single-process loss of the concatenated batch
+    with the same permutations, and the rank-mean of the gradients = its gradient, row for row.  One pairing for all ranks
+    (rank 0's draw) although the ranks' generators differ."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_global_pairing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b, s, c, h, w = 2, 3, 4, 6, 5
+    g = torch.Generator().manual_seed(77)
+    p_all = torch.rand(world * b, s, c, h, w, generator=g).requires_grad_(True)
+    ref_all = torch.rand(world * b, 3, h, w, generator=g) * 2
+    for mode in ("cpu", "explicit"):
+        ip, ib = torch.from_numpy(res[0][mode]["ip"]), torch.from_numpy(res[0][mode]["ib"])
+        assert np.array_equal(res[0][mode]["ip"], res[1][mode]["ip"]) and np.array_equal(res[0][mode]["ib"], res[1][mode]["ib"])
+        assert ib.numel() == world * b * s * h * w and torch.equal(torch.sort(ib).values, torch.arange(ib.numel()))
+        p_all.grad = None
+        want = ol.feature_mse(p_all, ref_all, ip, ib)
+        want.backward()
+        for r in range(world):
+            np.testing.assert_allclose(res[r][mode]["loss"], want.item(), rtol=1e-6)
+            np.testing.assert_allclose(res[r][mode]["grad"], p_all.grad.numpy(), rtol=1e-5, atol=1e-9)
+    torch.manual_seed(100)                     # rank 0's generator: its draw is the one every rank used
+    assert np.array_equal(res[1]["cpu"]["ip"], torch.randperm(s * h * w).numpy())
+    assert res[0]["local_rows"] == b * s * h * w and res[0]["local"] != res[1]["local"]
+
+
+def test_launcher_flag_surface_and_argument_errors():
+    """wcmc_amd.train_kpcn: the reference's flags (train_kpcn.py:376-425 + BasicArgumentParser, support/utils.py:69-100)
+    with their defaults, and its argument errors (train_kpcn.py:427-441)."""
+    from wcmc_amd import train_kpcn as tk
+    p = tk.build_parser()
+    a = p.parse_args(["--desc", "d"])
+    want = dict(model_name="tSUNet", data_dir="./data", visual=False, batch_size=64, num_epoch=100, val_epoch=1, start_epoch=0,
+                save="./weights", lr_dncnn=1e-4, lr_pnet=[0.0001], lr_ckpt=False, best_err=None, pnet_out_size=[3],
+                manif_loss=None, train_branches=False, use_llpm_buf=False, manif_learn=False, w_manif=[0.1],
+                disentangle="m11r11", single_gpu=False, device_id=0, kpcn_ref=False, kpcn_pre=False, not_save=False, local=False)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    # this build's own switches are off unless asked for
+    assert not a.graph and a.defer_check and not a.one_graph and not a.overlap_allreduce and a.pairing_rng == "cpu"
+    assert p.parse_args(["--desc", "d", "--graph", "--overlap_allreduce"]).overlap_allreduce
+    with pytest.raises(SystemExit):
+        p.parse_args([])                                                     # --desc is required
+    full = "--single_gpu --batch_size 8 --val_epoch 1 --data_dir /d --model_name M --desc x --num_epoch 8 --manif_loss FMSE " \
+           "--lr_dncnn 1e-4 --lr_pnet 1e-4 --use_llpm_buf --manif_learn --w_manif 0.1 --train_branches"
+    b = tk.check_args(p.parse_args(full.split()))                            # the README's KPCN-Manifold command line
+    assert b.batch_size == 8 and b.manif_loss == "FMSE" and b.train_branches and b.w_manif == [0.1]
+    for bad, msg in ((["--manif_learn"], "requires a llpm-specific buffer"),
+                     (["--manif_learn", "--use_llpm_buf"], "requires a manifold loss"),
+                     (["--manif_loss", "FMSE"], "not necessary"),
+                     (["--manif_learn", "--use_llpm_buf", "--manif_loss", "XYZ"], "either `FMSE` or `GRS`"),
+                     (["--disentangle", "m00r00"], "Argument `disentangle`"),
+                     (["--disentangle", "m10r01", "--pnet_out_size", "3"], "even numbers")):
+        with pytest.raises(RuntimeError, match=msg):
+            tk.check_args(p.parse_args(["--desc", "d"] + bad))
+
+
+class _CountingSched:                    # (module level: the loop pickles `params`, schedulers included, into its checkpoints)
+    n = 0
+
+    def step(self):
+        _CountingSched.n += 1
+
+
+def test_training_loop_checkpoints_latest_every_epoch_and_best_on_improvement(tmp_path):
+    """``train`` (train_kpcn.py:87-161) around a stand-in interface: interface calls per batch, ``latest_<name>.pth`` after
+    every epoch, validation every ``val_epoch`` epochs, ``<name>.pth`` only when the validation error improves, ``best_err``
+    carried in the file, the scheduler stepped once per epoch."""
+    from wcmc_amd import train_kpcn as tk
+    from wcmc_amd.support import checkpoint as ck_mod
+    errs = iter([0.5, 0.7, 0.2])                                            # validation errors of epochs 1, 3, 5
+    calls = []
+
+    class Itf:
+        def __init__(self):
+            self.models = {"dncnn": torch.nn.Linear(2, 2)}
+            self.optims = {"optim_dncnn": torch.optim.Adam(self.models["dncnn"].parameters(), lr=1e-3)}
+            self.best_err = 1e10
+
+        def to_train_mode(self): calls.append("train_mode")
+        def to_eval_mode(self): calls.append("eval_mode")
+        def preprocess(self, b): calls.append("pre")
+        def train_batch(self, b): calls.append("step")
+        def validate_batch(self, b): calls.append("val")
+
+        def get_epoch_summary(self, mode, norm):
+            calls.append((mode, norm))
+            return -1.0 if mode == "train" else next(errs)
+
+    Sched = _CountingSched
+    Sched.n = 0
+    itf = Itf()
+    args = types.SimpleNamespace(desc="t", model_name="m", start_epoch=0, num_epoch=6, val_epoch=2, visual=False,
+                                 not_save=False, save=str(tmp_path), graph=False)
+    loaders = {"train": [{"x": torch.zeros(1)}] * 3, "val": [{"x": torch.zeros(1)}] * 2}
+    params = {"data_device": "cpu", "sched_a": Sched()}
+    saved = []
+    orig = ck_mod.save_checkpoint
+    ck_mod.save_checkpoint = lambda path, *a, **k: (saved.append((os.path.basename(path), a[1], a[0].best_err)), orig(path, *a, **k))
+    try:
+        tk.train([itf], loaders, params, args)
+    finally:
+        ck_mod.save_checkpoint = orig
+    assert calls.count("step") == 18 and calls.count("pre") == 18 and calls.count("val") == 6
+    assert calls.count(("train", 3)) == 6 and calls.count(("eval", 2)) == 3
+    assert [s for s in saved if s[0] == "latest_m.pth"] == [("latest_m.pth", e, b) for e, b in
+                                                            zip(range(6), [1e10, 1e10, 0.5, 0.5, 0.5, 0.5])]
+    assert [s for s in saved if s[0] == "m.pth"] == [("m.pth", 1, 0.5), ("m.pth", 5, 0.2)]      # 0.7 did not improve
+    assert itf.best_err == 0.2 and Sched.n == 6
+    ck = ck_mod.load_checkpoint(str(tmp_path / "m.pth"))
+    assert ck["start_epoch"] == 6 and ck["best_err"] == 0.2 and ck["description"] == "t"
+    with pytest.raises(NotImplementedError):
+        tk.train([itf, itf], loaders, params, args)
+
+
+def test_init_model_restores_weight_normalised_pathnets_from_a_checkpoint(tmp_path):
+    """``init_model`` always built ``PathNet(weight_norm=False)``, so a checkpoint trained with upstream sbmc's
+    ConvChain default (``weight_g`` / ``weight_v`` per PathNet layer) could not be resumed.  The parametrisation is now a flag
+    (``--pathnet_weight_norm``) and is detected from the checkpoint on ``--start_epoch != 0``."""
+    from wcmc_amd import KPCN
+    from wcmc_amd import train_kpcn as tk
+    from wcmc_amd.support import checkpoint as ck_mod
+    from wcmc_amd.support.networks import PathNet
+    torch.manual_seed(3)
+    models = {"dncnn": KPCN(39), "backbone_diffuse": PathNet(36, outc=3, weight_norm=True),
+              "backbone_specular": PathNet(36, outc=3, weight_norm=True)}
+    assert any(k.endswith("weight_g") for k in models["backbone_diffuse"].state_dict())
+    itf = types.SimpleNamespace(models=models, best_err=0.25,
+                                optims={"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in models.items()})
+    argv = ["--desc", "d", "--model_name", "wn", "--save", str(tmp_path), "--use_llpm_buf", "--manif_learn", "--manif_loss", "FMSE",
+            "--train_branches", "--start_epoch", "1", "--best_err", "0.25", "--single_gpu"]
+    args = tk.check_args(tk.build_parser().parse_args(argv))
+    ck_mod.save_checkpoint(str(tmp_path / "wn.pth"), itf, 0, args)
+    sizes = {"dncnn_in_size": 34 + 5, "pnet_in_size": 36, "pnet_out_size": 3}
+    itfs, _ = tk.init_model(sizes, args, torch.device("cpu"))
+    got = itfs[0].models
+    for name in models:
+        sd_w, sd_g = models[name].state_dict(), got[name].state_dict()
+        assert list(sd_w) == list(sd_g), name
+        for k in sd_w:
+            assert torch.equal(sd_w[k], sd_g[k].cpu()), (name, k)
+    # a fresh start follows the flag (default: upstream's weight-normalised PathNets)
+    fresh = ["--desc", "d", "--save", str(tmp_path), "--use_llpm_buf", "--manif_learn", "--manif_loss", "FMSE", "--train_branches",
+             "--single_gpu"]
+    args0 = tk.check_args(tk.build_parser().parse_args(fresh + ["--model_name", "fresh"]))
+    m0 = tk.init_model(sizes, args0, torch.device("cpu"))[0][0].models["backbone_diffuse"]
+    assert any(k.endswith("weight_g") for k in m0.state_dict())
+    args1 = tk.check_args(tk.build_parser().parse_args(fresh + ["--model_name", "fresh1", "--no_pathnet_weight_norm"]))
+    m1 = tk.init_model(sizes, args1, torch.device("cpu"))[0][0].models["backbone_diffuse"]
+    assert not any(k.endswith("weight_g") for k in m1.state_dict())
+    # ... and a checkpoint of the plain parametrisation (this build's rounds 1-4) is restored as such whatever the flag says
+    plain = {"dncnn": KPCN(39), "backbone_diffuse": PathNet(36, outc=3, weight_norm=False),
+             "backbone_specular": PathNet(36, outc=3, weight_norm=False)}
+    itf_p = types.SimpleNamespace(models=plain, best_err=0.25,
+                                  optims={"optim_" + k: torch.optim.Adam(m.parameters(), lr=1e-4) for k, m in plain.items()})
+    argv_p = [a if a != "wn" else "plain" for a in argv]
+    args_p = tk.check_args(tk.build_parser().parse_args(argv_p))
+    ck_mod.save_checkpoint(str(tmp_path / "plain.pth"), itf_p, 0, args_p)
+    got_p = tk.init_model(sizes, args_p, torch.device("cpu"))[0][0].models
+    assert list(got_p["backbone_diffuse"].state_dict()) == list(plain["backbone_diffuse"].state_dict())
+
+
+def test_frozen_parameter_names_and_state_dict_round_trip():
+    """Specification choices that checkpoints depend on (oracle/modules.py docstring): parameter names of the chains
+    (``layers.<i>.weight|bias``; ``weight_g`` / ``weight_v`` with the explicit ``weight_norm=True`` option), module paths of
+    PathNet / KPCN, and that oracle and product state dicts are interchangeable in both parametrisations."""
+    from oracle.models import KPCN as OKPCN
+    from oracle.networks import PathNet as OPathNet
+    from wcmc_amd import KPCN
+    from wcmc_amd.support.networks import PathNet
+    ok, hk = OKPCN(34, depth=3, width=8), KPCN(34, depth=3, width=8)
+    assert list(ok.state_dict()) == list(hk.state_dict()) == [
+        "%s.layers.%d.%s" % (br, i, w) for br in ("diffuse", "specular") for i in range(3) for w in ("weight", "bias")]
+    hk.load_state_dict(ok.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(ok.state_dict().values(), hk.state_dict().values()))
+    op, hp = OPathNet(36, intermc=8, weight_norm=False), PathNet(36, intermc=8, weight_norm=False)
+    names = list(op.state_dict())
+    assert names == list(hp.state_dict())
+    assert names[:6] == ["embedding.layers.%d.%s" % (i, w) for i in range(3) for w in ("weight", "bias")]
+    assert "propagation.net.next_level.next_level.left.layers.2.bias" in names and names[-1] == "final.layers.1.bias"
+    assert op.propagation.net.right.layers[0].weight.shape == (8, 16 + 8, 3, 3)       # cat([upsampled deeper (16), skip (8)])
+    hp.load_state_dict(op.state_dict())
+    # the default: weight-normalised chains, torch.nn.utils.weight_norm's parameter names
+    on, hn = OPathNet(36, intermc=8), PathNet(36, intermc=8)
+    assert on.embedding.weight_norm and hn.embedding.weight_norm and hn.propagation.net.left.weight_norm and hn.final.weight_norm
+    wn = list(hn.state_dict())
+    assert set(wn) == set(on.state_dict()) and "embedding.layers.0.weight_g" in wn and "final.layers.1.weight_v" in wn
+    assert not any(k.endswith(".weight") for k in wn)
+    hn.load_state_dict(on.state_dict())
+    back = OPathNet(36, intermc=8)
+    back.load_state_dict(hn.state_dict())
+    x = {"paths": torch.rand(1, 2, 36, 8, 8)}
+    assert torch.equal(back(x), on(x))
+    # at initialisation g = ||v||: the effective weight is v, i.e. the un-normalised network
+    lay = hn.embedding.layers[0]
+    assert torch.allclose(lay.weight_g.flatten(), lay.weight_v.flatten(1).norm(dim=1), rtol=1e-6, atol=1e-7)
+    # the effective weight is formed by the HIP library only: no CPU path
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        lay.weight
+
+
+def test_bench_roofline_names_match_the_committed_profiles():
+    """The bench line's `traffic` and rocprof kernel names come from string tags (bench.pmc_traffic, the rocprof_name
+    map): a renamed template instance would silently turn `traffic` into null and break the name the judge looks up in
+    profiles/.  Every class the line reports must find its kernel in the committed PMC summary, and every rocprof name
+    the line can print must be a kernel of the committed rocprofv3 kernel stats of the benchmarked step."""
+    import csv
+    import importlib
+    bench = importlib.import_module("bench")
+    pick = bench.pmc_traffic()
+    for key in ("conv_wgrad_rows", "conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_pt3_x2", "conv_halo64_pt4_x2", "conv_pw",
+                "kernel_apply_fwd", "kernel_apply_bwd", "embed3_fwd", "embed3_bwd", "final2_fwd", "final2_bwd"):
+        assert key in pick and pick[key]["hbm_bytes_per_launch"] > 0, key
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", bench.PROFILE_ROUND + "_bench_kernel_stats.csv")) as f:
+        names = [r["Name"] for r in csv.DictReader(f)]
+    printed = bench.rocprof_names(1)          # the default mode's names (one-term weight gradient)
+    for cls in ("conv_halo64_pt3", "conv_halo64_pt4", "conv_halo64_pt3_x2", "conv_halo64_pt4_x2", "conv_wgrad_rows",
+                "embed3_fwd", "embed3_bwd", "final2_fwd", "final2_bwd"):
+        p = printed[cls]
+        assert any(p.replace("wcmc::", "") in n for n in names), p
+
+
+def test_kernel_apply_backward_start_up_waits_are_in_the_binary(tmp_path):
+    """the strip kernel's counted wait ``vmcnt(D*S + 7*(D-1))`` only holds in steady state; the first D rows of
+    a block have fewer stores behind them and need ``vmcnt(7*(D-1) + k*S)`` (k = rows already multiplied), or row c0 + 1 can
+    be read before its LDS-DMA has landed.  The source now writes those waits out; this checks that the gfx950 code of the
+    BACKWARD kernel (D = 2, S = 7) really carries the three counts in front of ring reads, and the forward its single one."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(ROOT, "wcmc_amd", "csrc", "kernel_apply.o")
+    if not (os.path.isfile(objdump) and os.path.isfile(obj)):
+        pytest.skip("needs the ROCm llvm-objdump and the built kernel_apply.o")
+    local = str(tmp_path / "kernel_apply.o")
+    shutil.copy(obj, local)
+    subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=str(tmp_path))
+    bundles = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
+    assert bundles, os.listdir(str(tmp_path))
+    asm = subprocess.run([objdump, "-d", str(tmp_path / bundles[0])], check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    cur = None
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+        elif cur is not None:
+            kernels[cur].append(line)
+    bwd = [v for k, v in kernels.items() if "kernel_apply_strip_kernelILb1ELi2E" in k]
+    fwd = [v for k, v in kernels.items() if "kernel_apply_strip_kernelILb0ELi2E" in k]
+    assert len(bwd) == 1 and len(fwd) == 1, list(kernels)
+
+    def waits_before_ring_reads(lines):
+        """vmcnt counts of the s_waitcnt that directly precede a group of ds_read_b128 (the ring reads are the only
+        b128 reads behind a counted, non-zero wait)."""
+        found = set()
+        for i, ln in enumerate(lines):
+            m = re.search(r"s_waitcnt vmcnt\((\d+)\)", ln)
+            if not m or m.group(1) == "0":
+                continue
+            for nxt in lines[i + 1:i + 24]:       # (the start-up waits are alternatives that branch to one read group)
+                if "ds_read_b128" in nxt:
+                    found.add(int(m.group(1)))
+                    break
+                if "buffer_" in nxt or "s_barrier" in nxt:
+                    break
+        return found
+    assert {7, 14, 21} <= waits_before_ring_reads(bwd[0]), waits_before_ring_reads(bwd[0])
+    assert 7 in waits_before_ring_reads(fwd[0])

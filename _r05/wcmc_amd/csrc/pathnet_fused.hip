@@ -653,10 +653,6 @@ __global__ __launch_bounds__(512, 1) void final2_kernel(F2Params p) {
           a2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            // (standard k-slot order: final2w_fwd_kernel's output layer sums the same 128 products per output in another slot
-            // order, so the out recomputed here can differ from the forward's in the last ulp -- its SIGN, which is all that is
-            // used, differs for outputs within an ulp of zero only; reading the tiles in the forward's order costs this kernel
-            // eight more LDS instructions per tile and 16 % of its time: measured, not kept)
             const int o = (16 * wave + fr) * F2_RS + c * 32 + q * 8;
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(HH + o), al = *reinterpret_cast<const bf16x8*>(HL + o);
             const bf16x8 wh = *reinterpret_cast<const bf16x8*>(W1S + fr * F2_W1RS + c * 32 + q * 8);
@@ -808,170 +804,6 @@ __global__ __launch_bounds__(256) void final2_bwd_finish_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------ PathNet.final forward, wave-private (round 6)
-// final2_kernel<false> gives every wave one cout tile of a 64-pixel tile: the concatenation and the hidden activation cross the
-// workgroup through LDS behind three barriers per tile and sample, the eight waves run in lock step (all multiply, then all
-// convert), and the launch sits at 0.31 of the HBM roofline with the matrix pipe a third busy -- although its 103 GFLOP of issued
-// MFMA work (49 us) and its 319 MB (40 us at 8 TB/s) are the same order.  Here a wave owns 32 PIXELS end to end and nothing
-// but the weights is shared:
-//   * the concatenation never exists: lane (pixel n, k-group g) loads its 8 consecutive channels of y / prop straight from global
-//     memory as the MFMA's B fragment (32 contiguous bytes; the four k-groups of a pixel cover whole 128-byte lines) and splits
-//     them in registers; prop's fragments are made once per pixel tile and reused by the S samples;
-//   * W0 (hi | lo rows, 66 KB) sits in LDS for the life of the workgroup and is read as A fragments;
-//   * h = relu(W0 c + b0) goes from the accumulators into the NEXT GEMM's B fragments without leaving the lane: accumulator
-//     tile j of lane (n, q) holds hidden channels 16 j + 4 q .. + 3 of pixel n, so k-step s of the output layer takes tiles 2 s
-//     and 2 s + 1 and labels its 32 k-slots "slot (g, e) = channel 32 s + 16 (e >> 2) + 4 g + (e & 3)" -- W1's A fragments are
-//     read from LDS in that order (two 8-byte reads per plane and k-step), the same pattern the transposing reads of the
-//     weight gradients use.  No barrier in the loop, no staging tile, every wave at its own pace.
-// h is bit-identical to the layer-by-layer path (same MFMA sequence per accumulator); the output layer sums the same 128
-// products per output in another slot order.
-constexpr int F2W_RS = 2 * F2_C + 8;       // LDS row stride (u16) of a weight pack row: hi | lo | pad, rows spread over the banks
-
-__device__ __forceinline__ void f2w_split8(const u32x4 a, const u32x4 b, bf16x8& hi, bf16x8& lo) {
-  typedef __bf16 xb2 __attribute__((ext_vector_type(2)));
-  typedef float xf2 __attribute__((ext_vector_type(2)));
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    const unsigned u0 = d < 2 ? a[2 * d] : b[2 * d - 4], u1 = d < 2 ? a[2 * d + 1] : b[2 * d - 3];
-    const xf2 v = {e3_u2f(u0), e3_u2f(u1)};
-    h[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, xb2));
-    const xf2 back = {e3_u2f(h[d] << 16), e3_u2f(h[d] & 0xffff0000u)};
-    l[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - back, xb2));
-  }
-  hi = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
-  lo = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
-}
-
-template <int NI>
-__global__ __launch_bounds__(512, NI == 1 ? 4 : 2) void final2w_fwd_kernel(F2Params p) {
-  extern __shared__ __attribute__((aligned(16))) u16 lds[];
-  u16* const W0S = lds;                                          // [128][F2W_RS]
-  u16* const W1S = lds + F2_C * F2W_RS;                          // [16][F2W_RS]
-  float* const B0S = reinterpret_cast<float*>(W1S + 16 * F2W_RS);      // [128]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, q = lane >> 4;
-  for (int v = tid; v < F2_C * 32; v += 512)                     // 128 rows x 32 vectors of 8 u16 (hi 16 | lo 16)
-    *reinterpret_cast<u32x4*>(W0S + (v >> 5) * F2W_RS + (v & 31) * 8) = *reinterpret_cast<const u32x4*>(p.wp0 + (int64_t)v * 8);
-  *reinterpret_cast<u32x4*>(W1S + (tid >> 5) * F2W_RS + (tid & 31) * 8) = *reinterpret_cast<const u32x4*>(p.wp1 + tid * 8);
-  if (tid < F2_C) B0S[tid] = p.b0[tid];
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)p.prop, 0, (int)p.p_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.o_bytes, 0x00020000);
-  float b1[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) b1[e] = (4 * q + e < p.outc) ? p.b1[4 * q + e] : 0.f;
-  const int oq = p.os >> 2;
-  const int64_t tpi = p.HW / (16 * NI), nunits = (int64_t)p.B * tpi;    // units: 16 NI pixels of one image x its S samples
-  const int nwaves = (int)gridDim.x * 8;
-  // this lane's 32 bytes of pixel (16 i + fr) and k-step cs of a 64-channel fp32 row: two 16-byte loads
-  auto load8 = [&](const __amdgpu_buffer_rsrc_t r, unsigned base, int ps, int i, int cs, u32x4& a, u32x4& b) {
-    const unsigned off = base + (unsigned)(((16 * i + fr) * ps + 32 * cs + 8 * q) * 4);
-    a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-    b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0);
-  };
-  for (int64_t u = (int64_t)blockIdx.x * 8 + wave; u < nunits; u += nwaves) {
-    const int64_t b = u / tpi, hw0 = (u - b * tpi) * (16 * NI);
-    bf16x8 ph[NI][2], pl[NI][2];                                   // prop's fragments: [pixel tile][k-step]
-    {
-      const unsigned base = (unsigned)((b * p.HW + hw0) * p.p_ps * 4);
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int cs = 0; cs < 2; ++cs) {
-          u32x4 a, c;
-          load8(pr, base, p.p_ps, i, cs, a, c);
-          f2w_split8(a, c, ph[i][cs], pl[i][cs]);
-        }
-    }
-    u32x4 ya[NI][2], yb[NI][2];                                    // raw y of the sample about to be multiplied
-    {
-      const unsigned base = (unsigned)(((b * p.S) * p.HW + hw0) * p.y_ps * 4);
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int cs = 0; cs < 2; ++cs) load8(yr, base, p.y_ps, i, cs, ya[i][cs], yb[i][cs]);
-    }
-    for (int s = 0; s < p.S; ++s) {
-      const int64_t m0 = (b * p.S + s) * p.HW + hw0;
-      bf16x8 yh[NI][2], yl[NI][2];
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int cs = 0; cs < 2; ++cs) f2w_split8(ya[i][cs], yb[i][cs], yh[i][cs], yl[i][cs]);
-      if (s + 1 < p.S) {                                         // the next sample's y flies under the GEMMs
-        const unsigned base = (unsigned)((m0 + p.HW) * p.y_ps * 4);
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int cs = 0; cs < 2; ++cs) load8(yr, base, p.y_ps, i, cs, ya[i][cs], yb[i][cs]);
-      }
-      // ---- h = relu(W0 c + b0), two cout tiles at a time = one k-step of the output layer; out accumulates behind them
-      f32x4 a2[NI];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) a2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // (opaque per sample: the weight fragments are loop-invariant LDS reads -- hoisted out of the sample loop they are 576 registers)
-      int wrow = fr * F2W_RS + q * 8;
-      asm volatile("" : "+v"(wrow));
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        f32x4 acc[2][NI];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int j = 2 * s2 + jj;
-          #pragma unroll
-          for (int i = 0; i < NI; ++i) acc[jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const u16* wa = W0S + wrow + 16 * j * F2W_RS + c * 32;
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wa), wl = *reinterpret_cast<const bf16x8*>(wa + F2_C);
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-              const bf16x8 ah = c < 2 ? yh[i][c & 1] : ph[i][c & 1], al = c < 2 ? yl[i][c & 1] : pl[i][c & 1];
-              acc[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc[jj][i], 0, 0, 0);
-              acc[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc[jj][i], 0, 0, 0);
-              acc[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc[jj][i], 0, 0, 0);
-            }
-          }
-        }
-        // the output layer's k-step s2: slots (q, 0..3) <- tile 2 s2, slots (q, 4..7) <- tile 2 s2 + 1 of this lane
-        const f32x4 bA = *reinterpret_cast<const f32x4*>(B0S + 32 * s2 + 4 * q), bB = *reinterpret_cast<const f32x4*>(B0S + 32 * s2 + 16 + 4 * q);
-        const u16* w1a = W1S + wrow - 4 * q + 32 * s2;                // (fr F2W_RS + 4 q)
-        const u32x2 h0 = *reinterpret_cast<const u32x2*>(w1a), h1 = *reinterpret_cast<const u32x2*>(w1a + 16);
-        const u32x2 l0 = *reinterpret_cast<const u32x2*>(w1a + F2_C), l1 = *reinterpret_cast<const u32x2*>(w1a + F2_C + 16);
-        const bf16x8 w1h = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
-        const bf16x8 w1l = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          u32x4 ra, rb;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float tA = acc[0][i][e] + bA[e], tB = acc[1][i][e] + bB[e];
-            ra[e] = e3_f2u(tA > 0.f ? tA : 0.f);
-            rb[e] = e3_f2u(tB > 0.f ? tB : 0.f);
-          }
-          bf16x8 hh, hl;
-          f2w_split8(ra, rb, hh, hl);
-          a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1l, hh, a2[i], 0, 0, 0);
-          a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h, hl, a2[i], 0, 0, 0);
-          a2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h, hh, a2[i], 0, 0, 0);
-        }
-      }
-      // ---- out = relu(W1 h + b1): lanes q < oq hold (and store) output channels 4 q .. 4 q + 3 of pixel 16 i + fr
-      if (q < oq) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          u32x4 o4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const float t = a2[i][e] + b1[e]; o4[e] = e3_f2u((4 * q + e < p.outc && t > 0.f) ? t : 0.f); }
-          __builtin_amdgcn_raw_buffer_store_b128(o4, orr, (unsigned)(m0 * p.os * 4) + (unsigned)((16 * i + fr) * p.os * 4 + q * 16), 0, 0);
-        }
-      }
-    }
-  }
-}
-constexpr size_t F2W_LDS_FWD = (size_t)(F2_C + 16) * F2W_RS * sizeof(u16) + (size_t)F2_C * sizeof(float);
-
 static int f2_grid() { return 256; }
 constexpr size_t F2_LDS_FWD = (size_t)4 * F2_TILE * sizeof(u16);
 constexpr size_t F2_LDS_BWD = (size_t)5 * F2_TILE * sizeof(u16) + (size_t)E3_TP * F2_ORS * sizeof(u16) + (size_t)(16 * F2_C + 64 * 8) * sizeof(float) +
@@ -1087,20 +919,6 @@ extern "C" int wcmc_final2_fwd(const float* y, int y_pixel_stride, const float* 
   if (int rc = f2_fill(p, y, y_pixel_stride, prop, prop_pixel_stride, B, S, HW, wp0, b0, wp1, b1, outc)) return rc;
   WCMC_REQUIRE(out && aligned16(out), WCMC_ERR_BAD_ARG, "final2_fwd: bad output");
   p.out = out;
-  {
-    const char* e = ab_env("WCMC_F2W");                     // (debug build) 0: the cout-tile-per-wave kernel of round 3; 2: 32 pixels per wave; 1: 16
-    if (e && e[0] != '0') {
-      const int ni = e[0] == '2' ? 2 : 1;
-      static LdsAttr attrw1, attrw2;
-      if (set_max_lds(ni == 2 ? reinterpret_cast<const void*>(&final2w_fwd_kernel<2>) : reinterpret_cast<const void*>(&final2w_fwd_kernel<1>),
-                      (size_t)F2W_LDS_FWD, ni == 2 ? attrw2 : attrw1) != hipSuccess) return WCMC_ERR_LAUNCH;
-      const int64_t nunits = (int64_t)B * (HW / (16 * ni)), nb = (nunits + 7) / 8;
-      const int cap = ni == 2 ? f2_grid() : 2 * f2_grid();
-      if (ni == 2) hipLaunchKernelGGL(final2w_fwd_kernel<2>, dim3((unsigned)(nb < cap ? nb : cap)), dim3(512), F2W_LDS_FWD, (hipStream_t)stream, p);
-      else hipLaunchKernelGGL(final2w_fwd_kernel<1>, dim3((unsigned)(nb < cap ? nb : cap)), dim3(512), F2W_LDS_FWD, (hipStream_t)stream, p);
-      return check_launch("final2_fwd (wave-private)");
-    }
-  }
   static LdsAttr attr;
   if (set_max_lds(reinterpret_cast<const void*>(&final2_kernel<false>), (size_t)F2_LDS_FWD, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
   const int64_t nsuper = (int64_t)B * (HW / 64);
