@@ -61,7 +61,7 @@ def rocprof_names(wgrad_terms):
             "conv_pw": "wcmc::conv_pw_bf16x3_kernel<4|8, U, split> (the 1x1 PathNet layers)",
             # the fused PathNet chains (csrc/pathnet_fused.hip); the backward brackets include their small finish kernels
             "embed3_fwd": "wcmc::embed3_fwd_kernel", "embed3_bwd": "wcmc::embed3_bwd_kernel",
-            "final2_fwd": "wcmc::final2w_fwd_kernel", "final2_bwd": "wcmc::final2_kernel<true>"}
+            "final2_fwd": "wcmc::final2_kernel<false>", "final2_bwd": "wcmc::final2_kernel<true>"}
 
 
 # bf16 MFMAs issued per algorithmic multiply-add, by profiler class (forward 3; "_x2" data gradients 2; weight gradient: the mode's)
@@ -231,7 +231,7 @@ def pmc_traffic():
                          ("conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>" if _rows8(1) else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, 1>", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("embed3_fwd_kernel", "embed3_fwd"), ("embed3_bwd_kernel", "embed3_bwd"),
-                         ("final2w_fwd_kernel", "final2_fwd"), ("final2_kernel<true>", "final2_bwd"),
+                         ("final2_kernel<false>", "final2_fwd"), ("final2_kernel<true>", "final2_bwd"),
                          ("conv_halo3_bf16x3_kernel<2, 2, 2, 0>", "conv_halo3"), ("conv_halo3_bf16x3_kernel<1, 2, 2, 0>", "conv_halo3_x2"),
                          ("kernel_apply_strip_kernel<false", "kernel_apply_fwd"), ("kernel_apply_strip_kernel<true", "kernel_apply_bwd")):
             if tag in k and v.get("hbm_bytes_per_launch_corrected"):

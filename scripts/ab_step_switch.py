@@ -39,7 +39,9 @@ for r in range(rounds):
         torch.manual_seed(1234)
         if ENV and VALS != ("0", "1"):
             itf.loss_funcs["l_manif"].check_finite = False   # (timing-only ablations: garbage losses)
-        step = GraphedTrainStep(itf, batch, two_stream=True, defer_check=True)
+        if os.environ.get("AB_SERIAL") == "1":                # one stream: the halves in series (what a kernel is worth alone on the chip)
+            ops.USE_BRANCH_STREAM = False
+        step = GraphedTrainStep(itf, batch, two_stream=os.environ.get("AB_SERIAL") != "1", defer_check=True)
         if ENV and VALS != ("0", "1"):
             step._check = lambda *a, **k: None
         b = step.static

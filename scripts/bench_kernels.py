@@ -50,7 +50,7 @@ def run():
     ye, me = o.conv_chain_spp_mean(xe, 8, 1, 0, ["relu", "relu", "linear"], pe)              # embed3_fwd / embed3_bwd
     torch.autograd.backward([ye, me], [gy, gm])
     yl = ye.detach().requires_grad_(True)
-    o.cat_broadcast_chain(yl, prop, 8, 1, 0, ["relu", "relu"], pf).backward(gout)             # final2w_fwd_kernel / final2_kernel<true>
+    o.cat_broadcast_chain(yl, prop, 8, 1, 0, ["relu", "relu"], pf).backward(gout)             # final2_kernel<false> / <true>
     y = o.conv2d_x_raw(xs, (n, c, h, h), wp, b, 100, 5, 0, "relu", out_split=True)          # bf16x3 fwd
     o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu")   # three-term dgrad (bf16x3 mode)
     o.conv2d_x_raw(dys, (n, 100, h - 4, h - 4), wpt2, None, 100, 5, 4, "linear", out_split=True, gate=xs, gate_act="relu", terms=2)   # two-term dgrad, 16x16 tiles

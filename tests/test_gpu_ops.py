@@ -773,7 +773,7 @@ def test_fused_embedding_chain_forward_is_bit_identical_and_backward_matches_its
 def test_fused_final_chain_forward_is_bit_identical_and_backward_matches_its_fp64_emulation(case, monkeypatch):
     """``wcmc_final2_fwd`` / ``_bwd`` (PathNet.final with the broadcast concatenation, one launch per direction: concatenation
     and hidden activation on chip / recomputed, d_prop summed over the samples in registers) against the layer-by-layer path
-    (``wcmc_cat_broadcast_split`` + the fused layer pair): output to 1e-6 (the hidden activation bit for bit); backward against an fp64 evaluation on the
+    (``wcmc_cat_broadcast_split`` + the fused layer pair): output BIT FOR BIT; backward against an fp64 evaluation on the
     product's own hidden activation and output that rounds where the kernel rounds (d_out, dh, c, h to bf16 as operands of
     the two-term data gradients / one-term weight gradients; exact sums for the bias gradients), and against the unfused
     backward of the same mode."""
@@ -799,11 +799,13 @@ def test_fused_final_chain_forward_is_bit_identical_and_backward_matches_its_fp6
     monkeypatch.setattr(o, "DEBUG_ACTS", None)
     from wcmc_amd._lib import lib
     assert lib().wcmc_final2_supported(64, 64, 128, outc, h * w) == 1
-    # (round 6: the wave-private forward keeps h bit-identical -- same MFMA sequence per accumulator -- and hands it to the output
-    # layer inside the lane, which labels that layer's 32 k-slots per step in another order: the same 128 exact products per
-    # output, summed in fp32 in a different order)
-    assert_close(res[True][0], res[False][0], tol=1e-6, what="fused final chain, output")
-    assert float(((res[True][0] > 0) != (res[False][0] > 0)).float().mean()) <= 1e-4
+    if os.environ.get("WCMC_DEBUG_LIB") == "1" and os.environ.get("WCMC_F2W", "0") != "0":
+        # (the debug library's wave-private forward experiment, final2w_fwd_kernel: h bit-identical, the output layer's 128 exact
+        # products per output summed in another k-slot order)
+        assert_close(res[True][0], res[False][0], tol=1e-6, what="fused final chain, output")
+        assert float(((res[True][0] > 0) != (res[False][0] > 0)).float().mean()) <= 1e-4
+    else:
+        assert torch.equal(res[True][0], res[False][0])
     bf = lambda t: t.float().bfloat16().double()
     W0, b0, W1, b1 = [t.double() for t in params]
     M = b * s * h * w
