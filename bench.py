@@ -584,6 +584,7 @@ def main():
                 # FLOPs once against the dense bf16 peak, so its ceiling is 1 / terms; for scale, the exact-fp32 MFMA peak is 157.3 TFLOP/s
                 t = mfma_terms(name, ops.wgrad_terms())
                 extra = {"mfma_flops_per_algorithmic_flop": t, "frac_of_issued_mfma_flops": round(ach * t / peak, 4),
+                         "issued_mfma_TFLOPs": round(ach * t, 1),
                          "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 3)}
             rocprof_name = rocprof_names(ops.wgrad_terms()).get(name, name + " (several kernels)")
             if ops.PRECISION == "fp32":
@@ -601,8 +602,11 @@ def main():
             work, ms = sum(summ[k]["work"] for k in keys), sum(summ[k]["ms"] for k in keys)
             ach = work / (ms * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS if ops.split_path() else PEAK_FP32_MFMA_TFLOPS
+            extra = {}
+            if ops.split_path():        # MFMA FLOPs the launches issue for their algorithmic ones (terms per product; padding not counted)
+                extra = {"issued_mfma_TFLOPs": round(sum(summ[k]["work"] * mfma_terms(k, ops.wgrad_terms()) for k in keys) / (ms * 1e-3) / 1e12, 1)}
             return {"family": label, "classes": keys, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "launches": sum(summ[k]["launches"] for k in keys),
+                    "frac": round(ach / peak, 4), **extra, "launches": sum(summ[k]["launches"] for k in keys),
                     "ms_per_profiled_step": round(ms / max(1, prof.step), 4),
                     "share_of_profiled_region": round(ms / (prof_elapsed * 1e3), 4)}
 
@@ -711,6 +715,14 @@ def main():
             "roofline_kernel_apply": ka,
         }
         line["measured_peaks"] = measured_peaks(device)
+        # the practical matrix peak of THIS box: what a dense 8192^3 bf16 hipBLASLt GEMM sustains (clock under MFMA load, not the 2.5 PF
+        # of the data sheet); `issued_vs_measured_gemm` = MFMA FLOPs a conv kernel issues per second (terms per product, padding not
+        # counted) / that rate -- how far the kernel is from what the matrix pipe delivers here, where `frac` is against the spec peak
+        gemm = line["measured_peaks"].get("bf16_gemm_8192_TFLOPs")
+        if gemm:
+            for obj in [line["roofline"]] + line["roofline_other_conv"] + line["roofline_family"]:
+                if obj and obj.get("issued_mfma_TFLOPs"):
+                    obj["issued_vs_measured_gemm"] = round(obj["issued_mfma_TFLOPs"] / gemm, 3)
         if world == 1 and not args.eager:
             ops.USE_SIDE_STREAM, ops.USE_BRANCH_STREAM = stream_defaults
             itf.fused_optim.leave_grads = False            # (back to the captured buffers: the long segment replays the graph)

@@ -51,6 +51,14 @@ if nsteps:
     for nm, v in solo.most_common(14):
         print("  %6.3f | %6.3f  %s" % (v / nsteps / 1e6, tot[nm] / nsteps / 1e6, nm[:110]))
     print("  %6.3f alone in total" % (sum(solo.values()) / nsteps / 1e6))
+    cnt = collections.Counter()
+    for a, b in list(zip(steps[:-1], steps[1:]))[8:14]:
+        for r in rows[a:b]:
+            cnt[r[2]] += 1
+    print("every kernel of the step (launches per step, ms per step, mean us), %d steps; under the profiler the two half-step graphs run in series:" % nsteps)
+    for nm, v in tot.most_common():
+        print("  %5.1f  %6.3f  %7.1f  %s" % (cnt[nm] / nsteps, v / nsteps / 1e6, v / cnt[nm] / 1e3, nm[:120]))
+    print("  %5.1f  %6.3f  in total" % (sum(cnt.values()) / nsteps, sum(tot.values()) / nsteps / 1e6))
 if len(steps) > 12:
     a, b = steps[10], steps[11]
     a = max(0, b - 30)
