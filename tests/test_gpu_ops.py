@@ -280,6 +280,45 @@ def test_conv5x5_kernel_variants_agree_with_fp64(case, monkeypatch):
     assert_close(yd, ref, tol=2e-5, what=name)
 
 
+@needs_debug_lib
+@pytest.mark.parametrize("case", [(2, 64, 40, 37, 64), (1, 128, 37, 21, 128), (3, 192, 19, 33, 64), (1, 384, 16, 18, 128), (2, 256, 9, 16, 256),
+                                  (1, 64, 8, 16, 64), (1, 64, 1, 1, 64), (2, 64, 33, 47, 128), (8, 64, 128, 128, 64)])
+def test_unet3x3_kernel_variant_equals_the_kernel_it_replaced(case, monkeypatch):
+    """conv_halo3_bf16x3_kernel (round 6: K split over two wave groups, swizzled halo) against conv_halo_bf16x3_kernel (WCMC_HALO3=0,
+    debug build) on the U-Net's launches: forward with bias + ReLU + gate mask out, two-term data gradient gated by that mask with
+    column sums, and the fp32-view output.  Same products, another summation order (the two K groups meet once): 2e-6 of the
+    tensor's scale in fp32, one unit of the lo plane in split outputs; masks equal wherever the value is not within rounding of zero."""
+    o = ops()
+    n, cin, h, w, cout = case
+    dims = (n, cin, h, w)
+    xs = o.split_raw(o.to_nhwc_raw(gen(n, cin, h, w, seed=400).to(DEV)))
+    wt = gen(cout, cin, 3, 3, seed=401, scale=(2.0 / (cin * 9)) ** 0.5 * 1.7).to(DEV)
+    b = gen(cout, seed=402, scale=0.2).to(DEV)
+    dys = o.split_raw(o.to_nhwc_raw(gen(n, cout, h, w, seed=403).to(DEV)))
+    wp0, wp2 = o._pack_x(wt, 0), o._pack_x(wt, 2)
+    cp = (cin + 7) // 8 * 8
+    keep = torch.zeros(n, h, w, cp, dtype=torch.bool)
+    keep[..., :cin] = (gen(n, cin, h, w, seed=404) > -0.3).permute(0, 2, 3, 1)
+    gmask = torch.from_numpy(np.packbits(keep.numpy().reshape(-1, cp), axis=1, bitorder="little").reshape(-1)).to(DEV)
+    got = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("WCMC_HALO3", sw)
+        y, mask = o.conv2d_x_raw(xs, dims, wp0, b, cout, 3, 1, "relu", out_split=True, mask_out=True)
+        yf = o.conv2d_x_raw(xs, dims, wp0, b, cout, 3, 1, "leaky_relu", out_split=False)
+        dx, part = o.conv2d_x_raw(dys, (n, cout, h, w), wp2, None, cin, 3, 1, "linear", out_split=True, gate_mask=gmask, gate_act="relu",
+                                    colsum=True, terms=2)
+        got[sw] = (o.unsplit_debug(y, n, cout, h, w), mask.clone(), yf.clone(),
+                   o.unsplit_debug(dx, n, cin, h, w), o.colsum_finish_raw(part, (n, cin, h, w)))
+    a, bb = got["1"], got["0"]
+    # (a split output resolves 2^-17 of an element: two fp32 sums an ulp apart may round its lo plane apart)
+    for i, what, tol in ((0, "forward", 1.6e-5), (2, "forward, fp32 view", 2e-6), (3, "data gradient", 1.6e-5), (4, "column sums (of the split values, with cancellation)", 1e-5)):
+        assert rel_err(a[i], bb[i]) < tol, what
+    bits = lambda m: np.unpackbits(m.cpu().numpy(), bitorder="little")
+    differ = int((bits(a[1]) != bits(bb[1])).sum())
+    near_zero = int((a[0].abs() < 1e-5 * float(a[0].abs().max())).sum() - (a[0] == 0).sum())
+    assert differ <= max(near_zero, 0), (differ, near_zero)
+
+
 @pytest.mark.parametrize("case", [(16, 36, 64, 64, 64, 1), (12, 128, 48, 40, 128, 1), (16, 128, 64, 64, 3, 1), (4, 128, 40, 37, 128, 3)])
 def test_weight_gradient_with_many_slabs_against_fp64(case, monkeypatch):
     """Weight and bias gradients at sizes where the split-K plan has MANY slabs (the unit cases above have one or a few):
@@ -362,8 +401,9 @@ TWO_TERM_FALLBACKS = ((2, 100, 30, 29, 39, 4, 5), (2, 120, 24, 24, 100, 4, 5), (
 
 
 @pytest.mark.parametrize("case", ((8, 100, 44, 44, 100, 0, 5), (2, 100, 36, 36, 100, 4, 5), (1, 441, 40, 37, 100, 4, 5), (2, 232, 24, 24, 100, 4, 5),
-                                  # the U-Net's 3x3 layers (conv_halo_bf16x3_kernel<4 | 7, .., AP = 1>): one 64- / 128-channel slab, two of 96,
-                                  # three of 128, 12 cout tiles (NT = 7), a 40-channel slab, the 16x16 and the 8x16 tiling
+                                  # the U-Net's 3x3 layers (conv_halo3_bf16x3_kernel<1, 2 | 4, 2> where couts come in 64s and cins in whole 64- / 128-channel
+                                  # slabs, conv_halo_bf16x3_kernel<4 | 7, .., AP = 1> elsewhere): one 64- / 128-channel slab, two of 96,
+                                  # three of 128, 12 cout tiles (NT = 7), a 40-channel slab, ragged tiles, the benchmark's shape
                                   (2, 64, 40, 37, 64, 1, 3), (1, 128, 37, 21, 128, 1, 3), (2, 192, 24, 24, 64, 1, 3), (1, 384, 33, 18, 128, 1, 3),
                                   (1, 256, 20, 36, 192, 1, 3), (1, 40, 20, 20, 64, 1, 3), (8, 64, 128, 128, 64, 1, 3),
                                   # the ONE-cout-tile 5x5 instance (conv_halo64<1, 3, PT, 0, 80, 1>: x_plan_k grants it to every two-term 5x5
