@@ -719,6 +719,18 @@ def main():
         # of the data sheet); `issued_vs_measured_gemm` = MFMA FLOPs a conv kernel issues per second (terms per product, padding not
         # counted) / that rate -- how far the kernel is from what the matrix pipe delivers here, where `frac` is against the spec peak
         gemm = line["measured_peaks"].get("bf16_gemm_8192_TFLOPs")
+        if gemm and ops.split_path() and ops.reduced_backward() and prof.step:
+            # MFMA FLOPs ONE step issues: the conv classes' algorithmic FLOPs x MFMAs per product (HIP-event classes of the profiled
+            # steps), + the fused 1x1 PathNet chains by their shapes (forward 3, data gradient 2, weight gradient 1 MFMAs per product;
+            # their recomputation in the backward and every padding NOT counted) -- against the step time and the measured GEMM rate
+            conv = sum(summ[k]["work"] * mfma_terms(k, ops.wgrad_terms()) for k in conv_keys) / prof.step
+            px = B_PER_GPU * SPP * PATCH * PATCH
+            emb, fin = 36 * 64 + 64 * 64 + 64 * 64, 128 * 128 + 128 * 3
+            fused = 2 * 2.0 * px * (emb * 3 + (64 * 64 * 2) * 2 + emb * 1 + fin * 6)
+            issued = (conv + fused) / 1e12
+            line["whole_step"]["issued_mfma_tflop_per_step"] = round(issued, 3)
+            line["whole_step"]["issued_mfma_TFLOPs"] = round(issued / (elapsed / args.steps), 1)
+            line["whole_step"]["issued_vs_measured_gemm"] = round(issued / (elapsed / args.steps) / gemm, 3)
         if gemm:
             for obj in [line["roofline"]] + line["roofline_other_conv"] + line["roofline_family"]:
                 if obj and obj.get("issued_mfma_TFLOPs"):
