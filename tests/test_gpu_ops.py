@@ -281,6 +281,36 @@ def test_conv5x5_kernel_variants_agree_with_fp64(case, monkeypatch):
 
 
 @needs_debug_lib
+@pytest.mark.parametrize("case", [(2, 100, 40, 37, 100, 0), (1, 100, 30, 30, 441, 0), (2, 36, 20, 33, 100, 0), (2, 100, 36, 36, 100, 4), (1, 97, 21, 26, 100, 4),
+                                  (8, 100, 116, 116, 100, 0)])
+def test_halo64_last_slab_variant_four_channel_k_order_equals_eight(case, monkeypatch):
+    """conv_halo64_bf16x3_kernel, input channels = slabs + at most four (KPCN's 100): the last slab in the four-channel K order (eight
+    taps per stage, x_last4) against the eight-channel order it replaced (WCMC_HALO64_L4=0, debug build) -- three-term forward, two-term
+    data-gradient orientation, the one-MFMA and the fp16 output-layer forms.  Same products, another order of summation."""
+    from wcmc_amd._lib import lib
+    o = ops()
+    n, cin, h, w, cout, pad = case
+    ks = 5
+    x = gen(n, cin, h, w, seed=410)
+    wt = gen(cout, cin, ks, ks, seed=411, scale=(2.0 / (cin * ks * ks)) ** 0.5 * 1.7).to(DEV)
+    b = gen(cout, seed=412, scale=0.2).to(DEV)
+    xs = o.split_raw(o.to_nhwc_raw(x.to(DEV)))
+    got = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("WCMC_HALO64_L4", sw)
+        dims = (n, cin, h, w)
+        y3 = o.conv2d_x_raw(xs, dims, o._pack_x(wt, 0), b, cout, ks, pad, "relu", out_split=False)
+        y2 = o.conv2d_x_raw(xs, dims, o._pack_x(wt, 3), b, cout, ks, pad, "linear", out_split=False, terms=2)
+        y1 = o.conv2d_x_raw(xs, dims, o._pack_x(wt, 3), b, cout, ks, pad, "linear", out_split=False, terms=1)
+        yh = o.conv2d_out_f16_raw(xs, dims, o._pack_x(wt, 4), b, cout, ks, pad) if lib().wcmc_conv2d_out_f16_supported(cin, cout, ks) else y1
+        got[sw] = [t.clone() for t in (y3, y2, y1, yh)]
+    for a, bb, what in zip(got["1"], got["0"], ("three terms", "two terms", "one term", "fp16")):
+        assert rel_err(a, bb) < 2e-6, what
+    ref = F.relu(F.conv2d(x.double(), wt.double().cpu(), b.double().cpu(), padding=pad))
+    assert_close(got["1"][0], ref, tol=2e-5, what="three-term forward against fp64")
+
+
+@needs_debug_lib
 @pytest.mark.parametrize("case", [(2, 64, 40, 37, 64), (1, 128, 37, 21, 128), (3, 192, 19, 33, 64), (1, 384, 16, 18, 128), (2, 256, 9, 16, 256),
                                   (1, 64, 8, 16, 64), (1, 64, 1, 1, 64), (2, 64, 33, 47, 128), (8, 64, 128, 128, 64)])
 def test_unet3x3_kernel_variant_equals_the_kernel_it_replaced(case, monkeypatch):

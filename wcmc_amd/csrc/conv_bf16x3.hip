@@ -359,6 +359,15 @@ static int x_env_on(const char* name) {           // switch is ON unless the var
 }
 struct XKPlan { bool halo; int Kp, CS, nslabs, Ks, Kt, PXS, CSl, Ksl, ap; };     // CSl / Ksl: the last (narrower) slab
 static int x_pick_nt(int tiles);
+// conv_halo64_bf16x3_kernel, last slab of at most FOUR real channels (KPCN's 100 = 6 x 16 + 4 = 3 x 32 + 4): its k order is four
+// channels per tap, EIGHT taps per 32-k stage -- 4 stages for the 25 taps instead of the 7 of an 8-channel slab (four taps per stage,
+// half of every k-group zeros): 85 -> 82 stages in the forward, 82 -> 79 in the data gradient (-3.6 % MFMAs).  CSl = 4 is the K ORDER
+// only: the halo still holds the slab as 8-channel units (one 16-byte DMA granule per plane); a lane's k-group is two 8-byte reads
+// from two neighbouring taps.  (WCMC_HALO64_L4=0, debug build: the 8-channel order.)
+static bool x_last4(int kchan, int CS, int nslabs) {
+  const int left = kchan - (nslabs - 1) * CS;
+  return nslabs >= 2 && left >= 1 && left <= 4 && x_env_on("WCMC_HALO64_L4");
+}
 // ap_req: planes of the A operand (the pixels) the caller wants multiplied -- 2 = hi + lo (three MFMAs per product), 1 = hi only
 // (two: W_lo*A_hi + W_hi*A_hi; the data gradient of the "bf16x321" mode).  q.ap is what the plan grants: 1 only where a
 // kernel instance for it exists (rows = the GEMM's output channels pick the instance), else the three-term plan.  The K
@@ -381,6 +390,7 @@ static XKPlan x_plan_k(int kchan, int ks, int ap_req = 2, int rows = 0) {
     q.ap = 1;
     q.nslabs = (q.Kp + 31) / 32;
     q.CS = 32; q.CSl = q.Kp - (q.nslabs - 1) * 32;            // 8, 16 or 32
+    if (x_last4(kchan, q.CS, q.nslabs)) q.CSl = 4;            // (see x_last4)
     q.PXS = 80;
     q.Ks = round_up(ks * ks * q.CS, 32); q.Ksl = round_up(ks * ks * q.CSl, 32);
     q.Kt = (q.nslabs - 1) * q.Ks + q.Ksl;
@@ -417,6 +427,7 @@ static XKPlan x_plan_k(int kchan, int ks, int ap_req = 2, int rows = 0) {
     }
     q.nslabs = (q.Kp + 15) / 16;
     q.CS = 16; q.CSl = q.Kp - (q.nslabs - 1) * 16;
+    if (x_last4(kchan, q.CS, q.nslabs)) q.CSl = 4;
     // halo pixel stride 80 B (5 slots of 16 B: hi 0-1, lo 2-3, one of pad).  The ds_read_b128 of the pixel fragments are
     // 2-way bank conflicts with it (PMC: 23-26 % of the LDS cycles; the four 16-lane groups of a b128 read take k-groups 0
     // and 1 of different pixel columns together and 5 f, 5 f' + 1 meet mod 16); 96 B is conflict-free for the 16-channel
@@ -1450,6 +1461,12 @@ __global__ __launch_bounds__(256 * KG, 4) void conv_halo3_bf16x3_kernel(XIgemmPa
   f32x4 acc[NT][2];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if (DBG & 256) {                        // (debug build) 128 vector instructions that change nothing: the price of a VALU in the step
+    int d = lane;
+#pragma unroll
+    for (int r = 0; r < 128; ++r) asm volatile("v_add_u32 %0, %0, %0" : "+v"(d));
+    if (d == 0x12345 && p.ys) p.ys[0] = 1;
+  }
 
   // ---- fragments
   const int frow = lane & 15, kg = lane >> 4;
@@ -1788,6 +1805,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   // scalar).  Decoding them again for every slab cost ~25 vector instructions per vector, ~800 cycles of vector issue per
   // wave in front of the MFMAs of each slab's last stage (the "six halo reloads per tile: 4 %" of the ablations).
   constexpr int NHV = PXST ? (((TH + 4) * (TW + 4) * (PXST / 16) + 63) / 64 + NWV - 1) / NWV : 0;
+  const int CSlh = p.CSl < 8 ? 8 : p.CSl;      // channels per plane the halo holds of the last slab (CSl = 4: a K order, x_last4)
   unsigned hoff[NHV ? NHV : 1], hoffl[NHV ? NHV : 1];
   if (PXST) {
 #pragma unroll
@@ -1802,7 +1820,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
           const unsigned pbase = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb);
           if (AP == 1) {                             // hi plane only: part = 16-byte unit of the slab's channels
             if (part < p.CS / 8 && (p.nslabs - 2) * p.CS + part * 8 < p.Cpi) hoff[kq] = pbase + (unsigned)(part * 16);
-            if (part < p.CSl / 8 && (p.nslabs - 1) * p.CS + part * 8 < p.Cpi) hoffl[kq] = pbase + (unsigned)(part * 16);
+            if (part < CSlh / 8 && (p.nslabs - 1) * p.CS + part * 8 < p.Cpi) hoffl[kq] = pbase + (unsigned)(part * 16);
           } else {
           {
             const int V = p.CS / 4, plane = part >= (V >> 1), vec = part - plane * (V >> 1);
@@ -1810,7 +1828,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
             if (part < V && (p.nslabs - 2) * p.CS + vec * 8 < p.Cpi) hoff[kq] = pbase + (unsigned)(plane * 2 * p.Cpi + vec * 16);
           }
           {
-            const int V = p.CSl / 4, plane = part >= (V >> 1), vec = part - plane * (V >> 1);
+            const int V = CSlh / 4, plane = part >= (V >> 1), vec = part - plane * (V >> 1);
             if (part < V && (p.nslabs - 1) * p.CS + vec * 8 < p.Cpi) hoffl[kq] = pbase + (unsigned)(plane * 2 * p.Cpi + vec * 16);
           }
           }
@@ -1833,7 +1851,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
       }
       return;
     }
-    const int V = (slab == p.nslabs - 1 ? p.CSl : p.CS) / (AP == 1 ? 8 : 4);      // data vectors per halo pixel (AP planes x cs/8)
+    const int V = (slab == p.nslabs - 1 ? CSlh : p.CS) / (AP == 1 ? 8 : 4);      // data vectors per halo pixel (AP planes x cs/8)
     for (int ii = wave; ii * 64 < hvecs; ii += NWV) {
       const int v = ii * 64 + lane;
       if (v < hvecs) {
@@ -1890,20 +1908,43 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   const int abase0 = (wave * HWd + frow) * p.PXS, dA = NWV * HWd * p.PXS;   // tile row i of the wave: + i * dA (a constant with PXST)
   // this lane's (tap, channel) of the stage whose A fragments are read next
   int cs_cur, sps_cur, lo_off, tps, coff, tdx, tdy;
+  bool cs4 = false;                                      // (wave-uniform) the slab being read is in the four-channel K order (x_last4)
   auto slab_begin = [&](int slab) {
     cs_cur = slab == p.nslabs - 1 ? p.CSl : p.CS;
     sps_cur = slab == p.nslabs - 1 ? p.SPSl : (p.SPS & 0xff);
-    lo_off = cs_cur * 2;
-    tps = 32 / cs_cur;                                   // taps per stage: 1 (32 channels), 2 (16) or 4 (8)
-    coff = ((kg * 8) & (cs_cur - 1)) * 2;
-    tdy = 0; tdx = cs_cur == 32 ? 0 : cs_cur == 16 ? (kg >> 1) : kg;        // (< ks)
+    cs4 = cs_cur == 4;
+    lo_off = (cs4 ? 8 : cs_cur) * 2;
+    tps = 32 / cs_cur;                                   // taps per stage: 1 (32 channels), 2 (16), 4 (8) or 8 (4)
+    coff = cs4 ? 0 : ((kg * 8) & (cs_cur - 1)) * 2;
+    tdy = 0; tdx = cs_cur == 32 ? 0 : cs_cur == 16 ? (kg >> 1) : cs4 ? 2 * kg : kg;        // (cs4: the FIRST of the lane's two taps)
+    if (tdx >= p.ks) { tdx -= p.ks; ++tdy; }             // (cs4, kg = 3: tap 6)
   };
   bf16x8 ah[PT], al[PT], wh[NT], wl[NT];
   // (24-bit multiplies: full-rate v_mad_u32_u24 instead of two 64-bit multiply-adds per stage)
   auto a_off = [&]() { return tdy < p.ks ? (int)__umul24(__umul24((unsigned)tdy, (unsigned)HWd) + (unsigned)tdx, (unsigned)p.PXS) + coff : coff; };
-  auto a_advance = [&]() { tdx += tps; if (tdx >= p.ks) { tdx -= p.ks; ++tdy; } };
-  auto read_a1 = [&](int i, int aoff) {
+  // (cs4) the lane's second tap: the next one in the filter's raster order
+  auto a_off2 = [&]() {
+    int x = tdx + 1, y = tdy;
+    if (x >= p.ks) { x = 0; ++y; }
+    return y < p.ks ? (int)__umul24(__umul24((unsigned)y, (unsigned)HWd) + (unsigned)x, (unsigned)p.PXS) : 0;
+  };
+  auto a_advance = [&]() {
+    tdx += tps;
+    if (tdx >= p.ks) { tdx -= p.ks; ++tdy; }
+    if (cs4 && tdx >= p.ks) { tdx -= p.ks; ++tdy; }      // (eight taps ahead: up to two rows of five)
+  };
+  auto read_a1 = [&](int i, int aoff, int aoff2) {
     const char* pa = halo + abase0 + aoff;
+    if (cs4) {                                            // two taps x four channels: 8 bytes each
+      const char* pb = halo + abase0 + aoff2;
+      const u32x2 a0 = *reinterpret_cast<const u32x2*>(pa + i * dA), a1 = *reinterpret_cast<const u32x2*>(pb + i * dA);
+      ah[i] = __builtin_bit_cast(bf16x8, u32x4{a0.x, a0.y, a1.x, a1.y});
+      if (AP == 2) {
+        const u32x2 l0 = *reinterpret_cast<const u32x2*>(pa + lo_off + i * dA), l1 = *reinterpret_cast<const u32x2*>(pb + lo_off + i * dA);
+        al[i] = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+      }
+      return;
+    }
     ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * dA);
     if (AP == 2) al[i] = *reinterpret_cast<const bf16x8*>(pa + lo_off + i * dA);
   };
@@ -1920,9 +1961,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
-    const int aoff = a_off();
+    const int aoff = a_off(), aoff2 = cs4 ? a_off2() : 0;
 #pragma unroll
-    for (int i = 0; i < PT; ++i) read_a1(i, aoff);
+    for (int i = 0; i < PT; ++i) read_a1(i, aoff, aoff2);
     a_advance();
   }
 #pragma unroll
@@ -1944,7 +1985,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
     bcur = b1;
     const bool last_of_slab = (s_in + 1 == sps_cur);
     if (last_of_slab && slab + 1 < p.nslabs && !(DBG & 4)) dma_halo(slab + 1);      // (no wave reads the halo during a slab's last stage)
-    const int aoff = a_off();
+    const int aoff = a_off(), aoff2 = cs4 ? a_off2() : 0;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -1957,7 +1998,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
           else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[i], acc[j][i], 0, 0, 0);
         }
         // the pixel tile's fragments of stage g+1 replace it as soon as its last MFMAs of this stage have issued
-        if (j == NT - 1 && !last_of_slab && !(DBG & 8)) read_a1(i, aoff);
+        if (j == NT - 1 && !last_of_slab && !(DBG & 8)) read_a1(i, aoff, aoff2);
       }
       if (!(DBG & 8)) read_b(b1, j);             // stage g+1, same cout tile, into the registers just consumed
       __builtin_amdgcn_sched_barrier(0);
@@ -1971,9 +2012,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
       slab_begin(slab < p.nslabs ? slab : p.nslabs - 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the new halo (and of the weight ring)
       __syncthreads();
-      const int a2 = a_off();
+      const int a2 = a_off(), a22 = cs4 ? a_off2() : 0;
 #pragma unroll
-      for (int i = 0; i < PT; ++i) read_a1(i, a2);
+      for (int i = 0; i < PT; ++i) read_a1(i, a2, a22);
       a_advance();
     }
   }
@@ -4108,6 +4149,14 @@ static int launch_xhalo3b(const XIgemmParams& q, hipStream_t stream) {
   if (set_max_lds(reinterpret_cast<const void*>(&conv_halo3_bf16x3_kernel<AP, SPT, KG>), lds, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
   const dim3 grid((unsigned)(q.N * q.tilesX * q.tilesY), (unsigned)(q.Np / 64));
 #ifdef WCMC_DEBUG_BUILD
+  {                                       // WCMC_HALO3_VALU=1: CORRECT results, 128 more vector instructions per wave (what is a VALU worth in the step?)
+    const char* e = ab_env("WCMC_HALO3_VALU");
+    if (e && e[0] == '1') {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo3_bf16x3_kernel<AP, SPT, KG, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((conv_halo3_bf16x3_kernel<AP, SPT, KG, 256>), grid, dim3(256 * KG), lds, stream, q);
+      return check_launch("conv2d_igemm_bf16x3(halo 3x3, +128 VALU)");
+    }
+  }
   if (AP == 2) {                          // WCMC_DEBUG_ABLATE=<mask>: timing-only ablations of the forward instance (scripts/time_unet_abl.py)
     const char* e = ab_env("WCMC_DEBUG_ABLATE");
     const int ab = e ? atoi(e) : 0;
