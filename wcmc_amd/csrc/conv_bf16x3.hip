@@ -596,6 +596,7 @@ struct XIgemmParams {
   int G;                                  // rows of colsum (tiles past the kernel's own are zero-filled)
   int CS, nslabs, SPS, PXS, tilesX, tilesY;   // halo kernel: channel slab, stages per slab, halo pixel stride
   int CSl, SPSl;                              // ... of the last slab
+  int rows16;                                 // conv_halo64, PT = 4 instance: tile rows [0, rows16) are 16 pixels high, the rest 12 (launch_xhalo64; set there)
   int ap;                                     // planes of x multiplied: 2 = hi + lo, 1 = hi only (two MFMAs per product)
   int wplanes;                                // planes of the weights multiplied: 2, or 1 with ap == 1 (ONE MFMA per product; conv_halo64 only)
   int f16;                                    // with ap == wplanes == 1: x is ONE fp16 plane [pixel][Cpi], the pack's hi rows are fp16
@@ -1762,7 +1763,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   constexpr int NG = (PT + 1) / 2;             // epilogue groups of two pixel tiles per wave (128 pixels of staging)
   extern __shared__ __attribute__((aligned(16))) u16 smem16[];
   constexpr int B_LO = BN * XROW + 32, B_ELEMS = 2 * BN * XROW + 64;
-  const int HWd = TW + p.ks - 1, HHt = TH + p.ks - 1, HP = HWd * HHt;
+  const int HWd = TW + p.ks - 1, HHt = TH + p.ks - 1, HP = HWd * HHt;     // (a 12-row workgroup of the PT = 4 instance keeps the 16-row layout)
   char* const halo = reinterpret_cast<char*>(smem16);
   u16* const bsm = smem16 + ((HP * p.PXS + 127) & ~127) / 2;
 
@@ -1789,7 +1790,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   }
   const int tpi = p.tilesX * p.tilesY;
   const int img = tile / tpi, trem = tile - img * tpi;
-  const int oy0 = (trem / p.tilesX) * TH, ox0 = (trem % p.tilesX) * TW;
+  // Mixed tile heights (PT = 4 instance): the launcher covers Ho EXACTLY with rows16 tile rows of 16 pixels followed by tile rows of
+  // 12 where it can (100 = 4 x 16 + 3 x 12: 100 rows of MFMAs instead of 108 or 112) -- a 12-row workgroup stages a 16-row halo and
+  // skips its fourth pixel tile (ptc, wave-uniform).
+  const int trow = trem / p.tilesX;
+  const int ptc = (PT == 4 && trow >= p.rows16) ? 3 : PT;
+  const int oy0 = PT == 4 ? (trow < p.rows16 ? trow * 16 : p.rows16 * 16 + (trow - p.rows16) * 12) : trow * TH;
+  const int ox0 = (trem - trow * p.tilesX) * TW;
   const int n0 = blockIdx.y * BN;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
@@ -1798,7 +1805,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
 
   // ---- halo: [pixel][hi cs][lo cs] at stride PXS, one linear run of 16-byte vectors filled by LDS-DMA
   const int VP = p.PXS / 16;
-  const int hvecs = HP * VP;
+  const int hvecs = HWd * (4 * ptc + p.ks - 1) * VP;      // (the rows this workgroup's pixel tiles reach)
   const float invVP = 1.0f / (float)VP, invHW = 1.0f / (float)HWd;
   // With the stride a template constant the per-lane source offsets of the halo's 16-byte vectors are worked out ONCE, for a
   // regular slab and for the last (narrower) one; a slab's fill is then one addition per instruction (+ slab * CS * 2, a
@@ -1963,7 +1970,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   {
     const int aoff = a_off(), aoff2 = cs4 ? a_off2() : 0;
 #pragma unroll
-    for (int i = 0; i < PT; ++i) read_a1(i, aoff, aoff2);
+    for (int i = 0; i < PT; ++i)
+      if (i < ptc) read_a1(i, aoff, aoff2);
     a_advance();
   }
 #pragma unroll
@@ -1991,6 +1999,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
       for (int i = 0; i < PT; ++i) {
+        if (i >= ptc) continue;                    // (PT = 4 instance on a 12-row tile: wave-uniform)
         if (!(DBG & 1)) {
           if (WP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[i], acc[j][i], 0, 0, 0);   // small terms first
           if (AP == 2) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[i], acc[j][i], 0, 0, 0);
@@ -2014,7 +2023,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
       __syncthreads();
       const int a2 = a_off(), a22 = cs4 ? a_off2() : 0;
 #pragma unroll
-      for (int i = 0; i < PT; ++i) read_a1(i, a2, a22);
+      for (int i = 0; i < PT; ++i)
+        if (i < ptc) read_a1(i, a2, a22);
       a_advance();
     }
   }
@@ -2047,7 +2057,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int oy = oy0 + wave + NWV * i, ox = ox0 + frow;
-    okp[i] = oy < p.Ho && ox < p.Wo;
+    okp[i] = i < ptc && oy < p.Ho && ox < p.Wo;
     mp[i] = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
   }
   if (use_gate) {
@@ -2083,7 +2093,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   auto pix_of = [&](int h, int pr, int& oy, int& ox) {
     const int i = 2 * h + ((pr >> 4) & 1);             // (PT odd: the last group holds one pixel tile)
     oy = oy0 + (pr >> 5) + NWV * i; ox = ox0 + (pr & 15);
-    return i < PT && oy < p.Ho && ox < p.Wo;
+    return i < ptc && oy < p.Ho && ox < p.Wo;
   };
   if (p.ys) {
     constexpr int OLD = 2 * BN + 8;
@@ -3992,9 +4002,19 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   // are 392 tiles of 16x16 (one round, a quarter of the slots empty) but 504 of 12x16 (one round of 3/4 the length).
   const int gy = (p.Np / 16 + NT - 1) / NT;
   auto rounds = [&](int th) { return ((int64_t)p.N * p.tilesX * ((p.Ho + th - 1) / th) * gy + 511) / 512 * th; };
-  const bool pt3 = p.PXS == 160 || (x_env_on("WCMC_HALO64_PT3") && rounds(12) < rounds(16));     // (32-channel slabs: 12x16 only)
+  bool pt3 = p.PXS == 160 || (x_env_on("WCMC_HALO64_PT3") && rounds(12) < rounds(16));     // (32-channel slabs: 12x16 only)
+  // Neither height divides Ho (KPCN: 124, 116, 104, 100, 92 rows): a tile rows of 16 + b of 12 cover it exactly -- the 16-row
+  // instance, whose workgroups of the last b tile rows skip their fourth pixel tile (p.rows16).  Smallest b: as many workgroups
+  // as the 16-row tiling, 3-7 % fewer rows of MFMAs than either pure tiling.  (The captured step follows the MFMAs issued, not the
+  // isolated launch time: DESIGN.md 7.1; WCMC_HALO64_MIX=0, debug build: the pure tilings.)
+  p.rows16 = 1 << 20;
+  if (p.PXS != 160 && p.Ho % 16 != 0 && p.Ho % 12 != 0 && x_env_on("WCMC_HALO64_MIX")) {
+    for (int b = 1; 12 * b < p.Ho; ++b)
+      if ((p.Ho - 12 * b) % 16 == 0) { p.rows16 = (p.Ho - 12 * b) / 16; pt3 = false; break; }
+  }
+  const bool mixed = p.rows16 != (1 << 20);
   const int th = pt3 ? 12 : 16;
-  p.tilesY = (p.Ho + th - 1) / th;
+  p.tilesY = mixed ? p.rows16 + (p.Ho - 16 * p.rows16) / 12 : (p.Ho + th - 1) / th;
   const int HP = (th + p.ks - 1) * (16 + p.ks - 1);
   const size_t halo = (size_t)((HP * p.PXS + 127) & ~127), bstage = (size_t)(2 * NT * 16 * XROW + 64) * sizeof(u16);
   const size_t out = p.ys ? (size_t)128 * (2 * NT * 16 + 8) * sizeof(u16) : (size_t)128 * (NT * 16 + 4) * sizeof(float);
