@@ -4003,12 +4003,20 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   const int gy = (p.Np / 16 + NT - 1) / NT;
   auto rounds = [&](int th) { return ((int64_t)p.N * p.tilesX * ((p.Ho + th - 1) / th) * gy + 511) / 512 * th; };
   bool pt3 = p.PXS == 160 || (x_env_on("WCMC_HALO64_PT3") && rounds(12) < rounds(16));     // (32-channel slabs: 12x16 only)
-  // Neither height divides Ho (KPCN: 124, 116, 104, 100, 92 rows): a tile rows of 16 + b of 12 cover it exactly -- the 16-row
-  // instance, whose workgroups of the last b tile rows skip their fourth pixel tile (p.rows16).  Smallest b: as many workgroups
-  // as the 16-row tiling, 3-7 % fewer rows of MFMAs than either pure tiling.  (The captured step follows the MFMAs issued, not the
-  // isolated launch time: DESIGN.md 7.1; WCMC_HALO64_MIX=0, debug build: the pure tilings.)
+  // 16 does not divide Ho (KPCN: 124, 120, 116, 108, 104, 100, 92 rows): a tile rows of 16 followed by b of 12 cover it EXACTLY -- the
+  // 16-row instance, whose workgroups of the last b tile rows skip their fourth pixel tile (p.rows16).  Smallest b: as many workgroups
+  // as the 16-row tiling and no padded rows (3-7 % fewer MFMAs than the better pure tiling where 12 does not divide Ho either; where
+  // it does -- 120, 108 -- the same MFMAs in fewer, taller workgroups: less weight streaming per pixel).  ALONE such a launch is slower
+  // (one round of 16-row workgroups where the 12-row tiling ran a shorter round: +2 % per branch); the captured two-stream step is
+  // faster by 1.8 %, every one of the seven heights contributing (profiles/r06_step_ab.txt).  Where 16 divides Ho
+  // the rule above stands (96 rows: 288 workgroups of 16 rows are slower than 384 of 12, in the step too).
+  // Debug build, WCMC_HALO64_MIX: 0 = pure tilings, 1 = mix only where 12 does not divide Ho either; WCMC_HALO64_NOMIX=<Ho>: one
+  // height keeps its pure tiling (the per-height A/B).
   p.rows16 = 1 << 20;
-  if (p.PXS != 160 && p.Ho % 16 != 0 && p.Ho % 12 != 0 && x_env_on("WCMC_HALO64_MIX")) {
+  const char* mixe = ab_env("WCMC_HALO64_MIX");
+  const bool mix12 = !(mixe && mixe[0] == '1');
+  const char* nomix = ab_env("WCMC_HALO64_NOMIX");
+  if (p.PXS != 160 && p.Ho % 16 != 0 && (p.Ho % 12 != 0 || mix12) && x_env_on("WCMC_HALO64_MIX") && !(nomix && atoi(nomix) == p.Ho)) {
     for (int b = 1; 12 * b < p.Ho; ++b)
       if ((p.Ho - 12 * b) % 16 == 0) { p.rows16 = (p.Ho - 12 * b) / 16; pt3 = false; break; }
   }
