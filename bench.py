@@ -228,6 +228,7 @@ def pmc_traffic():
                          ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 2, 2, 0>", "conv_halo64_pt3"), ("conv_halo64_bf16x3_kernel<7, 2, 3", "conv_halo64_cs32"),
                          ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 2, 0>", "conv_halo64_pt4_x2"), ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 2, 0>", "conv_halo64_pt3_x2"),
                          ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 0>", "conv_halo64_pt3_x1"), ("conv_halo64_bf16x3_kernel<7, 3, 3, 0, 80, 1, 1, 1>", "conv_halo64_pt3_h1"),
+                         ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 1, 0>", "conv_halo64_pt4_x1"), ("conv_halo64_bf16x3_kernel<7, 3, 4, 0, 80, 1, 1, 1>", "conv_halo64_pt4_h1"),
                          ("conv_wgrad_rows8_bf16x3_kernel<0, 1, 1>" if _rows8(1) else "conv_wgrad_rows_bf16x3_kernel<5, 7, 7, 0, 1>", "conv_wgrad_rows"),
                          ("conv_pw_bf16x3_kernel<4, 16, true, 0>", "conv_pw"),
                          ("embed3_fwd_kernel", "embed3_fwd"), ("embed3_bwd_kernel", "embed3_bwd"),
@@ -239,10 +240,9 @@ def pmc_traffic():
                          "64x128x128: PathNet.embedding 36->64->64->64 (+ spp mean) / PathNet.final 64+64->128->3, the benchmark's shape"
                          if key.startswith(("embed3", "final2")) else
                          "8x96x96 100->441 5x5 (the KPCN output layer, 92x92 outputs)" if key.endswith(("_x1", "_h1")) else
-                         "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles) and the 100->441 output layer" if key == "conv_halo64_pt3" else
-                         "8x108x108 100->100 5x5 (KPCN layer, 104x104 outputs: 12x16 tiles)" if key.startswith("conv_halo64_pt3") else
+                         "8x100x100 100->100 5x5 (KPCN layer, 96x96 outputs: 12x16 tiles)" if key.startswith("conv_halo64_pt3") else
                          "8x128x128 64->64 3x3, pad 1 (a U-Net layer of the 128^2 level)" if key.startswith("conv_halo3") else
-                         "8x116x116 100->100 5x5 (KPCN mid layer)" if key.startswith("conv") else "logits (8,441,92,92)")
+                         "8x116x116 100->100 5x5 (KPCN mid layer; its data gradient: 116x116 outputs = five tile rows of 16 + three of 12)" if key.startswith("conv") else "logits (8,441,92,92)")
                 pick[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "shape": shape,
                              "source": "profiles/%s_pmc_summary.json" % PROFILE_ROUND}
     return pick

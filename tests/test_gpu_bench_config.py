@@ -181,8 +181,12 @@ def parity_report(rng_mode, weight_norm, seed=0, pin_defaults=True, bars=None):
         # The Adam step itself: parameter DELTAS of this step against the oracle's.  Adam's first step is
         # -lr * g / (|g| + eps) = -lr * sign(g): an entry whose gradient is smaller than the gradient error may go the other
         # way (2 * lr apart) in two correct implementations.  So (i) entries whose oracle gradient is well conditioned (>= half
-        # the tensor's rms, in every step so far) must agree to 5 % of lr, and (ii) at most 1 % of a tensor's entries (one
-        # entry for tiny tensors) may be such ties (more than lr / 2 apart).  "No update" or "wrong sign" fails both everywhere.
+        # the tensor's rms, in every step so far) must agree to 5 % of lr, and (ii) at most 1 % of a tensor's entries (two
+        # entries for small tensors) may be such ties (more than lr / 2 apart), and in the first step every one of them must BE a
+        # tie: an oracle gradient below 5 % of the tensor's rms.  "No update" or "wrong sign" fails both everywhere.
+        # (Round 6: one entry -> two.  With a gradient error of ~2e-3 of the rms an entry lies within the error of zero with
+        # probability ~0.16 %; over the ~130 tensors of about a hundred entries and two steps a tensor with two such entries is
+        # an event of every few draws, and a change of summation order -- the exact tile heights of the KPCN launches -- met one.)
         for mn in omods:
             for (k, p), (_, q) in zip(hmods[mn].named_parameters(), omods[mn].named_parameters()):
                 d_h = p.detach().cpu() - p_prev[mn][k]
@@ -196,8 +200,13 @@ def parity_report(rng_mode, weight_norm, seed=0, pin_defaults=True, bars=None):
                 report.append(("step%d delta %s %s" % (step, mn, k), rel_l2(d_h, d_o), None, worst / lr))
                 if worst > 0.05 * lr:
                     fails.append("step %d parameter delta %s %s: %.3e lr apart on a well-conditioned entry" % (step, mn, k, worst / lr))
-                if ties > max(1, d_h.numel() // 100):
+                if ties > max(2, d_h.numel() // 100):
                     fails.append("step %d parameter delta %s %s: %d of %d entries more than lr/2 apart" % (step, mn, k, ties, d_h.numel()))
+                if step == 0 and ties:
+                    g0 = ograds[0][(mn, k)]
+                    big = float(g0[(d_h - d_o).abs() > 0.5 * lr].abs().max()) / max(float(g0.pow(2).mean().sqrt()), 1e-30)
+                    if big > 0.05:
+                        fails.append("step 0 parameter delta %s %s: an entry whose oracle gradient is %.3f of the tensor's rms went the other way" % (mn, k, big))
                 if float(d_h.abs().max()) <= 0.5 * lr:
                     fails.append("step %d: parameters of %s %s did not move" % (step, mn, k))
         # Step 2 starts from the PRODUCT's weights on both sides: the ~0.1 % of entries that took the other side of a sign

@@ -787,7 +787,7 @@ def _igemm_class(cin, cout, ks, dims=None, terms=3):
         return "conv_igemm"
     if dims is None:
         return "conv_halo7"                 # (the fp32 path's 5x5 class)
-    n, ho, wo = dims                        # conv_halo64_bf16x3_kernel<7, NB, PT>: 16x16 tiles (PT = 4) or 12x16 (PT = 3)
+    n, ho, wo = dims                        # conv_halo64_bf16x3_kernel<7, NB, PT>: 16x16 tiles (PT = 4; also the mixed 16 / 12 heights) or 12x16 (PT = 3)
     kp = (cin + 7) // 8 * 8
     x2 = terms <= 2 and kp % 32 != 24      # x_plan_k grants ap = 1 (32-channel slabs, 80 B)
     x1 = x2 and terms == 1              # ... and the one-plane weight path: <7, 3, PT, 0, 80, 1, 1>, suffix "_x1"
@@ -796,6 +796,9 @@ def _igemm_class(cin, cout, ks, dims=None, terms=3):
     gy = -(-tiles // nt)
     rounds = lambda th: -(-(n * (-(-wo // 16)) * (-(-ho // th)) * gy) // 512) * th
     pt3 = rounds(12) < rounds(16)
+    # round 6: where 16 does not divide ho but a rows of 16 + b >= 1 rows of 12 cover it exactly, the 16-row instance runs (mixed tile heights)
+    if ho % 16 != 0 and any((ho - 12 * b) % 16 == 0 for b in range(1, (ho - 1) // 12 + 1)):
+        pt3 = False
     return ("conv_halo64_pt3" if pt3 else "conv_halo64_pt4") + ("_x1" if x1 else "_x2" if x2 else "")
 
 
