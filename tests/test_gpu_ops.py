@@ -252,6 +252,12 @@ HALO5_CASES = [
     (1, 39, 128, 20, 100, 0, True),
     (1, 100, 24, 21, 100, 4, True),
     (1, 100, 112, 20, 100, 0, True),
+    # output widths that 16 does not divide: tile columns of 16 + a strip of TRANSPOSED 12-wide workgroups in the same launch (p.stripX):
+    # 28 x 28 = (16 + 12)^2, 32 x 44, 100 x 100 (KPCN: 4 + 3 columns, 4 + 3 tile rows), 28 x 40 with a padded halo (one column of 16, two of 12)
+    (1, 100, 32, 32, 100, 0, True),
+    (2, 100, 36, 48, 100, 0, True),
+    (1, 100, 104, 104, 100, 0, False),
+    (1, 100, 24, 36, 100, 4, True),
 ]
 
 
@@ -291,10 +297,12 @@ def test_conv5x5_kernel_variants_agree_with_fp64(case, monkeypatch):
 
 @needs_debug_lib
 @pytest.mark.parametrize("case", [(1, 100, 32, 37, 100, 0), (2, 100, 48, 20, 100, 0), (1, 100, 104, 33, 100, 0), (1, 39, 128, 20, 100, 0), (1, 100, 24, 21, 100, 4),
-                                  (8, 100, 120, 120, 100, 0), (2, 100, 96, 96, 441, 0), (1, 100, 112, 20, 100, 0), (1, 100, 124, 36, 100, 0)])
+                                  (8, 100, 120, 120, 100, 0), (2, 100, 96, 96, 441, 0), (1, 100, 112, 20, 100, 0), (1, 100, 124, 36, 100, 0),
+                                  (1, 100, 32, 32, 100, 0), (2, 100, 36, 48, 100, 0), (1, 100, 104, 104, 100, 0), (1, 39, 128, 128, 100, 0), (1, 100, 24, 36, 100, 4),
+                                  (2, 100, 112, 112, 100, 0)])
 def test_halo64_mixed_tile_heights_variant_is_bit_identical_to_the_pure_tilings(case, monkeypatch):
-    """Tile rows of 16 and of 12 pixels in one launch (p.rows16) against the pure 12x16 / 16x16 tilings (WCMC_HALO64_MIX=0, debug
-    build): a pixel's products are summed in the same order whatever tile it sits in, so outputs, gate masks and results of the
+    """Tile rows of 16 and of 12 pixels in one launch (p.rows16), and tile columns of 16 with a strip of transposed 12-wide workgroups
+    (p.stripX), against the pure 12x16 / 16x16 tilings (WCMC_HALO64_MIX=0, WCMC_HALO64_STRIP=0, debug build): a pixel's products are summed in the same order whatever tile it sits in, so outputs, gate masks and results of the
     data-gradient orientation are equal BIT FOR BIT; the per-tile column sums are different partitions of the same rows."""
     o = ops()
     n, cin, h, w, cout, pad = case
@@ -306,6 +314,7 @@ def test_halo64_mixed_tile_heights_variant_is_bit_identical_to_the_pure_tilings(
     got = {}
     for sw in ("2", "0"):
         monkeypatch.setenv("WCMC_HALO64_MIX", sw)
+        monkeypatch.setenv("WCMC_HALO64_STRIP", "1" if sw == "2" else "0")      # (the transposed 12-wide strip of the widths likewise)
         y, part, mask = o.conv2d_x_raw(xs, (n, cin, h, w), o._pack_x(wt, 0), b, cout, ks, pad, "relu", out_split=True, colsum=True, mask_out=True)
         yf = o.conv2d_x_raw(xs, (n, cin, h, w), o._pack_x(wt, 3), b, cout, ks, pad, "linear", out_split=False, terms=2)
         got[sw] = (y.clone(), mask.clone(), yf.clone(), o.colsum_finish_raw(part, (n, cout, ho, wo)))

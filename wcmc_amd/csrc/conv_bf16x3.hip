@@ -597,6 +597,7 @@ struct XIgemmParams {
   int CS, nslabs, SPS, PXS, tilesX, tilesY;   // halo kernel: channel slab, stages per slab, halo pixel stride
   int CSl, SPSl;                              // ... of the last slab
   int rows16;                                 // conv_halo64, PT = 4 instance: tile rows [0, rows16) are 16 pixels high, the rest 12 (launch_xhalo64; set there)
+  int stripX, stripY;                         // ... and a strip of stripX TRANSPOSED tile columns of 12 pixels (16 rows high, stripY of them) right of the tilesX columns of 16
   int ap;                                     // planes of x multiplied: 2 = hi + lo, 1 = hi only (two MFMAs per product)
   int wplanes;                                // planes of the weights multiplied: 2, or 1 with ap == 1 (ONE MFMA per product; conv_halo64 only)
   int f16;                                    // with ap == wplanes == 1: x is ONE fp16 plane [pixel][Cpi], the pack's hi rows are fp16
@@ -1788,15 +1789,24 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const int tpi = p.tilesX * p.tilesY;
-  const int img = tile / tpi, trem = tile - img * tpi;
+  const int nmain = p.tilesX * p.tilesY;
+  const int tpi = nmain + (PT == 4 ? p.stripX * p.stripY : 0);
+  const int img = tile / tpi, trem0 = tile - img * tpi;
+  // Transposed strip (PT = 4 instance): where 16 does not divide the output WIDTH either, the launcher covers it with tilesX columns
+  // of 16 (these tiles) and stripX columns of 12 whose workgroups hold their halo TRANSPOSED in LDS -- LDS row = image column, LDS
+  // column = image row: 16 image rows x 12 image columns look exactly like a 12-row tile to the stage loop (same pitch, same pixel
+  // tile distance, same bank pattern); only the halo fill (which pixel goes where), the LDS offset of a filter tap (dx rows, dy
+  // columns) and the epilogue's pixel coordinates know.  A pixel's products are summed in the same order in either orientation.
+  const bool tr = PT == 4 && trem0 >= nmain;
+  const int trem = tr ? trem0 - nmain : trem0;
   // Mixed tile heights (PT = 4 instance): the launcher covers Ho EXACTLY with rows16 tile rows of 16 pixels followed by tile rows of
   // 12 where it can (100 = 4 x 16 + 3 x 12: 100 rows of MFMAs instead of 108 or 112) -- a 12-row workgroup stages a 16-row halo and
   // skips its fourth pixel tile (ptc, wave-uniform).
-  const int trow = trem / p.tilesX;
-  const int ptc = (PT == 4 && trow >= p.rows16) ? 3 : PT;
-  const int oy0 = PT == 4 ? (trow < p.rows16 ? trow * 16 : p.rows16 * 16 + (trow - p.rows16) * 12) : trow * TH;
-  const int ox0 = (trem - trow * p.tilesX) * TW;
+  const int tcols = tr ? p.stripX : p.tilesX;
+  const int trow = trem / tcols;
+  const int ptc = tr ? 3 : (PT == 4 && trow >= p.rows16) ? 3 : PT;
+  const int oy0 = tr ? trow * 16 : PT == 4 ? (trow < p.rows16 ? trow * 16 : p.rows16 * 16 + (trow - p.rows16) * 12) : trow * TH;
+  const int ox0 = tr ? p.tilesX * TW + (trem - trow * tcols) * 12 : (trem - trow * tcols) * TW;
   const int n0 = blockIdx.y * BN;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
@@ -1822,7 +1832,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
       if (v < hvecs) {
         const int px = (int)(((float)v + 0.5f) * invVP), part = v - px * VP;     // exact: v < 2^13
         const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
-        const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+        const int iy = oy0 - p.pad + (tr ? hx : hy), ix = ox0 - p.pad + (tr ? hy : hx);       // (transposed: LDS row = image column)
         if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
           const unsigned pbase = (unsigned)(((img * p.H + iy) * p.W + ix) * pixb);
           if (AP == 1) {                             // hi plane only: part = 16-byte unit of the slab's channels
@@ -1864,7 +1874,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
       if (v < hvecs) {
         const int px = (int)(((float)v + 0.5f) * invVP), part = v - px * VP;     // exact: v < 2^13
         const int hy = (int)(((float)px + 0.5f) * invHW), hx = px - hy * HWd;
-        const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+        const int iy = oy0 - p.pad + (tr ? hx : hy), ix = ox0 - p.pad + (tr ? hy : hx);
         const int plane = AP == 1 ? 0 : part >= (V >> 1), vec = part - plane * (V >> 1);
         const int ch = slab * p.CS + vec * 8;
         unsigned off = XOOB;
@@ -1916,6 +1926,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   // this lane's (tap, channel) of the stage whose A fragments are read next
   int cs_cur, sps_cur, lo_off, tps, coff, tdx, tdy;
   bool cs4 = false;                                      // (wave-uniform) the slab being read is in the four-channel K order (x_last4)
+  // The LDS offset of the lane's tap is carried along instead of being worked out from (tdy, tdx) every stage: one filter column is
+  // sMx bytes away, one filter row sMy -- a pixel and a halo row in a regular workgroup, the other way round in a transposed one (the
+  // tap (dy, dx) is then dx LDS rows and dy LDS columns away) -- so the orientation costs the stage loop nothing.
+  const int sMx = tr ? HWd * p.PXS : p.PXS, sMy = tr ? p.PXS : HWd * p.PXS;
+  int toff = 0, dstep = 0;                               // toff: (tdy, tdx) as bytes + coff; dstep: one stage's taps in x
+  const int wrapc = sMy - p.ks * sMx;                    // ... and what a wrap into the next filter row adds
   auto slab_begin = [&](int slab) {
     cs_cur = slab == p.nslabs - 1 ? p.CSl : p.CS;
     sps_cur = slab == p.nslabs - 1 ? p.SPSl : (p.SPS & 0xff);
@@ -1925,20 +1941,21 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
     coff = cs4 ? 0 : ((kg * 8) & (cs_cur - 1)) * 2;
     tdy = 0; tdx = cs_cur == 32 ? 0 : cs_cur == 16 ? (kg >> 1) : cs4 ? 2 * kg : kg;        // (cs4: the FIRST of the lane's two taps)
     if (tdx >= p.ks) { tdx -= p.ks; ++tdy; }             // (cs4, kg = 3: tap 6)
+    toff = tdy * sMy + tdx * sMx + coff;
+    dstep = tps * sMx;
   };
   bf16x8 ah[PT], al[PT], wh[NT], wl[NT];
-  // (24-bit multiplies: full-rate v_mad_u32_u24 instead of two 64-bit multiply-adds per stage)
-  auto a_off = [&]() { return tdy < p.ks ? (int)__umul24(__umul24((unsigned)tdy, (unsigned)HWd) + (unsigned)tdx, (unsigned)p.PXS) + coff : coff; };
+  auto a_off = [&]() { return tdy < p.ks ? toff : coff; };          // (taps past ks * ks are slab padding: zero weights, any pixel)
   // (cs4) the lane's second tap: the next one in the filter's raster order
   auto a_off2 = [&]() {
-    int x = tdx + 1, y = tdy;
-    if (x >= p.ks) { x = 0; ++y; }
-    return y < p.ks ? (int)__umul24(__umul24((unsigned)y, (unsigned)HWd) + (unsigned)x, (unsigned)p.PXS) : 0;
+    const bool wrap = tdx + 1 >= p.ks;
+    const int y = tdy + (wrap ? 1 : 0);
+    return y < p.ks ? toff + sMx + (wrap ? wrapc : 0) : 0;
   };
   auto a_advance = [&]() {
-    tdx += tps;
-    if (tdx >= p.ks) { tdx -= p.ks; ++tdy; }
-    if (cs4 && tdx >= p.ks) { tdx -= p.ks; ++tdy; }      // (eight taps ahead: up to two rows of five)
+    tdx += tps; toff += dstep;
+    if (tdx >= p.ks) { tdx -= p.ks; ++tdy; toff += wrapc; }
+    if (cs4 && tdx >= p.ks) { tdx -= p.ks; ++tdy; toff += wrapc; }      // (eight taps ahead: up to two rows of five)
   };
   auto read_a1 = [&](int i, int aoff, int aoff2) {
     const char* pa = halo + abase0 + aoff;
@@ -2056,7 +2073,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   bool okp[PT]; int64_t mp[PT];
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
-    const int oy = oy0 + wave + NWV * i, ox = ox0 + frow;
+    const int oy = tr ? oy0 + frow : oy0 + wave + NWV * i, ox = tr ? ox0 + wave + NWV * i : ox0 + frow;
     okp[i] = i < ptc && oy < p.Ho && ox < p.Wo;
     mp[i] = ((int64_t)img * p.Ho + oy) * p.Wo + ox;
   }
@@ -2092,7 +2109,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16x3_kernel(XIgemmParams
   // workgroup): half h = pixel tiles 2h, 2h+1 of every wave; staging row pr = 32 * wave + 16 * (i & 1) + column
   auto pix_of = [&](int h, int pr, int& oy, int& ox) {
     const int i = 2 * h + ((pr >> 4) & 1);             // (PT odd: the last group holds one pixel tile)
-    oy = oy0 + (pr >> 5) + NWV * i; ox = ox0 + (pr & 15);
+    if (tr) { oy = oy0 + (pr & 15); ox = ox0 + (pr >> 5) + NWV * i; }
+    else { oy = oy0 + (pr >> 5) + NWV * i; ox = ox0 + (pr & 15); }
     return i < ptc && oy < p.Ho && ox < p.Wo;
   };
   if (p.ys) {
@@ -3974,7 +3992,7 @@ template <int NT, int NB, int PT, int PXST, int AP = 2, int WP = 2, int F16 = 0>
 static int launch_xhalo64c(const XIgemmParams& p, size_t lds, hipStream_t stream) {
   static LdsAttr attr;
   if (set_max_lds(reinterpret_cast<const void*>(&conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>), lds, attr) != hipSuccess) return WCMC_ERR_LAUNCH;
-  const dim3 grid((unsigned)(p.N * p.tilesX * p.tilesY), (unsigned)((p.Np / 16 + NT - 1) / NT));
+  const dim3 grid((unsigned)(p.N * (p.tilesX * p.tilesY + (PT == 4 ? p.stripX * p.stripY : 0))), (unsigned)((p.Np / 16 + NT - 1) / NT));
   hipLaunchKernelGGL((conv_halo64_bf16x3_kernel<NT, NB, PT, 0, PXST, AP, WP, F16>), grid, dim3(256), lds, stream, p);
   return check_launch("conv2d_igemm_bf16x3(halo, 64 pixels per wave)");
 }
@@ -4012,7 +4030,7 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   // the rule above stands (96 rows: 288 workgroups of 16 rows are slower than 384 of 12, in the step too).
   // Debug build, WCMC_HALO64_MIX: 0 = pure tilings, 1 = mix only where 12 does not divide Ho either; WCMC_HALO64_NOMIX=<Ho>: one
   // height keeps its pure tiling (the per-height A/B).
-  p.rows16 = 1 << 20;
+  p.rows16 = 1 << 20; p.stripX = p.stripY = 0;
   const char* mixe = ab_env("WCMC_HALO64_MIX");
   const bool mix12 = !(mixe && mixe[0] == '1');
   const char* nomix = ab_env("WCMC_HALO64_NOMIX");
@@ -4046,6 +4064,13 @@ static int launch_xhalo64(const XIgemmParams& p0, hipStream_t stream) {
   // three weight stages where two workgroups still fit a CU (80 KB each), else two
   const char* nbe = ab_env("WCMC_HALO_NB");
   const int nb = (p.ap == 1 || (!(nbe && nbe[0] == '2') && halo + 3 * bstage <= 80 * 1024)) ? 3 : 2;
+  // The width likewise: where 16 does not divide Wo, a tile columns of 16 + b columns of 12 cover it exactly; the b columns are a
+  // strip of workgroups that hold their halo transposed (see the kernel: 16 image rows x 12 image columns each, 16-row tile rows) --
+  // the 16-row instance only.  (WCMC_HALO64_STRIP=0, debug build: 16-wide tiles throughout.)
+  if (!pt3 && p.ks == 5 && p.Wo % 16 != 0 && p.Wo % 4 == 0 && x_env_on("WCMC_HALO64_STRIP")) {
+    for (int b = 1; b <= 3; ++b)
+      if (12 * b < p.Wo && (p.Wo - 12 * b) % 16 == 0) { p.stripX = b; p.tilesX = (p.Wo - 12 * b) / 16; p.stripY = (p.Ho + 15) / 16; break; }
+  }
   const size_t main_ = halo + nb * bstage;
   const size_t lds = main_ > out ? main_ : out;
   if (pt3) return nb == 3 ? launch_xhalo64b<NT, 3, 3>(p, lds, stream) : launch_xhalo64b<NT, 2, 3>(p, lds, stream);
