@@ -258,6 +258,9 @@ HALO5_CASES = [
     (2, 100, 36, 48, 100, 0, True),
     (1, 100, 104, 104, 100, 0, False),
     (1, 100, 24, 36, 100, 4, True),
+    # ... through the narrower cout blocks (NT = 4: 39 couts; NT = 1: 16 couts) and three images
+    (3, 100, 32, 32, 39, 0, True),
+    (2, 40, 32, 48, 16, 0, True),
 ]
 
 
@@ -299,7 +302,7 @@ def test_conv5x5_kernel_variants_agree_with_fp64(case, monkeypatch):
 @pytest.mark.parametrize("case", [(1, 100, 32, 37, 100, 0), (2, 100, 48, 20, 100, 0), (1, 100, 104, 33, 100, 0), (1, 39, 128, 20, 100, 0), (1, 100, 24, 21, 100, 4),
                                   (8, 100, 120, 120, 100, 0), (2, 100, 96, 96, 441, 0), (1, 100, 112, 20, 100, 0), (1, 100, 124, 36, 100, 0),
                                   (1, 100, 32, 32, 100, 0), (2, 100, 36, 48, 100, 0), (1, 100, 104, 104, 100, 0), (1, 39, 128, 128, 100, 0), (1, 100, 24, 36, 100, 4),
-                                  (2, 100, 112, 112, 100, 0)])
+                                  (2, 100, 112, 112, 100, 0), (3, 100, 32, 32, 39, 0), (2, 40, 32, 48, 16, 0), (1, 100, 44, 60, 441, 0)])
 def test_halo64_mixed_tile_heights_variant_is_bit_identical_to_the_pure_tilings(case, monkeypatch):
     """Tile rows of 16 and of 12 pixels in one launch (p.rows16), and tile columns of 16 with a strip of transposed 12-wide workgroups
     (p.stripX), against the pure 12x16 / 16x16 tilings (WCMC_HALO64_MIX=0, WCMC_HALO64_STRIP=0, debug build): a pixel's products are summed in the same order whatever tile it sits in, so outputs, gate masks and results of the
